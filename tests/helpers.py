@@ -1,0 +1,56 @@
+"""Shared test helpers: load golden fixtures, rebuild their deterministic weights."""
+import json
+import os
+
+import numpy as np
+import torch
+
+from oracle import detgen
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, 'tests', 'golden')
+
+G4_CASES = ['c2_stage1', 'c2_stage2', 'c1_stage1', 'c1_stage2', 'c5_stage1', 'c2_geo2human', 'c2_dot_st']
+
+
+def load_g4(name):
+    z = np.load(os.path.join(GOLDEN, f'g4_{name}.npz'), allow_pickle=False)
+    meta = json.loads(str(z['meta_json']))
+    return z, meta
+
+
+def det_state_dict(shapes: dict, seed: int, gain: float = 1.0, requires_grad: bool = False):
+    vals = detgen.fill_state_dict({k: tuple(v) for k, v in shapes.items()}, seed=seed, gain=gain)
+    sd = {}
+    for k, v in vals.items():
+        t = torch.from_numpy(np.asarray(v)).clone()
+        if requires_grad and t.is_floating_point() and 'running_' not in k:
+            t.requires_grad_(True)
+        sd[k] = t
+    return sd
+
+
+def g4_inputs(z):
+    kw = dict(x_human=torch.from_numpy(z['x_human']), x_objects=torch.from_numpy(z['x_objects']),
+              objects_mask=torch.from_numpy(z['objects_mask']))
+    bs, T = z['x_human'].shape[:2]
+    kw['steps_per_example'] = torch.full((bs,), float(T))
+    if 'human_segmentation' in z.files:
+        kw['human_segmentation'] = torch.from_numpy(z['human_segmentation'])
+    if 'objects_segmentation' in z.files:
+        kw['objects_segmentation'] = torch.from_numpy(z['objects_segmentation'])
+    return kw
+
+
+def sample_grad(g: torch.Tensor, limit=4096) -> np.ndarray:
+    flat = g.detach().flatten().cpu().numpy()
+    if flat.size <= limit:
+        return flat.copy()
+    stride = flat.size // limit
+    return flat[::stride][:limit].copy()
+
+
+def rel_err(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-12))

@@ -1,0 +1,292 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by running the REAL reference (imported from /root/reference).
+
+Runs only in the build container (the reference never travels to the GPU box). Weights come from the closed-form
+generator in oracle/detgen.py, so the fixtures hold just inputs, outputs, (sampled) gradients and the Gumbel noise
+the reference actually drew. Usage:  python tools/make_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = os.environ.get('TWOG_REFERENCE', '/root/reference')
+sys.path.insert(0, ROOT)
+sys.path.insert(0, REF)
+
+from oracle import detgen  # noqa: E402
+from vhoi.models import TGGCN, compute_attention_weights, compute_non_relational_message  # noqa: E402
+from vhoi.models import reorder_hidden_states, filter_soft_decisions  # noqa: E402
+from pyrutils.torch.models_gcn import Geo_gcn  # noqa: E402
+from pyrutils.torch.models import build_mlp  # noqa: E402
+import pyrutils.torch.distributions as ref_dist  # noqa: E402
+from vhoi.losses import select_loss  # noqa: E402
+
+OUT = os.path.join(ROOT, 'tests', 'golden')
+GRAD_SAMPLE_LIMIT = 4096
+
+
+def load_det(module, seed, gain=1.0):
+    shapes = {k: tuple(v.shape) for k, v in module.state_dict().items()}
+    vals = detgen.fill_state_dict(shapes, seed=seed, gain=gain)
+    module.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in vals.items()})
+
+
+def sample_grad(g: torch.Tensor) -> np.ndarray:
+    flat = g.detach().flatten().numpy()
+    if flat.size <= GRAD_SAMPLE_LIMIT:
+        return flat.copy()
+    stride = flat.size // GRAD_SAMPLE_LIMIT
+    return flat[::stride][:GRAD_SAMPLE_LIMIT].copy()
+
+
+class GumbelRecorder:
+    """Wraps torch.distributions.gumbel.Gumbel.sample to record the noise the reference draws."""
+
+    def __init__(self):
+        self.drawn = []
+        self._orig = torch.distributions.gumbel.Gumbel.sample
+
+    def __enter__(self):
+        rec = self
+
+        def sample(self_, sample_shape=torch.Size()):
+            g = rec._orig(self_, sample_shape)
+            rec.drawn.append(g.clone())
+            return g
+
+        torch.distributions.gumbel.Gumbel.sample = sample
+        return self
+
+    def __exit__(self, *a):
+        torch.distributions.gumbel.Gumbel.sample = self._orig
+
+
+# ---------------------------------------------------------------------------------------------------------------
+def g1_geo_gcn():
+    """G1: Geo_gcn(N, 4, 128) train/eval, outputs + running stats + parameter grads."""
+    out = {}
+    for N in (19, 26, 30, 34):
+        for mode in ('train', 'eval'):
+            bs, T = 2, 5
+            m = Geo_gcn(N, 4, 128)
+            load_det(m, seed=100 + N)
+            m.train(mode == 'train')
+            x = torch.from_numpy(detgen.normal(f'g1.x.{N}', (bs, 4, N, T), std=1.0, seed=1))
+            r = torch.from_numpy(detgen.normal(f'g1.r.{N}', (bs, 128, N, T), std=1.0, seed=2))
+            y = m(x)
+            (y * r).sum().backward()
+            key = f'N{N}_{mode}'
+            out[key + '_y'] = y.detach().numpy()
+            for name, p in m.named_parameters():
+                out[f'{key}_grad_{name}'] = p.grad.numpy().copy()
+            bn = m.joint_embed.cnn[0].bn
+            out[key + '_running_mean'] = bn.running_mean.numpy().copy()
+            out[key + '_running_var'] = bn.running_var.numpy().copy()
+            out[key + '_nbt'] = np.array(int(bn.num_batches_tracked))
+    np.savez_compressed(os.path.join(OUT, 'g1_geo_gcn.npz'), **out)
+    print('g1: ', len(out), 'arrays')
+
+
+def g3_messages():
+    """G3: compute_non_relational_message + compute_attention_weights for styles v1..v4 with masks, including a
+    fully masked row (NaN -> 0 path, models.py:1750-1753)."""
+    out = {}
+    bs, S, d, hm = 4, 5, 12, 6
+    q = torch.from_numpy(detgen.normal('g3.q', (bs, d), seed=3))
+    keys = torch.from_numpy(detgen.normal('g3.k', (bs, S, d), seed=3))
+    mask = torch.tensor([[1, 1, 1, 1, 1], [1, 0, 1, 0, 1], [0, 0, 0, 0, 0], [0, 0, 0, 1, 0]], dtype=torch.float32)
+    out['q'], out['keys'], out['mask'] = q.numpy(), keys.numpy(), mask.numpy()
+    msg = build_mlp([d, hm], ['relu'])
+    load_det(msg, seed=31)
+    out['msg_v1'] = compute_non_relational_message(q, keys, mask, 'v1', msg).detach().numpy()
+    msg2 = build_mlp([2 * d, hm], ['relu'])
+    load_det(msg2, seed=32)
+    out['msg_v2'] = compute_non_relational_message(q, keys, mask, 'v2', msg2).detach().numpy()
+    att1 = build_mlp([2 * d, 1], ['relu'])
+    load_det(att1, seed=33)
+    att4 = torch.nn.Bilinear(d, d, 1)
+    load_det(att4, seed=34)
+    for style, fn in (('v1', att1), ('v2', None), ('v3', None), ('v4', att4)):
+        out['att_' + style] = compute_attention_weights(q, keys, mask, style, fn).detach().numpy()
+    np.savez_compressed(os.path.join(OUT, 'g3_messages.npz'), **out)
+    print('g3: ', len(out), 'arrays')
+
+
+def g5_reorder_filter():
+    out = {}
+    bs, T, d = 5, 11, 3
+    hx = torch.from_numpy(detgen.normal('g5.hx', (bs, T, d), seed=5))
+    ux = (torch.from_numpy(detgen.uniform01('g5.ux', (bs, T), seed=5)) > 0.6).float()
+    ux[0, :] = 1.0
+    ux[1, :] = 0.0  # no end flag at all
+    ux[2, -1] = 0.0  # no trailing end flag
+    ux[3, -1] = 1.0
+    out['hx'], out['ux'] = hx.numpy(), ux.numpy()
+    out['reordered'] = reorder_hidden_states(hx, ux).numpy()
+    soft = torch.from_numpy(detgen.uniform01('g5.soft', (T, bs, 1), seed=6).astype(np.float32))
+    for thr in (0.1, 0.5):
+        f = filter_soft_decisions([s for s in soft], thr)
+        out[f'filtered_{thr}'] = torch.stack(f, 0).numpy()
+    out['soft'] = soft.numpy()
+    np.savez_compressed(os.path.join(OUT, 'g5_reorder_filter.npz'), **out)
+    print('g5: ', len(out), 'arrays')
+
+
+# ---------------------------------------------------------------------------------------------------------------
+STAGE1 = dict(add_segment_length=0, add_time_position=0, time_position_strategy='s', positional_encoding_style='e',
+              attention_style='v3', bias=True, cat_level_states=0, discrete_networks_num_layers=1,
+              discrete_optimization_strategy='gs', filter_discrete_updates=False, message_humans_to_human=True,
+              message_human_to_objects=True, message_objects_to_human=True, message_objects_to_object=True,
+              message_geometry_to_objects=True, message_geometry_to_human=False, message_segment=True,
+              message_type='v2', message_granularity='v1', message_aggregation='att',
+              object_segment_update_strategy='ind', share_level_mlps=0, update_segment_threshold=0.5)
+
+CASES = {
+    # name: (layout, H, O, N, hidden, bs, T, classes, cfg overrides, segmentation mode, seed)
+    'c2_stage1': ('mphoi', 2, 4, 26, 16, 3, 7, (13, None), {}, 'human_ones', 11),
+    'c2_stage2': ('mphoi', 2, 4, 26, 16, 2, 9, (13, None),
+                  dict(filter_discrete_updates=True, update_segment_threshold=0.1), 'none', 12),
+    'c1_stage1': ('cad120', 1, 5, 19, 16, 2, 8, (10, 12), dict(message_humans_to_human=False), 'both_given', 13),
+    'c1_stage2': ('cad120', 1, 5, 19, 8, 2, 6, (10, 12),
+                  dict(message_humans_to_human=False, filter_discrete_updates=True, update_segment_threshold=0.1),
+                  'none', 14),
+    'c5_stage1': ('bimanual', 2, 9, 30, 8, 2, 6, (14, None), {}, 'human_ones', 15),
+    'c2_geo2human': ('mphoi', 2, 4, 26, 8, 2, 5, (13, None), dict(message_geometry_to_human=True), 'human_ones', 16),
+    'c2_dot_st': ('mphoi', 2, 4, 26, 8, 2, 5, (13, None),
+                  dict(attention_style='v2', discrete_optimization_strategy='st'), 'none', 17),
+}
+
+
+def make_inputs(name, H, O, N, bs, T, seed):
+    F_h = 2048 + 4 * N
+    vis = np.maximum(detgen.normal(name + '.xh', (bs, T, H, 2048), seed=seed), 0.0)
+    pos = detgen.uniform(name + '.pos', (bs, T, N, 2), 0.0, 1.0, seed=seed)
+    vel = detgen.normal(name + '.vel', (bs, T, N, 2), std=0.5, seed=seed)
+    geo = np.concatenate([pos, vel], axis=-1).reshape(bs, T, 1, 4 * N)
+    geo = np.repeat(geo, H, axis=2)
+    x_human = np.concatenate([vis, geo], axis=-1).astype(np.float32)
+    assert x_human.shape[-1] == F_h
+    x_objects = np.maximum(detgen.normal(name + '.xo', (bs, T, O, 2048), seed=seed), 0.0).astype(np.float32)
+    mask = np.ones((bs, O), dtype=np.float32)
+    mask[0, O - 1] = 0.0  # one virtual object
+    if bs > 1 and O > 2:
+        mask[1, O - 2:] = 0.0
+    x_objects = x_objects * mask[:, None, :, None]
+    return x_human, x_objects, mask
+
+
+def g4_full():
+    for name, (layout, H, O, N, hid, bs, T, classes, over, segmode, seed) in CASES.items():
+        cfg = dict(STAGE1)
+        cfg.update(over)
+        cfg.update(hidden_size=hid, gcn_node=N)
+        F_h = 2048 + 4 * N
+        model = TGGCN(input_size=(F_h, 2048), num_classes=classes, **cfg)
+        load_det(model, seed=seed, gain=1.6)
+        model.train()
+        x_human, x_objects, mask = make_inputs(name, H, O, N, bs, T, seed)
+        kw = dict(x_human=torch.from_numpy(x_human), x_objects=torch.from_numpy(x_objects),
+                  objects_mask=torch.from_numpy(mask), steps_per_example=torch.full((bs,), float(T)))
+        seg_h = seg_o = None
+        if segmode == 'human_ones':
+            seg_h = np.ones((bs, T, H), dtype=np.float32)
+        elif segmode == 'both_given':
+            seg_h = (detgen.uniform01(name + '.segh', (bs, T, H), seed=seed) > 0.6).astype(np.float32)
+            seg_o = (detgen.uniform01(name + '.sego', (bs, T, O), seed=seed) > 0.6).astype(np.float32)
+            seg_h[:, -1] = 1.0
+            seg_o[:, -1] = 1.0
+        if seg_h is not None:
+            kw['human_segmentation'] = torch.from_numpy(seg_h)
+        if seg_o is not None:
+            kw['objects_segmentation'] = torch.from_numpy(seg_o)
+        torch.manual_seed(42)
+        with GumbelRecorder() as rec:
+            out = model(**kw)
+        noise = torch.stack(rec.drawn, 0).numpy() if rec.drawn else np.zeros((0, bs, 2), np.float32)
+        # scalar for backward: deterministic random projection of every output that carries grad
+        loss = 0
+        for i, o in enumerate(out):
+            if o.requires_grad:
+                r = torch.from_numpy(detgen.normal(f'{name}.r{i}', tuple(o.shape), seed=seed))
+                loss = loss + (o * r).sum()
+        backward_ok = True
+        try:
+            loss.backward()
+        except RuntimeError as e:  # upstream bug: StraightThroughEstimator.backward returns 1 grad for 2 inputs
+            backward_ok = False
+            print(f'   [{name}] reference backward fails upstream: {str(e)[:90]}')
+        save = dict(x_human=x_human, x_objects=x_objects, objects_mask=mask, gumbel_noise=noise,
+                    loss=np.array(float(loss)))
+        if seg_h is not None:
+            save['human_segmentation'] = seg_h
+        if seg_o is not None:
+            save['objects_segmentation'] = seg_o
+        for i, o in enumerate(out):
+            save[f'out{i}'] = o.detach().numpy()
+        none_grads = []
+        save['backward_ok'] = np.array(backward_ok)
+        for pname, p in (model.named_parameters() if backward_ok else []):
+            if p.grad is None:
+                none_grads.append(pname)
+            else:
+                save['grad_' + pname] = sample_grad(p.grad)
+        save['none_grads'] = np.array(none_grads)
+        bn = model.geometry_embedding_gcn.joint_embed.cnn[0].bn
+        save['bn_running_mean'] = bn.running_mean.numpy().copy()
+        save['bn_running_var'] = bn.running_var.numpy().copy()
+        meta = dict(layout=layout, H=H, O=O, N=N, hidden=hid, bs=bs, T=T, classes=list(classes), cfg=cfg,
+                    segmode=segmode, seed=seed, gain=1.6,
+                    state_dict_shapes={k: list(v.shape) for k, v in model.state_dict().items()})
+        save['meta_json'] = np.array(__import__('json').dumps(meta))
+        np.savez_compressed(os.path.join(OUT, f'g4_{name}.npz'), **save)
+        soft = [o for o in out[:4] if o.dim() == 3]
+        thr = cfg['update_segment_threshold']
+        margins = [float((o.detach() - thr).abs().min()) for o in soft]
+        print(f'g4 {name}: outs={len(out)} noise={noise.shape} none_grads={len(none_grads)} '
+              f'min|soft-thr|={min(margins):.4f} loss={float(loss):.5f}')
+
+
+def g7_losses():
+    """G7: vhoi.losses.select_loss list on fixed log-prob outputs/targets (pins the fwd+bwd scalar of bench.py)."""
+    class Cfg(dict):
+        def get(self, k, default_value=None, **kw):
+            return dict.get(self, k, default_value if default_value is not None else kw.get('default'))
+
+    out = {}
+    for ds, n_out, classes in (('mphoi', 6, 13), ('cad120', 12, 10)):
+        bs, T, E = 2, 6, 2
+        misc = dict(anticipation_loss_weight=1.0, budget_loss=dict(add=True, human_weight=0.5, object_weight=0.25),
+                    first_level_loss_weight=0.3, segmentation_loss=dict(add=True, pretrain=False, weight=0.7))
+        crit, names = select_loss('2G-GCN', 'multiple', ds, Cfg(misc=misc))
+        outs, tgts = [], []
+        n_b = 2 if ds == 'cad120' else 1
+        for i in range(n_out):
+            if i < 2 * n_b:
+                o = torch.from_numpy(detgen.uniform(f'g7.{ds}.o{i}', (bs, T, E), 0.05, 0.95, seed=7))
+                t = (torch.from_numpy(detgen.uniform01(f'g7.{ds}.t{i}', (bs, T, E), seed=7)) > 0.5).float()
+                t[0, -2:] = -1.0
+            else:
+                o = torch.log_softmax(torch.from_numpy(detgen.normal(f'g7.{ds}.o{i}', (bs, classes, T, E), seed=7)), 1)
+                t = torch.from_numpy((detgen.uniform01(f'g7.{ds}.t{i}', (bs, T, E), seed=7) * classes).astype(np.int64))
+                t[0, -2:] = -1
+            outs.append(o)
+            tgts.append(t)
+            out[f'{ds}_o{i}'], out[f'{ds}_t{i}'] = o.numpy(), t.numpy()
+        losses = crit(outs, tgts)
+        out[f'{ds}_losses'] = np.array([float(v) for v in losses], dtype=np.float64)
+        out[f'{ds}_names'] = np.array(names)
+    np.savez_compressed(os.path.join(OUT, 'g7_losses.npz'), **out)
+    print('g7: ', len(out), 'arrays')
+
+
+if __name__ == '__main__':
+    torch.set_num_threads(8)
+    os.makedirs(OUT, exist_ok=True)
+    g1_geo_gcn()
+    g3_messages()
+    g5_reorder_filter()
+    g4_full()
+    g7_losses()
