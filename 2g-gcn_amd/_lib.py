@@ -1,0 +1,157 @@
+"""ctypes binding of lib2ggcn_hip.so (C ABI declared in include/twog_gcn.h).
+
+The product path has NO fallback: if the shared library is missing or an entry point is absent, importing/using the
+kernels raises. Build it with ``python -c "import __graft_entry__ as g; g.build()"`` or ``make -C 2g-gcn_amd/csrc``.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'lib2ggcn_hip.so')
+
+c_float_p = C.POINTER(C.c_float)
+c_double_p = C.POINTER(C.c_double)
+c_int64_p = C.POINTER(C.c_int64)
+
+
+class Rows(C.Structure):  # twog_rows_t
+    _fields_ = [('ptr', C.c_void_p), ('ld_outer', C.c_int64), ('ld_inner', C.c_int64), ('inner', C.c_int32),
+                ('pad_', C.c_int32)]
+
+
+class Gemm(C.Structure):  # twog_gemm_t
+    _fields_ = [('A', Rows), ('B', Rows), ('C', Rows), ('bias', C.c_void_p), ('M', C.c_int32), ('N', C.c_int32),
+                ('K', C.c_int32), ('act', C.c_int32), ('accumulate', C.c_int32), ('batch', C.c_int32),
+                ('a_batch_stride', C.c_int64), ('b_batch_stride', C.c_int64), ('c_batch_stride', C.c_int64)]
+
+
+class GruStep(C.Structure):  # twog_gru_step_t
+    _fields_ = [('gi', Rows), ('gi2', Rows), ('gh', Rows), ('h_prev', Rows), ('h_out', Rows), ('save', Rows),
+                ('u', C.c_void_p), ('u_ld_outer', C.c_int64), ('u_ld_inner', C.c_int64), ('u_inner', C.c_int32),
+                ('rows', C.c_int32), ('hidden', C.c_int32), ('pad_', C.c_int32)]
+
+
+class GruStepBwd(C.Structure):  # twog_gru_step_bwd_t
+    _fields_ = [('dh', Rows), ('dh2', Rows), ('save', Rows), ('h_prev', Rows), ('dgi', Rows), ('dgh', Rows),
+                ('dh_prev', Rows), ('u', C.c_void_p), ('du', C.c_void_p), ('u_ld_outer', C.c_int64),
+                ('u_ld_inner', C.c_int64), ('u_inner', C.c_int32), ('rows', C.c_int32), ('hidden', C.c_int32),
+                ('dh_prev_accumulate', C.c_int32)]
+
+
+class BiGru(C.Structure):  # twog_bigru_t
+    _fields_ = [('gi', C.c_void_p), ('w_hh_f', C.c_void_p), ('b_hh_f', C.c_void_p), ('w_hh_r', C.c_void_p),
+                ('b_hh_r', C.c_void_p), ('out', C.c_void_p), ('save', C.c_void_p), ('tmp_gh', C.c_void_p),
+                ('zeros', C.c_void_p), ('E', C.c_int32), ('pad_', C.c_int32)]
+
+
+class BiGruBwd(C.Structure):  # twog_bigru_bwd_t
+    _fields_ = [('d_out', C.c_void_p), ('save', C.c_void_p), ('out', C.c_void_p), ('w_hh_f', C.c_void_p),
+                ('w_hh_r', C.c_void_p), ('d_gi', C.c_void_p), ('d_gh', C.c_void_p), ('carry', C.c_void_p),
+                ('E', C.c_int32), ('pad_', C.c_int32)]
+
+
+class Attn(C.Structure):  # twog_attn_t
+    _fields_ = [('feat_h', Rows), ('feat_o', Rows), ('msg_hh', Rows), ('msg_ho', Rows), ('msg_oh', Rows),
+                ('msg_oo', Rows), ('msg_so', Rows), ('msg_sh', Rows), ('out_hh', Rows), ('out_oh', Rows),
+                ('out_sh', Rows), ('out_ho', Rows), ('out_so', Rows), ('out_oo', Rows), ('obj_mask', C.c_void_p),
+                ('att', C.c_void_p), ('n_inst', C.c_int32), ('inst_per_clip', C.c_int32), ('H', C.c_int32),
+                ('O', C.c_int32), ('D', C.c_int32), ('hidden', C.c_int32), ('scale', C.c_float),
+                ('recv_mask_ho', C.c_int32)]
+
+
+class AttnBwd(C.Structure):  # twog_attn_bwd_t
+    _fields_ = [('f', Attn), ('dout_hh', Rows), ('dout_oh', Rows), ('dout_sh', Rows), ('dout_ho', Rows),
+                ('dout_so', Rows), ('dout_oo', Rows), ('dmsg_hh', Rows), ('dmsg_ho', Rows), ('dmsg_oh', Rows),
+                ('dmsg_oo', Rows), ('dmsg_so', Rows), ('dmsg_sh', Rows), ('dfeat_h', Rows), ('dfeat_o', Rows),
+                ('dfeat_accumulate', C.c_int32), ('relu_mask_dmsg', C.c_int32)]
+
+
+class SegRnn(C.Structure):  # twog_segrnn_t
+    _fields_ = [('bs', C.c_int32), ('T', C.c_int32), ('H', C.c_int32), ('O', C.c_int32), ('hidden', C.c_int32),
+                ('msg_segment', C.c_int32), ('rel_hh', C.c_int32), ('rel_ho', C.c_int32), ('rel_oh', C.c_int32),
+                ('rel_oo', C.c_int32), ('att_scale', C.c_float), ('pad_', C.c_int32),
+                ('gi_h', C.c_void_p), ('gi_o', C.c_void_p), ('u_h', C.c_void_p), ('u_o', C.c_void_p),
+                ('obj_mask', C.c_void_p),
+                ('w_hh_h', C.c_void_p * 2), ('b_hh_h', C.c_void_p * 2), ('w_hh_o', C.c_void_p * 2),
+                ('b_hh_o', C.c_void_p * 2), ('w_ihm_h', C.c_void_p * 2), ('w_ihm_o', C.c_void_p * 2),
+                ('ld_ih_h', C.c_int64), ('ld_ih_o', C.c_int64),
+                ('w_smsg_h', C.c_void_p), ('b_smsg_h', C.c_void_p), ('w_smsg_o', C.c_void_p), ('b_smsg_o', C.c_void_p),
+                ('hs_h', C.c_void_p), ('hs_o', C.c_void_p), ('save_h', C.c_void_p), ('save_o', C.c_void_p),
+                ('msrc_h', C.c_void_p), ('msrc_o', C.c_void_p), ('mg_h', C.c_void_p), ('mg_o', C.c_void_p),
+                ('att', C.c_void_p), ('tmp_gim_h', C.c_void_p), ('tmp_gim_o', C.c_void_p), ('tmp_gh_h', C.c_void_p),
+                ('tmp_gh_o', C.c_void_p), ('zeros', C.c_void_p)]
+
+
+class SegRnnBwd(C.Structure):  # twog_segrnn_bwd_t
+    _fields_ = [('d_hs_h', C.c_void_p), ('d_hs_o', C.c_void_p), ('d_gi_h', C.c_void_p), ('d_gi_o', C.c_void_p),
+                ('d_gh_h', C.c_void_p), ('d_gh_o', C.c_void_p), ('d_u_h', C.c_void_p), ('d_u_o', C.c_void_p),
+                ('d_pre_h', C.c_void_p), ('d_pre_o', C.c_void_p), ('carry_h', C.c_void_p), ('carry_o', C.c_void_p),
+                ('tmp_dmg_h', C.c_void_p), ('tmp_dmg_o', C.c_void_p), ('trash', C.c_void_p)]
+
+
+class Gate(C.Structure):  # twog_gate_t
+    _fields_ = [('x', Rows), ('seg_col', C.c_int32 * 8), ('n_seg', C.c_int32), ('hidden', C.c_int32),
+                ('w', C.c_void_p), ('b', C.c_void_p), ('noise', C.c_void_p), ('hard', C.c_void_p),
+                ('soft', C.c_void_p), ('p_save', C.c_void_p), ('bs', C.c_int32), ('T', C.c_int32), ('E', C.c_int32),
+                ('noise_entities', C.c_int32), ('noise_offset', C.c_int32), ('force_last', C.c_int32),
+                ('threshold', C.c_float), ('pad_', C.c_int32)]
+
+
+# name -> (argtypes) ; every function returns int except twog_version
+_I, _L, _F, _P = C.c_int, C.c_int64, C.c_float, C.c_void_p
+SIGNATURES = {
+    'twog_gemm_f32': [C.POINTER(Gemm), _I, _I, _I, _P, C.c_size_t, _P],
+    'twog_gcn_max_nodes': [],
+    'twog_bn_stats': [_P, _L, _I, _I, _P, _I, _P],
+    'twog_bn_finalize': [_P, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _P, _P],
+    'twog_gcn_embed1_fwd': [_P, _L, _I, _I, _P, _P, _P, _P, _P],
+    'twog_gcn_embed1_bwd': [_P, _L, _I, _I, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P],
+    'twog_gcn_attn_fwd': [_P, _P, _I, _I, _P, _P, _P],
+    'twog_gcn_attn_bwd': [_P, _P, _P, _P, _I, _I, _P, _P, _P],
+    'twog_gru_step_fwd': [C.POINTER(GruStep), _I, _P],
+    'twog_gru_step_bwd': [C.POINTER(GruStepBwd), _I, _P],
+    'twog_bigru_fwd': [C.POINTER(BiGru), _I, _I, _I, _I, _P],
+    'twog_bigru_bwd': [C.POINTER(BiGruBwd), _I, _I, _I, _I, _P],
+    'twog_attn_fwd': [C.POINTER(Attn), _I, _P],
+    'twog_attn_limits': [C.POINTER(C.c_int), C.POINTER(C.c_int)],
+    'twog_attn_bwd': [C.POINTER(AttnBwd), _I, _P],
+    'twog_segrnn_fwd': [C.POINTER(SegRnn), _P],
+    'twog_segrnn_bwd': [C.POINTER(SegRnn), C.POINTER(SegRnnBwd), _P],
+    'twog_gate_fwd': [C.POINTER(Gate), _P],
+    'twog_gate_bwd': [C.POINTER(Gate), _P, _P, _P, _P, _P],
+    'twog_rank1_update': [Rows, _P, _P, _I, _I, _P],
+    'twog_colsum': [Rows, _P, _I, _I, _P, _I, _P, _I, _P],
+    'twog_filter_fwd': [_P, _P, _P, _I, _I, _I, _F, _P],
+    'twog_reorder_fwd': [_P, _P, _P, _I, _I, _I, _I, _P],
+    'twog_reorder_bwd': [_P, _P, _P, _I, _I, _I, _I, _P],
+    'twog_logsoftmax_permute_fwd': [_P, _P, _I, _I, _I, _I, _P],
+    'twog_logsoftmax_permute_bwd': [_P, _P, _P, _I, _I, _I, _I, _P],
+    'twog_relu_bwd': [Rows, Rows, Rows, _I, _I, _P],
+    'twog_add_rows': [Rows, Rows, _I, _I, _P],
+    'twog_adam_step': [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _P],
+}
+
+_lib = None
+
+
+def load():
+    """Load lib2ggcn_hip.so and bind every entry point of include/twog_gcn.h. Raises if anything is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f'{LIB_PATH} not found: the HIP kernels are not built (run __graft_entry__.build() or '
+                           f'`make -C 2g-gcn_amd/csrc`). There is no fallback path.')
+    lib = C.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.argtypes = argtypes
+        fn.restype = C.c_int
+    lib.twog_version.restype = C.c_char_p
+    lib.twog_version.argtypes = []
+    _lib = lib
+    return lib
+
+
+def exported_symbols():
+    return ['twog_version'] + list(SIGNATURES.keys())

@@ -1,0 +1,152 @@
+// Segment-boundary gates ("state change detector").
+//
+// Reference: _update_human_segment / _update_object_segment (vhoi/models.py:1477-1533) with
+// discrete_networks_num_layers == 1: p = sigmoid(Linear([x, h_f, messages...] -> 1)); discrete_estimator (:1620-1627):
+//   'gs': y = softmax((log([p, 1-p] + 1e-20) + g) / 1)[0], g ~ Gumbel(0,1) PRE-DRAWN on the host in the reference's call
+//         order (t-major, humans then objects; pyrutils/torch/distributions.py:4-36); hard = (y > thr); the value
+//         used downstream is (hard - y).detach() + y, i.e. `hard` in the forward pass and d/dy = 1 in the backward pass;
+//   'st': hard = (p > thr), soft = p (distributions.py:39-53).
+// The hard gate of the last (padded) step is overwritten with 1 in place, which also cuts its gradient (:701-702).
+// One wave per entity row: the row's gate-input blocks are read in place from the concatenated entity buffer (the
+// weight vector is applied block-wise through seg_col[], so no torch.cat is materialised), reduced with wave shuffles.
+#include "twog_common.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void gate_fwd_kernel(const twog_gate_t G) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t rows = (int64_t)G.bs * G.T * G.E;
+    const int64_t row = (int64_t)blockIdx.x * 4 + wv;
+    if (row >= rows) return;
+    const float* x = twog_row_ptr(G.x, (int)row);
+    float acc = 0.f;
+    for (int s = 0; s < G.n_seg; ++s) {
+        const float* xs = x + G.seg_col[s];
+        const float* ws = G.w + s * G.hidden;
+        for (int j = lane; j < G.hidden; j += 64) acc = fmaf(xs[j], ws[j], acc);
+    }
+    acc = wave_sum(acc);
+    if (lane != 0) return;
+    if (G.b) acc += G.b[0];
+    const float p = 1.0f / (1.0f + expf(-acc));
+    const int e = (int)(row % G.E);
+    const int t = (int)((row / G.E) % G.T);
+    const int b = (int)(row / ((int64_t)G.E * G.T));
+    float y;
+    if (G.noise) {
+        const float* g = G.noise + (((int64_t)t * G.noise_entities + G.noise_offset + e) * G.bs + b) * 2;
+        const float a0 = logf(p + 1e-20f) + g[0];
+        const float a1 = logf((1.0f - p) + 1e-20f) + g[1];
+        const float m = fmaxf(a0, a1);
+        const float e0 = expf(a0 - m), e1 = expf(a1 - m);
+        y = e0 / (e0 + e1);
+    } else {
+        y = p;
+    }
+    float hard = y > G.threshold ? 1.f : 0.f;
+    if (G.force_last && t == G.T - 1) hard = 1.f;
+    G.hard[row] = hard;
+    G.soft[row] = y;
+    G.p_save[row] = p;
+}
+
+// total gradient reaching the soft decision -> gradient wrt the pre-sigmoid logit
+__global__ __launch_bounds__(256) void gate_bwd_kernel(const twog_gate_t G, const float* d_hard, const float* d_soft,
+                                                       const float* st_mask, float* dlogit) {
+    const int64_t rows = (int64_t)G.bs * G.T * G.E;
+    const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= rows) return;
+    const int t = (int)((row / G.E) % G.T);
+    float d = d_soft ? d_soft[row] : 0.f;
+    if (d_hard) {
+        float m = st_mask ? st_mask[row] : 1.f;
+        if (G.force_last && t == G.T - 1) m = 0.f;
+        d = fmaf(d_hard[row], m, d);
+    }
+    const float p = G.p_save[row];
+    float dp = d;
+    if (G.noise) {
+        const float y = G.soft[row];
+        dp = d * y * (1.0f - y) * (1.0f / (p + 1e-20f) + 1.0f / ((1.0f - p) + 1e-20f));
+    }
+    dlogit[row] = dp * p * (1.0f - p);
+}
+
+// dst[r][c] += s[r] * v[c]
+__global__ __launch_bounds__(256) void rank1_kernel(twog_rows_t dst, const float* s, const float* v, int rows, int cols) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < (int64_t)rows * cols;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int r = (int)(i / cols), c = (int)(i - (int64_t)r * cols);
+        float* d = twog_row_ptr(dst, r) + c;
+        *d = fmaf(s[r], v[c], *d);
+    }
+}
+
+// partial sums of s[r] * x[r][c] over row slabs (s may be NULL -> 1)
+__global__ __launch_bounds__(256) void wcolsum_partial_kernel(twog_rows_t x, const float* s, int rows, int cols,
+                                                              float* partials) {
+    __shared__ float red[4][64];
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    const int per = (rows + gridDim.y - 1) / gridDim.y;
+    const int r0 = blockIdx.y * per, r1 = min(rows, r0 + per);
+    float acc = 0.f;
+    if (c < cols)
+        for (int r = r0 + rl; r < r1; r += 4) acc = fmaf(s ? s[r] : 1.f, twog_row_ptr(x, r)[c], acc);
+    red[rl][cl] = acc;
+    __syncthreads();
+    if (rl == 0 && c < cols) partials[(int64_t)blockIdx.y * cols + c] = red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl];
+}
+
+__global__ __launch_bounds__(256) void wcolsum_final_kernel(const float* partials, int n_blocks, int cols, float* out,
+                                                            int accumulate) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= cols) return;
+    float acc = 0.f;
+    for (int b = 0; b < n_blocks; ++b) acc += partials[(int64_t)b * cols + c];
+    out[c] = accumulate ? out[c] + acc : acc;
+}
+
+}  // namespace
+
+extern "C" int twog_gate_fwd(const twog_gate_t* g, void* stream) {
+    const int64_t rows = (int64_t)g->bs * g->T * g->E;
+    if (rows <= 0) return 0;
+    if (g->n_seg > 8) return -1;
+    hipLaunchKernelGGL(gate_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, *g);
+    TWOG_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int twog_gate_bwd(const twog_gate_t* g, const float* d_hard, const float* d_soft, const float* st_mask,
+                             float* dlogit, void* stream) {
+    const int64_t rows = (int64_t)g->bs * g->T * g->E;
+    if (rows <= 0) return 0;
+    hipLaunchKernelGGL(gate_bwd_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *g,
+                       d_hard, d_soft, st_mask, dlogit);
+    TWOG_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int twog_rank1_update(twog_rows_t dst, const float* s, const float* v, int rows, int cols, void* stream) {
+    if (rows <= 0 || cols <= 0) return 0;
+    int64_t n = (int64_t)rows * cols;
+    int grid = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
+    hipLaunchKernelGGL(rank1_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, dst, s, v, rows, cols);
+    TWOG_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int twog_colsum(twog_rows_t x, const float* rowscale, int rows, int cols, float* out, int accumulate,
+                           float* partials, int n_blocks, void* stream) {
+    if (cols <= 0) return 0;
+    if (n_blocks < 1) n_blocks = 1;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(wcolsum_partial_kernel, dim3((cols + 63) / 64, n_blocks), dim3(256), 0, st, x, rowscale, rows,
+                       cols, partials);
+    TWOG_CHECK_LAUNCH();
+    hipLaunchKernelGGL(wcolsum_final_kernel, dim3((cols + 255) / 256), dim3(256), 0, st, partials, n_blocks, cols, out,
+                       accumulate);
+    TWOG_CHECK_LAUNCH();
+    return 0;
+}

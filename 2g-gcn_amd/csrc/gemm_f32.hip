@@ -1,0 +1,357 @@
+// Grouped fp32 GEMM on the gfx950 matrix cores (v_mfma_f32_32x32x2_f32: exact fp32, 256 FLOP/clk/CU).
+//
+//   C[m][n] = act( sum_k A(m,k) * B(n,k) + bias[n] ) (+ C)
+//
+// Replaces every dense projection of the hot path: build_mlp Linear layers (reference pyrutils/torch/models.py:31-36),
+// GRU / GRUCell input+hidden projections (vhoi/models.py:267-320), message MLPs (:323-520), label heads (:552-580)
+// and -- through the k-major operand forms -- their backward passes.
+//
+// Design (MI355X-first): 256-thread workgroups = 4 waves in a 2x2 grid, each wave owns (BM/2)x(BN/2) of the tile as
+// 32x32 MFMA accumulators. Operand tiles are staged global -> registers -> LDS with a 2-deep software pipeline
+// (loads for k-tile t+1 are issued before the MFMAs of tile t, written to the other LDS buffer after them; one
+// barrier per k-tile). K-contiguous operands are kept [row][BK+4] in LDS and read as one ds_read_b128 per 4 k-steps
+// (the MFMA k order is arbitrary as long as A and B agree, so lane half kh takes k = 4kh..4kh+3 of each 8-chunk;
+// the +4 pad makes the 16-lane b128 groups conflict-free); k-major operands are kept [k][rows+4] and read with
+// conflict-free ds_read_b32. Workgroup ids are remapped so that tiles sharing an A row-panel run on one XCD (its
+// L2 then serves the panel once). Tall reductions (dW = dY^T X, K = rows) use deterministic split-K: partial slabs in
+// the caller's workspace, summed in fixed order by a second kernel.
+#include "twog_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+constexpr int BK = 32;
+constexpr int MAXP = 8;
+
+struct Prob {
+    twog_rows_t A, B, C;
+    const float* bias;
+    int M, N, K;
+    int act, accumulate;
+    int tiles_m, tiles_n, tile_start;
+    int a_vec, b_vec;  // 16-byte vector loads legal for this operand
+    int batch;         // independent problems sharing shapes; operand b of batch i = ptr + i * *_bs
+    int64_t a_bs, b_bs, c_bs;
+};
+
+struct Group {
+    Prob p[MAXP];
+    int n;
+    int total_tiles;
+    int splitk;      // >= 1
+    int k_per_split; // multiple of BK
+    float* slabs;    // split-K partials: [problem-tile-major] see below
+};
+
+// tile of ROWS x COLS (COLS contiguous in memory) -> registers; out-of-range elements read as 0
+template <int ROWS, int COLS>
+struct TileRegs {
+    static constexpr int R = ROWS, C = COLS;
+    static constexpr int F4_PER_ROW = COLS / 4;
+    static constexpr int ROWS_PER_PASS = 256 / F4_PER_ROW;
+    static constexpr int PASSES = ROWS / ROWS_PER_PASS;
+    float4 v[PASSES];
+};
+
+template <int ROWS, int COLS>
+__device__ __forceinline__ void load_tile(TileRegs<ROWS, COLS>& t, const twog_rows_t& m, int r0, int c0, int rmax,
+                                          int cmax, int vec_ok) {
+    using T = TileRegs<ROWS, COLS>;
+    const int tid = threadIdx.x;
+    const int c = c0 + (tid % T::F4_PER_ROW) * 4;
+#pragma unroll
+    for (int i = 0; i < T::PASSES; ++i) {
+        const int r = r0 + tid / T::F4_PER_ROW + i * T::ROWS_PER_PASS;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r < rmax && c < cmax) {
+            const float* p = m.ptr + twog_row_off(m, r) + c;
+            if (vec_ok && c + 3 < cmax) {
+                v = *reinterpret_cast<const float4*>(p);
+            } else {
+                v.x = p[0];
+                if (c + 1 < cmax) v.y = p[1];
+                if (c + 2 < cmax) v.z = p[2];
+                if (c + 3 < cmax) v.w = p[3];
+            }
+        }
+        t.v[i] = v;
+    }
+}
+
+template <int ROWS, int COLS, int LD>
+__device__ __forceinline__ void store_tile(const TileRegs<ROWS, COLS>& t, float* s) {
+    using T = TileRegs<ROWS, COLS>;
+    const int tid = threadIdx.x;
+    const int c = (tid % T::F4_PER_ROW) * 4;
+#pragma unroll
+    for (int i = 0; i < T::PASSES; ++i) {
+        const int r = tid / T::F4_PER_ROW + i * T::ROWS_PER_PASS;
+        *reinterpret_cast<float4*>(s + r * LD + c) = t.v[i];
+    }
+}
+
+template <int BM, int BN, bool AKM, bool BKM>
+__global__ __launch_bounds__(256) void gemm_kernel(const Group g) {
+    constexpr int WM = BM / 2, WN = BN / 2;    // per-wave tile
+    constexpr int TM = WM / 32, TN = WN / 32;  // 32x32 MFMA tiles per wave
+    constexpr int LDA = AKM ? (BM + 4) : (BK + 4);
+    constexpr int LDB = BKM ? (BN + 4) : (BK + 4);
+    constexpr int A_ELEMS = AKM ? BK * LDA : BM * LDA;
+    constexpr int B_ELEMS = BKM ? BK * LDB : BN * LDB;
+    __shared__ __attribute__((aligned(16))) float smem[2 * (A_ELEMS + B_ELEMS)];
+    constexpr int STAGE = A_ELEMS + B_ELEMS;  // buffer b: A at smem + b*STAGE, B right behind it
+
+    // XCD-aware, bijective remap: consecutive logical tiles (same A row panel) land on the same XCD / L2
+    int bid = blockIdx.x;
+    {
+        const int nwg = gridDim.x, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    int pi = 0;
+#pragma unroll 1
+    for (int i = 1; i < g.n; ++i)
+        if (bid >= g.p[i].tile_start) pi = i;
+    Prob P = g.p[pi];
+    int tile = bid - P.tile_start;
+    {
+        const int per = P.tiles_m * P.tiles_n, bi = tile / per;
+        tile -= bi * per;
+        P.A.ptr += bi * P.a_bs;
+        P.B.ptr += bi * P.b_bs;
+        P.C.ptr += bi * P.c_bs;
+    }
+    const int tm_idx = tile / P.tiles_n, tn_idx = tile - tm_idx * P.tiles_n;
+    const int m0 = tm_idx * BM, n0 = tn_idx * BN;
+    const int split = blockIdx.y;
+    const int k_begin = split * g.k_per_split;
+    const int k_end = min(P.K, k_begin + g.k_per_split);
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 31, kh = lane >> 5;
+    const int wm = (wave >> 1) * WM, wn = (wave & 1) * WN;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    using ARegs = TileRegs<(AKM ? BK : BM), (AKM ? BM : BK)>;
+    using BRegs = TileRegs<(BKM ? BK : BN), (BKM ? BN : BK)>;
+    ARegs ra;
+    BRegs rb;
+
+    auto gload = [&](int k0) {
+        if constexpr (AKM) load_tile(ra, P.A, k0, m0, k_end, P.M, P.a_vec);
+        else               load_tile(ra, P.A, m0, k0, P.M, k_end, P.a_vec);
+        if constexpr (BKM) load_tile(rb, P.B, k0, n0, k_end, P.N, P.b_vec);
+        else               load_tile(rb, P.B, n0, k0, P.N, k_end, P.b_vec);
+    };
+    auto sstore = [&](int buf) {
+        store_tile<ARegs::R, ARegs::C, LDA>(ra, smem + buf * STAGE);
+        store_tile<BRegs::R, BRegs::C, LDB>(rb, smem + buf * STAGE + A_ELEMS);
+    };
+
+    const int nkt = (k_end > k_begin) ? (k_end - k_begin + BK - 1) / BK : 0;
+    if (nkt > 0) {
+        gload(k_begin);
+        sstore(0);
+    }
+    __syncthreads();
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nkt) gload(k_begin + (kt + 1) * BK);
+        const float* a_s = smem + buf * STAGE;
+        const float* b_s = a_s + A_ELEMS;
+#pragma unroll
+        for (int kk = 0; kk < BK / 8; ++kk) {
+            float af[TM][4], bf[TN][4];
+#pragma unroll
+            for (int a = 0; a < TM; ++a) {
+                if constexpr (AKM) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) af[a][r] = a_s[(kk * 8 + kh * 4 + r) * LDA + wm + a * 32 + li];
+                } else {
+                    const float4 v = *reinterpret_cast<const float4*>(a_s + (wm + a * 32 + li) * LDA + kk * 8 + kh * 4);
+                    af[a][0] = v.x; af[a][1] = v.y; af[a][2] = v.z; af[a][3] = v.w;
+                }
+            }
+#pragma unroll
+            for (int b = 0; b < TN; ++b) {
+                if constexpr (BKM) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) bf[b][r] = b_s[(kk * 8 + kh * 4 + r) * LDB + wn + b * 32 + li];
+                } else {
+                    const float4 v = *reinterpret_cast<const float4*>(b_s + (wn + b * 32 + li) * LDB + kk * 8 + kh * 4);
+                    bf[b][0] = v.x; bf[b][1] = v.y; bf[b][2] = v.z; bf[b][3] = v.w;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int a = 0; a < TM; ++a)
+#pragma unroll
+                    for (int b = 0; b < TN; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a][r], bf[b][r], acc[a][b], 0, 0, 0);
+        }
+        if (kt + 1 < nkt) sstore(buf ^ 1);
+        __syncthreads();
+    }
+
+    // epilogue. C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    if (g.splitk > 1) {
+        // raw partials: slab[split][tile][BM][BN]
+        float* slab = g.slabs + ((int64_t)split * g.total_tiles + bid) * (BM * BN);
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int b = 0; b < TN; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = wm + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                    const int col = wn + b * 32 + li;
+                    slab[row * BN + col] = acc[a][b][r];
+                }
+        return;
+    }
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = m0 + wm + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+            if (row >= P.M) continue;
+            float* crow = P.C.ptr + twog_row_off(P.C, row);
+#pragma unroll
+            for (int b = 0; b < TN; ++b) {
+                const int col = n0 + wn + b * 32 + li;
+                if (col >= P.N) continue;
+                float v = acc[a][b][r];
+                if (P.bias) v += P.bias[col];
+                if (P.accumulate) v += crow[col];
+                if (P.act == 1) v = fmaxf(v, 0.f);
+                crow[col] = v;
+            }
+        }
+}
+
+// sums split-K slabs in fixed order and applies the epilogue
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const Group g) {
+    int bid = blockIdx.x;
+    int pi = 0;
+#pragma unroll 1
+    for (int i = 1; i < g.n; ++i)
+        if (bid >= g.p[i].tile_start) pi = i;
+    Prob P = g.p[pi];
+    int tile = bid - P.tile_start;
+    {
+        const int per = P.tiles_m * P.tiles_n, bi = tile / per;
+        tile -= bi * per;
+        P.C.ptr += bi * P.c_bs;
+    }
+    const int tm_idx = tile / P.tiles_n, tn_idx = tile - tm_idx * P.tiles_n;
+    const int m0 = tm_idx * BM, n0 = tn_idx * BN;
+    for (int e = threadIdx.x; e < BM * BN; e += 256) {
+        const int row = e / BN, col = e - row * BN;
+        if (m0 + row >= P.M || n0 + col >= P.N) continue;
+        float v = 0.f;
+        for (int s = 0; s < g.splitk; ++s) v += g.slabs[((int64_t)s * g.total_tiles + bid) * (BM * BN) + e];
+        float* c = P.C.ptr + twog_row_off(P.C, m0 + row) + n0 + col;
+        if (P.bias) v += P.bias[n0 + col];
+        if (P.accumulate) v += *c;
+        if (P.act == 1) v = fmaxf(v, 0.f);
+        *c = v;
+    }
+}
+
+inline int vec_ok(const twog_rows_t& m, int64_t batch_stride) {
+    const bool aligned = (reinterpret_cast<uintptr_t>(m.ptr) % 16) == 0;
+    const bool ld_ok = (m.ld_outer % 4 == 0) && (m.inner <= 1 || m.ld_inner % 4 == 0) && (batch_stride % 4 == 0);
+    return (aligned && ld_ok) ? 1 : 0;
+}
+
+template <int BM, int BN>
+int launch(Group& g, int akm, int bkm, hipStream_t st) {
+    dim3 grid(g.total_tiles, g.splitk), block(256);
+    if (!akm && !bkm) hipLaunchKernelGGL((gemm_kernel<BM, BN, false, false>), grid, block, 0, st, g);
+    else if (!akm && bkm) hipLaunchKernelGGL((gemm_kernel<BM, BN, false, true>), grid, block, 0, st, g);
+    else if (akm && bkm) hipLaunchKernelGGL((gemm_kernel<BM, BN, true, true>), grid, block, 0, st, g);
+    else hipLaunchKernelGGL((gemm_kernel<BM, BN, true, false>), grid, block, 0, st, g);
+    TWOG_CHECK_LAUNCH();
+    if (g.splitk > 1) {
+        hipLaunchKernelGGL((splitk_reduce_kernel<BM, BN>), dim3(g.total_tiles), block, 0, st, g);
+        TWOG_CHECK_LAUNCH();
+    }
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int twog_gemm_f32(const twog_gemm_t* problems, int n_problems, int a_kmajor, int b_kmajor, void* workspace,
+                             size_t workspace_bytes, void* stream) {
+    if (n_problems <= 0) return 0;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    int done = 0;
+    while (done < n_problems) {
+        const int n = (n_problems - done) < MAXP ? (n_problems - done) : MAXP;
+        const twog_gemm_t* pr = problems + done;
+        // tile choice: 128x128 when that already fills the chip, else 64x64 (recurrent steps, small heads)
+        int64_t tiles128 = 0, tiles64 = 0;
+        int kmax = 0;
+        for (int i = 0; i < n; ++i) {
+            const int nb = pr[i].batch > 0 ? pr[i].batch : 1;
+            tiles128 += (int64_t)nb * ((pr[i].M + 127) / 128) * ((pr[i].N + 127) / 128);
+            tiles64 += (int64_t)nb * ((pr[i].M + 63) / 64) * ((pr[i].N + 63) / 64);
+            if (pr[i].K > kmax) kmax = pr[i].K;
+        }
+        const bool big = tiles128 >= 384;
+        const int BMN = big ? 128 : 64;
+        Group g;
+        g.n = n;
+        int t = 0;
+        for (int i = 0; i < n; ++i) {
+            Prob& P = g.p[i];
+            P.A = pr[i].A; P.B = pr[i].B; P.C = pr[i].C; P.bias = pr[i].bias;
+            P.M = pr[i].M; P.N = pr[i].N; P.K = pr[i].K;
+            P.act = pr[i].act; P.accumulate = pr[i].accumulate;
+            P.tiles_m = (P.M + BMN - 1) / BMN;
+            P.tiles_n = (P.N + BMN - 1) / BMN;
+            P.tile_start = t;
+            P.batch = pr[i].batch > 0 ? pr[i].batch : 1;
+            P.a_bs = pr[i].a_batch_stride; P.b_bs = pr[i].b_batch_stride; P.c_bs = pr[i].c_batch_stride;
+            t += P.batch * P.tiles_m * P.tiles_n;
+            P.a_vec = vec_ok(P.A, pr[i].a_batch_stride);
+            P.b_vec = vec_ok(P.B, pr[i].b_batch_stride);
+        }
+        g.total_tiles = t;
+        g.splitk = 1;
+        g.k_per_split = ((kmax + BK - 1) / BK) * BK;
+        g.slabs = nullptr;
+        // deterministic split-K when the grid would leave most CUs idle and the reduction is long
+        if (t < 256 && kmax >= 2048 && workspace) {
+            int want = (512 + t - 1) / t;
+            const int max_by_k = kmax / 512;
+            if (want > max_by_k) want = max_by_k;
+            if (want > 64) want = 64;
+            const size_t need = (size_t)want * t * BMN * BMN * sizeof(float);
+            if (want > 1 && need <= workspace_bytes) {
+                g.splitk = want;
+                int kps = (kmax + want - 1) / want;
+                g.k_per_split = ((kps + BK - 1) / BK) * BK;
+                g.splitk = (kmax + g.k_per_split - 1) / g.k_per_split;
+                g.slabs = reinterpret_cast<float*>(workspace);
+            }
+        }
+        const int rc = big ? launch<128, 128>(g, a_kmajor, b_kmajor, st) : launch<64, 64>(g, a_kmajor, b_kmajor, st);
+        if (rc) return rc;
+        done += n;
+    }
+    return 0;
+}
+
+extern "C" const char* twog_version(void) {
+    return "lib2ggcn_hip gfx950 fp32-MFMA(32x32x2) gemm tiles 128x128x32/64x64x32";
+}

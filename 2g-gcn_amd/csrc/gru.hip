@@ -1,0 +1,268 @@
+// GRU gate math + the frame-level bidirectional GRU recurrence.
+//
+// Reference: torch.nn.GRU (bidirectional, 1 layer) applied per entity slice in a Python loop
+// (vhoi/models.py:983-1002, modules :267-269, :274-276, :299-301) and the gated GRUCell step of the segment level,
+// h_t = u * GRUCell(x_t, h_{t-1}) + (1 - u) * h_{t-1} (vhoi/models.py:1535-1564). Gate order r, z, n.
+//
+// MI355X design: the input projection W_ih x + b_ih of ALL time steps is one large MFMA GEMM done by the caller; only
+// the truly sequential part runs here: per step one grouped MFMA GEMM gh = h_{t-1} W_hh^T + b_hh for every
+// (entity type, direction) at once -- all entities of a type are batched as rows, both directions advance in the same
+// launch -- followed by one fused gate kernel (one workgroup per row, lane-contiguous along the hidden dimension).
+// r, z, n and W_hn h are saved for the backward pass, which walks the chain in reverse with the transposed GEMM.
+#include "twog_common.h"
+
+namespace {
+
+constexpr int MAXS = 8;
+struct FwdGroup { twog_gru_step_t s[MAXS]; };
+struct BwdGroup { twog_gru_step_bwd_t s[MAXS]; };
+
+__device__ __forceinline__ float gate_u(const float* u, int64_t ldo, int64_t ldi, int inner, int r) {
+    if (!u) return 1.0f;
+    if (inner <= 1) return u[(int64_t)r * ldo];
+    const int o = r / inner;
+    return u[(int64_t)o * ldo + (int64_t)(r - o * inner) * ldi];
+}
+
+__global__ __launch_bounds__(256) void gru_step_fwd_kernel(const FwdGroup g) {
+    const twog_gru_step_t& S = g.s[blockIdx.y];
+    const int r = blockIdx.x;
+    if (r >= S.rows) return;
+    const int H = S.hidden;
+    const float* gi = twog_row_ptr(S.gi, r);
+    const float* gi2 = S.gi2.ptr ? twog_row_ptr(S.gi2, r) : nullptr;
+    const float* gh = twog_row_ptr(S.gh, r);
+    const float* hp = S.h_prev.ptr ? twog_row_ptr(S.h_prev, r) : nullptr;
+    float* ho = twog_row_ptr(S.h_out, r);
+    float* sv = S.save.ptr ? twog_row_ptr(S.save, r) : nullptr;
+    const float uu = gate_u(S.u, S.u_ld_outer, S.u_ld_inner, S.u_inner, r);
+    for (int j = threadIdx.x; j < H; j += blockDim.x) {
+        float ir = gi[j], iz = gi[H + j], in_ = gi[2 * H + j];
+        if (gi2) {
+            ir += gi2[j];
+            iz += gi2[H + j];
+            in_ += gi2[2 * H + j];
+        }
+        const float hr = gh[j], hz = gh[H + j], hn = gh[2 * H + j];
+        const float rg = 1.0f / (1.0f + expf(-(ir + hr)));
+        const float z = 1.0f / (1.0f + expf(-(iz + hz)));
+        const float n = tanhf(in_ + rg * hn);
+        const float h0 = hp ? hp[j] : 0.f;
+        const float gnew = (1.0f - z) * n + z * h0;
+        ho[j] = S.u ? uu * gnew + (1.0f - uu) * h0 : gnew;
+        if (sv) {
+            sv[j] = rg;
+            sv[H + j] = z;
+            sv[2 * H + j] = n;
+            sv[3 * H + j] = hn;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void gru_step_bwd_kernel(const BwdGroup g) {
+    __shared__ float red[16];
+    const twog_gru_step_bwd_t& S = g.s[blockIdx.y];
+    const int r = blockIdx.x;
+    if (r >= S.rows) return;
+    const int H = S.hidden;
+    const float* dh = twog_row_ptr(S.dh, r);
+    const float* dh2 = S.dh2.ptr ? twog_row_ptr(S.dh2, r) : nullptr;
+    const float* sv = twog_row_ptr(S.save, r);
+    const float* hp = S.h_prev.ptr ? twog_row_ptr(S.h_prev, r) : nullptr;
+    float* dgi = twog_row_ptr(S.dgi, r);
+    float* dgh = twog_row_ptr(S.dgh, r);
+    float* dhp = twog_row_ptr(S.dh_prev, r);
+    const float uu = gate_u(S.u, S.u_ld_outer, S.u_ld_inner, S.u_inner, r);
+    float du = 0.f;
+    for (int j = threadIdx.x; j < H; j += blockDim.x) {
+        float d = dh[j];
+        if (dh2) d += dh2[j];
+        const float rg = sv[j], z = sv[H + j], n = sv[2 * H + j], hn = sv[3 * H + j];
+        const float h0 = hp ? hp[j] : 0.f;
+        const float gnew = (1.0f - z) * n + z * h0;
+        du += d * (gnew - h0);
+        const float dg = S.u ? uu * d : d;
+        float dprev = S.u ? (1.0f - uu) * d : 0.f;
+        const float dn = dg * (1.0f - z);
+        const float dz = dg * (h0 - n);
+        dprev += dg * z;
+        const float dn_pre = dn * (1.0f - n * n);
+        const float dr_pre = dn_pre * hn * rg * (1.0f - rg);
+        const float dz_pre = dz * z * (1.0f - z);
+        dgi[j] = dr_pre;
+        dgi[H + j] = dz_pre;
+        dgi[2 * H + j] = dn_pre;
+        dgh[j] = dr_pre;
+        dgh[H + j] = dz_pre;
+        dgh[2 * H + j] = dn_pre * rg;
+        dhp[j] = S.dh_prev_accumulate ? dhp[j] + dprev : dprev;
+    }
+    if (S.du) {  // uniform per block
+        const float t = block_sum(du, red);
+        if (threadIdx.x == 0) {
+            int64_t off;
+            if (S.u_inner <= 1) off = (int64_t)r * S.u_ld_outer;
+            else { const int o = r / S.u_inner; off = (int64_t)o * S.u_ld_outer + (int64_t)(r - o * S.u_inner) * S.u_ld_inner; }
+            atomicAdd(&S.du[off], t);
+        }
+    }
+}
+
+inline twog_rows_t rows_be(const float* cbase, int E, int64_t row_w, int T) {
+    float* base = const_cast<float*>(cbase);
+    // rows (b, e) of a [bs][T][E][row_w] tensor at a fixed t (base already offset to t and column)
+    twog_rows_t r;
+    r.ptr = base;
+    r.inner = E;
+    r.ld_inner = row_w;
+    r.ld_outer = (int64_t)T * E * row_w;
+    r.pad_ = 0;
+    return r;
+}
+inline twog_rows_t rows_plain(const float* cbase, int64_t ld) {
+    float* base = const_cast<float*>(cbase);
+    twog_rows_t r;
+    r.ptr = base; r.inner = 1; r.ld_inner = ld; r.ld_outer = ld; r.pad_ = 0;
+    return r;
+}
+
+}  // namespace
+
+extern "C" int twog_gru_step_fwd(const twog_gru_step_t* steps, int n_steps, void* stream) {
+    int done = 0;
+    while (done < n_steps) {
+        const int n = (n_steps - done) < MAXS ? (n_steps - done) : MAXS;
+        FwdGroup g;
+        int maxrows = 0, maxh = 0;
+        for (int i = 0; i < n; ++i) {
+            g.s[i] = steps[done + i];
+            if (g.s[i].rows > maxrows) maxrows = g.s[i].rows;
+            if (g.s[i].hidden > maxh) maxh = g.s[i].hidden;
+        }
+        if (maxrows > 0) {
+            int bt = maxh >= 256 ? 256 : ((maxh + 63) / 64) * 64;
+            hipLaunchKernelGGL(gru_step_fwd_kernel, dim3(maxrows, n), dim3(bt), 0, (hipStream_t)stream, g);
+            TWOG_CHECK_LAUNCH();
+        }
+        done += n;
+    }
+    return 0;
+}
+
+extern "C" int twog_gru_step_bwd(const twog_gru_step_bwd_t* steps, int n_steps, void* stream) {
+    int done = 0;
+    while (done < n_steps) {
+        const int n = (n_steps - done) < MAXS ? (n_steps - done) : MAXS;
+        BwdGroup g;
+        int maxrows = 0, maxh = 0;
+        for (int i = 0; i < n; ++i) {
+            g.s[i] = steps[done + i];
+            if (g.s[i].rows > maxrows) maxrows = g.s[i].rows;
+            if (g.s[i].hidden > maxh) maxh = g.s[i].hidden;
+        }
+        if (maxrows > 0) {
+            int bt = maxh >= 256 ? 256 : ((maxh + 63) / 64) * 64;
+            hipLaunchKernelGGL(gru_step_bwd_kernel, dim3(maxrows, n), dim3(bt), 0, (hipStream_t)stream, g);
+            TWOG_CHECK_LAUNCH();
+        }
+        done += n;
+    }
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Frame-level BiGRU recurrence for up to 4 entity types at once (humans, objects, geometry).
+// ---------------------------------------------------------------------------------------------------------------
+extern "C" int twog_bigru_fwd(const twog_bigru_t* types, int n_types, int bs, int T, int hidden, void* stream) {
+    if (n_types > 4) return -1;
+    const int h = hidden;
+    for (int s = 0; s < T; ++s) {
+        twog_gemm_t gm[8];
+        twog_gru_step_t st[8];
+        int n = 0;
+        for (int k = 0; k < n_types; ++k) {
+            const twog_bigru_t& Y = types[k];
+            const int E = Y.E, rows = bs * E;
+            for (int dir = 0; dir < 2; ++dir) {
+                const int t = dir == 0 ? s : T - 1 - s;
+                const int tp = dir == 0 ? t - 1 : t + 1;
+                float* tmp = Y.tmp_gh + (int64_t)dir * rows * 3 * h;
+                twog_rows_t hprev = s == 0 ? rows_plain(Y.zeros, h)
+                                           : rows_be(Y.out + (int64_t)tp * E * 2 * h + dir * h, E, 2 * h, T);
+                twog_gemm_t& G = gm[n];
+                G.A = hprev;
+                G.B = rows_plain((dir == 0 ? Y.w_hh_f : Y.w_hh_r), h);
+                G.C = rows_plain(tmp, 3 * h);
+                G.bias = dir == 0 ? Y.b_hh_f : Y.b_hh_r;
+                G.M = rows; G.N = 3 * h; G.K = h; G.act = 0; G.accumulate = 0; G.batch = 1;
+                G.a_batch_stride = G.b_batch_stride = G.c_batch_stride = 0;
+                twog_gru_step_t& S = st[n];
+                S.gi = rows_be(Y.gi + (int64_t)t * E * 6 * h + dir * 3 * h, E, 6 * h, T);
+                S.gi2.ptr = nullptr; S.gi2.inner = 1; S.gi2.ld_inner = S.gi2.ld_outer = 0;
+                S.gh = rows_plain(tmp, 3 * h);
+                S.h_prev = hprev;
+                if (s == 0) S.h_prev.ptr = nullptr;
+                S.h_out = rows_be(Y.out + (int64_t)t * E * 2 * h + dir * h, E, 2 * h, T);
+                S.save = rows_be(Y.save + ((int64_t)dir * bs * T * E + (int64_t)t * E) * 4 * h, E, 4 * h, T);
+                S.u = nullptr; S.u_ld_outer = S.u_ld_inner = 0; S.u_inner = 1;
+                S.rows = rows; S.hidden = h;
+                ++n;
+            }
+        }
+        int rc = twog_gemm_f32(gm, n, 0, 0, nullptr, 0, stream);
+        if (rc) return rc;
+        rc = twog_gru_step_fwd(st, n, stream);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+// Backward through time. d_out: gradient wrt `out` [bs][T][E][2h]; writes d_gi [bs][T][E][6h] and
+// d_gh [bs][T][E][6h] (the caller turns them into dX / dW_ih / dW_hh / biases with large GEMMs).
+extern "C" int twog_bigru_bwd(const twog_bigru_bwd_t* types, int n_types, int bs, int T, int hidden, void* stream) {
+    if (n_types > 4) return -1;
+    const int h = hidden;
+    for (int s = T - 1; s >= 0; --s) {
+        twog_gemm_t gm[8];
+        twog_gru_step_bwd_t st[8];
+        int n = 0;
+        for (int k = 0; k < n_types; ++k) {
+            const twog_bigru_bwd_t& Y = types[k];
+            const int E = Y.E, rows = bs * E;
+            for (int dir = 0; dir < 2; ++dir) {
+                const int t = dir == 0 ? s : T - 1 - s;
+                const int tp = dir == 0 ? t - 1 : t + 1;
+                float* carry = Y.carry + (int64_t)dir * rows * h;
+                twog_gru_step_bwd_t& S = st[n];
+                S.dh = rows_be(Y.d_out + (int64_t)t * E * 2 * h + dir * h, E, 2 * h, T);
+                if (s == T - 1) { S.dh2.ptr = nullptr; S.dh2.inner = 1; S.dh2.ld_inner = S.dh2.ld_outer = 0; }
+                else S.dh2 = rows_plain(carry, h);
+                S.save = rows_be(Y.save + ((int64_t)dir * bs * T * E + (int64_t)t * E) * 4 * h, E,
+                                 4 * h, T);
+                if (s == 0) { S.h_prev.ptr = nullptr; S.h_prev.inner = 1; S.h_prev.ld_inner = S.h_prev.ld_outer = 0; }
+                else S.h_prev = rows_be(Y.out + (int64_t)tp * E * 2 * h + dir * h, E, 2 * h, T);
+                S.dgi = rows_be(Y.d_gi + (int64_t)t * E * 6 * h + dir * 3 * h, E, 6 * h, T);
+                S.dgh = rows_be(Y.d_gh + (int64_t)t * E * 6 * h + dir * 3 * h, E, 6 * h, T);
+                S.dh_prev = rows_plain(carry, h);
+                S.u = nullptr; S.du = nullptr; S.u_ld_outer = S.u_ld_inner = 0; S.u_inner = 1;
+                S.rows = rows; S.hidden = h; S.dh_prev_accumulate = 0;
+                // carried gradient: carry += d_gh W_hh   (reduction over the 3h gate rows of W_hh: k-major B)
+                twog_gemm_t& G = gm[n];
+                G.A = S.dgh;
+                G.B = rows_plain((dir == 0 ? Y.w_hh_f : Y.w_hh_r), h);
+                G.C = rows_plain(carry, h);
+                G.bias = nullptr;
+                G.M = rows; G.N = h; G.K = 3 * h; G.act = 0; G.accumulate = 1; G.batch = 1;
+                G.a_batch_stride = G.b_batch_stride = G.c_batch_stride = 0;
+                ++n;
+            }
+        }
+        int rc = twog_gru_step_bwd(st, n, stream);
+        if (rc) return rc;
+        if (s > 0) {
+            rc = twog_gemm_f32(gm, n, 0, 1, nullptr, 0, stream);
+            if (rc) return rc;
+        }
+    }
+    return 0;
+}

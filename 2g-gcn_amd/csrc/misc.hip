@@ -1,0 +1,233 @@
+// Small HBM-bound kernels of the 2G-GCN hot path: ReLU backward, row add, column sums (bias gradients), label-head
+// log-softmax + permuted store, reorder_hidden_states, filter_soft_decisions, fused Adam.
+// All are one-pass streaming kernels with lane-contiguous (coalesced) access along the feature dimension.
+#include "twog_common.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void relu_bwd_kernel(twog_rows_t dy, twog_rows_t y, twog_rows_t dx, int rows,
+                                                       int cols) {
+    const int c4 = cols >> 2;  // host guarantees cols % 4 == 0 and 16B alignment when vec != 0
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < (int64_t)rows * c4;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int r = (int)(i / c4), c = (int)(i - (int64_t)r * c4) * 4;
+        const float4 g = *reinterpret_cast<const float4*>(twog_row_ptr(dy, r) + c);
+        const float4 v = *reinterpret_cast<const float4*>(twog_row_ptr(y, r) + c);
+        float4 o;
+        o.x = v.x > 0.f ? g.x : 0.f;
+        o.y = v.y > 0.f ? g.y : 0.f;
+        o.z = v.z > 0.f ? g.z : 0.f;
+        o.w = v.w > 0.f ? g.w : 0.f;
+        *reinterpret_cast<float4*>(twog_row_ptr(dx, r) + c) = o;
+    }
+}
+
+__global__ __launch_bounds__(256) void relu_bwd_scalar_kernel(twog_rows_t dy, twog_rows_t y, twog_rows_t dx, int rows,
+                                                              int cols) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < (int64_t)rows * cols;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int r = (int)(i / cols), c = (int)(i - (int64_t)r * cols);
+        twog_row_ptr(dx, r)[c] = twog_row_ptr(y, r)[c] > 0.f ? twog_row_ptr(dy, r)[c] : 0.f;
+    }
+}
+
+__global__ __launch_bounds__(256) void add_rows_kernel(twog_rows_t src, twog_rows_t dst, int rows, int cols) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < (int64_t)rows * cols;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int r = (int)(i / cols), c = (int)(i - (int64_t)r * cols);
+        twog_row_ptr(dst, r)[c] += twog_row_ptr(src, r)[c];
+    }
+}
+
+// logits [(b,t,e)][C] -> out [b][C][t][e] = log_softmax over C        (vhoi/models.py:909-917)
+__global__ __launch_bounds__(256) void lsm_permute_fwd_kernel(const float* logits, float* out, int bs, int T, int E,
+                                                              int C) {
+    const int64_t row = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    const int64_t n_rows = (int64_t)bs * T * E;
+    if (row >= n_rows) return;
+    const float* l = logits + row * C;
+    float m = -INFINITY;
+    for (int c = 0; c < C; ++c) m = fmaxf(m, l[c]);
+    float s = 0.f;
+    for (int c = 0; c < C; ++c) s += expf(l[c] - m);
+    const float lse = m + logf(s);
+    const int64_t b = row / ((int64_t)T * E), te = row - b * (int64_t)T * E;
+    float* o = out + b * (int64_t)C * T * E + te;
+    for (int c = 0; c < C; ++c) o[(int64_t)c * T * E] = l[c] - lse;
+}
+
+// dlogits[row][c] = dout[b][c][t][e] - exp(out[b][c][t][e]) * sum_c' dout[b][c'][t][e]
+__global__ __launch_bounds__(256) void lsm_permute_bwd_kernel(const float* out, const float* dout, float* dlogits,
+                                                              int bs, int T, int E, int C) {
+    const int64_t row = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    const int64_t n_rows = (int64_t)bs * T * E;
+    if (row >= n_rows) return;
+    const int64_t b = row / ((int64_t)T * E), te = row - b * (int64_t)T * E;
+    const int64_t base = b * (int64_t)C * T * E + te, cs = (int64_t)T * E;
+    float s = 0.f;
+    for (int c = 0; c < C; ++c) s += dout[base + c * cs];
+    float* d = dlogits + row * C;
+    for (int c = 0; c < C; ++c) d[c] = dout[base + c * cs] - expf(out[base + c * cs]) * s;
+}
+
+// reorder_hidden_states (vhoi/models.py:1567-1586): one block per (clip, entity); idx[t] = first end frame >= t
+__global__ __launch_bounds__(256) void reorder_kernel(const float* src, const float* gate, float* dst, int T, int E,
+                                                      int cols, int backward) {
+    extern __shared__ int idx[];
+    const int b = blockIdx.x / E, e = blockIdx.x - b * E;
+    if (threadIdx.x == 0) {
+        int nxt = -1;
+        for (int t = T - 1; t >= 0; --t) {
+            if (gate[((int64_t)b * T + t) * E + e] != 0.f) nxt = t;
+            idx[t] = nxt >= 0 ? nxt : t;
+        }
+    }
+    __syncthreads();
+    const int64_t rs = (int64_t)E * cols;  // stride between frames of this (b, e)
+    const float* s = src + ((int64_t)b * T * E + e) * cols;
+    float* d = dst + ((int64_t)b * T * E + e) * cols;
+    if (!backward) {
+        for (int i = threadIdx.x; i < T * cols; i += blockDim.x) {
+            const int t = i / cols, c = i - t * cols;
+            d[t * rs + c] = s[idx[t] * rs + c];
+        }
+    } else {
+        // dhx[s] = sum of dout[t] over the frames t mapped to s (a contiguous run ending at s)
+        for (int c = threadIdx.x; c < cols; c += blockDim.x) {
+            float acc = 0.f;
+            for (int t = 0; t < T; ++t) {
+                acc += s[t * rs + c];
+                if (idx[t] == t) {
+                    d[t * rs + c] = acc;
+                    acc = 0.f;
+                } else {
+                    d[t * rs + c] = 0.f;
+                }
+            }
+        }
+    }
+}
+
+// filter_soft_decisions (vhoi/models.py:1637-1664). soft/hard/grad_mask: [bs][T][E]
+__global__ __launch_bounds__(256) void filter_kernel(const float* soft, float* hard, float* gmask, int bs, int T, int E,
+                                                     float thr) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= (int64_t)bs * T * E) return;
+    const int e = (int)(i % E);
+    const int t = (int)((i / E) % T);
+    (void)e;
+    const float u = soft[i];
+    const float um1 = t > 0 ? soft[i - E] : 0.f;
+    const float up1 = t + 1 < T ? soft[i + E] : 0.f;
+    const bool cond = (u > um1) && (u > up1) && (u >= thr);
+    // value: cond ? 1 : 0.   gradient wrt soft (straight-through + clamp(max=0) semantics): cond or u < thr -> 1
+    hard[i] = cond ? 1.f : 0.f;
+    gmask[i] = (cond || !(u >= thr)) ? 1.f : 0.f;
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(float* p, const float* g, float* m, float* v, int64_t n, float lr,
+                                                   float b1, float b2, float eps, float wd, float bc1, float bc2s) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float gi = g[i];
+        if (wd != 0.f) gi += wd * p[i];
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        p[i] -= (lr / bc1) * mi / (sqrtf(vi) / bc2s + eps);
+    }
+}
+
+inline int grid_for(int64_t n, int block = 256, int cap = 4096) {
+    int64_t g = (n + block - 1) / block;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+inline bool rows_vec_ok(const twog_rows_t& m) {
+    return (reinterpret_cast<uintptr_t>(m.ptr) % 16 == 0) && (m.ld_outer % 4 == 0) &&
+           (m.inner <= 1 || m.ld_inner % 4 == 0);
+}
+
+}  // namespace
+
+extern "C" int twog_relu_bwd(twog_rows_t dy, twog_rows_t y, twog_rows_t dx, int rows, int cols, void* stream) {
+    if (rows <= 0 || cols <= 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    if (cols % 4 == 0 && rows_vec_ok(dy) && rows_vec_ok(y) && rows_vec_ok(dx))
+        hipLaunchKernelGGL(relu_bwd_kernel, dim3(grid_for((int64_t)rows * cols / 4)), dim3(256), 0, st, dy, y, dx, rows,
+                           cols);
+    else
+        hipLaunchKernelGGL(relu_bwd_scalar_kernel, dim3(grid_for((int64_t)rows * cols)), dim3(256), 0, st, dy, y, dx,
+                           rows, cols);
+    TWOG_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int twog_add_rows(twog_rows_t src, twog_rows_t dst, int rows, int cols, void* stream) {
+    if (rows <= 0 || cols <= 0) return 0;
+    hipLaunchKernelGGL(add_rows_kernel, dim3(grid_for((int64_t)rows * cols)), dim3(256), 0, (hipStream_t)stream, src,
+                       dst, rows, cols);
+    TWOG_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int twog_logsoftmax_permute_fwd(const float* logits, float* out, int bs, int T, int E, int C,
+                                           void* stream) {
+    const int64_t n = (int64_t)bs * T * E;
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(lsm_permute_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       logits, out, bs, T, E, C);
+    TWOG_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int twog_logsoftmax_permute_bwd(const float* out, const float* dout, float* dlogits, int bs, int T, int E,
+                                           int C, void* stream) {
+    const int64_t n = (int64_t)bs * T * E;
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(lsm_permute_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       out, dout, dlogits, bs, T, E, C);
+    TWOG_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int twog_reorder_fwd(const float* hx, const float* gate, float* out, int bs, int T, int E, int cols,
+                                void* stream) {
+    if (bs * E <= 0) return 0;
+    hipLaunchKernelGGL(reorder_kernel, dim3(bs * E), dim3(256), T * sizeof(int), (hipStream_t)stream, hx, gate, out, T,
+                       E, cols, 0);
+    TWOG_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int twog_reorder_bwd(const float* dout, const float* gate, float* dhx, int bs, int T, int E, int cols,
+                                void* stream) {
+    if (bs * E <= 0) return 0;
+    hipLaunchKernelGGL(reorder_kernel, dim3(bs * E), dim3(256), T * sizeof(int), (hipStream_t)stream, dout, gate, dhx,
+                       T, E, cols, 1);
+    TWOG_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int twog_filter_fwd(const float* soft, float* hard, float* grad_mask, int bs, int T, int E, float threshold,
+                               void* stream) {
+    const int64_t n = (int64_t)bs * T * E;
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(filter_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, soft, hard,
+                       grad_mask, bs, T, E, threshold);
+    TWOG_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int twog_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
+                              float beta1, float beta2, float eps, float weight_decay, int step, void* stream) {
+    if (n <= 0) return 0;
+    const float bc1 = 1.f - powf(beta1, (float)step);
+    const float bc2s = sqrtf(1.f - powf(beta2, (float)step));
+    hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n, 256, 2048)), dim3(256), 0, (hipStream_t)stream, param, grad,
+                       exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2s);
+    TWOG_CHECK_LAUNCH();
+    return 0;
+}

@@ -1,0 +1,46 @@
+// Shared device helpers for the gfx950 kernels of the 2G-GCN hot path.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/twog_gcn.h"
+
+#define TWOG_WAVE 64
+
+#define TWOG_CHECK_LAUNCH()                         \
+    do {                                            \
+        hipError_t e_ = hipGetLastError();          \
+        if (e_ != hipSuccess) return -(int)e_;      \
+    } while (0)
+
+// address of row r in a twog_rows_t (see include/twog_gcn.h)
+__device__ __forceinline__ int64_t twog_row_off(const twog_rows_t& m, int r) {
+    if (m.inner <= 1) return (int64_t)r * m.ld_outer;
+    const int o = r / m.inner;
+    return (int64_t)o * m.ld_outer + (int64_t)(r - o * m.inner) * m.ld_inner;
+}
+__device__ __forceinline__ float* twog_row_ptr(const twog_rows_t& m, int r) { return m.ptr + twog_row_off(m, r); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// block-wide sum for blockDim.x a multiple of 64, <= 1024; `red` is >= 16 floats of LDS. All threads get the result.
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[w] = v;
+    __syncthreads();
+    float t = 0.f;
+    for (int i = 0; i < nw; ++i) t += red[i];
+    return t;
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }

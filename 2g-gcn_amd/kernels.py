@@ -1,0 +1,456 @@
+"""Tensor-level interface to the gfx950 kernels (lib2ggcn_hip.so).
+
+Every method takes torch CUDA fp32 tensors (or strided views of them), turns them into raw device pointers + strides
+and calls ONE C-ABI entry point of include/twog_gcn.h on torch's current HIP stream. torch is used only to own device
+memory and streams; no torch math runs here. There is no CPU / eager fallback: on a box without the built library
+``HipKernels()`` raises.
+
+Row-strided views: a matrix operand may be a 2-D view (rows, cols) or a 3-D view (outer, inner, cols) with unit
+stride on cols -- it maps onto twog_rows_t without a copy.
+"""
+import ctypes as C
+import math
+
+import torch
+
+from . import _lib as L
+
+
+def _ptr(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def rows_of(t):
+    """twog_rows_t of a 2-D (rows, cols) or 3-D (outer, inner, cols) fp32 view with unit column stride."""
+    r = L.Rows()
+    if t is None:
+        r.ptr, r.ld_outer, r.ld_inner, r.inner = 0, 0, 0, 1
+        return r
+    assert t.dtype == torch.float32, t.dtype
+    assert t.dim() in (2, 3), t.shape
+    assert t.shape[-1] == 1 or t.stride(-1) == 1, (t.shape, t.stride())
+    r.ptr = t.data_ptr()
+    if t.dim() == 2:
+        r.inner, r.ld_outer, r.ld_inner = 1, t.stride(0), t.stride(0)
+    else:
+        r.inner, r.ld_outer, r.ld_inner = t.shape[1], t.stride(0), t.stride(1)
+        if t.shape[1] == 1:
+            r.inner, r.ld_inner = 1, t.stride(0)
+    return r
+
+
+def n_rows(t):
+    return t.shape[0] if t.dim() == 2 else t.shape[0] * t.shape[1]
+
+
+class HipKernels:
+    """The product backend. `tests/fake_kernels.py` implements the same methods in plain torch for CPU-side tests of
+    the host logic; it is never reachable from this package."""
+
+    name = 'hip'
+
+    def __init__(self):
+        self.lib = L.load()
+        self._ws = {}
+
+    # ---------------------------------------------------------------- utilities
+    @staticmethod
+    def _stream():
+        return torch.cuda.current_stream().cuda_stream
+
+    @staticmethod
+    def _check(rc, what):
+        if rc != 0:
+            raise RuntimeError(f'{what} failed with code {rc}')
+
+    def empty(self, *shape, like=None, dtype=torch.float32):
+        return torch.empty(*shape, dtype=dtype, device=like.device)
+
+    def zeros(self, *shape, like=None, dtype=torch.float32):
+        return torch.zeros(*shape, dtype=dtype, device=like.device)
+
+    def workspace(self, nbytes, device, key='ws'):
+        """A persistent scratch buffer per (device, key); grown on demand, contents undefined between calls."""
+        k = (str(device), key)
+        buf = self._ws.get(k)
+        if buf is None or buf.numel() * 4 < nbytes:
+            buf = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=device)
+            self._ws[k] = buf
+        return buf
+
+    def version(self):
+        return self.lib.twog_version().decode()
+
+    # ---------------------------------------------------------------- GEMM
+    def gemm(self, problems, a_kmajor=False, b_kmajor=False, split_k_workspace=True):
+        """problems: list of dicts with keys A, B, C (row-strided views), bias (1-D or None), act (0/1), accumulate.
+        Logical shapes: A (M,K) [or stored (K,M) if a_kmajor], B (N,K) [or (K,N) if b_kmajor], C (M,N).
+        Optional 'batch': (n, a_stride, b_stride, c_stride) in elements."""
+        n = len(problems)
+        if n == 0:
+            return
+        arr = (L.Gemm * n)()
+        dev = problems[0]['C'].device
+        for i, p in enumerate(problems):
+            A, B, Cm = p['A'], p['B'], p['C']
+            g = arr[i]
+            g.A, g.B, g.C = rows_of(A), rows_of(B), rows_of(Cm)
+            if a_kmajor:
+                K, M = n_rows(A), A.shape[-1]
+            else:
+                M, K = n_rows(A), A.shape[-1]
+            if b_kmajor:
+                Kb, N = n_rows(B), B.shape[-1]
+            else:
+                N, Kb = n_rows(B), B.shape[-1]
+            assert K == Kb, (A.shape, B.shape, a_kmajor, b_kmajor)
+            assert n_rows(Cm) == M and Cm.shape[-1] == N, (Cm.shape, M, N)
+            bias = p.get('bias')
+            if bias is not None:
+                assert bias.numel() == N and bias.is_contiguous()
+            g.bias = _ptr(bias)
+            g.M, g.N, g.K = M, N, K
+            g.act = int(p.get('act', 0))
+            g.accumulate = int(bool(p.get('accumulate', False)))
+            b = p.get('batch')
+            if b is None:
+                g.batch, g.a_batch_stride, g.b_batch_stride, g.c_batch_stride = 1, 0, 0, 0
+            else:
+                g.batch, g.a_batch_stride, g.b_batch_stride, g.c_batch_stride = b
+        ws_ptr, ws_bytes = 0, 0
+        if split_k_workspace:
+            ws = self.workspace(64 << 20, dev, 'splitk')
+            ws_ptr, ws_bytes = ws.data_ptr(), ws.numel() * 4
+        rc = self.lib.twog_gemm_f32(arr, n, int(a_kmajor), int(b_kmajor), ws_ptr, ws_bytes, self._stream())
+        self._check(rc, 'twog_gemm_f32')
+
+    # ---------------------------------------------------------------- geometric-level GCN
+    @staticmethod
+    def _geo(x_human):
+        """x_human (bs, T, H, 2048+4N) contiguous -> (pointer to geometry of human 0 of frame 0, frame stride, frames)."""
+        assert x_human.is_contiguous() and x_human.dtype == torch.float32
+        bs, T, H, Fh = x_human.shape
+        return x_human.data_ptr() + 2048 * 4, H * Fh, bs * T
+
+    def bn_fold(self, x_human, n_nodes, gamma, beta, running_mean, running_var, num_batches_tracked, training):
+        ptr, fstride, nf = self._geo(x_human)
+        nch = 4 * n_nodes
+        ab = torch.empty(2, nch, dtype=torch.float32, device=x_human.device)
+        mi = torch.empty(2, nch, dtype=torch.float32, device=x_human.device)
+        nblk = 64
+        partials = torch.empty(nblk * 2 * nch, dtype=torch.float64, device=x_human.device)
+        if training:
+            self._check(self.lib.twog_bn_stats(ptr, fstride, nf, n_nodes, partials.data_ptr(), nblk, self._stream()),
+                        'twog_bn_stats')
+        self._check(self.lib.twog_bn_finalize(partials.data_ptr(), nblk, nf, n_nodes, gamma.data_ptr(),
+                                              beta.data_ptr(), running_mean.data_ptr(), running_var.data_ptr(),
+                                              _ptr(num_batches_tracked), int(training), ab.data_ptr(), mi.data_ptr(),
+                                              self._stream()), 'twog_bn_finalize')
+        return ab, mi
+
+    def gcn_embed1_fwd(self, x_human, n_nodes, ab, w1, b1):
+        ptr, fstride, nf = self._geo(x_human)
+        e1 = torch.empty(nf * n_nodes, 64, dtype=torch.float32, device=x_human.device)
+        self._check(self.lib.twog_gcn_embed1_fwd(ptr, fstride, nf, n_nodes, ab.data_ptr(), w1.data_ptr(),
+                                                 b1.data_ptr(), e1.data_ptr(), self._stream()), 'twog_gcn_embed1_fwd')
+        return e1
+
+    def gcn_embed1_bwd(self, x_human, n_nodes, ab, mean_invstd, w1, de1):
+        ptr, fstride, nf = self._geo(x_human)
+        dev = x_human.device
+        nblk = 128
+        partials = torch.empty(nblk * (320 + 8 * n_nodes), dtype=torch.float32, device=dev)
+        dw1 = torch.empty(64, 4, dtype=torch.float32, device=dev)
+        db1 = torch.empty(64, dtype=torch.float32, device=dev)
+        dgamma = torch.empty(4 * n_nodes, dtype=torch.float32, device=dev)
+        dbeta = torch.empty(4 * n_nodes, dtype=torch.float32, device=dev)
+        self._check(self.lib.twog_gcn_embed1_bwd(ptr, fstride, nf, n_nodes, ab.data_ptr(), mean_invstd.data_ptr(),
+                                                 w1.data_ptr(), de1.data_ptr(), partials.data_ptr(), nblk,
+                                                 dw1.data_ptr(), db1.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
+                                                 self._stream()), 'twog_gcn_embed1_bwd')
+        return dw1, db1, dgamma, dbeta
+
+    def gcn_attn_fwd(self, qk, x, n_frames, n_nodes):
+        s = torch.empty(n_frames, n_nodes, n_nodes, dtype=torch.float32, device=qk.device)
+        z = torch.empty(n_frames * n_nodes, 64, dtype=torch.float32, device=qk.device)
+        self._check(self.lib.twog_gcn_attn_fwd(qk.data_ptr(), x.data_ptr(), n_frames, n_nodes, s.data_ptr(),
+                                               z.data_ptr(), self._stream()), 'twog_gcn_attn_fwd')
+        return s, z
+
+    def gcn_attn_bwd(self, qk, x, s, dz, n_frames, n_nodes):
+        dx = torch.empty(n_frames * n_nodes, 64, dtype=torch.float32, device=qk.device)
+        dqk = torch.empty(n_frames * n_nodes, 256, dtype=torch.float32, device=qk.device)
+        self._check(self.lib.twog_gcn_attn_bwd(qk.data_ptr(), x.data_ptr(), s.data_ptr(), dz.data_ptr(), n_frames,
+                                               n_nodes, dx.data_ptr(), dqk.data_ptr(), self._stream()),
+                    'twog_gcn_attn_bwd')
+        return dx, dqk
+
+    # ---------------------------------------------------------------- frame-level BiGRU
+    def bigru_fwd(self, types, bs, T, h):
+        """types: list of dicts {gi (bs,T,E,6h), w_hh_f, b_hh_f, w_hh_r, b_hh_r}. Returns [(out (bs,T,E,2h), save)]."""
+        n = len(types)
+        arr = (L.BiGru * n)()
+        outs, keep = [], []
+        for i, y in enumerate(types):
+            gi = y['gi']
+            E = gi.shape[2]
+            dev = gi.device
+            assert gi.is_contiguous() and gi.shape == (bs, T, E, 6 * h)
+            out = torch.empty(bs, T, E, 2 * h, dtype=torch.float32, device=dev)
+            save = torch.empty(2, bs, T, E, 4 * h, dtype=torch.float32, device=dev)
+            tmp = torch.empty(2, bs * E, 3 * h, dtype=torch.float32, device=dev)
+            zeros = torch.zeros(bs * E, h, dtype=torch.float32, device=dev)
+            keep += [tmp, zeros]
+            a = arr[i]
+            a.gi, a.w_hh_f, a.b_hh_f, a.w_hh_r, a.b_hh_r = (gi.data_ptr(), y['w_hh_f'].data_ptr(),
+                                                             y['b_hh_f'].data_ptr(), y['w_hh_r'].data_ptr(),
+                                                             y['b_hh_r'].data_ptr())
+            a.out, a.save, a.tmp_gh, a.zeros, a.E = out.data_ptr(), save.data_ptr(), tmp.data_ptr(), zeros.data_ptr(), E
+            outs.append((out, save))
+        self._check(self.lib.twog_bigru_fwd(arr, n, bs, T, h, self._stream()), 'twog_bigru_fwd')
+        return outs
+
+    def bigru_bwd(self, types, bs, T, h):
+        """types: list of dicts {d_out, save, out, w_hh_f, w_hh_r}. Returns [(d_gi, d_gh)] each (bs,T,E,6h)."""
+        n = len(types)
+        arr = (L.BiGruBwd * n)()
+        outs, keep = [], []
+        for i, y in enumerate(types):
+            d_out = y['d_out']
+            E = d_out.shape[2]
+            dev = d_out.device
+            assert d_out.is_contiguous() and d_out.shape == (bs, T, E, 2 * h)
+            d_gi = torch.empty(bs, T, E, 6 * h, dtype=torch.float32, device=dev)
+            d_gh = torch.empty(bs, T, E, 6 * h, dtype=torch.float32, device=dev)
+            carry = torch.empty(2, bs * E, h, dtype=torch.float32, device=dev)
+            keep.append(carry)
+            a = arr[i]
+            a.d_out, a.save, a.out = d_out.data_ptr(), y['save'].data_ptr(), y['out'].data_ptr()
+            a.w_hh_f, a.w_hh_r = y['w_hh_f'].data_ptr(), y['w_hh_r'].data_ptr()
+            a.d_gi, a.d_gh, a.carry, a.E = d_gi.data_ptr(), d_gh.data_ptr(), carry.data_ptr(), E
+            outs.append((d_gi, d_gh))
+        self._check(self.lib.twog_bigru_bwd(arr, n, bs, T, h, self._stream()), 'twog_bigru_bwd')
+        return outs
+
+    # ---------------------------------------------------------------- entity attention
+    _ATTN_ROWS = ['feat_h', 'feat_o', 'msg_hh', 'msg_ho', 'msg_oh', 'msg_oo', 'msg_so', 'msg_sh', 'out_hh', 'out_oh',
+                  'out_sh', 'out_ho', 'out_so', 'out_oo']
+
+    def _fill_attn(self, a, d):
+        for k in self._ATTN_ROWS:
+            setattr(a, k, rows_of(d.get(k)))
+        a.obj_mask = _ptr(d.get('obj_mask'))
+        a.att = _ptr(d.get('att'))
+        a.n_inst, a.inst_per_clip, a.H, a.O = d['n_inst'], d['inst_per_clip'], d['H'], d['O']
+        a.D, a.hidden, a.scale, a.recv_mask_ho = d['D'], d['hidden'], float(d['scale']), int(d['recv_mask_ho'])
+
+    def attn_fwd(self, descs):
+        n = len(descs)
+        arr = (L.Attn * n)()
+        for i, d in enumerate(descs):
+            self._fill_attn(arr[i], d)
+        self._check(self.lib.twog_attn_fwd(arr, n, self._stream()), 'twog_attn_fwd')
+
+    def attn_bwd(self, descs):
+        n = len(descs)
+        arr = (L.AttnBwd * n)()
+        for i, d in enumerate(descs):
+            self._fill_attn(arr[i].f, d['f'])
+            for k in ['dout_hh', 'dout_oh', 'dout_sh', 'dout_ho', 'dout_so', 'dout_oo', 'dmsg_hh', 'dmsg_ho',
+                      'dmsg_oh', 'dmsg_oo', 'dmsg_so', 'dmsg_sh', 'dfeat_h', 'dfeat_o']:
+                setattr(arr[i], k, rows_of(d.get(k)))
+            arr[i].dfeat_accumulate = int(d.get('dfeat_accumulate', 0))
+            arr[i].relu_mask_dmsg = int(d.get('relu_mask_dmsg', 0))
+        self._check(self.lib.twog_attn_bwd(arr, n, self._stream()), 'twog_attn_bwd')
+
+    # ---------------------------------------------------------------- segment-level recurrence
+    @staticmethod
+    def _seg_dims(p):
+        nsh = int(p['rel_hh']) + int(p['rel_ho'])
+        nso = int(p['rel_oh']) + int(p['rel_oo'])
+        nmh = int(p['rel_hh']) + int(p['rel_oh'])
+        nmo = int(p['rel_ho']) + int(p['rel_oo'])
+        return nsh, nso, nmh, nmo
+
+    def _fill_seg(self, s, p, bufs):
+        s.bs, s.T, s.H, s.O, s.hidden = p['bs'], p['T'], p['H'], p['O'], p['hidden']
+        s.msg_segment = int(p['msg_segment'])
+        s.rel_hh, s.rel_ho, s.rel_oh, s.rel_oo = (int(p['rel_hh']), int(p['rel_ho']), int(p['rel_oh']),
+                                                   int(p['rel_oo']))
+        s.att_scale = float(p['att_scale'])
+        s.gi_h, s.gi_o, s.u_h, s.u_o = _ptr(p['gi_h']), _ptr(p['gi_o']), _ptr(p['u_h']), _ptr(p['u_o'])
+        s.obj_mask = _ptr(p['obj_mask'])
+        for d in range(2):
+            s.w_hh_h[d], s.b_hh_h[d] = _ptr(p['w_hh_h'][d]), _ptr(p['b_hh_h'][d])
+            s.w_hh_o[d], s.b_hh_o[d] = _ptr(p['w_hh_o'][d]), _ptr(p['b_hh_o'][d])
+            s.w_ihm_h[d], s.w_ihm_o[d] = _ptr(p['w_ihm_h'][d]), _ptr(p['w_ihm_o'][d])
+        s.ld_ih_h, s.ld_ih_o = p['ld_ih_h'], p['ld_ih_o']
+        s.w_smsg_h, s.b_smsg_h = _ptr(p.get('w_smsg_h')), _ptr(p.get('b_smsg_h'))
+        s.w_smsg_o, s.b_smsg_o = _ptr(p.get('w_smsg_o')), _ptr(p.get('b_smsg_o'))
+        for k in ['hs_h', 'hs_o', 'save_h', 'save_o', 'msrc_h', 'msrc_o', 'mg_h', 'mg_o', 'att', 'tmp_gim_h',
+                  'tmp_gim_o', 'tmp_gh_h', 'tmp_gh_o', 'zeros']:
+            setattr(s, k, _ptr(bufs[k]))
+
+    def segrnn_fwd(self, p):
+        """p: parameter/input dict (see ops.SegmentRecurrence). Allocates and returns the state/saved buffers."""
+        bs, T, H, O, h = p['bs'], p['T'], p['H'], p['O'], p['hidden']
+        dev = p['gi_h'].device if p['gi_h'] is not None else p['gi_o'].device
+        nsh, nso, nmh, nmo = self._seg_dims(p)
+        natt = H * H + 2 * H * O + O * O
+
+        def e(*shape):
+            return torch.empty(*[max(int(x), 0) for x in shape], dtype=torch.float32, device=dev)
+
+        bufs = dict(hs_h=e(bs, T, H, 2 * h), hs_o=e(bs, T, O, 2 * h), save_h=e(2, bs, T, H, 4 * h),
+                    save_o=e(2, bs, T, O, 4 * h), msrc_h=e(2, bs, T, H, nsh * h), msrc_o=e(2, bs, T, O, nso * h),
+                    mg_h=e(2, bs, T, H, nmh * h), mg_o=e(2, bs, T, O, nmo * h), att=e(2, T, bs, natt),
+                    tmp_gim_h=e(2, bs * H, 3 * h), tmp_gim_o=e(2, bs * O, 3 * h), tmp_gh_h=e(2, bs * H, 3 * h),
+                    tmp_gh_o=e(2, bs * O, 3 * h),
+                    zeros=torch.zeros(bs * max(H, O, 1), h, dtype=torch.float32, device=dev))
+        s = L.SegRnn()
+        self._fill_seg(s, p, bufs)
+        self._check(self.lib.twog_segrnn_fwd(C.byref(s), self._stream()), 'twog_segrnn_fwd')
+        return bufs
+
+    def segrnn_bwd(self, p, bufs, d_hs_h, d_hs_o):
+        bs, T, H, O, h = p['bs'], p['T'], p['H'], p['O'], p['hidden']
+        dev = bufs['hs_h'].device
+        nsh, nso, nmh, nmo = self._seg_dims(p)
+
+        def e(*shape):
+            return torch.empty(*[max(int(x), 0) for x in shape], dtype=torch.float32, device=dev)
+
+        out = dict(d_gi_h=e(bs, T, H, 6 * h), d_gi_o=e(bs, T, O, 6 * h), d_gh_h=e(bs, T, H, 6 * h),
+                   d_gh_o=e(bs, T, O, 6 * h),
+                   d_u_h=torch.zeros(bs, T, H, dtype=torch.float32, device=dev),
+                   d_u_o=torch.zeros(bs, T, O, dtype=torch.float32, device=dev),
+                   d_pre_h=e(2, bs, T, H, nsh * h), d_pre_o=e(2, bs, T, O, nso * h))
+        scratch = dict(carry_h=e(2, bs * H, h), carry_o=e(2, bs * O, h), tmp_dmg_h=e(2, bs * H, nmh * h),
+                       tmp_dmg_o=e(2, bs * O, nmo * h), trash=e(bs * max(H, O, 1), h))
+        s = L.SegRnn()
+        self._fill_seg(s, p, bufs)
+        b = L.SegRnnBwd()
+        b.d_hs_h, b.d_hs_o = _ptr(d_hs_h), _ptr(d_hs_o)
+        for k, v in list(out.items()) + list(scratch.items()):
+            setattr(b, k, _ptr(v))
+        self._check(self.lib.twog_segrnn_bwd(C.byref(s), C.byref(b), self._stream()), 'twog_segrnn_bwd')
+        return out
+
+    # ---------------------------------------------------------------- gates
+    def _fill_gate(self, g, d):
+        g.x = rows_of(d['x'])
+        for i, c in enumerate(d['seg_col']):
+            g.seg_col[i] = int(c)
+        g.n_seg, g.hidden = len(d['seg_col']), d['hidden']
+        g.w, g.b, g.noise = _ptr(d['w']), _ptr(d.get('b')), _ptr(d.get('noise'))
+        g.hard, g.soft, g.p_save = _ptr(d['hard']), _ptr(d['soft']), _ptr(d['p_save'])
+        g.bs, g.T, g.E = d['bs'], d['T'], d['E']
+        g.noise_entities, g.noise_offset = int(d.get('noise_entities', 0)), int(d.get('noise_offset', 0))
+        g.force_last, g.threshold = int(d['force_last']), float(d['threshold'])
+
+    def gate_fwd(self, d):
+        """d: x (rows (bs*T*E), W) view, seg_col, hidden, w, b, noise, bs, T, E, ... Fills d['hard'|'soft'|'p_save']."""
+        dev = d['x'].device
+        for k in ('hard', 'soft', 'p_save'):
+            d[k] = torch.empty(d['bs'], d['T'], d['E'], dtype=torch.float32, device=dev)
+        g = L.Gate()
+        self._fill_gate(g, d)
+        self._check(self.lib.twog_gate_fwd(C.byref(g), self._stream()), 'twog_gate_fwd')
+        return d['hard'], d['soft']
+
+    def gate_bwd(self, d, d_hard, d_soft, st_mask):
+        g = L.Gate()
+        self._fill_gate(g, d)
+        dlogit = torch.empty(d['bs'] * d['T'] * d['E'], dtype=torch.float32, device=d['x'].device)
+        self._check(self.lib.twog_gate_bwd(C.byref(g), _ptr(d_hard), _ptr(d_soft), _ptr(st_mask), dlogit.data_ptr(),
+                                           self._stream()), 'twog_gate_bwd')
+        return dlogit
+
+    def rank1_update(self, dst, s, v):
+        """dst[r][c] += s[r] * v[c] on a row-strided view."""
+        self._check(self.lib.twog_rank1_update(rows_of(dst), s.data_ptr(), v.data_ptr(), n_rows(dst), dst.shape[-1],
+                                               self._stream()), 'twog_rank1_update')
+
+    def colsum(self, x, rowscale=None, out=None, accumulate=False):
+        rows, cols = n_rows(x), x.shape[-1]
+        if out is None:
+            out = torch.empty(cols, dtype=torch.float32, device=x.device)
+            accumulate = False
+        nblk = max(1, min(256, rows // 64))
+        partials = self.workspace(nblk * cols * 4, x.device, 'colsum')
+        self._check(self.lib.twog_colsum(rows_of(x), _ptr(rowscale), rows, cols, out.data_ptr(), int(accumulate),
+                                         partials.data_ptr(), nblk, self._stream()), 'twog_colsum')
+        return out
+
+    def filter_fwd(self, soft, threshold):
+        bs, T, E = soft.shape
+        hard, gmask = torch.empty_like(soft), torch.empty_like(soft)
+        self._check(self.lib.twog_filter_fwd(soft.data_ptr(), hard.data_ptr(), gmask.data_ptr(), bs, T, E,
+                                             float(threshold), self._stream()), 'twog_filter_fwd')
+        return hard, gmask
+
+    # ---------------------------------------------------------------- reorder / heads / elementwise
+    def reorder_fwd(self, hx, gate):
+        bs, T, E, cols = hx.shape
+        assert hx.is_contiguous() and gate.is_contiguous() and gate.shape == (bs, T, E)
+        out = torch.empty_like(hx)
+        self._check(self.lib.twog_reorder_fwd(hx.data_ptr(), gate.data_ptr(), out.data_ptr(), bs, T, E, cols,
+                                              self._stream()), 'twog_reorder_fwd')
+        return out
+
+    def reorder_bwd(self, dout, gate):
+        bs, T, E, cols = dout.shape
+        assert dout.is_contiguous()
+        dhx = torch.empty_like(dout)
+        self._check(self.lib.twog_reorder_bwd(dout.data_ptr(), gate.data_ptr(), dhx.data_ptr(), bs, T, E, cols,
+                                              self._stream()), 'twog_reorder_bwd')
+        return dhx
+
+    def logsoftmax_permute_fwd(self, logits, bs, T, E, Cn):
+        out = torch.empty(bs, Cn, T, E, dtype=torch.float32, device=logits.device)
+        self._check(self.lib.twog_logsoftmax_permute_fwd(logits.data_ptr(), out.data_ptr(), bs, T, E, Cn,
+                                                         self._stream()), 'twog_logsoftmax_permute_fwd')
+        return out
+
+    def logsoftmax_permute_bwd(self, out, dout):
+        bs, Cn, T, E = out.shape
+        assert out.is_contiguous() and dout.is_contiguous()
+        dlogits = torch.empty(bs * T * E, Cn, dtype=torch.float32, device=out.device)
+        self._check(self.lib.twog_logsoftmax_permute_bwd(out.data_ptr(), dout.data_ptr(), dlogits.data_ptr(), bs, T,
+                                                         E, Cn, self._stream()), 'twog_logsoftmax_permute_bwd')
+        return dlogits
+
+    def relu_bwd(self, dy, y, dx=None):
+        """dx = dy * (y > 0) on row-strided views (dx may alias dy)."""
+        if dx is None:
+            dx = torch.empty(n_rows(dy), dy.shape[-1], dtype=torch.float32, device=dy.device)
+        self._check(self.lib.twog_relu_bwd(rows_of(dy), rows_of(y), rows_of(dx), n_rows(dy), dy.shape[-1],
+                                           self._stream()), 'twog_relu_bwd')
+        return dx
+
+    def add_rows(self, src, dst):
+        self._check(self.lib.twog_add_rows(rows_of(src), rows_of(dst), n_rows(src), src.shape[-1], self._stream()),
+                    'twog_add_rows')
+
+    def adam_step(self, param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, step):
+        self._check(self.lib.twog_adam_step(param.data_ptr(), grad.data_ptr(), exp_avg.data_ptr(),
+                                            exp_avg_sq.data_ptr(), param.numel(), lr, beta1, beta2, eps, weight_decay,
+                                            step, self._stream()), 'twog_adam_step')
+
+
+_backend = None
+
+
+def get_kernels():
+    """The process-wide kernel backend. Always the HIP library; raises if it is not built."""
+    global _backend
+    if _backend is None:
+        _backend = HipKernels()
+    return _backend
+
+
+def _set_backend_for_tests(backend):
+    """Test hook: tests/ inject a torch implementation of this interface to exercise the host logic without a GPU.
+    Never called from the product path."""
+    global _backend
+    _backend = backend

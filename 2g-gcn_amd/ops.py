@@ -1,0 +1,644 @@
+"""Host-side composition of the 2G-GCN hot path out of the gfx950 kernels.
+
+``TGGCNFunction`` is ONE autograd node covering TGGCN.forward of the reference (vhoi/models.py:584-933): the forward
+pass and the hand-derived backward pass are sequences of C-ABI kernel calls (see kernels.py / include/twog_gcn.h) on
+buffers laid out for those kernels:
+
+  * per entity type one "entity row" buffer  [bs, T, E, (2 + n_msg) * h] = [ x | h_f | received messages ... ]
+    -- the embedding GEMM, the BiGRU-embedding GEMM and the attention kernel each write their column block in
+    place, so none of the reference's torch.cat calls (models.py:705, :748, :1021-1024, ...) is materialised: the
+    attention features cat[x, h_f] are columns [0, 2h), the segment-level input xx is columns [h, end);
+  * time-sequential stages run inside the library (twog_bigru_*, twog_segrnn_*), everything that can be batched over
+    (clip, time) is one large MFMA GEMM.
+
+No torch math is used on the data path (torch owns memory, streams, and the autograd graph edge).
+"""
+import math
+
+import torch
+
+from .kernels import get_kernels
+
+SUPPORTED_NOTE = ("the HIP path implements message_type 'v2' + message_granularity 'v1' + message_aggregation 'att' "
+                  "with attention_style 'v2'/'v3', discrete_networks_num_layers == 1, "
+                  "object_segment_update_strategy 'ind', no time-position / segment-length features, "
+                  "cat_level_states off (every configuration shipped in the reference's conf/models/)")
+
+
+def _v2(t, width=None):
+    """(rows, width) 2-D view of a contiguous tensor whose last dim is the row."""
+    return t.view(-1, t.shape[-1] if width is None else width)
+
+
+class Plan:
+    """Static description of one forward call (shapes + which relations/gates are on)."""
+
+    def __init__(self, cfg, bs, T, H, O, N, F_o, n_sub, n_aff, human_seg_given, object_seg_given):
+        h = cfg['hidden_size']
+        self.cfg, self.bs, self.T, self.H, self.O, self.N, self.h, self.F_o = cfg, bs, T, H, O, N, h, F_o
+        self.n_sub, self.n_aff = n_sub, n_aff
+        c = cfg
+        self.rel_hh = bool(c['message_humans_to_human'])
+        self.rel_ho = bool(c['message_human_to_objects'])
+        self.rel_oh = bool(c['message_objects_to_human'])
+        self.rel_oo = bool(c['message_objects_to_object'])
+        self.rel_so = bool(c['message_geometry_to_objects'])
+        self.rel_sh = bool(c['message_geometry_to_human'])
+        self.msg_segment = bool(c['message_segment'])
+        # column layout of the entity rows (order of received messages follows models.py:705 / :748)
+        col = 2 * h
+        self.col_h = {}
+        for name, on in (('hh', self.rel_hh), ('oh', self.rel_oh), ('sh', self.rel_sh)):
+            if on:
+                self.col_h[name] = col
+                col += h
+        self.Wh = col
+        col = 2 * h
+        self.col_o = {}
+        for name, on in (('ho', self.rel_ho), ('so', self.rel_so), ('oo', self.rel_oo)):
+            if on:
+                self.col_o[name] = col
+                col += h
+        self.Wo = col
+        self.Ws = 2 * h
+        # sender-message buffers (frame level): humans send (hh | ho), objects (oh | oo), geometry (so | sh)
+        self.snd_h = [r for r, on in (('hh', self.rel_hh), ('ho', self.rel_ho)) if on]
+        self.snd_o = [r for r, on in (('oh', self.rel_oh), ('oo', self.rel_oo)) if on]
+        self.snd_s = [r for r, on in (('so', self.rel_so), ('sh', self.rel_sh)) if on]
+        self.learn_h = not human_seg_given
+        self.learn_o = not object_seg_given
+        self.filter = bool(c['filter_discrete_updates'])
+        self.thr = float(c['update_segment_threshold'])
+        self.gs = c['discrete_optimization_strategy'] in {'gumbel-sigmoid', 'gs'}
+        style = c['attention_style']
+        self.scale_frame = 1.0 / math.sqrt(2 * h) if style in {'v3', 'scaled_dot-product'} else 1.0
+        self.scale_seg = 1.0 / math.sqrt(h) if style in {'v3', 'scaled_dot-product'} else 1.0
+        # segment-level message blocks appended to the GRUCell input (models.py:798,807 / :843,851)
+        self.seg_mh = [r for r, on in (('hh', self.rel_hh), ('oh', self.rel_oh)) if on] if self.msg_segment else []
+        self.seg_mo = [r for r, on in (('ho', self.rel_ho), ('oo', self.rel_oo)) if on] if self.msg_segment else []
+        self.fw_h = self.Wh - h  # width of the frame-level part xx_hs of the human GRUCell input
+        self.fw_o = self.Wo - h
+
+    # gate input column blocks, in the reference's weight order
+    def gate_cols_h(self):  # [x, h, m_hh, m_oh, m_sh]  (models.py:1494)
+        return [0, self.h] + [self.col_h[r] for r in ('hh', 'oh', 'sh') if r in self.col_h]
+
+    def gate_cols_o(self):  # [x, h, m_ho, m_oo, m_so]  (models.py:1527) -- differs from the xx_os order
+        return [0, self.h] + [self.col_o[r] for r in ('ho', 'oo', 'so') if r in self.col_o]
+
+
+_FRAME_MLP = {'hh': 'humans_to_human_message_mlp', 'ho': 'human_to_object_message_mlp',
+              'oh': 'objects_to_human_message_mlp', 'oo': 'objects_to_object_message_mlp',
+              'so': 'geometry_to_object_message_mlp', 'sh': 'geometry_to_human_message_mlp'}
+_SEG_MLP = {'hh': 'humans_to_human_segment_message_mlp', 'ho': 'human_to_object_segment_message_mlp',
+            'oh': 'objects_to_human_segment_message_mlp', 'oo': 'objects_to_object_segment_message_mlp'}
+
+
+def used_parameter_names(plan: Plan):
+    """Names (reference state_dict keys) of the parameters this forward reads, in a fixed order."""
+    g = 'geometry_embedding_gcn.'
+    names = [g + 'joint_embed.cnn.0.bn.weight', g + 'joint_embed.cnn.0.bn.bias',
+             g + 'joint_embed.cnn.1.cnn.weight', g + 'joint_embed.cnn.1.cnn.bias',
+             g + 'joint_embed.cnn.3.cnn.weight', g + 'joint_embed.cnn.3.cnn.bias',
+             g + 'get_s.s1.cnn.weight', g + 'get_s.s1.cnn.bias', g + 'get_s.s2.cnn.weight', g + 'get_s.s2.cnn.bias',
+             g + 'weight']
+    for m in ('geometry_embedding_mlp.0', 'geometry_embedding_mlp.2', 'human_embedding_mlp.0',
+              'object_embedding_mlp.0', 'human_bd_embedding_mlp.0', 'object_bd_embedding_mlp.0',
+              'geometry_bd_embedding_mlp.0'):
+        names += [m + '.weight', m + '.bias']
+    for r in ('human_bd_rnn', 'object_bd_rnn', 'geometry_bd_rnn'):
+        for sfx in ('', '_reverse'):
+            names += [f'{r}.weight_ih_l0{sfx}', f'{r}.weight_hh_l0{sfx}', f'{r}.bias_ih_l0{sfx}', f'{r}.bias_hh_l0{sfx}']
+    for rel in plan.snd_h + plan.snd_o + plan.snd_s:
+        names += [_FRAME_MLP[rel] + '.0.weight', _FRAME_MLP[rel] + '.0.bias']
+    if plan.msg_segment:
+        for rel in ('hh', 'ho', 'oh', 'oo'):
+            if getattr(plan, 'rel_' + rel):
+                names += [_SEG_MLP[rel] + '.0.weight', _SEG_MLP[rel] + '.0.bias']
+    for cell in ('human_segment_rnn_fcell', 'human_segment_rnn_bcell', 'object_segment_rnn_fcell',
+                 'object_segment_rnn_bcell'):
+        names += [cell + '.weight_ih', cell + '.weight_hh', cell + '.bias_ih', cell + '.bias_hh']
+    if plan.learn_h:
+        names += ['update_human_segment_mlp.0.weight', 'update_human_segment_mlp.0.bias']
+    if plan.learn_o:
+        names += ['update_object_segment_mlp.0.weight', 'update_object_segment_mlp.0.bias']
+    heads = ['human_frame_recognition_mlp', 'human_frame_prediction_mlp', 'human_recognition_mlp',
+             'human_prediction_mlp']
+    if plan.n_aff is not None:
+        heads += ['object_frame_recognition_mlp', 'object_frame_prediction_mlp', 'object_recognition_mlp',
+                  'object_prediction_mlp']
+    for m in heads:
+        names += [m + '.0.weight', m + '.0.bias']
+    # share_level_mlps aliases produce duplicate names; keep the first occurrence
+    seen, out = set(), []
+    for n in names:
+        if n not in seen:
+            seen.add(n)
+            out.append(n)
+    return out
+
+
+class _Grads:
+    """Accumulates parameter gradients by name (several stages can contribute to one parameter)."""
+
+    def __init__(self, K):
+        self.K, self.g = K, {}
+
+    def add(self, name, t):
+        if name in self.g:
+            self.K.add_rows(_v2(t.reshape(1, -1)), _v2(self.g[name].view(1, -1)))
+        else:
+            self.g[name] = t
+
+
+def _lin_w_grads(K, G, wname, bname, dY, X):
+    """dW = dY^T X (tall reduction -> k-major x k-major GEMM with split-K), db = column sums of dY."""
+    N, Kin = dY.shape[-1], X.shape[-1]
+    dW = torch.empty(N, Kin, dtype=torch.float32, device=dY.device)
+    K.gemm([dict(A=dY, B=X, C=dW)], a_kmajor=True, b_kmajor=True)
+    G.add(wname, dW)
+    if bname is not None:
+        G.add(bname, K.colsum(dY))
+
+
+def tggcn_forward(K, plan: Plan, P, x_human, x_objects, objects_mask, human_seg, object_seg, noise, training, bn_bufs):
+    """Returns (outputs list, saved dict). P: dict name -> parameter tensor."""
+    p = plan
+    bs, T, H, O, N, h = p.bs, p.T, p.H, p.O, p.N, p.h
+    dev = x_human.device
+    S = {}  # saved for backward
+    nF = bs * T
+
+    def empty(*shape):
+        return torch.empty(*shape, dtype=torch.float32, device=dev)
+
+    # ------------------------------------------------------------------ A. geometric-level GCN (models_gcn.py:30-37)
+    g = 'geometry_embedding_gcn.'
+    ab, mi = K.bn_fold(x_human, N, P[g + 'joint_embed.cnn.0.bn.weight'], P[g + 'joint_embed.cnn.0.bn.bias'],
+                       bn_bufs['running_mean'], bn_bufs['running_var'], bn_bufs['num_batches_tracked'], training)
+    w1 = P[g + 'joint_embed.cnn.1.cnn.weight'].view(64, 4)
+    e1 = K.gcn_embed1_fwd(x_human, N, ab, w1, P[g + 'joint_embed.cnn.1.cnn.bias'])
+    w2 = P[g + 'joint_embed.cnn.3.cnn.weight'].view(64, 64)
+    X = empty(nF * N, 64)
+    K.gemm([dict(A=e1, B=w2, C=X, bias=P[g + 'joint_embed.cnn.3.cnn.bias'], act=1)])
+    QK = empty(nF * N, 256)
+    wq, wk = P[g + 'get_s.s1.cnn.weight'].view(128, 64), P[g + 'get_s.s2.cnn.weight'].view(128, 64)
+    K.gemm([dict(A=X, B=wq, C=QK[:, :128], bias=P[g + 'get_s.s1.cnn.bias']),
+            dict(A=X, B=wk, C=QK[:, 128:], bias=P[g + 'get_s.s2.cnn.bias'])])
+    adj, Z = K.gcn_attn_fwd(QK, X, nF, N)
+    # Y = Z W, stored (bs, 128, N, T) with T fastest so that the reference's raw .view (models.py:644-645) is free
+    Gout = empty(bs, 128, N, T)
+    Zv = Z.view(bs, T, N, 64).permute(0, 2, 1, 3)  # (bs, N, T, 64) view
+    K.gemm([dict(A=P[g + 'weight'], B=Zv[0], C=Gout[0].view(128, N * T), batch=(bs, 0, T * N * 64, 128 * N * T))],
+           a_kmajor=True, b_kmajor=False)
+    S.update(ab=ab, mi=mi, e1=e1, X=X, QK=QK, adj=adj, Z=Z)
+    geo_in = Gout.view(nF, 128 * N)  # raw reinterpretation of the (c, n, t)-ordered block
+
+    # ------------------------------------------------------------------ B. embeddings (models.py:646)
+    HUM, OBJ, GEO = empty(bs, T, H, p.Wh), empty(bs, T, O, p.Wo), empty(bs, T, 1, p.Ws)
+    HUMv, OBJv, GEOv = _v2(HUM), _v2(OBJ), _v2(GEO)
+    xh_in = x_human.view(nF * H, x_human.shape[-1])[:, :2048]
+    xo_in = x_objects.view(nF * O, x_objects.shape[-1])
+    t1 = empty(nF, 2048)
+    K.gemm([dict(A=xh_in, B=P['human_embedding_mlp.0.weight'], C=HUMv[:, :h], bias=P['human_embedding_mlp.0.bias'], act=1),
+            dict(A=xo_in, B=P['object_embedding_mlp.0.weight'], C=OBJv[:, :h], bias=P['object_embedding_mlp.0.bias'], act=1),
+            dict(A=geo_in, B=P['geometry_embedding_mlp.0.weight'], C=t1, bias=P['geometry_embedding_mlp.0.bias'], act=1)])
+    K.gemm([dict(A=t1, B=P['geometry_embedding_mlp.2.weight'], C=GEOv[:, :h], bias=P['geometry_embedding_mlp.2.bias'], act=1)])
+    S.update(Gout=Gout, t1=t1)
+
+    # ------------------------------------------------------------------ C. frame-level BiGRUs (models.py:983-1002)
+    ents = (('human', HUMv, H), ('object', OBJv, O), ('geometry', GEOv, 1))
+    gis, probs = [], []
+    for name, Ev, E in ents:
+        gi = empty(bs, T, E, 6 * h)
+        giv = _v2(gi)
+        for d, sfx in enumerate(('', '_reverse')):
+            probs.append(dict(A=Ev[:, :h], B=P[f'{name}_bd_rnn.weight_ih_l0{sfx}'], C=giv[:, d * 3 * h:(d + 1) * 3 * h],
+                              bias=P[f'{name}_bd_rnn.bias_ih_l0{sfx}']))
+        gis.append(gi)
+    K.gemm(probs)
+    res = K.bigru_fwd([dict(gi=gi, w_hh_f=P[f'{n}_bd_rnn.weight_hh_l0'], b_hh_f=P[f'{n}_bd_rnn.bias_hh_l0'],
+                            w_hh_r=P[f'{n}_bd_rnn.weight_hh_l0_reverse'], b_hh_r=P[f'{n}_bd_rnn.bias_hh_l0_reverse'])
+                       for gi, (n, _, _) in zip(gis, ents)], bs, T, h)
+    HFR = [r[0] for r in res]
+    S['bigru_save'] = [r[1] for r in res]
+    K.gemm([dict(A=_v2(hfr), B=P[f'{n}_bd_embedding_mlp.0.weight'], C=Ev[:, h:2 * h],
+                 bias=P[f'{n}_bd_embedding_mlp.0.bias'], act=1) for hfr, (n, Ev, _) in zip(HFR, ents)])
+    S['HFR'] = HFR
+
+    # ------------------------------------------------------------------ D. frame-level messages + attention
+    MSGH = empty(nF * H, max(len(p.snd_h), 1) * h)
+    MSGO = empty(nF * O, max(len(p.snd_o), 1) * h)
+    MSGS = empty(nF, max(len(p.snd_s), 1) * h)
+    probs = []
+    for buf, Ev, rels in ((MSGH, HUMv, p.snd_h), (MSGO, OBJv, p.snd_o), (MSGS, GEOv, p.snd_s)):
+        for i, rel in enumerate(rels):
+            probs.append(dict(A=Ev[:, :2 * h], B=P[_FRAME_MLP[rel] + '.0.weight'], C=buf[:, i * h:(i + 1) * h],
+                              bias=P[_FRAME_MLP[rel] + '.0.bias'], act=1))
+    K.gemm(probs)
+    natt = H * H + 2 * H * O + O * O
+    att = empty(nF, natt)
+
+    def msgv(buf, rels, rel):
+        if rel not in rels:
+            return None
+        i = rels.index(rel)
+        return buf[:, i * h:(i + 1) * h]
+
+    fdesc = dict(feat_h=HUMv[:, :2 * h], feat_o=OBJv[:, :2 * h],
+                 msg_hh=msgv(MSGH, p.snd_h, 'hh'), msg_ho=msgv(MSGH, p.snd_h, 'ho'),
+                 msg_oh=msgv(MSGO, p.snd_o, 'oh'), msg_oo=msgv(MSGO, p.snd_o, 'oo'),
+                 msg_so=msgv(MSGS, p.snd_s, 'so'), msg_sh=msgv(MSGS, p.snd_s, 'sh'),
+                 obj_mask=objects_mask, att=att, n_inst=nF, inst_per_clip=T, H=H, O=O, D=2 * h, hidden=h,
+                 scale=p.scale_frame, recv_mask_ho=1)
+    for rel, c in p.col_h.items():
+        fdesc['out_' + rel] = HUMv[:, c:c + h]
+    for rel, c in p.col_o.items():
+        fdesc['out_' + rel] = OBJv[:, c:c + h]
+    K.attn_fwd([fdesc])
+    S.update(HUM=HUM, OBJ=OBJ, GEO=GEO, MSGH=MSGH, MSGO=MSGO, MSGS=MSGS, att=att)
+
+    # ------------------------------------------------------------------ gates (models.py:697-702, :738-745, :751-753)
+    n_gated = (H if p.learn_h else 0) + (O if p.learn_o else 0)
+    gates = {}
+    for kind, learn, seg, Ev, E, cols, mlp, off in (
+            ('h', p.learn_h, human_seg, HUMv, H, p.gate_cols_h(), 'update_human_segment_mlp', 0),
+            ('o', p.learn_o, object_seg, OBJv, O, p.gate_cols_o(), 'update_object_segment_mlp', H if p.learn_h else 0)):
+        if not learn:
+            gates[kind] = dict(hard=seg.contiguous(), soft=seg.contiguous(), learned=False)
+            continue
+        d = dict(x=Ev, seg_col=cols, hidden=h, w=P[mlp + '.0.weight'], b=P.get(mlp + '.0.bias'),
+                 noise=noise if p.gs else None, bs=bs, T=T, E=E, noise_entities=n_gated, noise_offset=off,
+                 force_last=1, threshold=p.thr)
+        hard, soft = K.gate_fwd(d)
+        gmask = None
+        if p.filter:
+            hard, gmask = K.filter_fwd(soft, p.thr)
+        gates[kind] = dict(hard=hard, soft=soft, learned=True, desc=d, gmask=gmask)
+    S['gates'] = gates
+    u_h, u_o = gates['h']['hard'], gates['o']['hard']
+
+    # ------------------------------------------------------------------ F. segment-level recurrence (models.py:785-880)
+    cells = {('h', 0): 'human_segment_rnn_fcell', ('h', 1): 'human_segment_rnn_bcell',
+             ('o', 0): 'object_segment_rnn_fcell', ('o', 1): 'object_segment_rnn_bcell'}
+    gi_h, gi_o = empty(bs, T, H, 6 * h), empty(bs, T, O, 6 * h)
+    probs = []
+    for kind, gi, Ev, fw in (('h', gi_h, HUMv, p.fw_h), ('o', gi_o, OBJv, p.fw_o)):
+        for d in range(2):
+            c = cells[(kind, d)]
+            probs.append(dict(A=Ev[:, h:h + fw], B=P[c + '.weight_ih'][:, :fw], C=_v2(gi)[:, d * 3 * h:(d + 1) * 3 * h],
+                              bias=P[c + '.bias_ih']))
+    K.gemm(probs)
+    seg_p = dict(bs=bs, T=T, H=H, O=O, hidden=h, msg_segment=p.msg_segment, rel_hh=p.rel_hh and p.msg_segment,
+                 rel_ho=p.rel_ho and p.msg_segment, rel_oh=p.rel_oh and p.msg_segment,
+                 rel_oo=p.rel_oo and p.msg_segment, att_scale=p.scale_seg, gi_h=gi_h, gi_o=gi_o, u_h=u_h, u_o=u_o,
+                 obj_mask=objects_mask,
+                 w_hh_h=[P[cells[('h', d)] + '.weight_hh'] for d in range(2)],
+                 b_hh_h=[P[cells[('h', d)] + '.bias_hh'] for d in range(2)],
+                 w_hh_o=[P[cells[('o', d)] + '.weight_hh'] for d in range(2)],
+                 b_hh_o=[P[cells[('o', d)] + '.bias_hh'] for d in range(2)],
+                 w_ihm_h=[P[cells[('h', d)] + '.weight_ih'][:, p.fw_h:] for d in range(2)],
+                 w_ihm_o=[P[cells[('o', d)] + '.weight_ih'][:, p.fw_o:] for d in range(2)],
+                 ld_ih_h=P[cells[('h', 0)] + '.weight_ih'].shape[1], ld_ih_o=P[cells[('o', 0)] + '.weight_ih'].shape[1])
+    if p.msg_segment:
+        # packed sender MLPs (a copy of four h x h matrices; keeps one GEMM per sender type inside the time loop)
+        sh_rel = [r for r in ('hh', 'ho') if getattr(p, 'rel_' + r)]
+        so_rel = [r for r in ('oh', 'oo') if getattr(p, 'rel_' + r)]
+        seg_p['w_smsg_h'] = torch.cat([P[_SEG_MLP[r] + '.0.weight'] for r in sh_rel], 0) if sh_rel else None
+        seg_p['b_smsg_h'] = torch.cat([P[_SEG_MLP[r] + '.0.bias'] for r in sh_rel], 0) if sh_rel else None
+        seg_p['w_smsg_o'] = torch.cat([P[_SEG_MLP[r] + '.0.weight'] for r in so_rel], 0) if so_rel else None
+        seg_p['b_smsg_o'] = torch.cat([P[_SEG_MLP[r] + '.0.bias'] for r in so_rel], 0) if so_rel else None
+        S['seg_rels'] = (sh_rel, so_rel)
+    seg_bufs = K.segrnn_fwd(seg_p)
+    S.update(seg_p=seg_p, seg_bufs=seg_bufs)
+    HS_h, HS_o = seg_bufs['hs_h'], seg_bufs['hs_o']
+
+    # ------------------------------------------------------------------ G. reorder (models.py:885-899), H. heads (:909-926)
+    R_h = K.reorder_fwd(HS_h, u_h)
+    R_o = K.reorder_fwd(HS_o, u_o) if O > 0 else HS_o
+    S.update(R_h=R_h, R_o=R_o)
+
+    def head(name, Xin, E, C):
+        logits = empty(nF * E, C)
+        K.gemm([dict(A=_v2(Xin), B=P[name + '.0.weight'], C=logits, bias=P.get(name + '.0.bias'))])
+        return K.logsoftmax_permute_fwd(logits, bs, T, E, C)
+
+    y_h = [head('human_frame_recognition_mlp', HFR[0], H, p.n_sub), head('human_frame_prediction_mlp', HFR[0], H, p.n_sub),
+           head('human_recognition_mlp', R_h, H, p.n_sub), head('human_prediction_mlp', R_h, H, p.n_sub)]
+    if p.n_aff is None:
+        outputs = [gates['h']['hard'], gates['h']['soft']] + y_h
+    else:
+        y_o = [head('object_frame_recognition_mlp', HFR[1], O, p.n_aff), head('object_frame_prediction_mlp', HFR[1], O, p.n_aff),
+               head('object_recognition_mlp', R_o, O, p.n_aff), head('object_prediction_mlp', R_o, O, p.n_aff)]
+        outputs = [gates['h']['hard'], gates['o']['hard'], gates['h']['soft'], gates['o']['soft'],
+                   y_h[0], y_h[1], y_o[0], y_o[1], y_h[2], y_h[3], y_o[2], y_o[3]]
+    S['outputs'] = outputs
+    return outputs, S
+
+
+def tggcn_backward(K, plan: Plan, P, S, x_human, x_objects, objects_mask, d_outputs):
+    """Hand-derived backward pass. d_outputs: list aligned with the forward outputs (None = no gradient).
+    Returns dict name -> gradient for every parameter used by the forward."""
+    p = plan
+    bs, T, H, O, N, h = p.bs, p.T, p.H, p.O, p.N, p.h
+    dev = x_human.device
+    nF = bs * T
+    G = _Grads(K)
+
+    def empty(*shape):
+        return torch.empty(*shape, dtype=torch.float32, device=dev)
+
+    def zeros(*shape):
+        return torch.zeros(*shape, dtype=torch.float32, device=dev)
+
+    outs = S['outputs']
+    if p.n_aff is None:
+        d_hard = {'h': d_outputs[0], 'o': None}
+        d_soft = {'h': d_outputs[1], 'o': None}
+        dy_h, dy_o = d_outputs[2:6], None
+        y_h, y_o = outs[2:6], None
+    else:
+        d_hard = {'h': d_outputs[0], 'o': d_outputs[1]}
+        d_soft = {'h': d_outputs[2], 'o': d_outputs[3]}
+        dy_h = [d_outputs[4], d_outputs[5], d_outputs[8], d_outputs[9]]
+        dy_o = [d_outputs[6], d_outputs[7], d_outputs[10], d_outputs[11]]
+        y_h = [outs[4], outs[5], outs[8], outs[9]]
+        y_o = [outs[6], outs[7], outs[10], outs[11]]
+    HFR = S['HFR']
+
+    # ---- H. heads: d logits -> dW, db, dX
+    def head_bwd(names, ys, dys, Xin, E):
+        """two heads (recognition, prediction) on the same input; returns dX (same shape as Xin) or None."""
+        dX, first = None, True
+        for name, y, dy in zip(names, ys, dys):
+            if dy is None:
+                continue
+            dlog = K.logsoftmax_permute_bwd(y, dy.contiguous())
+            _lin_w_grads(K, G, name + '.0.weight', name + '.0.bias' if (name + '.0.bias') in P else None, dlog, _v2(Xin))
+            if dX is None:
+                dX = empty(*Xin.shape)
+            K.gemm([dict(A=dlog, B=P[name + '.0.weight'], C=_v2(dX), accumulate=not first)], b_kmajor=True)
+            first = False
+        return dX
+
+    dHFR_h = head_bwd(['human_frame_recognition_mlp', 'human_frame_prediction_mlp'], y_h[:2], dy_h[:2], HFR[0], H)
+    dR_h = head_bwd(['human_recognition_mlp', 'human_prediction_mlp'], y_h[2:], dy_h[2:], S['R_h'], H)
+    dHFR_o = dR_o = None
+    if p.n_aff is not None:
+        dHFR_o = head_bwd(['object_frame_recognition_mlp', 'object_frame_prediction_mlp'], y_o[:2], dy_o[:2], HFR[1], O)
+        dR_o = head_bwd(['object_recognition_mlp', 'object_prediction_mlp'], y_o[2:], dy_o[2:], S['R_o'], O)
+
+    # ---- G. reorder backward
+    gates = S['gates']
+    dHS_h = K.reorder_bwd(dR_h, gates['h']['hard']) if dR_h is not None else zeros(bs, T, H, 2 * h)
+    dHS_o = (K.reorder_bwd(dR_o, gates['o']['hard']) if dR_o is not None else zeros(bs, T, O, 2 * h))
+
+    # ---- F. segment-level recurrence backward
+    seg_p, sb = S['seg_p'], S['seg_bufs']
+    so = K.segrnn_bwd(seg_p, sb, dHS_h, dHS_o)
+    HUM, OBJ, GEO = S['HUM'], S['OBJ'], S['GEO']
+    HUMv, OBJv, GEOv = _v2(HUM), _v2(OBJ), _v2(GEO)
+    dHUM, dOBJ, dGEO = zeros(bs, T, H, p.Wh), zeros(bs, T, O, p.Wo), zeros(bs, T, 1, p.Ws)
+    dHUMv, dOBJv, dGEOv = _v2(dHUM), _v2(dOBJ), _v2(dGEO)
+    cells = {('h', 0): 'human_segment_rnn_fcell', ('h', 1): 'human_segment_rnn_bcell',
+             ('o', 0): 'object_segment_rnn_fcell', ('o', 1): 'object_segment_rnn_bcell'}
+    for kind, E, Ev, dEv, fw, dgi, dgh, HS, mg in (('h', H, HUMv, dHUMv, p.fw_h, so['d_gi_h'], so['d_gh_h'], sb['hs_h'], sb['mg_h']),
+                                                    ('o', O, OBJv, dOBJv, p.fw_o, so['d_gi_o'], so['d_gh_o'], sb['hs_o'], sb['mg_o'])):
+        if E == 0:
+            continue
+        dgiv, dghv = _v2(dgi), _v2(dgh)
+        for d in range(2):
+            c = cells[(kind, d)]
+            dgi_d = dgiv[:, d * 3 * h:(d + 1) * 3 * h]
+            w_ih = P[c + '.weight_ih']
+            dW_ih = empty(*w_ih.shape)
+            K.gemm([dict(A=dgi_d, B=Ev[:, h:h + fw], C=dW_ih[:, :fw])], a_kmajor=True, b_kmajor=True)
+            if w_ih.shape[1] > fw:
+                K.gemm([dict(A=dgi_d, B=_v2(mg[d]), C=dW_ih[:, fw:])], a_kmajor=True, b_kmajor=True)
+            G.add(c + '.weight_ih', dW_ih)
+            G.add(c + '.bias_ih', K.colsum(dgi_d))
+            # dW_hh = sum over steps with a previous state: forward chain pairs (t, t-1), backward chain (t, t+1)
+            dW_hh = empty(3 * h, h)
+            if T > 1:
+                if d == 0:
+                    A = dgh[:, 1:, :, 0:3 * h].reshape(bs, (T - 1) * E, 3 * h)
+                    B = HS[:, :T - 1, :, 0:h].reshape(bs, (T - 1) * E, h)
+                else:
+                    A = dgh[:, :T - 1, :, 3 * h:6 * h].reshape(bs, (T - 1) * E, 3 * h)
+                    B = HS[:, 1:, :, h:2 * h].reshape(bs, (T - 1) * E, h)
+                assert A.data_ptr() != 0 and A._base is not None and B._base is not None  # views, not copies
+                K.gemm([dict(A=A, B=B, C=dW_hh)], a_kmajor=True, b_kmajor=True)
+            else:
+                dW_hh.zero_()
+            G.add(c + '.weight_hh', dW_hh)
+            G.add(c + '.bias_hh', K.colsum(dghv[:, d * 3 * h:(d + 1) * 3 * h]))
+            # d xx (frame-level part of the GRUCell input) -> entity-row gradient columns [h, h+fw)
+            K.gemm([dict(A=dgi_d, B=w_ih[:, :fw], C=dEv[:, h:h + fw], accumulate=True)], b_kmajor=True)
+    if p.msg_segment:
+        sh_rel, so_rel = S['seg_rels']
+        for rels, E, dpre, HS, key in ((sh_rel, H, so['d_pre_h'], sb['hs_h'], 'h'), (so_rel, O, so['d_pre_o'], sb['hs_o'], 'o')):
+            if not rels or E == 0:
+                continue
+            n = len(rels)
+            dWp = empty(n * h, h)
+            if T > 1:
+                K.gemm([dict(A=dpre[0][:, 1:].reshape(bs, (T - 1) * E, n * h), B=HS[:, :T - 1, :, 0:h].reshape(bs, (T - 1) * E, h),
+                             C=dWp)], a_kmajor=True, b_kmajor=True)
+                K.gemm([dict(A=dpre[1][:, :T - 1].reshape(bs, (T - 1) * E, n * h), B=HS[:, 1:, :, h:2 * h].reshape(bs, (T - 1) * E, h),
+                             C=dWp, accumulate=True)], a_kmajor=True, b_kmajor=True)
+            else:
+                dWp.zero_()
+            dbp = K.colsum(dpre.view(-1, n * h))
+            for i, r in enumerate(rels):
+                G.add(_SEG_MLP[r] + '.0.weight', dWp[i * h:(i + 1) * h])
+                G.add(_SEG_MLP[r] + '.0.bias', dbp[i * h:(i + 1) * h])
+
+    # ---- gates backward (straight-through: d hard / d soft = 1, cut at the forced last step; models.py:701-702)
+    for kind, Ev, dEv, E, cols, mlp, du in (('h', HUMv, dHUMv, H, p.gate_cols_h(), 'update_human_segment_mlp', so['d_u_h']),
+                                             ('o', OBJv, dOBJv, O, p.gate_cols_o(), 'update_object_segment_mlp', so['d_u_o'])):
+        gt = gates[kind]
+        if not gt['learned'] or E == 0:
+            continue
+        dh_ext = d_hard[kind]
+        if dh_ext is not None:
+            K.add_rows(_v2(dh_ext.contiguous().view(1, -1)), _v2(du.view(1, -1)))
+        d = gt['desc']
+        if p.filter:
+            d = dict(d)
+            d['force_last'] = 0  # the filter rebuilds the hard gates from the soft ones (Appendix A13)
+        dlogit = K.gate_bwd(d, du, d_soft[kind].contiguous() if d_soft[kind] is not None else None, gt['gmask'])
+        w = P[mlp + '.0.weight'].view(-1)
+        dw = empty(w.numel())
+        for i, c in enumerate(cols):
+            K.rank1_update(dEv[:, c:c + h], dlogit, w[i * h:(i + 1) * h])
+            K.colsum(Ev[:, c:c + h], rowscale=dlogit, out=dw[i * h:(i + 1) * h])
+        G.add(mlp + '.0.weight', dw.view(1, -1))
+        if (mlp + '.0.bias') in P:
+            G.add(mlp + '.0.bias', K.colsum(dlogit.view(-1, 1)))
+
+    # ---- D. frame-level attention + sender MLPs backward
+    MSGH, MSGO, MSGS = S['MSGH'], S['MSGO'], S['MSGS']
+    dMSGH, dMSGO, dMSGS = empty(*MSGH.shape), empty(*MSGO.shape), empty(*MSGS.shape)
+
+    def msgv(buf, rels, rel):
+        if rel not in rels:
+            return None
+        i = rels.index(rel)
+        return buf[:, i * h:(i + 1) * h]
+
+    f = dict(feat_h=HUMv[:, :2 * h], feat_o=OBJv[:, :2 * h],
+             msg_hh=msgv(MSGH, p.snd_h, 'hh'), msg_ho=msgv(MSGH, p.snd_h, 'ho'),
+             msg_oh=msgv(MSGO, p.snd_o, 'oh'), msg_oo=msgv(MSGO, p.snd_o, 'oo'),
+             msg_so=msgv(MSGS, p.snd_s, 'so'), msg_sh=msgv(MSGS, p.snd_s, 'sh'),
+             obj_mask=objects_mask, att=S['att'], n_inst=nF, inst_per_clip=T, H=H, O=O, D=2 * h, hidden=h,
+             scale=p.scale_frame, recv_mask_ho=1)
+    bdesc = dict(f=f, dfeat_h=dHUMv[:, :2 * h], dfeat_o=dOBJv[:, :2 * h], dfeat_accumulate=1, relu_mask_dmsg=1,
+                 dmsg_hh=msgv(dMSGH, p.snd_h, 'hh'), dmsg_ho=msgv(dMSGH, p.snd_h, 'ho'),
+                 dmsg_oh=msgv(dMSGO, p.snd_o, 'oh'), dmsg_oo=msgv(dMSGO, p.snd_o, 'oo'),
+                 dmsg_so=msgv(dMSGS, p.snd_s, 'so'), dmsg_sh=msgv(dMSGS, p.snd_s, 'sh'))
+    for rel, c in p.col_h.items():
+        bdesc['dout_' + rel] = dHUMv[:, c:c + h]
+    for rel, c in p.col_o.items():
+        bdesc['dout_' + rel] = dOBJv[:, c:c + h]
+    K.attn_bwd([bdesc])
+    for dbuf, Ev, dEv, rels in ((dMSGH, HUMv, dHUMv, p.snd_h), (dMSGO, OBJv, dOBJv, p.snd_o), (dMSGS, GEOv, dGEOv, p.snd_s)):
+        for i, rel in enumerate(rels):
+            dpre = dbuf[:, i * h:(i + 1) * h]
+            name = _FRAME_MLP[rel]
+            _lin_w_grads(K, G, name + '.0.weight', name + '.0.bias', dpre, Ev[:, :2 * h])
+            K.gemm([dict(A=dpre, B=P[name + '.0.weight'], C=dEv[:, :2 * h], accumulate=True)], b_kmajor=True)
+
+    # ---- C. BiGRU embedding + BiGRU backward
+    ents = (('human', HUMv, dHUMv, H, dHFR_h), ('object', OBJv, dOBJv, O, dHFR_o), ('geometry', GEOv, dGEOv, 1, None))
+    types, dhfrs = [], []
+    for (name, Ev, dEv, E, dhfr), hfr, save in zip(ents, HFR, S['bigru_save']):
+        dpre = K.relu_bwd(dEv[:, h:2 * h], Ev[:, h:2 * h])
+        _lin_w_grads(K, G, name + '_bd_embedding_mlp.0.weight', name + '_bd_embedding_mlp.0.bias', dpre, _v2(hfr))
+        acc = dhfr is not None
+        if dhfr is None:
+            dhfr = empty(bs, T, E, 2 * h)
+        K.gemm([dict(A=dpre, B=P[name + '_bd_embedding_mlp.0.weight'], C=_v2(dhfr), accumulate=acc)], b_kmajor=True)
+        dhfrs.append(dhfr)
+        types.append(dict(d_out=dhfr, save=save, out=hfr, w_hh_f=P[name + '_bd_rnn.weight_hh_l0'],
+                          w_hh_r=P[name + '_bd_rnn.weight_hh_l0_reverse']))
+    res = K.bigru_bwd(types, bs, T, h)
+    for (name, Ev, dEv, E, _), hfr, (dgi, dgh) in zip(ents, HFR, res):
+        dgiv, dghv = _v2(dgi), _v2(dgh)
+        for d, sfx in enumerate(('', '_reverse')):
+            dgi_d = dgiv[:, d * 3 * h:(d + 1) * 3 * h]
+            _lin_w_grads(K, G, f'{name}_bd_rnn.weight_ih_l0{sfx}', f'{name}_bd_rnn.bias_ih_l0{sfx}', dgi_d, Ev[:, :h])
+            dW_hh = empty(3 * h, h)
+            if T > 1:
+                if d == 0:
+                    A = dgh[:, 1:, :, 0:3 * h].reshape(bs, (T - 1) * E, 3 * h)
+                    B = hfr[:, :T - 1, :, 0:h].reshape(bs, (T - 1) * E, h)
+                else:
+                    A = dgh[:, :T - 1, :, 3 * h:6 * h].reshape(bs, (T - 1) * E, 3 * h)
+                    B = hfr[:, 1:, :, h:2 * h].reshape(bs, (T - 1) * E, h)
+                K.gemm([dict(A=A, B=B, C=dW_hh)], a_kmajor=True, b_kmajor=True)
+            else:
+                dW_hh.zero_()
+            G.add(f'{name}_bd_rnn.weight_hh_l0{sfx}', dW_hh)
+            G.add(f'{name}_bd_rnn.bias_hh_l0{sfx}', K.colsum(dghv[:, d * 3 * h:(d + 1) * 3 * h]))
+            K.gemm([dict(A=dgi_d, B=P[f'{name}_bd_rnn.weight_ih_l0{sfx}'], C=dEv[:, :h], accumulate=True)], b_kmajor=True)
+
+    # ---- B. embeddings backward
+    xh_in = x_human.view(nF * H, x_human.shape[-1])[:, :2048]
+    xo_in = x_objects.view(nF * O, x_objects.shape[-1])
+    dpre_h = K.relu_bwd(dHUMv[:, :h], HUMv[:, :h])
+    _lin_w_grads(K, G, 'human_embedding_mlp.0.weight', 'human_embedding_mlp.0.bias', dpre_h, xh_in)
+    if O > 0:
+        dpre_o = K.relu_bwd(dOBJv[:, :h], OBJv[:, :h])
+        _lin_w_grads(K, G, 'object_embedding_mlp.0.weight', 'object_embedding_mlp.0.bias', dpre_o, xo_in)
+    dpre_s = K.relu_bwd(dGEOv[:, :h], GEOv[:, :h])
+    t1 = S['t1']
+    _lin_w_grads(K, G, 'geometry_embedding_mlp.2.weight', 'geometry_embedding_mlp.2.bias', dpre_s, t1)
+    dt1 = empty(nF, 2048)
+    K.gemm([dict(A=dpre_s, B=P['geometry_embedding_mlp.2.weight'], C=dt1)], b_kmajor=True)
+    K.relu_bwd(dt1, t1, dt1)
+    geo_in = S['Gout'].view(nF, 128 * N)
+    _lin_w_grads(K, G, 'geometry_embedding_mlp.0.weight', 'geometry_embedding_mlp.0.bias', dt1, geo_in)
+    dGout = empty(bs, 128, N, T)
+    K.gemm([dict(A=dt1, B=P['geometry_embedding_mlp.0.weight'], C=dGout.view(nF, 128 * N))], b_kmajor=True)
+
+    # ---- A. GCN backward
+    g = 'geometry_embedding_gcn.'
+    Z, X, QK, e1 = S['Z'], S['X'], S['QK'], S['e1']
+    dZ = empty(nF * N, 64)
+    dZv = dZ.view(bs, T, N, 64).permute(0, 2, 1, 3)
+    K.gemm([dict(A=dGout[0].view(128, N * T), B=P[g + 'weight'], C=dZv[0], batch=(bs, 128 * N * T, 0, T * N * 64))],
+           a_kmajor=True, b_kmajor=False)
+    Zv = Z.view(bs, T, N, 64).permute(0, 2, 1, 3)
+    dWp = empty(bs, 64, 128)
+    K.gemm([dict(A=Zv[0], B=dGout[0].view(128, N * T), C=dWp[0], batch=(bs, T * N * 64, 128 * N * T, 64 * 128))],
+           a_kmajor=True, b_kmajor=False)
+    G.add(g + 'weight', K.colsum(dWp.view(bs, 64 * 128)).view(64, 128))
+    dX, dQK = K.gcn_attn_bwd(QK, X, S['adj'], dZ, nF, N)
+    wq, wk = P[g + 'get_s.s1.cnn.weight'].view(128, 64), P[g + 'get_s.s2.cnn.weight'].view(128, 64)
+    K.gemm([dict(A=dQK[:, :128], B=wq, C=dX, accumulate=True)], b_kmajor=True)
+    K.gemm([dict(A=dQK[:, 128:], B=wk, C=dX, accumulate=True)], b_kmajor=True)
+    dwq, dwk = empty(128, 64), empty(128, 64)
+    K.gemm([dict(A=dQK[:, :128], B=X, C=dwq), dict(A=dQK[:, 128:], B=X, C=dwk)], a_kmajor=True, b_kmajor=True)
+    G.add(g + 'get_s.s1.cnn.weight', dwq.view(128, 64, 1, 1))
+    G.add(g + 'get_s.s2.cnn.weight', dwk.view(128, 64, 1, 1))
+    G.add(g + 'get_s.s1.cnn.bias', K.colsum(dQK[:, :128]))
+    G.add(g + 'get_s.s2.cnn.bias', K.colsum(dQK[:, 128:]))
+    K.relu_bwd(dX, X, dX)
+    w2 = P[g + 'joint_embed.cnn.3.cnn.weight'].view(64, 64)
+    dw2 = empty(64, 64)
+    K.gemm([dict(A=dX, B=e1, C=dw2)], a_kmajor=True, b_kmajor=True)
+    G.add(g + 'joint_embed.cnn.3.cnn.weight', dw2.view(64, 64, 1, 1))
+    G.add(g + 'joint_embed.cnn.3.cnn.bias', K.colsum(dX))
+    de1 = empty(nF * N, 64)
+    K.gemm([dict(A=dX, B=w2, C=de1)], b_kmajor=True)
+    K.relu_bwd(de1, e1, de1)
+    w1 = P[g + 'joint_embed.cnn.1.cnn.weight'].view(64, 4)
+    dw1, db1, dgamma, dbeta = K.gcn_embed1_bwd(x_human, N, S['ab'], S['mi'], w1, de1)
+    G.add(g + 'joint_embed.cnn.1.cnn.weight', dw1.view(64, 4, 1, 1))
+    G.add(g + 'joint_embed.cnn.1.cnn.bias', db1)
+    G.add(g + 'joint_embed.cnn.0.bn.weight', dgamma)
+    G.add(g + 'joint_embed.cnn.0.bn.bias', dbeta)
+    return G.g
+
+
+class TGGCNFunction(torch.autograd.Function):
+    """One autograd node for the whole hot path. Inputs after the fixed ones are the parameters in the order of
+    ``used_parameter_names(plan)``."""
+
+    @staticmethod
+    def forward(ctx, plan, names, training, bn_bufs, x_human, x_objects, objects_mask, human_seg, object_seg, noise,
+                *params):
+        K = get_kernels()
+        P = dict(zip(names, params))
+        outputs, S = tggcn_forward(K, plan, P, x_human, x_objects, objects_mask, human_seg, object_seg, noise,
+                                   training, bn_bufs)
+        ctx.plan, ctx.names, ctx.S, ctx.P = plan, names, S, P
+        ctx.inputs = (x_human, x_objects, objects_mask)
+        n_gate = 2 if plan.n_aff is None else 4
+        hard = outputs[:n_gate // 2]
+        ctx.mark_non_differentiable(*[o for o, gk in zip(hard, ('h', 'o')) if not S['gates'][gk]['learned']])
+        ctx.set_materialize_grads(False)
+        return tuple(outputs)
+
+    @staticmethod
+    def backward(ctx, *d_outputs):
+        K = get_kernels()
+        plan = ctx.plan
+        x_human, x_objects, objects_mask = ctx.inputs
+        d_outputs = list(d_outputs)
+        gates = ctx.S['gates']
+        # a gate tensor that was given as an input (not learned) carries no gradient
+        n_gate = 2 if plan.n_aff is None else 4
+        kinds = ['h', 'h'] if plan.n_aff is None else ['h', 'o', 'h', 'o']
+        for i in range(n_gate):
+            if not gates[kinds[i]]['learned']:
+                d_outputs[i] = None
+        grads = tggcn_backward(K, plan, ctx.P, ctx.S, x_human, x_objects, objects_mask, d_outputs)
+        out = [None] * 10
+        for n in ctx.names:
+            g = grads.get(n)
+            if g is not None:
+                g = g.reshape(ctx.P[n].shape)
+            out.append(g)
+        ctx.S = None
+        return tuple(out)

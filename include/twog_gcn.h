@@ -1,0 +1,320 @@
+/*
+ * twog_gcn.h -- C ABI of lib2ggcn_hip.so: the MI355X (gfx950) kernels of the 2G-GCN hot path.
+ *
+ * The reference (tanqiu98/2G-GCN) is pure Python/PyTorch and has no FFI of its own; its hot path is TGGCN.forward
+ * (vhoi/models.py:584-933) and the ATen ops that forward dispatches. Each entry point below replaces one group of
+ * those ops (cited per function; all citations are relative to the reference tree). Conventions:
+ *   - every pointer is a DEVICE pointer to fp32 unless stated, owned by the caller, and must stay alive until the work
+ *     enqueued on `stream` has completed (torch autograd's saved tensors guarantee that on the Python side);
+ *   - no entry point allocates, synchronises the device, or keeps global mutable state (re-entrant per stream);
+ *   - return value: 0 on success, a negative hipError_t / negative argument-error code otherwise; nothing throws;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream).
+ *
+ * Strided rows: most kernels address matrix rows through `twog_rows_t`, so a (clip, entity) row set living inside a
+ * larger (clip, time, entity, feature) tensor is used in place, with no gather/cat copy:
+ *      address(row r, col c) = ptr + (r / inner) * ld_outer + (r % inner) * ld_inner + c        (c contiguous)
+ */
+#ifndef TWOG_GCN_H
+#define TWOG_GCN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct {
+    float* ptr;
+    int64_t ld_outer; /* elements between consecutive outer groups    */
+    int64_t ld_inner; /* elements between consecutive rows in a group */
+    int32_t inner;    /* rows per outer group (<= 1: plain row stride = ld_outer) */
+    int32_t pad_;
+} twog_rows_t;
+
+/* Human-readable build/info string (arch, tile sizes). */
+const char* twog_version(void);
+
+/* ===============================================================================================================
+ * Dense projections on fp32 MFMA (v_mfma_f32_32x32x2_f32). Replaces every nn.Linear of build_mlp
+ * (pyrutils/torch/models.py:31-36), the GRU/GRUCell input and hidden projections (vhoi/models.py:267-320), the
+ * message MLPs (:323-520), the label heads (:552-580), the 1x1 convolutions of Geo_gcn (pyrutils/torch/
+ * models_gcn.py:57-63, :95-96, :35) and, with the k-major operand forms, all their backward passes.
+ *      C[m][n] = act( sum_k A(m,k) * B(n,k) + bias[n] ) (+ C[m][n] if accumulate)
+ * a_kmajor = 0: A stored [M rows][K contiguous];            1: A stored [K rows][M contiguous].
+ * b_kmajor = 0: B stored [N rows][K contiguous] (nn.Linear weight); 1: B stored [K rows][N contiguous].
+ * The strided index of each operand goes through twog_rows_t. All problems of one call share the layout flags and run
+ * as grouped launches. `workspace` (may be NULL) enables deterministic split-K for tall-reduction/small-output shapes.
+ * =============================================================================================================== */
+typedef struct {
+    twog_rows_t A, B, C;
+    const float* bias;  /* [N] or NULL */
+    int32_t M, N, K;
+    int32_t act;        /* 0 none, 1 relu */
+    int32_t accumulate; /* 0: C = ..., 1: C += ... */
+    int32_t batch;      /* >= 1 independent problems of this shape; operand of batch i = ptr + i * *_batch_stride */
+    int64_t a_batch_stride, b_batch_stride, c_batch_stride;
+} twog_gemm_t;
+int twog_gemm_f32(const twog_gemm_t* problems, int n_problems, int a_kmajor, int b_kmajor, void* workspace,
+                  size_t workspace_bytes, void* stream);
+
+/* ===============================================================================================================
+ * Geometric-level GCN (pyrutils/torch/models_gcn.py:6-100; called at vhoi/models.py:640-645).
+ * x_geo = x_human + 2048 (geometry of human 0, vhoi/models.py:636-639), frame f at x_geo + f*frame_stride, node n,
+ * feature c at [n*4 + c]; BatchNorm channel = c*N + n (models_gcn.py:47).
+ * =============================================================================================================== */
+int twog_gcn_max_nodes(void);
+/* norm_data train-mode batch statistics (models_gcn.py:43-49): per-block fp64 partial sums
+ * partials[n_blocks][2][4N] (sum, sum of squares; channel order). */
+int twog_bn_stats(const float* x_geo, int64_t frame_stride, int n_frames, int n_nodes, double* partials, int n_blocks,
+                  void* stream);
+/* Folds BatchNorm into x^ = a*x + b per channel: ab[2][4N]; mean_invstd[2][4N] is kept for the backward pass.
+ * training != 0: batch statistics (biased variance), running stats updated with momentum 0.1 / unbiased variance,
+ * num_batches_tracked += 1 (torch BatchNorm1d semantics); training == 0: running statistics. */
+int twog_bn_finalize(const double* partials, int n_blocks, int n_frames, int n_nodes, const float* gamma,
+                     const float* beta, float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                     int training, float* ab, float* mean_invstd, void* stream);
+/* embed layer 1 (models_gcn.py:57-59): e1[(f,n)][64] = relu(W1 (a*x+b) + b1), W1 [64][4]. */
+int twog_gcn_embed1_fwd(const float* x_geo, int64_t frame_stride, int n_frames, int n_nodes, const float* ab,
+                        const float* w1, const float* b1, float* e1, void* stream);
+/* Backward of layer 1 given de1 (already ReLU-masked): dw1[64][4], db1[64], dgamma[4N], dbeta[4N].
+ * partials: scratch [n_blocks][320 + 8N] floats. */
+int twog_gcn_embed1_bwd(const float* x_geo, int64_t frame_stride, int n_frames, int n_nodes, const float* ab,
+                        const float* mean_invstd, const float* w1, const float* de1, float* partials, int n_blocks,
+                        float* dw1, float* db1, float* dgamma, float* dbeta, void* stream);
+/* compute_similarity + aggregation per frame (models_gcn.py:95-100, :33-34): qk [(f,n)][256] = [theta(x) | phi(x)],
+ * x [(f,n)][64]; s_out [f][N][N] = softmax_j(q_i . k_j) (no 1/sqrt(d)); z [(f,n)][64] = S x. */
+int twog_gcn_attn_fwd(const float* qk, const float* x, int n_frames, int n_nodes, float* s_out, float* z,
+                      void* stream);
+/* Backward: dx_att [(f,n)][64] = S^T dz ; dqk [(f,n)][256] = [dP k | dP^T q], dP = S*(dS - rowsum(dS*S)), dS = dz x^T. */
+int twog_gcn_attn_bwd(const float* qk, const float* x, const float* s, const float* dz, int n_frames, int n_nodes,
+                      float* dx_att, float* dqk, void* stream);
+
+/* ===============================================================================================================
+ * GRU gate math (torch.nn.GRU / GRUCell semantics, gate order r,z,n) for the frame-level BiGRUs
+ * (vhoi/models.py:983-1002) and the gated segment-level step h_t = u*GRUCell(x,h) + (1-u)*h (vhoi/models.py:1535-1564).
+ * gi / gh are the input / hidden projections (biases included) produced by twog_gemm_f32.
+ * =============================================================================================================== */
+typedef struct {
+    twog_rows_t gi;     /* [rows][3h]  W_ih x + b_ih                                      */
+    twog_rows_t gi2;    /* optional second addend of gi (ptr NULL if unused)              */
+    twog_rows_t gh;     /* [rows][3h]  W_hh h_prev + b_hh                                 */
+    twog_rows_t h_prev; /* [rows][h]   (ptr NULL => zeros)                                */
+    twog_rows_t h_out;  /* [rows][h]                                                      */
+    twog_rows_t save;   /* [rows][4h]  r, z, n, (W_hn h + b_hn) for backward (ptr NULL ok) */
+    const float* u;     /* gate per row or NULL (plain GRU): u[(r/u_inner)*u_ld_outer + (r%u_inner)*u_ld_inner] */
+    int64_t u_ld_outer, u_ld_inner;
+    int32_t u_inner;
+    int32_t rows, hidden;
+    int32_t pad_;
+} twog_gru_step_t;
+int twog_gru_step_fwd(const twog_gru_step_t* steps, int n_steps, void* stream);
+
+typedef struct {
+    twog_rows_t dh;      /* [rows][h] gradient wrt h_out of this step                                  */
+    twog_rows_t dh2;     /* optional second addend of dh (carried gradient; ptr NULL if unused)         */
+    twog_rows_t save;    /* [rows][4h] from the forward step                                            */
+    twog_rows_t h_prev;  /* [rows][h] (ptr NULL => zeros)                                               */
+    twog_rows_t dgi;     /* out [rows][3h]                                                              */
+    twog_rows_t dgh;     /* out [rows][3h]                                                              */
+    twog_rows_t dh_prev; /* out [rows][h]: direct path (1-u)*dh + u*dh*z; the W_hh path is added by a GEMM */
+    const float* u;      /* as in twog_gru_step_t                                                       */
+    float* du;           /* += sum_j dh_j*(gru_j - h_prev_j) per row (atomic add), addressed like u; NULL ok */
+    int64_t u_ld_outer, u_ld_inner;
+    int32_t u_inner;
+    int32_t rows, hidden;
+    int32_t dh_prev_accumulate; /* 1: dh_prev += */
+} twog_gru_step_bwd_t;
+int twog_gru_step_bwd(const twog_gru_step_bwd_t* steps, int n_steps, void* stream);
+
+/* Frame-level bidirectional GRU recurrence (vhoi/models.py:983-1002), all entities of a type batched as rows,
+ * both directions and up to 4 entity types advancing in the same launches. */
+typedef struct {
+    const float* gi;     /* [bs][T][E][6h] W_ih x + b_ih: cols [0,3h) forward direction, [3h,6h) reverse */
+    const float* w_hh_f; /* [3h][h] weight_hh_l0          */
+    const float* b_hh_f; /* [3h]                          */
+    const float* w_hh_r; /* [3h][h] weight_hh_l0_reverse  */
+    const float* b_hh_r;
+    float* out;          /* [bs][T][E][2h] (forward | reverse), = h_fr of the reference                  */
+    float* save;         /* [2][bs][T][E][4h]                                                            */
+    float* tmp_gh;       /* scratch [2][bs*E][3h]                                                        */
+    float* zeros;        /* [bs*E][h] zeros (initial state)                                              */
+    int32_t E;
+    int32_t pad_;
+} twog_bigru_t;
+int twog_bigru_fwd(const twog_bigru_t* types, int n_types, int bs, int T, int hidden, void* stream);
+
+typedef struct {
+    const float* d_out;  /* [bs][T][E][2h] gradient wrt out                                              */
+    const float* save;
+    const float* out;
+    const float* w_hh_f;
+    const float* w_hh_r;
+    float* d_gi;         /* out [bs][T][E][6h] gradient wrt gi                                           */
+    float* d_gh;         /* out [bs][T][E][6h] gradient wrt (W_hh h_prev + b_hh)                         */
+    float* carry;        /* scratch [2][bs*E][h]                                                         */
+    int32_t E;
+    int32_t pad_;
+} twog_bigru_bwd_t;
+int twog_bigru_bwd(const twog_bigru_bwd_t* types, int n_types, int bs, int T, int hidden, void* stream);
+
+/* ===============================================================================================================
+ * Fusion-level attention message passing (vhoi/models.py:1004-1475, :1693-1754) for message_type 'v2', granularity
+ * 'v1' (generic), aggregation 'att', attention styles 'v2'/'v3' (dot / scaled dot product).
+ * One instance = one (clip, frame) at frame level, one clip at segment level; entities: H humans, O objects, plus the
+ * single-sender geometry relations. Per instance and relation with receiver r and senders s:
+ *      w_rs = softmax_s( q_r . k_s * scale ) over non-virtual senders (objects_mask), NaN -> 0 (:1750-1753)
+ *      out_r = [recv_mask_r] * sum_s w_rs * msg_s
+ * relations: hh (human<-other humans), oh (human<-objects), sh (human<-geometry), ho (object<-humans),
+ *            so (object<-geometry), oo (object<-other objects). A relation is off when its msg ptr is NULL.
+ * =============================================================================================================== */
+typedef struct {
+    twog_rows_t feat_h;  /* [inst*H][D] query/key features of humans */
+    twog_rows_t feat_o;  /* [inst*O][D] of objects                   */
+    twog_rows_t msg_hh, msg_ho; /* [inst*H][hidden] messages sent BY humans (to humans / to objects)          */
+    twog_rows_t msg_oh, msg_oo; /* [inst*O][hidden] messages sent BY objects (to humans / to objects)         */
+    twog_rows_t msg_so, msg_sh; /* [inst][hidden]   messages sent by the geometry node (to objects / humans)  */
+    twog_rows_t out_hh, out_oh, out_sh; /* [inst*H][hidden] received by humans  */
+    twog_rows_t out_ho, out_so, out_oo; /* [inst*O][hidden] received by objects */
+    const float* obj_mask; /* [clips][O], clip = inst / inst_per_clip; NULL => all real */
+    float* att;            /* saved weights [inst][H*H + H*O + O*H + O*O] (hh, oh, ho, oo); NULL ok in forward */
+    int32_t n_inst, inst_per_clip, H, O, D, hidden;
+    float scale;           /* 1 ('v2') or 1/sqrt(D) ('v3', :1745) */
+    int32_t recv_mask_ho;  /* 1: out_ho and out_so are multiplied by obj_mask of the receiver (frame level,
+                              vhoi/models.py:720,729); 0: not (segment level, :841-843) */
+} twog_attn_t;
+int twog_attn_fwd(const twog_attn_t* a, int n, void* stream);
+int twog_attn_limits(int* max_h, int* max_o);
+
+typedef struct {
+    twog_attn_t f;       /* the forward descriptor (features, messages, saved att; out_* unused) */
+    twog_rows_t dout_hh, dout_oh, dout_sh, dout_ho, dout_so, dout_oo; /* incoming gradients wrt out_*         */
+    twog_rows_t dmsg_hh, dmsg_ho, dmsg_oh, dmsg_oo, dmsg_so, dmsg_sh; /* out: gradient wrt sender messages    */
+    twog_rows_t dfeat_h, dfeat_o; /* out: gradient wrt features [..][D]                                       */
+    int32_t dfeat_accumulate;     /* 1: dfeat += */
+    int32_t relu_mask_dmsg;       /* 1: dmsg *= (msg > 0), i.e. gradient wrt the pre-ReLU activation of the message MLP */
+} twog_attn_bwd_t;
+int twog_attn_bwd(const twog_attn_bwd_t* a, int n, void* stream);
+
+/* ===============================================================================================================
+ * Segment-level gated bidirectional recurrence with message passing (vhoi/models.py:785-880, :1535-1564,
+ * :1051, :1145, :1239, :1334). Buffers are (clip, time, entity)-ordered; [2] = direction (0 forward, 1 backward).
+ * nsh/nso = number of enabled sender MLPs on human/object states ((hh|ho) / (oh|oo)); nmh/nmo = number of message
+ * blocks received by a human/object ((hh|oh) / (ho|oo)).
+ * =============================================================================================================== */
+typedef struct {
+    int32_t bs, T, H, O, hidden;
+    int32_t msg_segment;                    /* message_segment */
+    int32_t rel_hh, rel_ho, rel_oh, rel_oo; /* enabled relations */
+    float att_scale;
+    int32_t pad_;
+    const float* gi_h;     /* [bs][T][H][6h] frame part of W_ih x + b_ih: fcell cols [0,3h), bcell [3h,6h) */
+    const float* gi_o;     /* [bs][T][O][6h] */
+    const float* u_h;      /* hard gates [bs][T][H] */
+    const float* u_o;      /* [bs][T][O] */
+    const float* obj_mask; /* [bs][O] */
+    const float* w_hh_h[2]; const float* b_hh_h[2]; /* human_segment_rnn_{f,b}cell.weight_hh [3h][h], bias_hh */
+    const float* w_hh_o[2]; const float* b_hh_o[2];
+    const float* w_ihm_h[2]; /* &weight_ih[0][first message column] of the human cells, row stride ld_ih_h */
+    const float* w_ihm_o[2];
+    int64_t ld_ih_h, ld_ih_o;
+    const float* w_smsg_h; const float* b_smsg_h; /* packed sender MLPs on human states [(nsh*h)][h], [(nsh*h)] */
+    const float* w_smsg_o; const float* b_smsg_o; /* packed sender MLPs on object states */
+    float* hs_h;    /* out [bs][T][H][2h] (forward | backward states) */
+    float* hs_o;    /* out [bs][T][O][2h] */
+    float* save_h;  /* [2][bs][T][H][4h] */
+    float* save_o;  /* [2][bs][T][O][4h] */
+    float* msrc_h;  /* [2][bs][T][H][nsh*h] post-ReLU sender messages from humans */
+    float* msrc_o;  /* [2][bs][T][O][nso*h] */
+    float* mg_h;    /* [2][bs][T][H][nmh*h] aggregated messages received by humans */
+    float* mg_o;    /* [2][bs][T][O][nmo*h] */
+    float* att;     /* [2][T][bs][H*H + 2*H*O + O*O] */
+    float* tmp_gim_h; /* scratch [2][bs*H][3h] */
+    float* tmp_gim_o; /* scratch [2][bs*O][3h] */
+    float* tmp_gh_h;  /* scratch [2][bs*H][3h] */
+    float* tmp_gh_o;  /* scratch [2][bs*O][3h] */
+    float* zeros;     /* [bs*max(H,O)][h] zeros */
+} twog_segrnn_t;
+int twog_segrnn_fwd(const twog_segrnn_t* desc, void* stream);
+
+typedef struct {
+    const float* d_hs_h; /* [bs][T][H][2h] gradient wrt hs_h */
+    const float* d_hs_o;
+    float* d_gi_h;  /* out [bs][T][H][6h] gradient wrt the full W_ih x + b_ih (frame + message part) */
+    float* d_gi_o;
+    float* d_gh_h;  /* out [bs][T][H][6h] gradient wrt W_hh h_prev + b_hh */
+    float* d_gh_o;
+    float* d_u_h;   /* += [bs][T][H] gradient wrt the hard gates (caller zeroes) */
+    float* d_u_o;
+    float* d_pre_h; /* out [2][bs][T][H][nsh*h] gradient wrt the pre-ReLU sender-MLP activations */
+    float* d_pre_o;
+    float* carry_h; /* scratch [2][bs*H][h] */
+    float* carry_o; /* scratch [2][bs*O][h] */
+    float* tmp_dmg_h; /* scratch [2][bs*H][nmh*h] */
+    float* tmp_dmg_o; /* scratch [2][bs*O][nmo*h] */
+    float* trash;     /* scratch [bs*max(H,O)][h] */
+} twog_segrnn_bwd_t;
+int twog_segrnn_bwd(const twog_segrnn_t* desc, const twog_segrnn_bwd_t* bdesc, void* stream);
+
+/* ===============================================================================================================
+ * Segment-boundary gates (vhoi/models.py:1477-1533, :1620-1627; pyrutils/torch/distributions.py:4-53) with
+ * discrete_networks_num_layers == 1: p = sigmoid(w . [column blocks of the entity row] + b); 'gs': Gumbel-sigmoid
+ * with PRE-DRAWN noise, 'st' (noise == NULL): straight-through; hard = soft > thr; last step forced to 1 (:701-702).
+ * Rows are (b, t, e)-ordered; hard/soft/p_save are [bs][T][E].
+ * =============================================================================================================== */
+typedef struct {
+    twog_rows_t x;        /* entity rows; gate input = concat of n_seg column blocks of width `hidden` */
+    int32_t seg_col[8];   /* starting column in x of weight block i */
+    int32_t n_seg, hidden;
+    const float* w;       /* [n_seg*hidden] */
+    const float* b;       /* [1] or NULL    */
+    const float* noise;   /* Gumbel noise [T][noise_entities][bs][2] (reference call order) or NULL ('st') */
+    float* hard;
+    float* soft;
+    float* p_save;
+    int32_t bs, T, E;
+    int32_t noise_entities, noise_offset; /* this type's entity e uses noise slot noise_offset + e */
+    int32_t force_last;   /* 1: hard[:, T-1, :] = 1 and no gradient through it */
+    float threshold;
+    int32_t pad_;
+} twog_gate_t;
+int twog_gate_fwd(const twog_gate_t* g, void* stream);
+/* dlogit[row] = (d_soft[row] + d_hard[row]*st_mask[row]) * d soft / d logit. d_soft, d_hard, st_mask may be NULL
+ * (st_mask NULL => 1; with force_last the last step's d_hard is dropped). */
+int twog_gate_bwd(const twog_gate_t* g, const float* d_hard, const float* d_soft, const float* st_mask, float* dlogit,
+                  void* stream);
+/* dst[r][c] += s[r] * v[c]  (gate input gradient, one call per column block) */
+int twog_rank1_update(twog_rows_t dst, const float* s, const float* v, int rows, int cols, void* stream);
+/* out[c] (+)= sum_r rowscale[r] * x[r][c] (rowscale NULL => 1): bias gradients and gate weight gradients.
+ * Deterministic two-pass reduction; partials: scratch [n_blocks][cols]. */
+int twog_colsum(twog_rows_t x, const float* rowscale, int rows, int cols, float* out, int accumulate,
+                float* partials, int n_blocks, void* stream);
+
+/* filter_soft_decisions (vhoi/models.py:1637-1664): local-maximum filter on soft gates [bs][T][E];
+ * grad_mask = d hard / d soft (0 or 1) under the reference's straight-through + clamp semantics. */
+int twog_filter_fwd(const float* soft, float* hard, float* grad_mask, int bs, int T, int E, float threshold,
+                    void* stream);
+
+/* reorder_hidden_states (vhoi/models.py:1567-1586) without the host sync: out[b,t,e,:] = hx[b,idx,e,:], idx = first
+ * frame >= t whose gate is non-zero (t itself if none). hx/out: [bs][T][E][cols], gate: [bs][T][E]. */
+int twog_reorder_fwd(const float* hx, const float* gate, float* out, int bs, int T, int E, int cols, void* stream);
+int twog_reorder_bwd(const float* dout, const float* gate, float* dhx, int bs, int T, int E, int cols, void* stream);
+
+/* Label-head epilogue (vhoi/models.py:909-917): log_softmax over classes of logits [(b,t,e)][C] + the
+ * permute(0,3,1,2) store to [bs][C][T][E]; backward returns dlogits [(b,t,e)][C]. */
+int twog_logsoftmax_permute_fwd(const float* logits, float* out, int bs, int T, int E, int C, void* stream);
+int twog_logsoftmax_permute_bwd(const float* out, const float* dout, float* dlogits, int bs, int T, int E, int C,
+                                void* stream);
+
+/* Elementwise helpers between GEMMs in the backward pass: dx = dy * (y > 0) (ReLU'), dst += src. */
+int twog_relu_bwd(twog_rows_t dy, twog_rows_t y, twog_rows_t dx, int rows, int cols, void* stream);
+int twog_add_rows(twog_rows_t src, twog_rows_t dst, int rows, int cols, void* stream);
+
+/* Fused Adam on one flat fp32 parameter buffer (torch.optim.Adam semantics; reference train.py:39). */
+int twog_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
+                   float beta1, float beta2, float eps, float weight_decay, int step, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TWOG_GCN_H */

@@ -1,0 +1,519 @@
+"""TEST DOUBLE of the kernel interface (2g-gcn_amd/kernels.py::HipKernels) written in plain torch.
+
+Test infrastructure only (lives under tests/, injected explicitly through kernels._set_backend_for_tests):
+  * `-m "not gpu"` tests run the host logic (ops.py / models.py: buffer layouts, GEMM operand forms, the hand-derived
+    backward pass) on CPU against the oracle;
+  * `-m gpu` tests use each method here as the executable specification of the corresponding HIP kernel.
+It follows the *kernel contracts* of include/twog_gcn.h, not the product code.
+"""
+import math
+
+import torch
+
+
+def _mat(t):
+    return t.reshape(-1, t.shape[-1])
+
+
+class FakeKernels:
+    name = 'fake-torch'
+
+    def __init__(self):
+        self.calls = []
+
+    def version(self):
+        return 'fake'
+
+    def empty(self, *shape, like=None, dtype=torch.float32):
+        return torch.empty(*shape, dtype=dtype, device=like.device)
+
+    # ------------------------------------------------------------------ GEMM
+    def gemm(self, problems, a_kmajor=False, b_kmajor=False, split_k_workspace=True):
+        self.calls.append(('gemm', len(problems)))
+        for p in problems:
+            batch = p.get('batch') or (1, 0, 0, 0)
+            nb, sa, sb, sc = batch
+            for i in range(nb):
+                A = self._shift(p['A'], i * sa)
+                B = self._shift(p['B'], i * sb)
+                Cm = self._shift(p['C'], i * sc)
+                Am = _mat(A).t() if a_kmajor else _mat(A)
+                Bm = _mat(B).t() if b_kmajor else _mat(B)  # (N, K)
+                out = Am @ Bm.t()
+                if p.get('bias') is not None:
+                    out = out + p['bias']
+                if p.get('accumulate'):
+                    out = out + _mat(Cm)
+                if p.get('act', 0) == 1:
+                    out = torch.relu(out)
+                Cm.copy_(out.reshape(Cm.shape))
+
+    @staticmethod
+    def _shift(t, off):
+        if off == 0:
+            return t
+        return torch.as_strided(t, t.shape, t.stride(), t.storage_offset() + off)
+
+    # ------------------------------------------------------------------ GCN
+    @staticmethod
+    def _geo(x_human, N):
+        bs, T = x_human.shape[:2]
+        return x_human[:, :, 0, 2048:].reshape(bs * T, N, 4)
+
+    def bn_fold(self, x_human, n_nodes, gamma, beta, running_mean, running_var, num_batches_tracked, training):
+        N = n_nodes
+        x = self._geo(x_human, N).double()  # (F, N, 4)
+        xc = x.permute(2, 1, 0).reshape(4 * N, -1)  # channel c*N+n
+        nf = xc.shape[1]
+        if training:
+            mean = xc.mean(1)
+            var = (xc * xc).mean(1) - mean * mean
+            running_mean.mul_(0.9).add_(0.1 * mean.float())
+            running_var.mul_(0.9).add_(0.1 * (var * nf / max(nf - 1, 1)).float())
+            if num_batches_tracked is not None:
+                num_batches_tracked.add_(1)
+            mean, var = mean.float(), var.float()
+        else:
+            mean, var = running_mean.clone(), running_var.clone()
+        invstd = 1.0 / torch.sqrt(var + 1e-5)
+        a = gamma * invstd
+        return torch.stack([a, beta - mean * a]), torch.stack([mean, invstd])
+
+    def _xhat(self, x_human, N, ab):
+        x = self._geo(x_human, N)  # (F, N, 4)
+        a = ab[0].view(4, N).t()
+        b = ab[1].view(4, N).t()
+        return x * a + b  # (F, N, 4)
+
+    def gcn_embed1_fwd(self, x_human, n_nodes, ab, w1, b1):
+        xh = self._xhat(x_human, n_nodes, ab)
+        return torch.relu(xh.reshape(-1, 4) @ w1.t() + b1)
+
+    def gcn_embed1_bwd(self, x_human, n_nodes, ab, mean_invstd, w1, de1):
+        N = n_nodes
+        x = self._geo(x_human, N)
+        xh = self._xhat(x_human, N, ab).reshape(-1, 4)
+        dw1 = de1.t() @ xh
+        db1 = de1.sum(0)
+        dxh = (de1 @ w1).view(-1, N, 4)  # (F, N, 4)
+        da = (dxh * x).sum(0).t().reshape(-1)  # channel c*N+n
+        db = dxh.sum(0).t().reshape(-1)
+        mean, invstd = mean_invstd[0], mean_invstd[1]
+        return dw1, db1, invstd * (da - mean * db), db
+
+    def gcn_attn_fwd(self, qk, x, n_frames, n_nodes):
+        q = qk[:, :128].view(n_frames, n_nodes, 128)
+        k = qk[:, 128:].view(n_frames, n_nodes, 128)
+        xs = x.view(n_frames, n_nodes, 64)
+        s = torch.softmax(q @ k.transpose(1, 2), dim=-1)
+        return s.contiguous(), (s @ xs).reshape(-1, 64)
+
+    def gcn_attn_bwd(self, qk, x, s, dz, n_frames, n_nodes):
+        q = qk[:, :128].view(n_frames, n_nodes, 128)
+        k = qk[:, 128:].view(n_frames, n_nodes, 128)
+        xs = x.view(n_frames, n_nodes, 64)
+        dzs = dz.view(n_frames, n_nodes, 64)
+        dS = dzs @ xs.transpose(1, 2)
+        dx = s.transpose(1, 2) @ dzs
+        dP = s * (dS - (dS * s).sum(-1, keepdim=True))
+        dq = dP @ k
+        dk = dP.transpose(1, 2) @ q
+        return dx.reshape(-1, 64), torch.cat([dq, dk], -1).reshape(-1, 256)
+
+    # ------------------------------------------------------------------ GRU
+    @staticmethod
+    def _gates(gi, gh, hp, h):
+        r = torch.sigmoid(gi[..., :h] + gh[..., :h])
+        z = torch.sigmoid(gi[..., h:2 * h] + gh[..., h:2 * h])
+        hn = gh[..., 2 * h:]
+        n = torch.tanh(gi[..., 2 * h:] + r * hn)
+        return r, z, n, hn, (1 - z) * n + z * hp
+
+    @staticmethod
+    def _gates_bwd(d, save, hp, h, u=None):
+        r, z, n, hn = save[..., :h], save[..., h:2 * h], save[..., 2 * h:3 * h], save[..., 3 * h:]
+        g = (1 - z) * n + z * hp
+        du = (d * (g - hp)).sum(-1)
+        dg = d if u is None else u.unsqueeze(-1) * d
+        dprev = torch.zeros_like(d) if u is None else (1 - u.unsqueeze(-1)) * d
+        dn = dg * (1 - z)
+        dz = dg * (hp - n)
+        dprev = dprev + dg * z
+        dn_pre = dn * (1 - n * n)
+        dr_pre = dn_pre * hn * r * (1 - r)
+        dz_pre = dz * z * (1 - z)
+        dgi = torch.cat([dr_pre, dz_pre, dn_pre], -1)
+        dgh = torch.cat([dr_pre, dz_pre, dn_pre * r], -1)
+        return dgi, dgh, dprev, du
+
+    def bigru_fwd(self, types, bs, T, h):
+        outs = []
+        for y in types:
+            gi = y['gi']
+            E = gi.shape[2]
+            out = torch.zeros(bs, T, E, 2 * h, device=gi.device)
+            save = torch.zeros(2, bs, T, E, 4 * h, device=gi.device)
+            for d, (w, b) in enumerate(((y['w_hh_f'], y['b_hh_f']), (y['w_hh_r'], y['b_hh_r']))):
+                hp = torch.zeros(bs, E, h, device=gi.device)
+                order = range(T) if d == 0 else range(T - 1, -1, -1)
+                for t in order:
+                    gh = hp @ w.t() + b
+                    r, z, n, hn, g = self._gates(gi[:, t, :, d * 3 * h:(d + 1) * 3 * h], gh, hp, h)
+                    out[:, t, :, d * h:(d + 1) * h] = g
+                    save[d, :, t] = torch.cat([r, z, n, hn], -1)
+                    hp = g
+            outs.append((out, save))
+        return outs
+
+    def bigru_bwd(self, types, bs, T, h):
+        outs = []
+        for y in types:
+            d_out, save, out = y['d_out'], y['save'], y['out']
+            E = d_out.shape[2]
+            d_gi = torch.zeros(bs, T, E, 6 * h, device=d_out.device)
+            d_gh = torch.zeros_like(d_gi)
+            for d, w in enumerate((y['w_hh_f'], y['w_hh_r'])):
+                carry = torch.zeros(bs, E, h, device=d_out.device)
+                order = range(T - 1, -1, -1) if d == 0 else range(T)
+                for t in order:
+                    tp = t - 1 if d == 0 else t + 1
+                    hp = out[:, tp, :, d * h:(d + 1) * h] if 0 <= tp < T else torch.zeros(bs, E, h, device=d_out.device)
+                    dh = d_out[:, t, :, d * h:(d + 1) * h] + carry
+                    dgi, dgh, dprev, _ = self._gates_bwd(dh, save[d, :, t], hp, h)
+                    d_gi[:, t, :, d * 3 * h:(d + 1) * 3 * h] = dgi
+                    d_gh[:, t, :, d * 3 * h:(d + 1) * 3 * h] = dgh
+                    carry = dprev + dgh @ w
+            outs.append((d_gi, d_gh))
+        return outs
+
+    # ------------------------------------------------------------------ entity attention
+    @staticmethod
+    def _rows(t, inst, E):
+        return None if t is None else t.reshape(inst, E, t.shape[-1])
+
+    def _attn_weights(self, d):
+        n, H, O = d['n_inst'], d['H'], d['O']
+        fh = self._rows(d['feat_h'], n, H)
+        fo = self._rows(d['feat_o'], n, O)
+        sc = d['scale']
+        mask = d.get('obj_mask')
+        dev = fh.device
+        if mask is None:
+            m = torch.ones(n, O, device=dev)
+        else:
+            m = mask.repeat_interleave(d['inst_per_clip'], dim=0)[:n]
+
+        def sm(scores, ok):
+            s = torch.where(ok, scores, torch.full_like(scores, float('-inf')))
+            w = torch.softmax(s, dim=-1)
+            return torch.where(torch.isnan(w), torch.zeros_like(w), w)
+
+        eyeH = torch.eye(H, dtype=torch.bool, device=dev)
+        eyeO = torch.eye(O, dtype=torch.bool, device=dev)
+        w = {}
+        w['hh'] = sm(fh @ fh.transpose(1, 2) * sc, (~eyeH).expand(n, H, H))
+        w['oh'] = sm(fh @ fo.transpose(1, 2) * sc, (m != 0).unsqueeze(1).expand(n, H, O))
+        w['ho'] = sm(fo @ fh.transpose(1, 2) * sc, torch.ones(n, O, H, dtype=torch.bool, device=dev))
+        w['oo'] = sm(fo @ fo.transpose(1, 2) * sc, (~eyeO).unsqueeze(0) & (m != 0).unsqueeze(1))
+        for r in ('hh', 'oh', 'ho', 'oo'):
+            if d.get('msg_' + r) is None:
+                w[r] = torch.zeros_like(w[r])
+        return w, m, fh, fo
+
+    def attn_fwd(self, descs):
+        for d in descs:
+            n, H, O = d['n_inst'], d['H'], d['O']
+            w, m, fh, fo = self._attn_weights(d)
+            if d.get('att') is not None:
+                d['att'].copy_(torch.cat([w['hh'].reshape(n, -1), w['oh'].reshape(n, -1), w['ho'].reshape(n, -1),
+                                          w['oo'].reshape(n, -1)], -1).reshape(d['att'].shape))
+            rm = m if d['recv_mask_ho'] else torch.ones_like(m)
+            if d.get('msg_hh') is not None:
+                d['out_hh'].copy_((w['hh'] @ self._rows(d['msg_hh'], n, H)).reshape(d['out_hh'].shape))
+            if d.get('msg_oh') is not None:
+                d['out_oh'].copy_((w['oh'] @ self._rows(d['msg_oh'], n, O)).reshape(d['out_oh'].shape))
+            if d.get('msg_sh') is not None:
+                d['out_sh'].copy_(d['msg_sh'].reshape(n, 1, -1).expand(n, H, -1).reshape(d['out_sh'].shape))
+            if d.get('msg_ho') is not None:
+                d['out_ho'].copy_(((w['ho'] @ self._rows(d['msg_ho'], n, H)) * rm.unsqueeze(-1)).reshape(d['out_ho'].shape))
+            if d.get('msg_so') is not None:
+                d['out_so'].copy_((d['msg_so'].reshape(n, 1, -1) * rm.unsqueeze(-1)).reshape(d['out_so'].shape))
+            if d.get('msg_oo') is not None:
+                d['out_oo'].copy_((w['oo'] @ self._rows(d['msg_oo'], n, O)).reshape(d['out_oo'].shape))
+
+    def attn_bwd(self, descs):
+        for b in descs:
+            d = b['f']
+            n, H, O = d['n_inst'], d['H'], d['O']
+            att = d['att'].reshape(n, -1)
+            o = 0
+            w = {}
+            for r, (R, S_) in (('hh', (H, H)), ('oh', (H, O)), ('ho', (O, H)), ('oo', (O, O))):
+                w[r] = att[:, o:o + R * S_].reshape(n, R, S_)
+                o += R * S_
+            _, m, fh, fo = self._attn_weights(d)
+            rm = m if d['recv_mask_ho'] else torch.ones_like(m)
+            sc = d['scale']
+            dfh = torch.zeros_like(fh)
+            dfo = torch.zeros_like(fo)
+
+            def one(rel, R, S_, recv_scale, fq, fk, dfq, dfk):
+                msg = d.get('msg_' + rel)
+                if msg is None:
+                    return
+                msgs = self._rows(msg, n, S_)
+                g = self._rows(b['dout_' + rel], n, R)
+                if recv_scale is not None:
+                    g = g * recv_scale.unsqueeze(-1)
+                dmsg = w[rel].transpose(1, 2) @ g
+                if b.get('relu_mask_dmsg'):
+                    dmsg = dmsg * (msgs > 0)
+                b['dmsg_' + rel].copy_(dmsg.reshape(b['dmsg_' + rel].shape))
+                dw = g @ msgs.transpose(1, 2)
+                ds = w[rel] * (dw - (w[rel] * dw).sum(-1, keepdim=True)) * sc
+                dfq += ds @ fk
+                dfk += ds.transpose(1, 2) @ fq
+
+            one('hh', H, H, None, fh, fh, dfh, dfh)
+            one('oh', H, O, None, fh, fo, dfh, dfo)
+            one('ho', O, H, rm, fo, fh, dfo, dfh)
+            one('oo', O, O, None, fo, fo, dfo, dfo)
+            if d.get('msg_sh') is not None:
+                dm = self._rows(b['dout_sh'], n, H).sum(1)
+                if b.get('relu_mask_dmsg'):
+                    dm = dm * (d['msg_sh'].reshape(n, -1) > 0)
+                b['dmsg_sh'].copy_(dm.reshape(b['dmsg_sh'].shape))
+            if d.get('msg_so') is not None:
+                dm = (self._rows(b['dout_so'], n, O) * rm.unsqueeze(-1)).sum(1)
+                if b.get('relu_mask_dmsg'):
+                    dm = dm * (d['msg_so'].reshape(n, -1) > 0)
+                b['dmsg_so'].copy_(dm.reshape(b['dmsg_so'].shape))
+            for key, val in (('dfeat_h', dfh), ('dfeat_o', dfo)):
+                dst = b[key]
+                if b.get('dfeat_accumulate'):
+                    dst.add_(val.reshape(dst.shape))
+                else:
+                    dst.copy_(val.reshape(dst.shape))
+
+    # ------------------------------------------------------------------ segment-level recurrence
+    @staticmethod
+    def _seg_dims(p):
+        return (int(p['rel_hh']) + int(p['rel_ho']), int(p['rel_oh']) + int(p['rel_oo']),
+                int(p['rel_hh']) + int(p['rel_oh']), int(p['rel_ho']) + int(p['rel_oo']))
+
+    def _seg_attn_desc(self, p, bufs, d, t, prev_h, prev_o):
+        bs, H, O, h = p['bs'], p['H'], p['O'], p['hidden']
+        nsh, nso, nmh, nmo = self._seg_dims(p)
+        msh, mso = bufs['msrc_h'][d, :, t], bufs['msrc_o'][d, :, t]  # (bs, E, ns*h)
+        mgh, mgo = bufs['mg_h'][d, :, t], bufs['mg_o'][d, :, t]
+        desc = dict(feat_h=prev_h, feat_o=prev_o, obj_mask=p['obj_mask'], att=bufs['att'][d, t], n_inst=bs,
+                    inst_per_clip=1, H=H, O=O, D=h, hidden=h, scale=p['att_scale'], recv_mask_ho=0)
+        if p['rel_hh']:
+            desc['msg_hh'], desc['out_hh'] = msh[..., :h], mgh[..., :h]
+        if p['rel_ho']:
+            o = h if p['rel_hh'] else 0
+            desc['msg_ho'], desc['out_ho'] = msh[..., o:o + h], mgo[..., :h]
+        if p['rel_oh']:
+            o = h if p['rel_hh'] else 0
+            desc['msg_oh'], desc['out_oh'] = mso[..., :h], mgh[..., o:o + h]
+        if p['rel_oo']:
+            o1 = h if p['rel_oh'] else 0
+            o2 = h if p['rel_ho'] else 0
+            desc['msg_oo'], desc['out_oo'] = mso[..., o1:o1 + h], mgo[..., o2:o2 + h]
+        return desc
+
+    def segrnn_fwd(self, p):
+        bs, T, H, O, h = p['bs'], p['T'], p['H'], p['O'], p['hidden']
+        dev = p['gi_h'].device
+        nsh, nso, nmh, nmo = self._seg_dims(p)
+        natt = H * H + 2 * H * O + O * O
+        z = lambda *s: torch.zeros(*s, device=dev)
+        bufs = dict(hs_h=z(bs, T, H, 2 * h), hs_o=z(bs, T, O, 2 * h), save_h=z(2, bs, T, H, 4 * h),
+                    save_o=z(2, bs, T, O, 4 * h), msrc_h=z(2, bs, T, H, nsh * h), msrc_o=z(2, bs, T, O, nso * h),
+                    mg_h=z(2, bs, T, H, nmh * h), mg_o=z(2, bs, T, O, nmo * h), att=z(2, T, bs, natt))
+        msg = p['msg_segment'] and (nmh + nmo) > 0
+        for d in range(2):
+            prev_h, prev_o = z(bs, H, h), z(bs, O, h)
+            order = range(T) if d == 0 else range(T - 1, -1, -1)
+            for t in order:
+                if msg:
+                    if nsh:
+                        bufs['msrc_h'][d, :, t] = torch.relu(prev_h @ p['w_smsg_h'].t() + p['b_smsg_h'])
+                    if nso:
+                        bufs['msrc_o'][d, :, t] = torch.relu(prev_o @ p['w_smsg_o'].t() + p['b_smsg_o'])
+                    self.attn_fwd([self._seg_attn_desc(p, bufs, d, t, prev_h, prev_o)])
+                new = []
+                for kind, E, prev in (('h', H, prev_h), ('o', O, prev_o)):
+                    gi = p['gi_' + kind][:, t, :, d * 3 * h:(d + 1) * 3 * h]
+                    nm = nmh if kind == 'h' else nmo
+                    if msg and nm:
+                        gi = gi + bufs['mg_' + kind][d, :, t] @ p['w_ihm_' + kind][d].t()
+                    gh = prev @ p['w_hh_' + kind][d].t() + p['b_hh_' + kind][d]
+                    r, zz, n, hn, g = self._gates(gi, gh, prev, h)
+                    u = p['u_' + kind][:, t].unsqueeze(-1)
+                    hnew = u * g + (1 - u) * prev
+                    bufs['hs_' + kind][:, t, :, d * h:(d + 1) * h] = hnew
+                    bufs['save_' + kind][d, :, t] = torch.cat([r, zz, n, hn], -1)
+                    new.append(hnew)
+                prev_h, prev_o = new
+        return bufs
+
+    def segrnn_bwd(self, p, bufs, d_hs_h, d_hs_o):
+        bs, T, H, O, h = p['bs'], p['T'], p['H'], p['O'], p['hidden']
+        dev = bufs['hs_h'].device
+        nsh, nso, nmh, nmo = self._seg_dims(p)
+        z = lambda *s: torch.zeros(*s, device=dev)
+        out = dict(d_gi_h=z(bs, T, H, 6 * h), d_gi_o=z(bs, T, O, 6 * h), d_gh_h=z(bs, T, H, 6 * h),
+                   d_gh_o=z(bs, T, O, 6 * h), d_u_h=z(bs, T, H), d_u_o=z(bs, T, O),
+                   d_pre_h=z(2, bs, T, H, nsh * h), d_pre_o=z(2, bs, T, O, nso * h))
+        msg = p['msg_segment'] and (nmh + nmo) > 0
+        dhs = {'h': d_hs_h, 'o': d_hs_o}
+        for d in range(2):
+            carry = {'h': z(bs, H, h), 'o': z(bs, O, h)}
+            order = range(T - 1, -1, -1) if d == 0 else range(T)
+            for t in order:
+                tp = t - 1 if d == 0 else t + 1
+                has_prev = 0 <= tp < T
+                prev = {k: (bufs['hs_' + k][:, tp, :, d * h:(d + 1) * h] if has_prev else z(bs, E, h))
+                        for k, E in (('h', H), ('o', O))}
+                newc = {}
+                dmg = {}
+                for kind, E in (('h', H), ('o', O)):
+                    dh = dhs[kind][:, t, :, d * h:(d + 1) * h] + carry[kind]
+                    u = p['u_' + kind][:, t]
+                    dgi, dgh, dprev, du = self._gates_bwd(dh, bufs['save_' + kind][d, :, t], prev[kind], h, u)
+                    out['d_gi_' + kind][:, t, :, d * 3 * h:(d + 1) * 3 * h] = dgi
+                    out['d_gh_' + kind][:, t, :, d * 3 * h:(d + 1) * 3 * h] = dgh
+                    out['d_u_' + kind][:, t] += du
+                    newc[kind] = dprev + dgh @ p['w_hh_' + kind][d]
+                    nm = nmh if kind == 'h' else nmo
+                    if msg and nm:
+                        dmg[kind] = dgi @ p['w_ihm_' + kind][d]
+                if msg:
+                    desc = self._seg_attn_desc(p, bufs, d, t, prev['h'], prev['o'])
+                    b = dict(f=desc, relu_mask_dmsg=1, dfeat_accumulate=1, dfeat_h=newc['h'], dfeat_o=newc['o'])
+                    dph, dpo = out['d_pre_h'][d, :, t], out['d_pre_o'][d, :, t]
+                    if p['rel_hh']:
+                        b['dout_hh'], b['dmsg_hh'] = dmg['h'][..., :h], dph[..., :h]
+                    if p['rel_ho']:
+                        o = h if p['rel_hh'] else 0
+                        b['dout_ho'], b['dmsg_ho'] = dmg['o'][..., :h], dph[..., o:o + h]
+                    if p['rel_oh']:
+                        o = h if p['rel_hh'] else 0
+                        b['dout_oh'], b['dmsg_oh'] = dmg['h'][..., o:o + h], dpo[..., :h]
+                    if p['rel_oo']:
+                        o1 = h if p['rel_oh'] else 0
+                        o2 = h if p['rel_ho'] else 0
+                        b['dout_oo'], b['dmsg_oo'] = dmg['o'][..., o2:o2 + h], dpo[..., o1:o1 + h]
+                    self.attn_bwd([b])
+                    if nsh:
+                        newc['h'] = newc['h'] + dph @ p['w_smsg_h']
+                    if nso:
+                        newc['o'] = newc['o'] + dpo @ p['w_smsg_o']
+                carry = newc
+        return out
+
+    # ------------------------------------------------------------------ gates
+    def gate_fwd(self, d):
+        bs, T, E, h = d['bs'], d['T'], d['E'], d['hidden']
+        x = d['x']
+        w = d['w'].reshape(-1)
+        logit = 0
+        for i, c in enumerate(d['seg_col']):
+            logit = logit + x[:, c:c + h] @ w[i * h:(i + 1) * h]
+        if d.get('b') is not None:
+            logit = logit + d['b'][0]
+        p = torch.sigmoid(logit).view(bs, T, E)
+        if d.get('noise') is not None:
+            g = d['noise'].reshape(T, d['noise_entities'], bs, 2)[:, d['noise_offset']:d['noise_offset'] + E]
+            g = g.permute(2, 0, 1, 3)  # (bs, T, E, 2)
+            a = torch.stack([torch.log(p + 1e-20) + g[..., 0], torch.log((1 - p) + 1e-20) + g[..., 1]], -1)
+            y = torch.softmax(a, dim=-1)[..., 0]
+        else:
+            y = p
+        hard = (y > d['threshold']).float()
+        if d['force_last']:
+            hard[:, T - 1] = 1.0
+        d['hard'], d['soft'], d['p_save'] = hard, y.contiguous(), p.contiguous()
+        return hard, d['soft']
+
+    def gate_bwd(self, d, d_hard, d_soft, st_mask):
+        bs, T, E = d['bs'], d['T'], d['E']
+        tot = torch.zeros(bs, T, E, device=d['x'].device)
+        if d_soft is not None:
+            tot = tot + d_soft.view(bs, T, E)
+        if d_hard is not None:
+            m = st_mask.view(bs, T, E).clone() if st_mask is not None else torch.ones(bs, T, E, device=tot.device)
+            if d['force_last']:
+                m[:, T - 1] = 0.0
+            tot = tot + d_hard.view(bs, T, E) * m
+        p = d['p_save']
+        if d.get('noise') is not None:
+            y = d['soft']
+            tot = tot * y * (1 - y) * (1 / (p + 1e-20) + 1 / ((1 - p) + 1e-20))
+        return (tot * p * (1 - p)).reshape(-1)
+
+    def rank1_update(self, dst, s, v):
+        dst.add_((s.reshape(-1, 1) * v.reshape(1, -1)).reshape(dst.shape))
+
+    def colsum(self, x, rowscale=None, out=None, accumulate=False):
+        m = _mat(x)
+        r = (m * rowscale.reshape(-1, 1)).sum(0) if rowscale is not None else m.sum(0)
+        if out is None:
+            return r
+        if accumulate:
+            out.add_(r)
+        else:
+            out.copy_(r)
+        return out
+
+    def filter_fwd(self, soft, threshold):
+        um1 = torch.cat([torch.zeros_like(soft[:, :1]), soft[:, :-1]], 1)
+        up1 = torch.cat([soft[:, 1:], torch.zeros_like(soft[:, :1])], 1)
+        cond = (soft > um1) & (soft > up1) & (soft >= threshold)
+        return cond.float(), (cond | ~(soft >= threshold)).float()
+
+    # ------------------------------------------------------------------ reorder / heads / elementwise
+    @staticmethod
+    def _reorder_idx(gate):
+        bs, T, E = gate.shape
+        idx = torch.arange(T, device=gate.device).view(1, T, 1).repeat(bs, 1, E)
+        nxt = torch.full((bs, E), -1, dtype=torch.long, device=gate.device)
+        for t in range(T - 1, -1, -1):
+            nz = gate[:, t] != 0
+            nxt = torch.where(nz, torch.full_like(nxt, t), nxt)
+            idx[:, t] = torch.where(nxt >= 0, nxt, torch.full_like(nxt, t))
+        return idx
+
+    def reorder_fwd(self, hx, gate):
+        idx = self._reorder_idx(gate)
+        return torch.gather(hx, 1, idx.unsqueeze(-1).expand_as(hx))
+
+    def reorder_bwd(self, dout, gate):
+        idx = self._reorder_idx(gate)
+        return torch.zeros_like(dout).scatter_add_(1, idx.unsqueeze(-1).expand_as(dout), dout)
+
+    def logsoftmax_permute_fwd(self, logits, bs, T, E, Cn):
+        return torch.log_softmax(logits.view(bs, T, E, Cn), -1).permute(0, 3, 1, 2).contiguous()
+
+    def logsoftmax_permute_bwd(self, out, dout):
+        o = out.permute(0, 2, 3, 1)
+        g = dout.permute(0, 2, 3, 1)
+        return (g - torch.exp(o) * g.sum(-1, keepdim=True)).reshape(-1, out.shape[1]).contiguous()
+
+    def relu_bwd(self, dy, y, dx=None):
+        r = _mat(dy) * (_mat(y) > 0)
+        if dx is None:
+            return r.contiguous()
+        dx.copy_(r.reshape(dx.shape))
+        return dx
+
+    def add_rows(self, src, dst):
+        dst.add_(src.reshape(dst.shape))
+
+    def adam_step(self, param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, step):
+        g = grad + weight_decay * param if weight_decay else grad
+        exp_avg.mul_(beta1).add_(g, alpha=1 - beta1)
+        exp_avg_sq.mul_(beta2).addcmul_(g, g, value=1 - beta2)
+        bc1, bc2 = 1 - beta1 ** step, 1 - beta2 ** step
+        param.addcdiv_(exp_avg, exp_avg_sq.sqrt() / math.sqrt(bc2) + eps, value=-lr / bc1)

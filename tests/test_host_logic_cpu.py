@@ -1,0 +1,97 @@
+"""CPU: the host-side composition (2g-gcn_amd/ops.py + models.py: buffer layouts, GEMM operand forms, hand-derived
+backward) executed with the torch test double of the kernel interface, against golden vectors captured from the real
+reference. The HIP kernels themselves are checked on the GPU (tests/test_kernels_gpu.py, test_parity_gpu.py)."""
+import numpy as np
+import pytest
+import torch
+
+import twog_gcn_amd  # noqa: F401
+from twog_gcn_amd import kernels as twog_kernels
+from twog_gcn_amd.models import TGGCN, select_model
+from tests.fake_kernels import FakeKernels
+from tests.helpers import G4_CASES, load_g4, det_state_dict, g4_inputs, sample_grad
+from oracle import detgen
+
+
+@pytest.fixture()
+def fake_backend():
+    twog_kernels._set_backend_for_tests(FakeKernels())
+    yield
+    twog_kernels._set_backend_for_tests(None)
+
+
+def build_model(meta):
+    N = meta['N']
+    m = TGGCN(input_size=(2048 + 4 * N, 2048), num_classes=tuple(meta['classes']), **meta['cfg'])
+    sd = det_state_dict(meta['state_dict_shapes'], seed=meta['seed'], gain=meta['gain'])
+    m.load_state_dict(sd)
+    return m
+
+
+@pytest.mark.parametrize('name', G4_CASES)
+def test_full_forward_backward_vs_reference(name, fake_backend):
+    z, meta = load_g4(name)
+    m = build_model(meta)
+    m.train()
+    noise = torch.from_numpy(z['gumbel_noise'])
+    m._gumbel_noise_override = noise if len(noise) else None
+    out = m(**g4_inputs(z))
+    n_out = len([k for k in z.files if k.startswith('out')])
+    assert len(out) == n_out
+    for i, o in enumerate(out):
+        ref = z[f'out{i}']
+        assert tuple(o.shape) == ref.shape, (i, o.shape, ref.shape)
+        if ref.ndim == 3 and np.all((ref == 0) | (ref == 1)) and i < n_out - 4:
+            assert np.array_equal(o.detach().numpy(), ref), f'out{i}'
+        else:
+            assert np.abs(o.detach().numpy() - ref).max() < 1e-4 * max(1.0, np.abs(ref).max()), f'out{i}'
+    bn = m.geometry_embedding_gcn.joint_embed.cnn[0].bn
+    assert np.allclose(bn.running_mean.numpy(), z['bn_running_mean'], rtol=1e-5, atol=1e-6)
+    assert np.allclose(bn.running_var.numpy(), z['bn_running_var'], rtol=1e-5, atol=1e-6)
+    if name == 'c2_dot_st':
+        # the reference's own backward is broken for 'st' (upstream bug); check ours at least runs
+        loss = sum((o * o).sum() for o in out if o.requires_grad)
+        loss.backward()
+        return
+    loss = 0
+    for i, o in enumerate(out):
+        if o.requires_grad:
+            r = torch.from_numpy(detgen.normal(f'{name}.r{i}', tuple(o.shape), seed=meta['seed']))
+            loss = loss + (o * r).sum()
+    assert abs(float(loss.detach()) - float(z['loss'])) < 1e-3 * max(1.0, abs(float(z['loss'])))
+    loss.backward()
+    none_ref = set(z['none_grads'].tolist())
+    for pname, p in m.named_parameters():
+        if pname in none_ref:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, pname
+            continue
+        assert p.grad is not None, pname
+        g_ref = z['grad_' + pname]
+        g = sample_grad(p.grad)
+        scale = max(np.abs(g_ref).max(), 1e-6)
+        assert np.abs(g - g_ref).max() < 3e-4 * scale + 2e-6, (pname, float(np.abs(g - g_ref).max()), float(scale))
+
+
+def test_select_model_and_errors():
+    assert select_model('2G-GCN') is TGGCN
+    with pytest.raises(KeyError):
+        select_model('nope')
+    with pytest.raises(ValueError):
+        TGGCN(input_size=(2152, 2048), num_classes=(13, None), hidden_size=8, discrete_optimization_strategy='bogus',
+              message_type='v2', message_granularity='v1', attention_style='v3')
+    m = TGGCN(input_size=(2152, 2048), num_classes=(13, None), hidden_size=8)  # reference defaults: relational/concat
+    with pytest.raises(NotImplementedError):
+        m(torch.zeros(1, 2, 2, 2152), torch.zeros(1, 2, 4, 2048), torch.ones(1, 4))
+
+
+def test_eval_mode_uses_running_stats(fake_backend):
+    z, meta = load_g4('c2_stage1')
+    m = build_model(meta)
+    m.eval()
+    m._gumbel_noise_override = torch.from_numpy(z['gumbel_noise'])
+    bn = m.geometry_embedding_gcn.joint_embed.cnn[0].bn
+    rm = bn.running_mean.clone()
+    with torch.no_grad():
+        out = m(**g4_inputs(z))
+    assert torch.equal(bn.running_mean, rm)
+    assert len(out) == 6
