@@ -128,7 +128,7 @@ SIGNATURES = {
     'twog_logsoftmax_permute_bwd': [_P, _P, _P, _I, _I, _I, _I, _P],
     'twog_relu_bwd': [Rows, Rows, Rows, _I, _I, _P],
     'twog_add_rows': [Rows, Rows, _I, _I, _P],
-    'twog_adam_step': [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _P],
+    'twog_adam_step': [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _F, _P],
 }
 
 _lib = None

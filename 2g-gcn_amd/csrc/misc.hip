@@ -126,9 +126,9 @@ __global__ __launch_bounds__(256) void filter_kernel(const float* soft, float* h
 }
 
 __global__ __launch_bounds__(256) void adam_kernel(float* p, const float* g, float* m, float* v, int64_t n, float lr,
-                                                   float b1, float b2, float eps, float wd, float bc1, float bc2s) {
+                                                   float b1, float b2, float eps, float wd, float bc1, float bc2s, float gscale) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        float gi = g[i];
+        float gi = g[i] * gscale;
         if (wd != 0.f) gi += wd * p[i];
         const float mi = b1 * m[i] + (1.f - b1) * gi;
         const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
@@ -222,12 +222,13 @@ extern "C" int twog_filter_fwd(const float* soft, float* hard, float* grad_mask,
 }
 
 extern "C" int twog_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
-                              float beta1, float beta2, float eps, float weight_decay, int step, void* stream) {
+                              float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale,
+                              void* stream) {
     if (n <= 0) return 0;
     const float bc1 = 1.f - powf(beta1, (float)step);
     const float bc2s = sqrtf(1.f - powf(beta2, (float)step));
     hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n, 256, 2048)), dim3(256), 0, (hipStream_t)stream, param, grad,
-                       exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2s);
+                       exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2s, grad_scale);
     TWOG_CHECK_LAUNCH();
     return 0;
 }

@@ -432,10 +432,10 @@ class HipKernels:
         self._check(self.lib.twog_add_rows(rows_of(src), rows_of(dst), n_rows(src), src.shape[-1], self._stream()),
                     'twog_add_rows')
 
-    def adam_step(self, param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, step):
+    def adam_step(self, param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
         self._check(self.lib.twog_adam_step(param.data_ptr(), grad.data_ptr(), exp_avg.data_ptr(),
                                             exp_avg_sq.data_ptr(), param.numel(), lr, beta1, beta2, eps, weight_decay,
-                                            step, self._stream()), 'twog_adam_step')
+                                            step, grad_scale, self._stream()), 'twog_adam_step')
 
 
 _backend = None

@@ -1,0 +1,238 @@
+#!/usr/bin/env python3
+"""Headline benchmark of the 2G-GCN hot path on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: launched by torch.distributed.run, one rank per GPU over RCCL)
+
+Workload (BASELINE.json configs[2]): synthetic clips T=120, N=34 geometry nodes (H=2 humans, O=8 objects), C=h=512,
+64 clips per GPU per step (weak scaling: global batch = 64*N), fp32. One "step" = forward + the reference's stage-1
+loss list (NLL on the two segment-level heads, vhoi/losses.py:53-61) + backward + gradient all-reduce (N > 1) + fused
+Adam; inputs are resident in HBM before the timed region. Prints ONE JSON line on rank 0.
+
+Also measured live: the dominant kernel's roofline (fp32-MFMA GEMM, HIP events around every GEMM launch made from the
+host composition during the timed steps) and, on rank 0 at N=1, the CPU baseline (the oracle = port of the reference's
+PyTorch-CPU path) on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CFG = dict(hidden_size=512, gcn_node=34, attention_style='v3', bias=True, discrete_networks_num_layers=1,
+           discrete_optimization_strategy='gs', filter_discrete_updates=False, message_humans_to_human=True,
+           message_human_to_objects=True, message_objects_to_human=True, message_objects_to_object=True,
+           message_geometry_to_objects=True, message_geometry_to_human=False, message_segment=True, message_type='v2',
+           message_granularity='v1', message_aggregation='att', object_segment_update_strategy='ind',
+           update_segment_threshold=0.5)  # conf/models/2G-GCN_stage1.yaml:5-29 with gcn_node=34
+T, H, O, N_NODES, BS, N_CLASSES = 120, 2, 8, 34, 64, 13
+PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 FLOP/clk/CU
+PEAK_HBM_GBS = 8000.0
+
+
+def synthetic_batch(bs, device, seed):
+    g = torch.Generator().manual_seed(seed)
+    vis = torch.relu(torch.randn(bs, T, H, 2048, generator=g))
+    pos = torch.rand(bs, T, N_NODES, 2, generator=g)
+    vel = torch.randn(bs, T, N_NODES, 2, generator=g) * 0.5
+    geo = torch.cat([pos, vel], -1).reshape(bs, T, 1, 4 * N_NODES).expand(bs, T, H, 4 * N_NODES)
+    x_human = torch.cat([vis, geo], -1).contiguous()
+    x_objects = torch.relu(torch.randn(bs, T, O, 2048, generator=g))
+    mask = torch.ones(bs, O)
+    targets = [torch.randint(0, N_CLASSES, (bs, T, H), generator=g) for _ in range(2)]
+    to = lambda t: t.to(device)
+    return to(x_human), to(x_objects), to(mask), [to(t) for t in targets]
+
+
+class GemmProfiler:
+    """HIP-event timing of every GEMM launch issued by the host composition (on torch's current stream, which is the
+    stream the kernels are enqueued on). Launches are classed by the tile variant the library picks."""
+
+    def __init__(self, K):
+        self.K, self.orig, self.records = K, K.gemm, []
+
+    def __enter__(self):
+        def gemm(problems, a_kmajor=False, b_kmajor=False, split_k_workspace=True):
+            from twog_gcn_amd.kernels import n_rows
+            flops, tiles128 = 0.0, 0
+            for p in problems:
+                A, Cm = p['A'], p['C']
+                M, Nn = n_rows(Cm), Cm.shape[-1]
+                Kk = n_rows(A) if a_kmajor else A.shape[-1]
+                nb = p['batch'][0] if p.get('batch') else 1
+                flops += 2.0 * M * Nn * Kk * nb
+                tiles128 += nb * math.ceil(M / 128) * math.ceil(Nn / 128)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            self.orig(problems, a_kmajor, b_kmajor, split_k_workspace)
+            e1.record()
+            self.records.append(('128x128' if tiles128 >= 384 else '64x64', flops, e0, e1))
+        self.K.gemm = gemm
+        return self
+
+    def __exit__(self, *a):
+        self.K.gemm = self.orig
+
+    def summary(self):
+        torch.cuda.synchronize()
+        agg = {}
+        for kind, flops, e0, e1 in self.records:
+            a = agg.setdefault(kind, [0.0, 0.0, 0])
+            a[0] += flops
+            a[1] += e0.elapsed_time(e1) * 1e-3
+            a[2] += 1
+        return agg
+
+
+def cpu_baseline(sample_frames=24):
+    """The oracle (port of the reference's PyTorch-CPU path) forward+backward on a bounded sample: one clip, the first
+    `sample_frames` of its 120 frames (cost is linear in frames: per-step Python loops dominate)."""
+    from oracle import cpu_ref
+    import twog_gcn_amd  # noqa: F401
+    from twog_gcn_amd.models import TGGCN
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    torch.manual_seed(0)
+    m = TGGCN(input_size=(2048 + 4 * N_NODES, 2048), num_classes=(N_CLASSES, None), **CFG)
+    sd = {k: (v.detach().clone().requires_grad_(True) if v.is_floating_point() and 'running' not in k else v.clone())
+          for k, v in m.state_dict().items()}
+    g = torch.Generator().manual_seed(1)
+    Ts = sample_frames
+    x_human = torch.rand(1, Ts, H, 2048 + 4 * N_NODES, generator=g)
+    x_objects = torch.rand(1, Ts, O, 2048, generator=g)
+    mask, seg = torch.ones(1, O), torch.ones(1, Ts, H)
+    tgt = [torch.randint(0, N_CLASSES, (1, Ts, H), generator=g) for _ in range(2)]
+    t0 = time.perf_counter()
+    out = cpu_ref.tggcn_forward(sd, CFG, x_human, x_objects, mask, human_segmentation=seg, training=True)
+    t_fwd = time.perf_counter() - t0
+    loss = torch.nn.functional.nll_loss(out[4], tgt[0]) + torch.nn.functional.nll_loss(out[5], tgt[1])
+    loss.backward()
+    dt = time.perf_counter() - t0
+    clips = Ts / T
+    return dict(value=clips / dt, unit='clips/s', cores=cores, kind='port',
+                sample=f'1 clip x first {Ts} of {T} frames (H=2,O=8,N=34,h=512), forward+backward once, '
+                       f'scaled linearly in frames; forward alone {clips / t_fwd:.4f} clips/s',
+                forward_clips_per_s=clips / t_fwd)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=6)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--batch', type=int, default=BS, help='clips per GPU per step')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--forward-only', action='store_true', help='additionally report forward-only clips/s')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    import torch.distributed as dist
+    if world > 1:
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+    device = torch.device('cuda', local_rank)
+    torch.cuda.set_device(device)
+
+    import twog_gcn_amd  # noqa: F401
+    from twog_gcn_amd.models import TGGCN
+    from twog_gcn_amd.kernels import get_kernels
+    from twog_gcn_amd.distributed import DataParallel, FusedAdam
+    K = get_kernels()
+    assert K.name == 'hip'
+
+    torch.manual_seed(0)
+    model = TGGCN(input_size=(2048 + 4 * N_NODES, 2048), num_classes=(N_CLASSES, None), **CFG).to(device).train()
+    dp = DataParallel(model)
+    opt = FusedAdam(dp.flat, lr=1e-4)
+    bs = args.batch
+    x_human, x_objects, mask, targets = synthetic_batch(bs, device, seed=1234 + rank)
+    seg = torch.ones(bs, T, H, device=device)  # feeder semantics: impose_segmentation_pattern == 1
+    nll = torch.nn.functional.nll_loss
+
+    def step():
+        dp.zero_grad()
+        out = model(x_human, x_objects, mask, human_segmentation=seg)
+        # stage-1 loss list: budget/BCE/frame-level weights are 0, the two segment-level NLL terms weigh 1
+        loss = nll(out[4], targets[0], ignore_index=-1) + nll(out[5], targets[1], ignore_index=-1)
+        loss.backward()
+        dp.all_reduce_gradients()
+        opt.step(dp.grad_scale)
+        return loss
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    with GemmProfiler(K) as prof:
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            loss = step()
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    agg = prof.summary()
+
+    fwd_only = None
+    if args.forward_only:
+        with torch.no_grad():
+            model(x_human, x_objects, mask, human_segmentation=seg)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(max(2, args.steps // 2)):
+                model(x_human, x_objects, mask, human_segmentation=seg)
+            torch.cuda.synchronize()
+            fwd_only = bs * world * max(2, args.steps // 2) / (time.perf_counter() - t1)
+
+    if rank == 0:
+        total_gemm_s = sum(v[1] for v in agg.values())
+        dom = max(agg.items(), key=lambda kv: kv[1][1])
+        kind, (flops, secs, calls) = dom
+        achieved = flops / secs / 1e12 if secs > 0 else 0.0
+        result = {
+            'metric': 'clips/sec fwd+bwd, T=120 N=34 C=512', 'value': bs * world * args.steps / dt, 'unit': 'clips/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'fp32', 'data': 'synthetic',
+            'config': {'workload': f'Synthetic T=120 N=34 C=512 bs{bs} per GPU (BASELINE configs[2]; H=2, O=8, '
+                                   f'classes 13, 2G-GCN_stage1 parameters)',
+                       'global_batch': bs * world, 'per_gpu_batch': bs, 'parallelism': f'dp{world}',
+                       'step': 'forward + NLL losses + backward + gradient all-reduce + fused Adam',
+                       'loss_last': float(loss.detach())},
+            'roofline': {'bound': 'mfma', 'kernel': f'gemm_kernel<{kind.replace("x", ",")},*> (fp32 v_mfma_f32_32x32x2_f32)',
+                         'achieved': achieved, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                         'frac': achieved / PEAK_FP32_MFMA_TFLOPS, 'traffic': None,
+                         'launches_per_step': calls / args.steps, 'avg_launch_ms': secs / max(calls, 1) * 1e3,
+                         'algorithmic_gflop_per_step': flops / args.steps / 1e9,
+                         'share_of_step_time': secs / dt},
+            'gemm_classes': {k: {'tflops': (v[0] / v[1] / 1e12 if v[1] else 0.0), 'ms_per_step': v[1] / args.steps * 1e3,
+                                 'launches_per_step': v[2] / args.steps} for k, v in agg.items()},
+            'host_gemm_share_of_step': total_gemm_s / dt,
+        }
+        if fwd_only is not None:
+            result['forward_only_clips_per_s'] = fwd_only
+        if world == 1 and not args.no_cpu_baseline:
+            result['cpu_baseline'] = cpu_baseline()
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -310,9 +310,10 @@ int twog_logsoftmax_permute_bwd(const float* out, const float* dout, float* dlog
 int twog_relu_bwd(twog_rows_t dy, twog_rows_t y, twog_rows_t dx, int rows, int cols, void* stream);
 int twog_add_rows(twog_rows_t src, twog_rows_t dst, int rows, int cols, void* stream);
 
-/* Fused Adam on one flat fp32 parameter buffer (torch.optim.Adam semantics; reference train.py:39). */
+/* Fused Adam on one flat fp32 parameter buffer (torch.optim.Adam semantics; reference train.py:39). The gradient is
+ * multiplied by grad_scale first (1/world_size after a sum all-reduce). */
 int twog_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
-                   float beta1, float beta2, float eps, float weight_decay, int step, void* stream);
+                   float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale, void* stream);
 
 #ifdef __cplusplus
 }

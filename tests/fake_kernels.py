@@ -511,7 +511,8 @@ class FakeKernels:
     def add_rows(self, src, dst):
         dst.add_(src.reshape(dst.shape))
 
-    def adam_step(self, param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, step):
+    def adam_step(self, param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
+        grad = grad * grad_scale
         g = grad + weight_decay * param if weight_decay else grad
         exp_avg.mul_(beta1).add_(g, alpha=1 - beta1)
         exp_avg_sq.mul_(beta2).addcmul_(g, g, value=1 - beta2)

@@ -1,0 +1,400 @@
+"""GPU: every HIP kernel entry point (through the C ABI, via kernels.HipKernels) against its executable specification
+(tests/fake_kernels.py, plain torch fp32 on CPU) on seeded random inputs, including strided views, ragged sizes,
+masks and the split-K / grouped / batched GEMM forms. Tolerances are fp32 summation-order tolerances."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+import twog_gcn_amd  # noqa: F401
+from twog_gcn_amd import kernels as twog_kernels
+from tests.fake_kernels import FakeKernels
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+@pytest.fixture(scope='module')
+def K():
+    twog_kernels._set_backend_for_tests(None)
+    k = twog_kernels.get_kernels()
+    assert k.name == 'hip'
+    return k
+
+
+F = FakeKernels()
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed + sum(shape))
+    return (torch.randn(*shape, generator=g) * scale).float()
+
+
+def close(a, b, rtol=2e-5, atol=1e-5, what=''):
+    a = a.detach().cpu().double()
+    b = b.detach().cpu().double()
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    err = (a - b).abs().max().item() if a.numel() else 0.0
+    tol = atol + rtol * b.abs().max().item() if b.numel() else atol
+    assert err <= tol, f'{what}: max err {err:.3e} > tol {tol:.3e} (ref max {b.abs().max().item():.3e})'
+
+
+def both(fn, bases):
+    """run fn(K-like, {name: tensor}) on cpu(fake) and gpu(hip) from the same base tensors; returns (cpu, gpu) bases."""
+    cpu = {k: v.clone() for k, v in bases.items()}
+    gpu = {k: v.clone().to(DEV) for k, v in bases.items()}
+    return cpu, gpu
+
+
+# ---------------------------------------------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize('akm,bkm', [(False, False), (False, True), (True, True), (True, False)])
+@pytest.mark.parametrize('M,N,K_', [(300, 200, 100), (70, 13, 64), (1000, 520, 264), (33, 65, 36)])
+def test_gemm_layouts(K, akm, bkm, M, N, K_):
+    A = rnd(K_, M) if akm else rnd(M, K_)
+    B = rnd(K_, N, seed=1) if bkm else rnd(N, K_, seed=1)
+    bias = rnd(N, seed=2)
+    for act, acc in ((0, False), (1, True)):
+        C0 = rnd(M, N, seed=3)
+        c_cpu = C0.clone()
+        F.gemm([dict(A=A, B=B, C=c_cpu, bias=bias, act=act, accumulate=acc)], a_kmajor=akm, b_kmajor=bkm)
+        c_gpu = C0.clone().to(DEV)
+        K.gemm([dict(A=A.to(DEV), B=B.to(DEV), C=c_gpu, bias=bias.to(DEV), act=act, accumulate=acc)], a_kmajor=akm,
+               b_kmajor=bkm)
+        close(c_gpu, c_cpu, rtol=3e-5, atol=3e-5, what=f'gemm {akm}{bkm} {M}x{N}x{K_} act{act}')
+
+
+def test_gemm_unaligned_k(K):
+    # K not a multiple of 4 and odd leading dimensions -> scalar load path
+    M, N, K_ = 50, 40, 13
+    A, B = rnd(M, K_), rnd(N, K_, seed=1)
+    c_cpu = torch.zeros(M, N)
+    F.gemm([dict(A=A, B=B, C=c_cpu)])
+    c_gpu = torch.zeros(M, N, device=DEV)
+    K.gemm([dict(A=A.to(DEV), B=B.to(DEV), C=c_gpu)])
+    close(c_gpu, c_cpu, what='gemm unaligned')
+
+
+def test_gemm_big_tiles_and_views(K):
+    # 128x128 tile path + row-strided views (column slices of wider buffers, 3-D (outer, inner, cols) rows)
+    bs, T, E, w = 4, 30, 5, 96
+    base = rnd(bs, T, E, w)
+    W = rnd(640, 32, seed=1)
+    out = torch.zeros(bs, T, E, 700)
+    bias = rnd(640, seed=2)
+
+    def run(Kx, base, W, out, bias):
+        A = base.view(-1, w)[:, 16:48]  # (rows, 32) stride w
+        C = out.view(-1, 700)[:, 20:660]
+        Kx.gemm([dict(A=A, B=W, C=C, bias=bias, act=1)])
+        # 3-D rows: (b, e) rows at fixed t
+        A3 = base[:, 7, :, 0:32]
+        C3 = out[:, 9, :, 660:692]
+        Kx.gemm([dict(A=A3, B=W[:32], C=C3)])
+
+    o_cpu = out.clone()
+    run(F, base, W, o_cpu, bias)
+    o_gpu = out.clone().to(DEV)
+    run(K, base.to(DEV), W.to(DEV), o_gpu, bias.to(DEV))
+    close(o_gpu, o_cpu, what='gemm views')
+
+
+def test_gemm_grouped_batched_splitk(K):
+    # grouped: several problems in one call; batched: GCN projection form; split-K: tall reduction
+    A1, B1 = rnd(200, 64), rnd(96, 64, seed=1)
+    A2, B2 = rnd(77, 64, seed=2), rnd(130, 64, seed=3)
+    c1, c2 = torch.zeros(200, 96), torch.zeros(77, 130)
+    F.gemm([dict(A=A1, B=B1, C=c1), dict(A=A2, B=B2, C=c2, act=1)])
+    g1, g2 = torch.zeros(200, 96, device=DEV), torch.zeros(77, 130, device=DEV)
+    K.gemm([dict(A=A1.to(DEV), B=B1.to(DEV), C=g1), dict(A=A2.to(DEV), B=B2.to(DEV), C=g2, act=1)])
+    close(g1, c1, what='grouped 1')
+    close(g2, c2, what='grouped 2')
+    # batched GCN projection: out[b] (128, N*T) = W^T (k-major) x Z[b] rows (n,t) 2-level
+    bs, T, N = 3, 7, 19
+    Z, W = rnd(bs * T * N, 64), rnd(64, 128, seed=5)
+
+    def proj(Kx, Z, W, out):
+        Zv = Z.view(bs, T, N, 64).permute(0, 2, 1, 3)
+        Kx.gemm([dict(A=W, B=Zv[0], C=out[0].view(128, N * T), batch=(bs, 0, T * N * 64, 128 * N * T))], a_kmajor=True)
+
+    o_cpu = torch.zeros(bs, 128, N, T)
+    proj(F, Z, W, o_cpu)
+    o_gpu = torch.zeros(bs, 128, N, T, device=DEV)
+    proj(K, Z.to(DEV), W.to(DEV), o_gpu)
+    close(o_gpu, o_cpu, what='batched projection')
+    ref = (Z.view(bs, T, N, 64) @ W).permute(0, 3, 2, 1)
+    close(o_gpu, ref, what='batched projection vs einsum')
+    # split-K weight gradient: dW (96, 64) = dY^T X with 30000 rows
+    dY, X = rnd(30000, 96, scale=0.1), rnd(30000, 64, seed=7)
+    w_cpu = torch.zeros(96, 64)
+    F.gemm([dict(A=dY, B=X, C=w_cpu)], a_kmajor=True, b_kmajor=True)
+    w_gpu = torch.zeros(96, 64, device=DEV)
+    K.gemm([dict(A=dY.to(DEV), B=X.to(DEV), C=w_gpu)], a_kmajor=True, b_kmajor=True)
+    close(w_gpu, w_cpu, rtol=1e-4, atol=1e-3, what='split-K dW')
+    w_gpu2 = torch.zeros(96, 64, device=DEV)
+    K.gemm([dict(A=dY.to(DEV), B=X.to(DEV), C=w_gpu2)], a_kmajor=True, b_kmajor=True)
+    assert torch.equal(w_gpu, w_gpu2), 'split-K reduction must be deterministic'
+
+
+# ----------------------------------------------------------------------------------------------------------------- GCN
+@pytest.mark.parametrize('N', [19, 34])
+def test_gcn_kernels(K, N):
+    bs, T, H = 3, 6, 2
+    xh = rnd(bs, T, H, 2048 + 4 * N)
+    gamma, beta = rnd(4 * N, seed=1).abs() + 0.5, rnd(4 * N, seed=2)
+    for training in (True, False):
+        rm, rv = rnd(4 * N, seed=3) * 0.1, rnd(4 * N, seed=4).abs() + 0.5
+        nbt = torch.tensor(5, dtype=torch.int64)
+        rm_g, rv_g, nbt_g = rm.clone().to(DEV), rv.clone().to(DEV), nbt.clone().to(DEV)
+        ab_c, mi_c = F.bn_fold(xh, N, gamma, beta, rm, rv, nbt, training)
+        ab_g, mi_g = K.bn_fold(xh.to(DEV), N, gamma.to(DEV), beta.to(DEV), rm_g, rv_g, nbt_g, training)
+        close(ab_g, ab_c, what=f'bn ab train={training}')
+        close(mi_g, mi_c, what='bn mean/invstd')
+        close(rm_g, rm, what='running_mean')
+        close(rv_g, rv, what='running_var')
+        assert int(nbt_g) == int(nbt)
+    w1, b1 = rnd(64, 4, seed=5), rnd(64, seed=6)
+    e1_c = F.gcn_embed1_fwd(xh, N, ab_c, w1, b1)
+    e1_g = K.gcn_embed1_fwd(xh.to(DEV), N, ab_c.to(DEV), w1.to(DEV), b1.to(DEV))
+    close(e1_g, e1_c, what='embed1 fwd')
+    de1 = rnd(bs * T * N, 64, seed=7) * (e1_c > 0)
+    r_c = F.gcn_embed1_bwd(xh, N, ab_c, mi_c, w1, de1)
+    r_g = K.gcn_embed1_bwd(xh.to(DEV), N, ab_c.to(DEV), mi_c.to(DEV), w1.to(DEV), de1.to(DEV))
+    for a, b, nm in zip(r_g, r_c, ('dw1', 'db1', 'dgamma', 'dbeta')):
+        close(a, b, rtol=1e-4, atol=1e-4, what='embed1 bwd ' + nm)
+    nF = bs * T
+    qk, x = rnd(nF * N, 256, seed=8, scale=0.3), rnd(nF * N, 64, seed=9)
+    s_c, z_c = F.gcn_attn_fwd(qk, x, nF, N)
+    s_g, z_g = K.gcn_attn_fwd(qk.to(DEV), x.to(DEV), nF, N)
+    close(s_g, s_c, rtol=1e-4, atol=1e-6, what='gcn attn S')
+    close(z_g, z_c, rtol=1e-4, atol=1e-5, what='gcn attn Z')
+    dz = rnd(nF * N, 64, seed=10)
+    dx_c, dqk_c = F.gcn_attn_bwd(qk, x, s_c, dz, nF, N)
+    dx_g, dqk_g = K.gcn_attn_bwd(qk.to(DEV), x.to(DEV), s_c.to(DEV), dz.to(DEV), nF, N)
+    close(dx_g, dx_c, rtol=1e-4, atol=1e-5, what='gcn attn dX')
+    close(dqk_g, dqk_c, rtol=1e-4, atol=1e-5, what='gcn attn dQK')
+
+
+# --------------------------------------------------------------------------------------------------------------- BiGRU
+@pytest.mark.parametrize('h', [16, 72])
+def test_bigru(K, h):
+    bs, T = 3, 5
+    types_c, types_g = [], []
+    for i, E in enumerate((2, 3, 1)):
+        d = dict(gi=rnd(bs, T, E, 6 * h, seed=i), w_hh_f=rnd(3 * h, h, seed=10 + i, scale=0.2), b_hh_f=rnd(3 * h, seed=20 + i),
+                 w_hh_r=rnd(3 * h, h, seed=30 + i, scale=0.2), b_hh_r=rnd(3 * h, seed=40 + i))
+        types_c.append(d)
+        types_g.append({k: v.to(DEV) for k, v in d.items()})
+    res_c = F.bigru_fwd(types_c, bs, T, h)
+    res_g = K.bigru_fwd(types_g, bs, T, h)
+    for (oc, sc), (og, sg) in zip(res_c, res_g):
+        close(og, oc, rtol=1e-4, atol=1e-5, what='bigru out')
+        close(sg, sc, rtol=1e-4, atol=1e-5, what='bigru save')
+    bt_c, bt_g = [], []
+    for i, ((oc, sc), d) in enumerate(zip(res_c, types_c)):
+        dout = rnd(*oc.shape, seed=50 + i)
+        bt_c.append(dict(d_out=dout, save=sc, out=oc, w_hh_f=d['w_hh_f'], w_hh_r=d['w_hh_r']))
+        bt_g.append({k: v.to(DEV) for k, v in bt_c[-1].items()})
+    for (gc, hc), (gg, hg) in zip(F.bigru_bwd(bt_c, bs, T, h), K.bigru_bwd(bt_g, bs, T, h)):
+        close(gg, gc, rtol=1e-4, atol=1e-5, what='bigru d_gi')
+        close(hg, hc, rtol=1e-4, atol=1e-5, what='bigru d_gh')
+
+
+# ---------------------------------------------------------------------------------------------------- entity attention
+def _attn_case(dev, H, O, D, h, n_inst, ipc, geo, recv_mask, seed=0):
+    t = lambda *s, sd=0: rnd(*s, seed=seed + sd).to(dev)
+    W = 3 * h
+    d = dict(feat_h=t(n_inst * H, D + 8, sd=1)[:, :D], feat_o=t(n_inst * O, D, sd=2),
+             msg_hh=t(n_inst * H, 2 * h, sd=3)[:, :h], msg_ho=t(n_inst * H, 2 * h, sd=4)[:, h:],
+             msg_oh=t(n_inst * O, h, sd=5), msg_oo=t(n_inst * O, h, sd=6),
+             out_hh=torch.zeros(n_inst * H, W, device=dev)[:, :h], out_oh=torch.zeros(n_inst * H, W, device=dev)[:, h:2 * h],
+             out_ho=torch.zeros(n_inst * O, W, device=dev)[:, :h], out_oo=torch.zeros(n_inst * O, W, device=dev)[:, 2 * h:],
+             att=torch.zeros(n_inst, H * H + 2 * H * O + O * O, device=dev), n_inst=n_inst, inst_per_clip=ipc, H=H, O=O,
+             D=D, hidden=h, scale=1.0 / math.sqrt(D), recv_mask_ho=recv_mask)
+    mask = (rnd(n_inst // ipc, O, seed=seed + 7) > -0.3).float()
+    mask[0] = 0.0  # a clip with only virtual objects (NaN -> 0 path)
+    d['obj_mask'] = mask.to(dev)
+    if geo:
+        d.update(msg_so=t(n_inst, h, sd=8), msg_sh=t(n_inst, h, sd=9),
+                 out_so=torch.zeros(n_inst * O, h, device=dev), out_sh=torch.zeros(n_inst * H, h, device=dev))
+    return d
+
+
+@pytest.mark.parametrize('H,O,D,h,ipc,geo,rm', [(2, 4, 64, 32, 3, True, 1), (1, 5, 32, 32, 1, False, 0),
+                                                (2, 9, 128, 64, 2, True, 1), (2, 8, 1024, 512, 2, True, 1)])
+def test_entity_attention(K, H, O, D, h, ipc, geo, rm):
+    n_inst = 6
+    dc = _attn_case('cpu', H, O, D, h, n_inst, ipc, geo, rm)
+    dg = _attn_case(DEV, H, O, D, h, n_inst, ipc, geo, rm)
+    if H == 1:
+        for d in (dc, dg):
+            d['msg_hh'] = None
+            d.pop('out_hh')
+    F.attn_fwd([dc])
+    K.attn_fwd([dg])
+    close(dg['att'], dc['att'], rtol=1e-4, atol=1e-6, what='att weights')
+    for k in dc:
+        if k.startswith('out_'):
+            close(dg[k], dc[k], rtol=1e-4, atol=1e-5, what=k)
+    assert not torch.isnan(dg['att']).any()
+
+    def bwd(dev, d, seed=100):
+        t = lambda *s, sd=0: rnd(*s, seed=seed + sd).to(dev)
+        b = dict(f=d, dfeat_accumulate=1, relu_mask_dmsg=1, dfeat_h=t(n_inst * H, D, sd=1), dfeat_o=t(n_inst * O, D, sd=2))
+        for i, (rel, R) in enumerate((('hh', H), ('oh', H), ('ho', O), ('oo', O), ('so', O), ('sh', H))):
+            if d.get('msg_' + rel) is None:
+                continue
+            b['dout_' + rel] = t(n_inst * R, h, sd=10 + i)
+            S_ = {'hh': H, 'ho': H, 'oh': O, 'oo': O, 'so': 0, 'sh': 0}[rel]
+            b['dmsg_' + rel] = torch.zeros(n_inst * S_ if S_ else n_inst, h, device=dev)
+        return b
+
+    bc, bg = bwd('cpu', dc), bwd(DEV, dg)
+    F.attn_bwd([bc])
+    K.attn_bwd([bg])
+    for k in bc:
+        if k.startswith('dmsg_') or k.startswith('dfeat_h') or k.startswith('dfeat_o'):
+            close(bg[k], bc[k], rtol=2e-4, atol=2e-5, what=k)
+
+
+# ---------------------------------------------------------------------------------------------- segment-level recurrence
+def _seg_params(dev, bs, T, H, O, h, rels, msg_segment=True, seed=0):
+    t = lambda *s, sd=0, sc=0.3: rnd(*s, seed=seed + sd, scale=sc).to(dev)
+    rel_hh, rel_ho, rel_oh, rel_oo = rels
+    nmh, nmo = int(rel_hh) + int(rel_oh), int(rel_ho) + int(rel_oo)
+    nsh, nso = int(rel_hh) + int(rel_ho), int(rel_oh) + int(rel_oo)
+    fw_h, fw_o = 3 * h, 4 * h
+    wih_h = [t(3 * h, fw_h + nmh * h, sd=1 + d) for d in range(2)]
+    wih_o = [t(3 * h, fw_o + nmo * h, sd=3 + d) for d in range(2)]
+    mask = torch.ones(bs, O)
+    mask[0, O - 1] = 0
+    if bs > 1:
+        mask[1] = 0
+    p = dict(bs=bs, T=T, H=H, O=O, hidden=h, msg_segment=msg_segment, rel_hh=rel_hh, rel_ho=rel_ho, rel_oh=rel_oh,
+             rel_oo=rel_oo, att_scale=1 / math.sqrt(h), gi_h=t(bs, T, H, 6 * h, sd=5, sc=1.0), gi_o=t(bs, T, O, 6 * h, sd=6, sc=1.0),
+             u_h=(rnd(bs, T, H, seed=seed + 7) > 0).float().to(dev), u_o=(rnd(bs, T, O, seed=seed + 8) > 0).float().to(dev),
+             obj_mask=mask.to(dev),
+             w_hh_h=[t(3 * h, h, sd=9 + d) for d in range(2)], b_hh_h=[t(3 * h, sd=11 + d) for d in range(2)],
+             w_hh_o=[t(3 * h, h, sd=13 + d) for d in range(2)], b_hh_o=[t(3 * h, sd=15 + d) for d in range(2)],
+             w_ihm_h=[w[:, fw_h:] for w in wih_h], w_ihm_o=[w[:, fw_o:] for w in wih_o],
+             ld_ih_h=fw_h + nmh * h, ld_ih_o=fw_o + nmo * h,
+             w_smsg_h=t(max(nsh, 1) * h, h, sd=17)[:nsh * h], b_smsg_h=t(max(nsh, 1) * h, sd=18)[:nsh * h],
+             w_smsg_o=t(max(nso, 1) * h, h, sd=19)[:nso * h], b_smsg_o=t(max(nso, 1) * h, sd=20)[:nso * h])
+    p['_keep'] = (wih_h, wih_o)
+    return p
+
+
+@pytest.mark.parametrize('bs,T,H,O,h,rels,msg', [(3, 5, 2, 4, 16, (True, True, True, True), True),
+                                                 (2, 4, 1, 5, 32, (False, True, True, True), True),
+                                                 (2, 3, 2, 3, 16, (True, True, True, True), False),
+                                                 (4, 6, 2, 8, 64, (True, True, True, True), True)])
+def test_segment_recurrence(K, bs, T, H, O, h, rels, msg):
+    pc = _seg_params('cpu', bs, T, H, O, h, rels, msg)
+    pg = _seg_params(DEV, bs, T, H, O, h, rels, msg)
+    bc = F.segrnn_fwd(pc)
+    bg = K.segrnn_fwd(pg)
+    keys = ['hs_h', 'hs_o', 'save_h', 'save_o'] + (['msrc_h', 'msrc_o', 'mg_h', 'mg_o', 'att'] if msg else [])
+    for k in keys:
+        close(bg[k], bc[k], rtol=2e-4, atol=2e-5, what='segrnn fwd ' + k)
+    dh_h, dh_o = rnd(bs, T, H, 2 * h, seed=31), rnd(bs, T, O, 2 * h, seed=32)
+    oc = F.segrnn_bwd(pc, bc, dh_h, dh_o)
+    # feed the GPU backward with the CPU forward buffers so that the comparison isolates the backward kernels
+    bg2 = {k: v.to(DEV) for k, v in bc.items()}
+    for k in bg:
+        if k not in bg2:
+            bg2[k] = bg[k]
+    og = K.segrnn_bwd(pg, bg2, dh_h.to(DEV), dh_o.to(DEV))
+    for k in oc:
+        if k.startswith('d_pre') and not msg:
+            continue  # unused scratch when message_segment is off
+        close(og[k], oc[k], rtol=3e-4, atol=3e-5, what='segrnn bwd ' + k)
+
+
+# --------------------------------------------------------------------------------------------------------------- gates
+@pytest.mark.parametrize('gs', [True, False])
+def test_gates_filter_reorder_heads(K, gs):
+    bs, T, E, h = 3, 6, 4, 32
+    W = 5 * h
+    x = rnd(bs * T * E, W, scale=0.5)
+    cols = [0, h, 2 * h, 4 * h, 3 * h]
+    w, b = rnd(1, 5 * h, seed=1, scale=0.2), rnd(1, seed=2)
+    noise = torch.distributions.gumbel.Gumbel(0.0, 1.0).sample((T * (E + 2), bs, 2)) if gs else None
+
+    def desc(dev):
+        return dict(x=x.to(dev), seg_col=cols, hidden=h, w=w.to(dev), b=b.to(dev),
+                    noise=noise.to(dev) if noise is not None else None, bs=bs, T=T, E=E, noise_entities=E + 2,
+                    noise_offset=2, force_last=1, threshold=0.5)
+
+    dc, dg = desc('cpu'), desc(DEV)
+    hc, sc = F.gate_fwd(dc)
+    hg, sg = K.gate_fwd(dg)
+    close(sg, sc, rtol=1e-4, atol=1e-6, what='gate soft')
+    safe = (sc - 0.5).abs() > 1e-4
+    assert torch.equal(hg.cpu()[safe], hc[safe])
+    assert torch.all(hg[:, T - 1] == 1)
+    d_hard, d_soft, stm = rnd(bs, T, E, seed=3), rnd(bs, T, E, seed=4), (rnd(bs, T, E, seed=5) > 0).float()
+    dg['p_save'], dg['soft'] = dc['p_save'].to(DEV), dc['soft'].to(DEV)
+    lc = F.gate_bwd(dc, d_hard, d_soft, stm)
+    lg = K.gate_bwd(dg, d_hard.to(DEV), d_soft.to(DEV), stm.to(DEV))
+    close(lg, lc, rtol=1e-4, atol=1e-6, what='gate dlogit')
+    lc2 = F.gate_bwd(dc, d_hard, None, None)
+    lg2 = K.gate_bwd(dg, d_hard.to(DEV), None, None)
+    close(lg2, lc2, rtol=1e-4, atol=1e-6, what='gate dlogit (no soft/mask)')
+    # rank-1 update + weighted column sum on strided views
+    dst = rnd(bs * T * E, W, seed=6)
+    dst_g = dst.clone().to(DEV)
+    F.rank1_update(dst[:, h:2 * h], lc, w.view(-1)[:h])
+    K.rank1_update(dst_g[:, h:2 * h], lc.to(DEV), w.view(-1)[:h].contiguous().to(DEV))
+    close(dst_g, dst, what='rank1')
+    cs_c = F.colsum(x[:, h:3 * h], rowscale=lc)
+    cs_g = K.colsum(x.to(DEV)[:, h:3 * h], rowscale=lc.to(DEV))
+    close(cs_g, cs_c, rtol=1e-4, atol=1e-5, what='weighted colsum')
+    big = rnd(20000, 48, seed=8)
+    close(K.colsum(big.to(DEV)), F.colsum(big), rtol=1e-4, atol=1e-3, what='colsum tall')
+    # filter
+    soft = torch.rand(bs, T, E)
+    for thr in (0.1, 0.5):
+        fc = F.filter_fwd(soft, thr)
+        fg = K.filter_fwd(soft.to(DEV), thr)
+        assert torch.equal(fg[0].cpu(), fc[0]) and torch.equal(fg[1].cpu(), fc[1])
+    # reorder
+    hx = rnd(bs, T, E, 2 * h, seed=9)
+    gate = (rnd(bs, T, E, seed=10) > 0.3).float()
+    gate[0] = 0
+    gate[1, :, 0] = 1
+    assert torch.equal(K.reorder_fwd(hx.to(DEV), gate.to(DEV)).cpu(), F.reorder_fwd(hx, gate))
+    close(K.reorder_bwd(hx.to(DEV), gate.to(DEV)), F.reorder_bwd(hx, gate), what='reorder bwd')
+    # heads epilogue
+    C = 13
+    logits = rnd(bs * T * E, C, seed=11, scale=3)
+    oc = F.logsoftmax_permute_fwd(logits, bs, T, E, C)
+    og = K.logsoftmax_permute_fwd(logits.to(DEV), bs, T, E, C)
+    close(og, oc, rtol=1e-5, atol=1e-5, what='logsoftmax permute')
+    dout = rnd(bs, C, T, E, seed=12)
+    close(K.logsoftmax_permute_bwd(oc.to(DEV), dout.to(DEV)), F.logsoftmax_permute_bwd(oc, dout), rtol=1e-4, atol=1e-5,
+          what='logsoftmax bwd')
+    # elementwise
+    y, dy = rnd(500, 36, seed=13), rnd(500, 36, seed=14)
+    close(K.relu_bwd(dy.to(DEV), y.to(DEV)), F.relu_bwd(dy, y), what='relu bwd')
+    ybig, dybig = rnd(100, 80, seed=15), rnd(100, 80, seed=16)
+    close(K.relu_bwd(dybig.to(DEV)[:, 3:40], ybig.to(DEV)[:, 3:40]), F.relu_bwd(dybig[:, 3:40], ybig[:, 3:40]),
+          what='relu bwd unaligned view')
+    a, bdst = rnd(64, 20, seed=17), rnd(64, 20, seed=18)
+    bg = bdst.clone().to(DEV)
+    F.add_rows(a, bdst)
+    K.add_rows(a.to(DEV), bg)
+    close(bg, bdst, what='add_rows')
+    # adam
+    p0, g0 = rnd(1000, seed=19), rnd(1000, seed=20)
+    pc, mc, vc = p0.clone(), torch.zeros(1000), torch.zeros(1000)
+    pg, mg, vg = p0.clone().to(DEV), torch.zeros(1000, device=DEV), torch.zeros(1000, device=DEV)
+    for step in (1, 2, 3):
+        F.adam_step(pc, g0, mc, vc, 1e-3, 0.9, 0.999, 1e-8, 0.0, step)
+        K.adam_step(pg, g0.to(DEV), mg, vg, 1e-3, 0.9, 0.999, 1e-8, 0.0, step)
+    close(pg, pc, rtol=1e-5, atol=1e-6, what='adam')
+    ref = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.Adam([ref], lr=1e-3)
+    for _ in range(3):
+        ref.grad = g0.clone()
+        opt.step()
+    close(pg, ref.data, rtol=1e-5, atol=1e-6, what='adam vs torch.optim.Adam')

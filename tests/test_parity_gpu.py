@@ -1,0 +1,189 @@
+"""GPU: the shipped path (TGGCN on cuda through lib2ggcn_hip.so) against
+  (1) the golden vectors captured from the real reference (small layouts C1/C2/C5, stage-1 and stage-2 semantics),
+  (2) the CPU oracle on the synthetic N=34 layout (C3) at a reduced width, forward and backward,
+  (3) the CPU oracle at the full BASELINE width (T=120, N=34, h=512), forward,
+  (4) size-independent properties at the full bench size: run-to-run bit determinism, batch independence in eval mode.
+Tolerance: 1e-4 relative (north_star), stated per assertion."""
+import numpy as np
+import pytest
+import torch
+
+import twog_gcn_amd  # noqa: F401
+from twog_gcn_amd import kernels as twog_kernels
+from twog_gcn_amd.models import TGGCN
+from oracle import cpu_ref, detgen
+from tests.helpers import G4_CASES, load_g4, det_state_dict, g4_inputs, sample_grad
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+REL = 1e-4
+
+STAGE1 = dict(attention_style='v3', discrete_optimization_strategy='gs', filter_discrete_updates=False,
+              message_humans_to_human=True, message_human_to_objects=True, message_objects_to_human=True,
+              message_objects_to_object=True, message_geometry_to_objects=True, message_geometry_to_human=False,
+              message_segment=True, message_type='v2', message_granularity='v1', message_aggregation='att',
+              object_segment_update_strategy='ind', update_segment_threshold=0.5)
+
+
+@pytest.fixture(autouse=True)
+def hip_backend():
+    twog_kernels._set_backend_for_tests(None)
+    assert twog_kernels.get_kernels().name == 'hip'
+    yield
+
+
+def _model_from_meta(meta):
+    N = meta['N']
+    m = TGGCN(input_size=(2048 + 4 * N, 2048), num_classes=tuple(meta['classes']), **meta['cfg'])
+    m.load_state_dict(det_state_dict(meta['state_dict_shapes'], seed=meta['seed'], gain=meta['gain']))
+    return m.to(DEV)
+
+
+@pytest.mark.parametrize('name', G4_CASES)
+def test_golden_reference_vectors(name):
+    z, meta = load_g4(name)
+    m = _model_from_meta(meta)
+    m.train()
+    noise = torch.from_numpy(z['gumbel_noise'])
+    m._gumbel_noise_override = noise if len(noise) else None
+    kw = {k: v.to(DEV) for k, v in g4_inputs(z).items()}
+    out = m(**kw)
+    n_out = len([k for k in z.files if k.startswith('out')])
+    assert len(out) == n_out
+    for i, o in enumerate(out):
+        ref = z[f'out{i}']
+        got = o.detach().cpu().numpy()
+        if ref.ndim == 3 and np.all((ref == 0) | (ref == 1)) and i < n_out - 4:
+            assert np.array_equal(got, ref), f'{name} out{i} (hard gates must be exact)'
+        else:
+            assert np.abs(got - ref).max() < REL * max(1.0, np.abs(ref).max()), (name, i, float(np.abs(got - ref).max()))
+    bn = m.geometry_embedding_gcn.joint_embed.cnn[0].bn
+    assert np.allclose(bn.running_mean.cpu().numpy(), z['bn_running_mean'], rtol=1e-5, atol=1e-6)
+    assert np.allclose(bn.running_var.cpu().numpy(), z['bn_running_var'], rtol=1e-5, atol=1e-6)
+    if not bool(z['backward_ok']):
+        return
+    loss = 0
+    for i, o in enumerate(out):
+        if o.requires_grad:
+            r = torch.from_numpy(detgen.normal(f'{name}.r{i}', tuple(o.shape), seed=meta['seed'])).to(DEV)
+            loss = loss + (o * r).sum()
+    assert abs(float(loss.detach()) - float(z['loss'])) < 1e-3 * max(1.0, abs(float(z['loss'])))
+    loss.backward()
+    none_ref = set(z['none_grads'].tolist())
+    worst = 0.0
+    for pname, p in m.named_parameters():
+        if pname in none_ref:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, pname
+            continue
+        assert p.grad is not None, pname
+        g_ref = z['grad_' + pname]
+        g = sample_grad(p.grad)
+        scale = max(np.abs(g_ref).max(), 1e-6)
+        err = float(np.abs(g - g_ref).max())
+        worst = max(worst, err / scale)
+        assert err < 5e-4 * scale + 5e-6, (name, pname, err, float(scale))
+    print(f'{name}: worst relative gradient error {worst:.2e}')
+
+
+def _synthetic(bs, T, H, O, N, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    vis = torch.relu(torch.randn(bs, T, H, 2048, generator=g))
+    pos = torch.rand(bs, T, N, 2, generator=g)
+    vel = torch.randn(bs, T, N, 2, generator=g) * 0.5
+    geo = torch.cat([pos, vel], -1).reshape(bs, T, 1, 4 * N).expand(bs, T, H, 4 * N)
+    x_human = torch.cat([vis, geo], -1).contiguous()
+    x_objects = torch.relu(torch.randn(bs, T, O, 2048, generator=g))
+    mask = torch.ones(bs, O)
+    if bs > 1:
+        mask[1, O - 2:] = 0.0
+        x_objects[1, :, O - 2:] = 0.0
+    return x_human, x_objects, mask
+
+
+def _oracle_vs_hip(bs, T, H, O, N, h, backward, seed=3):
+    torch.manual_seed(seed)
+    m = TGGCN(input_size=(2048 + 4 * N, 2048), num_classes=(13, None), hidden_size=h, gcn_node=N, **STAGE1)
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    x_human, x_objects, mask = _synthetic(bs, T, H, O, N, seed)
+    seg = torch.ones(bs, T, H)
+    noise = torch.distributions.gumbel.Gumbel(0.0, 1.0).sample((T * O, bs, 2))
+    # oracle (CPU)
+    osd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and 'running' not in k else v.clone())
+           for k, v in sd.items()}
+    ref = cpu_ref.tggcn_forward(osd, dict(m.cfg), x_human, x_objects, mask, human_segmentation=seg, training=True,
+                                gumbel_noise=noise)
+    # HIP
+    m = m.to(DEV).train()
+    m._gumbel_noise_override = noise
+    out = m(x_human.to(DEV), x_objects.to(DEV), mask.to(DEV), human_segmentation=seg.to(DEV))
+    soft_ref = None
+    for i, (o, r) in enumerate(zip(out, ref)):
+        got, want = o.detach().cpu(), r.detach()
+        assert got.shape == want.shape
+        err = (got - want).abs().max().item()
+        assert err < REL * max(1.0, want.abs().max().item()), (i, err)
+    if not backward:
+        return
+    rs = [torch.randn(o.shape, generator=torch.Generator().manual_seed(i)) for i, o in enumerate(ref)]
+    sum((o * r).sum() for o, r in zip(ref, rs) if o.requires_grad).backward()
+    sum((o * r.to(DEV)).sum() for o, r in zip(out, rs) if o.requires_grad).backward()
+    worst = 0.0
+    for pname, p in m.named_parameters():
+        g_ref = osd[pname].grad
+        if g_ref is None:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, pname
+            continue
+        assert p.grad is not None, pname
+        scale = max(g_ref.abs().max().item(), 1e-6)
+        err = (p.grad.cpu() - g_ref).abs().max().item()
+        worst = max(worst, err / scale)
+        assert err < 5e-4 * scale + 5e-6, (pname, err, scale)
+    print(f'worst relative gradient error {worst:.2e}')
+
+
+def test_oracle_parity_c3_layout_reduced_width():
+    """Synthetic layout of BASELINE configs[2] (H=2, O=8, N=34) at h=64, T=16: forward + backward vs the oracle."""
+    _oracle_vs_hip(bs=3, T=16, H=2, O=8, N=34, h=64, backward=True)
+
+
+def test_oracle_parity_c2_layout_hs128():
+    _oracle_vs_hip(bs=2, T=10, H=2, O=4, N=26, h=128, backward=True, seed=5)
+
+
+def test_oracle_parity_full_width_forward():
+    """BASELINE width: T=120, N=34, h=512 (one clip pair; the oracle needs ~1 min on host cores)."""
+    _oracle_vs_hip(bs=2, T=120, H=2, O=8, N=34, h=512, backward=False, seed=7)
+
+
+def test_full_size_determinism_and_batch_independence():
+    """bench-size properties: two identical steps are bit-identical (split-K and all reductions are ordered);
+    in eval mode a clip's outputs do not depend on the other clips of the batch."""
+    bs, T, H, O, N, h = 16, 120, 2, 8, 34, 512
+    torch.manual_seed(0)
+    m = TGGCN(input_size=(2048 + 4 * N, 2048), num_classes=(13, None), hidden_size=h, gcn_node=N, **STAGE1).to(DEV)
+    x_human, x_objects, mask = (t.to(DEV) for t in _synthetic(bs, T, H, O, N, 1))
+    seg = torch.ones(bs, T, H, device=DEV)
+    noise = torch.distributions.gumbel.Gumbel(0.0, 1.0).sample((T * O, bs, 2))
+    m._gumbel_noise_override = noise
+    m.train()
+    runs = []
+    for _ in range(2):
+        m.zero_grad(set_to_none=True)
+        bn = m.geometry_embedding_gcn.joint_embed.cnn[0].bn
+        bn.running_mean.zero_(); bn.running_var.fill_(1.0)
+        out = m(x_human, x_objects, mask, human_segmentation=seg)
+        (out[4].sum() + out[5].sum() + out[1].sum()).backward()
+        runs.append(([o.detach().clone() for o in out], {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}))
+    for a, b in zip(runs[0][0], runs[1][0]):
+        assert torch.equal(a, b)
+    for n in runs[0][1]:
+        assert torch.equal(runs[0][1][n], runs[1][1][n]), n
+    assert all(torch.isfinite(g).all() for g in runs[0][1].values())
+    m.eval()
+    with torch.no_grad():
+        full = m(x_human, x_objects, mask, human_segmentation=seg)
+        m._gumbel_noise_override = noise[:, 3:5]
+        part = m(x_human[3:5], x_objects[3:5], mask[3:5], human_segmentation=seg[3:5])
+    for a, b in zip(full[1:], part[1:]):
+        err = (a[3:5] - b).abs().max().item()
+        assert err < REL * max(1.0, b.abs().max().item()), err
