@@ -15,9 +15,11 @@
 // conflict-free ds_read_b32. Workgroup ids are remapped so that tiles sharing an A row-panel run on one XCD (its
 // L2 then serves the panel once). Tall reductions (dW = dY^T X, K = rows) use deterministic split-K: partial slabs in
 // the caller's workspace, summed in fixed order by a second kernel.
+#include <cstdlib>
 #include "twog_common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));  // native vector: loads/stores stay in registers (SROA)
 
 namespace {
 
@@ -51,9 +53,10 @@ struct TileRegs {
     static constexpr int F4_PER_ROW = COLS / 4;
     static constexpr int ROWS_PER_PASS = 256 / F4_PER_ROW;
     static constexpr int PASSES = ROWS / ROWS_PER_PASS;
-    float4 v[PASSES];
+    f32x4 v[PASSES];
 };
 
+// guarded load (edge tiles / unaligned operands): out-of-range elements read as 0
 template <int ROWS, int COLS>
 __device__ __forceinline__ void load_tile(TileRegs<ROWS, COLS>& t, const twog_rows_t& m, int r0, int c0, int rmax,
                                           int cmax, int vec_ok) {
@@ -63,11 +66,11 @@ __device__ __forceinline__ void load_tile(TileRegs<ROWS, COLS>& t, const twog_ro
 #pragma unroll
     for (int i = 0; i < T::PASSES; ++i) {
         const int r = r0 + tid / T::F4_PER_ROW + i * T::ROWS_PER_PASS;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (r < rmax && c < cmax) {
             const float* p = m.ptr + twog_row_off(m, r) + c;
             if (vec_ok && c + 3 < cmax) {
-                v = *reinterpret_cast<const float4*>(p);
+                v = *reinterpret_cast<const f32x4*>(p);
             } else {
                 v.x = p[0];
                 if (c + 1 < cmax) v.y = p[1];
@@ -87,12 +90,124 @@ __device__ __forceinline__ void store_tile(const TileRegs<ROWS, COLS>& t, float*
 #pragma unroll
     for (int i = 0; i < T::PASSES; ++i) {
         const int r = tid / T::F4_PER_ROW + i * T::ROWS_PER_PASS;
-        *reinterpret_cast<float4*>(s + r * LD + c) = t.v[i];
+        *reinterpret_cast<f32x4*>(s + r * LD + c) = t.v[i];
+    }
+}
+
+template <int BM, int BN, bool AKM, bool BKM, bool FAST, int TM, int TN>
+__device__ __forceinline__ void gemm_mainloop(const twog_rows_t A, const twog_rows_t B, int M, int N, int a_vec,
+                                              int b_vec, int m0, int n0, int k_begin, int k_end, float* smem,
+                                              f32x16 (&acc)[TM][TN]) {
+    constexpr int WM = BM / 2, WN = BN / 2;
+    constexpr int LDA = AKM ? (BM + 4) : (BK + 4);
+    constexpr int LDB = BKM ? (BN + 4) : (BK + 4);
+    constexpr int A_ELEMS = AKM ? BK * LDA : BM * LDA;
+    constexpr int B_ELEMS = BKM ? BK * LDB : BN * LDB;
+    constexpr int STAGE = A_ELEMS + B_ELEMS;  // buffer b: A at smem + b*STAGE, B right behind it
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 31, kh = lane >> 5;
+    const int wm = (wave >> 1) * WM, wn = (wave & 1) * WN;
+
+    using ARegs = TileRegs<(AKM ? BK : BM), (AKM ? BM : BK)>;
+    using BRegs = TileRegs<(BKM ? BK : BN), (BKM ? BN : BK)>;
+    ARegs ra;
+    BRegs rb;
+    // FAST: 16-byte aligned operands and only whole k-tiles -> every lane issues unconditional global_load_dwordx4
+    // (row / column indices beyond the matrix are clamped: they only feed outputs that are never stored), so the
+    // loads of k-tile t+1 stay in flight under the MFMAs of tile t.
+    const int tid = threadIdx.x;
+    auto gload = [&](int k0) {
+        if constexpr (FAST) {
+            if constexpr (AKM) {
+                const int c = min(m0 + (tid % ARegs::F4_PER_ROW) * 4, M - 4);
+#pragma unroll
+                for (int i = 0; i < ARegs::PASSES; ++i)
+                    ra.v[i] = *reinterpret_cast<const f32x4*>(
+                        A.ptr + twog_row_off(A, k0 + tid / ARegs::F4_PER_ROW + i * ARegs::ROWS_PER_PASS) + c);
+            } else {
+#pragma unroll
+                for (int i = 0; i < ARegs::PASSES; ++i) {
+                    const int row = min(m0 + tid / ARegs::F4_PER_ROW + i * ARegs::ROWS_PER_PASS, M - 1);
+                    ra.v[i] = *reinterpret_cast<const f32x4*>(A.ptr + twog_row_off(A, row) + (tid % ARegs::F4_PER_ROW) * 4 + k0);
+                }
+            }
+            if constexpr (BKM) {
+                const int c = min(n0 + (tid % BRegs::F4_PER_ROW) * 4, N - 4);
+#pragma unroll
+                for (int i = 0; i < BRegs::PASSES; ++i)
+                    rb.v[i] = *reinterpret_cast<const f32x4*>(
+                        B.ptr + twog_row_off(B, k0 + tid / BRegs::F4_PER_ROW + i * BRegs::ROWS_PER_PASS) + c);
+            } else {
+#pragma unroll
+                for (int i = 0; i < BRegs::PASSES; ++i) {
+                    const int row = min(n0 + tid / BRegs::F4_PER_ROW + i * BRegs::ROWS_PER_PASS, N - 1);
+                    rb.v[i] = *reinterpret_cast<const f32x4*>(B.ptr + twog_row_off(B, row) + (tid % BRegs::F4_PER_ROW) * 4 + k0);
+                }
+            }
+        } else {
+            if constexpr (AKM) load_tile(ra, A, k0, m0, k_end, M, a_vec);
+            else               load_tile(ra, A, m0, k0, M, k_end, a_vec);
+            if constexpr (BKM) load_tile(rb, B, k0, n0, k_end, N, b_vec);
+            else               load_tile(rb, B, n0, k0, N, k_end, b_vec);
+        }
+    };
+
+    const int nkt = (k_end > k_begin) ? (k_end - k_begin + BK - 1) / BK : 0;
+    if (nkt > 0) {
+        gload(k_begin);
+        store_tile<ARegs::R, ARegs::C, LDA>(ra, smem);
+        store_tile<BRegs::R, BRegs::C, LDB>(rb, smem + A_ELEMS);
+    }
+    __syncthreads();
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nkt) {
+            gload(k_begin + (kt + 1) * BK);
+        }
+        const float* a_s = smem + buf * STAGE;
+        const float* b_s = a_s + A_ELEMS;
+#pragma unroll
+        for (int kk = 0; kk < BK / 8; ++kk) {
+            float af[TM][4], bf[TN][4];
+#pragma unroll
+            for (int a = 0; a < TM; ++a) {
+                if constexpr (AKM) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) af[a][r] = a_s[(kk * 8 + kh * 4 + r) * LDA + wm + a * 32 + li];
+                } else {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(a_s + (wm + a * 32 + li) * LDA + kk * 8 + kh * 4);
+                    af[a][0] = v.x; af[a][1] = v.y; af[a][2] = v.z; af[a][3] = v.w;
+                }
+            }
+#pragma unroll
+            for (int b = 0; b < TN; ++b) {
+                if constexpr (BKM) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) bf[b][r] = b_s[(kk * 8 + kh * 4 + r) * LDB + wn + b * 32 + li];
+                } else {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(b_s + (wn + b * 32 + li) * LDB + kk * 8 + kh * 4);
+                    bf[b][0] = v.x; bf[b][1] = v.y; bf[b][2] = v.z; bf[b][3] = v.w;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int a = 0; a < TM; ++a)
+#pragma unroll
+                    for (int b = 0; b < TN; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a][r], bf[b][r], acc[a][b], 0, 0, 0);
+        }
+        if (kt + 1 < nkt) {
+            float* nxt = smem + (buf ^ 1) * STAGE;
+            store_tile<ARegs::R, ARegs::C, LDA>(ra, nxt);
+            store_tile<BRegs::R, BRegs::C, LDB>(rb, nxt + A_ELEMS);
+        }
+        __syncthreads();
     }
 }
 
 template <int BM, int BN, bool AKM, bool BKM>
-__global__ __launch_bounds__(256) void gemm_kernel(const Group g) {
+__global__ __launch_bounds__(256, 2) void gemm_kernel(const Group g) {
     constexpr int WM = BM / 2, WN = BN / 2;    // per-wave tile
     constexpr int TM = WM / 32, TN = WN / 32;  // 32x32 MFMA tiles per wave
     constexpr int LDA = AKM ? (BM + 4) : (BK + 4);
@@ -100,7 +215,6 @@ __global__ __launch_bounds__(256) void gemm_kernel(const Group g) {
     constexpr int A_ELEMS = AKM ? BK * LDA : BM * LDA;
     constexpr int B_ELEMS = BKM ? BK * LDB : BN * LDB;
     __shared__ __attribute__((aligned(16))) float smem[2 * (A_ELEMS + B_ELEMS)];
-    constexpr int STAGE = A_ELEMS + B_ELEMS;  // buffer b: A at smem + b*STAGE, B right behind it
 
     // XCD-aware, bijective remap: consecutive logical tiles (same A row panel) land on the same XCD / L2
     int bid = blockIdx.x;
@@ -112,20 +226,22 @@ __global__ __launch_bounds__(256) void gemm_kernel(const Group g) {
 #pragma unroll 1
     for (int i = 1; i < g.n; ++i)
         if (bid >= g.p[i].tile_start) pi = i;
-    Prob P = g.p[pi];
-    int tile = bid - P.tile_start;
-    {
-        const int per = P.tiles_m * P.tiles_n, bi = tile / per;
-        tile -= bi * per;
-        P.A.ptr += bi * P.a_bs;
-        P.B.ptr += bi * P.b_bs;
-        P.C.ptr += bi * P.c_bs;
-    }
-    const int tm_idx = tile / P.tiles_n, tn_idx = tile - tm_idx * P.tiles_n;
+    const Prob& G = g.p[pi];
+    int tile = bid - G.tile_start;
+    const int per_batch = G.tiles_m * G.tiles_n, bi = tile / per_batch;
+    tile -= bi * per_batch;
+    twog_rows_t A = G.A, B = G.B, C = G.C;
+    A.ptr += bi * G.a_bs;
+    B.ptr += bi * G.b_bs;
+    C.ptr += bi * G.c_bs;
+    const int M = G.M, N = G.N, K = G.K, a_vec = G.a_vec, b_vec = G.b_vec, act = G.act, accumulate = G.accumulate;
+    const float* bias = G.bias;
+    const int tiles_n = G.tiles_n;
+    const int tm_idx = tile / tiles_n, tn_idx = tile - tm_idx * tiles_n;
     const int m0 = tm_idx * BM, n0 = tn_idx * BN;
     const int split = blockIdx.y;
     const int k_begin = split * g.k_per_split;
-    const int k_end = min(P.K, k_begin + g.k_per_split);
+    const int k_end = min(K, k_begin + g.k_per_split);
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int li = lane & 31, kh = lane >> 5;
@@ -139,67 +255,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(const Group g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-    using ARegs = TileRegs<(AKM ? BK : BM), (AKM ? BM : BK)>;
-    using BRegs = TileRegs<(BKM ? BK : BN), (BKM ? BN : BK)>;
-    ARegs ra;
-    BRegs rb;
-
-    auto gload = [&](int k0) {
-        if constexpr (AKM) load_tile(ra, P.A, k0, m0, k_end, P.M, P.a_vec);
-        else               load_tile(ra, P.A, m0, k0, P.M, k_end, P.a_vec);
-        if constexpr (BKM) load_tile(rb, P.B, k0, n0, k_end, P.N, P.b_vec);
-        else               load_tile(rb, P.B, n0, k0, P.N, k_end, P.b_vec);
-    };
-    auto sstore = [&](int buf) {
-        store_tile<ARegs::R, ARegs::C, LDA>(ra, smem + buf * STAGE);
-        store_tile<BRegs::R, BRegs::C, LDB>(rb, smem + buf * STAGE + A_ELEMS);
-    };
-
-    const int nkt = (k_end > k_begin) ? (k_end - k_begin + BK - 1) / BK : 0;
-    if (nkt > 0) {
-        gload(k_begin);
-        sstore(0);
-    }
-    __syncthreads();
-    for (int kt = 0; kt < nkt; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nkt) gload(k_begin + (kt + 1) * BK);
-        const float* a_s = smem + buf * STAGE;
-        const float* b_s = a_s + A_ELEMS;
-#pragma unroll
-        for (int kk = 0; kk < BK / 8; ++kk) {
-            float af[TM][4], bf[TN][4];
-#pragma unroll
-            for (int a = 0; a < TM; ++a) {
-                if constexpr (AKM) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) af[a][r] = a_s[(kk * 8 + kh * 4 + r) * LDA + wm + a * 32 + li];
-                } else {
-                    const float4 v = *reinterpret_cast<const float4*>(a_s + (wm + a * 32 + li) * LDA + kk * 8 + kh * 4);
-                    af[a][0] = v.x; af[a][1] = v.y; af[a][2] = v.z; af[a][3] = v.w;
-                }
-            }
-#pragma unroll
-            for (int b = 0; b < TN; ++b) {
-                if constexpr (BKM) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) bf[b][r] = b_s[(kk * 8 + kh * 4 + r) * LDB + wn + b * 32 + li];
-                } else {
-                    const float4 v = *reinterpret_cast<const float4*>(b_s + (wn + b * 32 + li) * LDB + kk * 8 + kh * 4);
-                    bf[b][0] = v.x; bf[b][1] = v.y; bf[b][2] = v.z; bf[b][3] = v.w;
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-                for (int a = 0; a < TM; ++a)
-#pragma unroll
-                    for (int b = 0; b < TN; ++b)
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a][r], bf[b][r], acc[a][b], 0, 0, 0);
-        }
-        if (kt + 1 < nkt) sstore(buf ^ 1);
-        __syncthreads();
-    }
+    // uniform per workgroup: aligned operands and a reduction range made of whole k-tiles -> branch-free staging
+    const bool fast = a_vec && b_vec && ((k_end - k_begin) % BK == 0);
+    if (fast)
+        gemm_mainloop<BM, BN, AKM, BKM, true, TM, TN>(A, B, M, N, a_vec, b_vec, m0, n0, k_begin, k_end, smem, acc);
+    else
+        gemm_mainloop<BM, BN, AKM, BKM, false, TM, TN>(A, B, M, N, a_vec, b_vec, m0, n0, k_begin, k_end, smem, acc);
 
     // epilogue. C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
     if (g.splitk > 1) {
@@ -222,16 +283,16 @@ __global__ __launch_bounds__(256) void gemm_kernel(const Group g) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = m0 + wm + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-            if (row >= P.M) continue;
-            float* crow = P.C.ptr + twog_row_off(P.C, row);
+            if (row >= M) continue;
+            float* crow = C.ptr + twog_row_off(C, row);
 #pragma unroll
             for (int b = 0; b < TN; ++b) {
                 const int col = n0 + wn + b * 32 + li;
-                if (col >= P.N) continue;
+                if (col >= N) continue;
                 float v = acc[a][b][r];
-                if (P.bias) v += P.bias[col];
-                if (P.accumulate) v += crow[col];
-                if (P.act == 1) v = fmaxf(v, 0.f);
+                if (bias) v += bias[col];
+                if (accumulate) v += crow[col];
+                if (act == 1) v = fmaxf(v, 0.f);
                 crow[col] = v;
             }
         }
@@ -245,21 +306,22 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const Group g) {
 #pragma unroll 1
     for (int i = 1; i < g.n; ++i)
         if (bid >= g.p[i].tile_start) pi = i;
-    Prob P = g.p[pi];
+    const Prob& P = g.p[pi];
     int tile = bid - P.tile_start;
-    {
-        const int per = P.tiles_m * P.tiles_n, bi = tile / per;
-        tile -= bi * per;
-        P.C.ptr += bi * P.c_bs;
-    }
+    const int per_batch = P.tiles_m * P.tiles_n, bi = tile / per_batch;
+    tile -= bi * per_batch;
+    twog_rows_t C = P.C;
+    C.ptr += bi * P.c_bs;
     const int tm_idx = tile / P.tiles_n, tn_idx = tile - tm_idx * P.tiles_n;
     const int m0 = tm_idx * BM, n0 = tn_idx * BN;
-    for (int e = threadIdx.x; e < BM * BN; e += 256) {
+    // grid.y slices the tile so that small-output / deep-split problems still spread over the chip
+    const int chunk = (BM * BN) / gridDim.y;
+    for (int e = blockIdx.y * chunk + threadIdx.x; e < (blockIdx.y + 1) * chunk; e += 256) {
         const int row = e / BN, col = e - row * BN;
         if (m0 + row >= P.M || n0 + col >= P.N) continue;
         float v = 0.f;
         for (int s = 0; s < g.splitk; ++s) v += g.slabs[((int64_t)s * g.total_tiles + bid) * (BM * BN) + e];
-        float* c = P.C.ptr + twog_row_off(P.C, m0 + row) + n0 + col;
+        float* c = C.ptr + twog_row_off(C, m0 + row) + n0 + col;
         if (P.bias) v += P.bias[n0 + col];
         if (P.accumulate) v += *c;
         if (P.act == 1) v = fmaxf(v, 0.f);
@@ -267,10 +329,10 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const Group g) {
     }
 }
 
-inline int vec_ok(const twog_rows_t& m, int64_t batch_stride) {
+inline int vec_ok(const twog_rows_t& m, int64_t batch_stride, int contiguous_extent) {
     const bool aligned = (reinterpret_cast<uintptr_t>(m.ptr) % 16) == 0;
     const bool ld_ok = (m.ld_outer % 4 == 0) && (m.inner <= 1 || m.ld_inner % 4 == 0) && (batch_stride % 4 == 0);
-    return (aligned && ld_ok) ? 1 : 0;
+    return (aligned && ld_ok && contiguous_extent >= 4 && contiguous_extent % 4 == 0) ? 1 : 0;
 }
 
 template <int BM, int BN>
@@ -282,7 +344,7 @@ int launch(Group& g, int akm, int bkm, hipStream_t st) {
     else hipLaunchKernelGGL((gemm_kernel<BM, BN, true, false>), grid, block, 0, st, g);
     TWOG_CHECK_LAUNCH();
     if (g.splitk > 1) {
-        hipLaunchKernelGGL((splitk_reduce_kernel<BM, BN>), dim3(g.total_tiles), block, 0, st, g);
+        hipLaunchKernelGGL((splitk_reduce_kernel<BM, BN>), dim3(g.total_tiles, (BM * BN) / 1024), block, 0, st, g);
         TWOG_CHECK_LAUNCH();
     }
     return 0;
@@ -298,16 +360,23 @@ extern "C" int twog_gemm_f32(const twog_gemm_t* problems, int n_problems, int a_
     while (done < n_problems) {
         const int n = (n_problems - done) < MAXP ? (n_problems - done) : MAXP;
         const twog_gemm_t* pr = problems + done;
-        // tile choice: 128x128 when that already fills the chip, else 64x64 (recurrent steps, small heads)
-        int64_t tiles128 = 0, tiles64 = 0;
+        // tile choice: 128x128 tiles (4 MFMA tiles per wave, half the LDS traffic per FLOP) whenever the problems are
+        // at least one tile wide and -- possibly with split-K -- still fill the chip; 64x64 for the skinny ones.
+        int64_t tiles128 = 0;
         int kmax = 0;
+        bool wide = true;
         for (int i = 0; i < n; ++i) {
             const int nb = pr[i].batch > 0 ? pr[i].batch : 1;
             tiles128 += (int64_t)nb * ((pr[i].M + 127) / 128) * ((pr[i].N + 127) / 128);
-            tiles64 += (int64_t)nb * ((pr[i].M + 63) / 64) * ((pr[i].N + 63) / 64);
             if (pr[i].K > kmax) kmax = pr[i].K;
+            if (pr[i].M < 96 || pr[i].N < 96) wide = false;
         }
-        const bool big = tiles128 >= 384;
+        static const int force_tile = getenv("TWOG_GEMM_TILE") ? atoi(getenv("TWOG_GEMM_TILE")) : 0;
+        static const int force_split = getenv("TWOG_GEMM_SPLITK") ? atoi(getenv("TWOG_GEMM_SPLITK")) : 0;
+        const int64_t reach128 = tiles128 * (workspace ? (kmax >= 1024 ? kmax / 512 : 1) : 1);
+        bool big = wide && (tiles128 >= 256 || reach128 >= 256);
+        if (force_tile == 128) big = true;
+        if (force_tile == 64) big = false;
         const int BMN = big ? 128 : 64;
         Group g;
         g.n = n;
@@ -323,22 +392,22 @@ extern "C" int twog_gemm_f32(const twog_gemm_t* problems, int n_problems, int a_
             P.batch = pr[i].batch > 0 ? pr[i].batch : 1;
             P.a_bs = pr[i].a_batch_stride; P.b_bs = pr[i].b_batch_stride; P.c_bs = pr[i].c_batch_stride;
             t += P.batch * P.tiles_m * P.tiles_n;
-            P.a_vec = vec_ok(P.A, pr[i].a_batch_stride);
-            P.b_vec = vec_ok(P.B, pr[i].b_batch_stride);
+            P.a_vec = vec_ok(P.A, pr[i].a_batch_stride, a_kmajor ? P.M : P.K);
+            P.b_vec = vec_ok(P.B, pr[i].b_batch_stride, b_kmajor ? P.N : P.K);
         }
         g.total_tiles = t;
         g.splitk = 1;
         g.k_per_split = ((kmax + BK - 1) / BK) * BK;
         g.slabs = nullptr;
-        // deterministic split-K when the grid would leave most CUs idle and the reduction is long
-        if (t < 256 && kmax >= 2048 && workspace) {
-            int want = (512 + t - 1) / t;
+        // deterministic split-K when the grid would leave CUs idle and the reduction is long
+        if (t < 384 && kmax >= 1024 && workspace) {
+            int want = (768 + t - 1) / t;
             const int max_by_k = kmax / 512;
             if (want > max_by_k) want = max_by_k;
             if (want > 64) want = 64;
+            if (force_split > 0) want = force_split;
             const size_t need = (size_t)want * t * BMN * BMN * sizeof(float);
             if (want > 1 && need <= workspace_bytes) {
-                g.splitk = want;
                 int kps = (kmax + want - 1) / want;
                 g.k_per_split = ((kps + BK - 1) / BK) * BK;
                 g.splitk = (kmax + g.k_per_split - 1) / g.k_per_split;

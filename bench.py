@@ -90,35 +90,54 @@ class GemmProfiler:
         return agg
 
 
-def cpu_baseline(sample_frames=24):
-    """The oracle (port of the reference's PyTorch-CPU path) forward+backward on a bounded sample: one clip, the first
-    `sample_frames` of its 120 frames (cost is linear in frames: per-step Python loops dominate)."""
+def cpu_baseline(sample_frames=12, sample_clips=8):
+    """The oracle (port of the reference's PyTorch-CPU path) forward+backward on a bounded sample of the same workload:
+    `sample_clips` clips (the reference's own batch size, conf/models/2G-GCN_stage1.yaml:31) x the first `sample_frames`
+    of their 120 frames; the cost is linear in frames (per-step Python loops dominate), so it is scaled linearly."""
     from oracle import cpu_ref
     import twog_gcn_amd  # noqa: F401
     from twog_gcn_amd.models import TGGCN
-    cores = os.cpu_count() or 1
+    cores = min(32, os.cpu_count() or 1)  # the reference's default resources.num_threads (conf/config.yaml:9)
     torch.set_num_threads(cores)
     torch.manual_seed(0)
     m = TGGCN(input_size=(2048 + 4 * N_NODES, 2048), num_classes=(N_CLASSES, None), **CFG)
     sd = {k: (v.detach().clone().requires_grad_(True) if v.is_floating_point() and 'running' not in k else v.clone())
           for k, v in m.state_dict().items()}
     g = torch.Generator().manual_seed(1)
-    Ts = sample_frames
-    x_human = torch.rand(1, Ts, H, 2048 + 4 * N_NODES, generator=g)
-    x_objects = torch.rand(1, Ts, O, 2048, generator=g)
-    mask, seg = torch.ones(1, O), torch.ones(1, Ts, H)
-    tgt = [torch.randint(0, N_CLASSES, (1, Ts, H), generator=g) for _ in range(2)]
+    Ts, nb = sample_frames, sample_clips
+    x_human = torch.rand(nb, Ts, H, 2048 + 4 * N_NODES, generator=g)
+    x_objects = torch.rand(nb, Ts, O, 2048, generator=g)
+    mask, seg = torch.ones(nb, O), torch.ones(nb, Ts, H)
+    tgt = [torch.randint(0, N_CLASSES, (nb, Ts, H), generator=g) for _ in range(2)]
     t0 = time.perf_counter()
     out = cpu_ref.tggcn_forward(sd, CFG, x_human, x_objects, mask, human_segmentation=seg, training=True)
     t_fwd = time.perf_counter() - t0
     loss = torch.nn.functional.nll_loss(out[4], tgt[0]) + torch.nn.functional.nll_loss(out[5], tgt[1])
     loss.backward()
     dt = time.perf_counter() - t0
-    clips = Ts / T
+    clips = nb * Ts / T
     return dict(value=clips / dt, unit='clips/s', cores=cores, kind='port',
-                sample=f'1 clip x first {Ts} of {T} frames (H=2,O=8,N=34,h=512), forward+backward once, '
-                       f'scaled linearly in frames; forward alone {clips / t_fwd:.4f} clips/s',
+                sample=f'{nb} clips (reference batch size) x first {Ts} of {T} frames (H=2,O=8,N=34,h=512), one '
+                       f'forward+backward in {dt:.1f} s, scaled linearly in frames',
                 forward_clips_per_s=clips / t_fwd)
+
+
+def cpu_baseline_in_child(timeout_s=240):
+    """Runs the CPU leg in a child process (bounded by a timeout) so it can never take the bench line down."""
+    import subprocess
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), '--cpu-baseline-only'], capture_output=True,
+                           text=True, timeout=timeout_s, env=dict(os.environ, HIP_VISIBLE_DEVICES='', CUDA_VISIBLE_DEVICES=''))
+        for line in reversed(r.stdout.strip().splitlines()):
+            if line.startswith('{'):
+                return json.loads(line)
+        return dict(value=None, unit='clips/s', cores=None, kind='port', sample=f'failed: {r.stderr[-300:]}')
+    except subprocess.TimeoutExpired:
+        return dict(value=None, unit='clips/s', cores=None, kind='port', sample=f'timed out after {timeout_s} s')
+
+
+def log(msg):
+    print(f'[bench {time.strftime("%H:%M:%S")}] {msg}', file=sys.stderr, flush=True)
 
 
 def main():
@@ -128,8 +147,12 @@ def main():
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--batch', type=int, default=BS, help='clips per GPU per step')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-baseline-only', action='store_true', help=argparse.SUPPRESS)
     ap.add_argument('--forward-only', action='store_true', help='additionally report forward-only clips/s')
     args = ap.parse_args()
+    if args.cpu_baseline_only:
+        print(json.dumps(cpu_baseline()), flush=True)
+        return
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -171,8 +194,12 @@ def main():
         if world > 1:
             dist.barrier()
 
-    for _ in range(args.warmup):
+    log('model + data ready; warmup')
+    for i in range(args.warmup):
+        tw = time.perf_counter()
         step()
+        torch.cuda.synchronize()
+        log(f'warmup step {i}: {time.perf_counter() - tw:.3f} s')
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
@@ -189,6 +216,7 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     agg = prof.summary()
+    log(f'timed region done: {dt / args.steps * 1e3:.1f} ms/step')
 
     fwd_only = None
     if args.forward_only:
@@ -228,7 +256,9 @@ def main():
         if fwd_only is not None:
             result['forward_only_clips_per_s'] = fwd_only
         if world == 1 and not args.no_cpu_baseline:
-            result['cpu_baseline'] = cpu_baseline()
+            log('cpu baseline ...')
+            result['cpu_baseline'] = cpu_baseline_in_child()
+            log('cpu baseline done')
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.destroy_process_group()
