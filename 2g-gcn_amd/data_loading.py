@@ -1,0 +1,398 @@
+"""Per-clip batching for the 2G-GCN path: counterpart of the batching half of the reference's ``vhoi/data_loading.py``
+(``create_data_loader`` :362-379, ``assemble_tensors`` :436-471, ``assemble_bimanual_tensors`` :480-501,
+``assemble_mphoi_tensors`` :504-522, the per-dataset human/object assemblers :562-982, distances :985-1203,
+``assemble_num_steps`` :1206, fetcher/feeder :1215-1315, ``determine_num_classes`` :1318, ``input_size_from_data_loader``
+:1332). Dataset I/O (zarr/json/pickle readers, :23-350) is out of scope: the functions here start from the same in-memory
+``data`` lists those readers produce.
+
+Same outputs as the reference (tuple slot order of SURVEY.md Appendix B, NaN padding to the split maximum then
+``nan_to_num``, float32 / int64 dtypes), but assembled with whole-video numpy operations instead of the reference's
+per-frame Python loops, and with an optional pinned-memory + non-blocking fetcher for the GPU.
+"""
+from functools import partial
+from itertools import groupby
+from typing import Optional
+
+import numpy as np
+import torch
+from torch.utils.data import DataLoader, TensorDataset
+
+# layout constants per dataset (reference lines in comments)
+_SPECS = {
+    'mphoi': dict(scale=1000.0, keypoints=[1, 2, 4, 6, 7, 11, 13, 14, 27], max_objects=4,  # :784-809
+                  keys=('Human1', 'Human2'), dims=(3840.0, 2160.0)),
+    'bimanual': dict(scale=100.0, keypoints=[0, 4, 8, 12, 16, 20], max_objects=9,  # :668-693
+                     keys=('left_hand', 'right_hand'), dims=(640.0, 480.0)),
+}
+
+
+def _ds(x, d):
+    return x[d - 1::d]
+
+
+def _pos_vel(points):
+    """(L, K, 2) positions -> (L, K*4): per point (x, y, vx, vy) with v = (next - cur)*100, 0 at the last frame."""
+    points = np.asarray(points, dtype=np.float64)  # the reference's intermediates are float64 (np.zeros padding)
+    vel = np.zeros_like(points)
+    vel[:-1] = (points[1:] - points[:-1]) * 100
+    return np.concatenate([points, vel], axis=-1).reshape(points.shape[0], -1)
+
+
+def _boxes_as_points(obb, max_objects):
+    """(L, n, 4) boxes -> (L, 2*max_objects, 2) corner points, zero rows for missing objects (:790-803)."""
+    L, n = obb.shape[0], obb.shape[1]
+    b = np.zeros((L, max_objects, 4), dtype=obb.dtype)
+    b[:, :n] = obb
+    return b.reshape(L, 2 * max_objects, 2)
+
+
+def run_length_encoding(seq):
+    for k, v in groupby(seq):
+        yield k, len(list(v))
+
+
+def _next_labels(y):
+    rle = list(run_length_encoding(y))
+    out = []
+    for (_, prev_len), (nxt, _) in zip(rle[:-1], rle[1:]):
+        out += [nxt] * prev_len
+    return out
+
+
+def segmentation_from_output_class(y, segmentation_type='input'):
+    """Frame is a segment end iff the label changes at the next frame (last frame always); :885-896."""
+    x = np.array(y, dtype=np.float32)
+    missing = y == -1.0
+    x = np.where(missing, np.nan, x)
+    ends = (x[:, 1:] - x[:, :-1]) != 0.0
+    ends = np.concatenate([ends, np.full_like(ends, fill_value=True)[:, -1:]], axis=1)
+    x[ends] = 1.0
+    x[~ends & ~np.isnan(x)] = 0.0
+    x[np.isnan(x)] = 1.0
+    if segmentation_type == 'output':
+        x[missing] = -1.0
+    return x
+
+
+def ignore_last_step_end_flag(x):
+    """:524-533: clears the last end flag of every example. x (num_examples, num_steps)."""
+    for m in range(x.shape[0]):
+        idx = np.nonzero(x[m] == 1.0)[0]
+        if len(idx):
+            x[m, idx[-1]] = 0.0
+    return x
+
+
+def ignore_last_step_end_flag_general(x):
+    for e in range(x.shape[-1]):
+        x[:, :, e] = ignore_last_step_end_flag(x[:, :, e])
+    return x
+
+
+def smooth_segmentation(x, sigma: float):
+    """:544-559."""
+    if sigma:
+        from scipy.ndimage import gaussian_filter1d
+        missing = x == -1.0
+        x[missing] = 0.0
+        x = np.clip(gaussian_filter1d(x, sigma=sigma, axis=1, mode='constant') * 2.5 * sigma, 0.0, 1.0)
+        x[missing] = -1.0
+    return x
+
+
+def compute_centroid(bb):
+    return np.concatenate([(bb[..., :1] + bb[..., 2:3]) / 2, (bb[..., 1:2] + bb[..., 3:4]) / 2], axis=-1)
+
+
+def _pad_stack(arrays, shape_tail, fill=np.nan, dtype=np.float32):
+    out = np.full([len(arrays)] + list(shape_tail), fill_value=fill, dtype=dtype)
+    for m, a in enumerate(arrays):
+        out[(m,) + tuple(slice(0, s) for s in a.shape)] = a
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# two-human datasets (MPHOI :769-882, Bimanual :653-766); data item:
+#   [h1_feat (L,2048), h2_feat, objects (L,n,F), ground_truth dict, h1_bb, h2_bb, objects_bb (L,n,4), h1_pose (L,J,2), h2_pose]
+# ---------------------------------------------------------------------------------------------------------------
+def assemble_two_human_frame_level_recurrent_human(data, dataset: str, downsampling: int = 1, test_data: bool = False):
+    sp = _SPECS[dataset]
+    kp, mo = sp['keypoints'], sp['max_objects']
+    xs, max_len = [], 0
+    for h1, h2, _, _, _, _, obb, h1p, h2p in data:
+        max_len = max(max_len, h1.shape[0])
+        h1, h2 = _ds(h1, downsampling), _ds(h2, downsampling)
+        p1 = _ds(h1p, downsampling)[:, kp] / sp['scale']
+        p2 = _ds(h2p, downsampling)[:, kp] / sp['scale']
+        ob = _boxes_as_points(_ds(obb, downsampling) / sp['scale'], mo)
+        context = np.concatenate([_pos_vel(p1), _pos_vel(p2), _pos_vel(ob)], axis=-1)  # (L, 4N)
+        xs.append(np.stack([np.concatenate([h1, context], -1), np.concatenate([h2, context], -1)], axis=1))
+    T = max(x.shape[0] for x in xs)
+    x_hs = _pad_stack(xs, [T, 2, xs[0].shape[-1]])
+    y_rec = np.full([len(xs), max_len, 2], fill_value=-1, dtype=np.int64)
+    y_pred = np.full_like(y_rec, fill_value=-1)
+    for m, item in enumerate(data):
+        gt = item[3]
+        for e, key in enumerate(sp['keys']):
+            y = gt[key]
+            y_rec[m, :len(y), e] = y
+            yp = _next_labels(y)
+            y_pred[m, :len(yp), e] = yp
+    x_seg = segmentation_from_output_class(y_rec[:, downsampling - 1::downsampling], segmentation_type='input')
+    if not test_data:
+        y_rec, y_pred = y_rec[:, downsampling - 1::downsampling], y_pred[:, downsampling - 1::downsampling]
+    y_seg = segmentation_from_output_class(y_rec, segmentation_type='output')
+    return [x_hs, x_seg], [y_rec, y_pred, y_seg]
+
+
+def assemble_two_human_frame_level_recurrent_objects(data, downsampling: int = 1):
+    objs = [_ds(item[2], downsampling) for item in data]
+    T = max(o.shape[0] for o in objs)
+    O = max(o.shape[1] for o in objs)
+    x_objects = _pad_stack(objs, [T, O, objs[-1].shape[-1]])
+    mask = np.zeros([len(objs), O], dtype=np.float32)
+    for m, o in enumerate(objs):
+        mask[m, :o.shape[1]] = 1.0
+    return [x_objects, mask]
+
+
+def _two_human_distances(data, dataset, downsampling):
+    dims = np.array(_SPECS[dataset]['dims'], dtype=np.float32)
+    hh, ho1, ho2, oo = [], [], [], []
+    for item in data:
+        c1 = compute_centroid(_ds(item[4], downsampling)) / dims
+        c2 = compute_centroid(_ds(item[5], downsampling)) / dims
+        co = compute_centroid(_ds(item[6], downsampling)) / dims  # (L, n, 2)
+        hh.append(np.linalg.norm(c1 - c2, ord=2, axis=-1))
+        ho1.append(np.linalg.norm(co - c1[:, None], ord=2, axis=-1))
+        ho2.append(np.linalg.norm(co - c2[:, None], ord=2, axis=-1))
+        oo.append(np.linalg.norm(co[:, None, :, :] - co[:, :, None, :], ord=2, axis=-1))
+    T = max(len(d) for d in hh)
+    O = max(d.shape[1] for d in ho1)
+    x_hh = np.full([len(hh), T, 2, 2], np.nan, dtype=np.float32)
+    x_ho = np.full([len(hh), T, 2, O], np.nan, dtype=np.float32)
+    for m in range(len(hh)):
+        L = len(hh[m])
+        x_hh[m, :L, 0, 1] = hh[m]
+        x_hh[m, :L, 1, 0] = hh[m]
+        x_hh[m, :L, 0, 0] = 0.0
+        x_hh[m, :L, 1, 1] = 0.0
+        x_ho[m, :L, 0, :ho1[m].shape[1]] = ho1[m]
+        x_ho[m, :L, 1, :ho2[m].shape[1]] = ho2[m]
+    x_oo = _pad_stack(oo, [T, O, O])
+    return x_hh, x_ho, x_oo
+
+
+def assemble_num_steps(data, downsampling: int = 1):
+    return np.array([len(_ds(item[0], downsampling)) for item in data], dtype=np.float32)
+
+
+def _assemble_two_human_tensors(data, dataset, model_name, sigma=0.0, downsampling=1, test_data=False):
+    if model_name != '2G-GCN':
+        raise ValueError(f'{dataset} code not implemented for {model_name} yet.')
+    xs, ys = assemble_two_human_frame_level_recurrent_human(data, dataset, downsampling, test_data)
+    xs_objects = assemble_two_human_frame_level_recurrent_objects(data, downsampling)
+    if sigma:
+        ys[2] = ignore_last_step_end_flag_general(ys[2])
+    ys[2] = smooth_segmentation(ys[2], sigma)
+    ys_budget = ys[2]
+    x_hh, x_ho, x_oo = _two_human_distances(data, dataset, downsampling)
+    xs = xs[:1] + xs_objects + xs[1:] + [x_hh, x_ho, x_oo, assemble_num_steps(data, downsampling)]
+    ys = [ys_budget] + ys[2:] + ys[:2]
+    ys += ys[-2:]
+    return xs, ys
+
+
+def assemble_mphoi_tensors(data, model_name, sigma=0.0, downsampling=1, test_data=False):
+    return _assemble_two_human_tensors(data, 'mphoi', model_name, sigma, downsampling, test_data)
+
+
+def assemble_bimanual_tensors(data, model_name, sigma=0.0, downsampling=1, test_data=False):
+    return _assemble_two_human_tensors(data, 'bimanual', model_name, sigma, downsampling, test_data)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# CAD-120 (:562-650, :899-941); data item:
+#   [human_feat (L,2048), object_feat (L,n,F), skeleton_bb (L,4), objects_bb (L,n,4), skeleton_pose (L,9,2), segments]
+# ---------------------------------------------------------------------------------------------------------------
+def assemble_tensors(data, model_name, model_input_type='multiple', sigma=0.0, downsampling=1, test_data=False):
+    if model_name != '2G-GCN':
+        raise ValueError(f'{model_name} is not an option for model name.')
+    xs_h, max_len = [], 0
+    for hf, _, _, obb, pose, _ in data:
+        max_len = max(max_len, hf.shape[0])
+        p = _ds(pose, downsampling) / 100
+        ob = _boxes_as_points(_ds(obb, downsampling) / 100, 5)
+        xs_h.append(np.concatenate([_ds(hf, downsampling), _pos_vel(p), _pos_vel(ob)], axis=-1))
+    T = max(x.shape[0] for x in xs_h)
+    x_human = _pad_stack(xs_h, [T, xs_h[-1].shape[-1]])
+    objs = [_ds(item[1], downsampling) for item in data]
+    O = max(o.shape[1] for o in objs)
+    x_objects = _pad_stack(objs, [T, O, objs[-1].shape[-1]])
+    mask = np.zeros([len(objs), O], dtype=np.float32)
+    for m, o in enumerate(objs):
+        mask[m, :o.shape[1]] = 1.0
+    M = len(data)
+    y_rec_h = np.full([M, max_len], -1, dtype=np.int64)
+    y_pred_h = np.full_like(y_rec_h, -1)
+    y_rec_o = np.full([M, max_len, O], -1, dtype=np.int64)
+    y_pred_o = np.full_like(y_rec_o, -1)
+    for m, item in enumerate(data):
+        for seg in item[5]:
+            if seg.start_frame is None or seg.end_frame is None:
+                continue
+            s, e = seg.start_frame - 1, seg.end_frame - 1
+            y_rec_h[m, s:e + 1] = seg.subactivity - 1
+            y_pred_h[m, s:e + 1] = seg.next_subactivity - 1 if seg.next_subactivity is not None else -1
+            for oid, aff in seg.object_affordance.items():
+                y_rec_o[m, s:e + 1, oid - 1] = aff - 1
+            for oid, aff in seg.next_object_affordance.items():
+                y_pred_o[m, s:e + 1, oid - 1] = aff - 1
+    d = downsampling
+    x_seg_h = segmentation_from_output_class(y_rec_h[:, d - 1::d], 'input')
+    x_seg_o = segmentation_from_output_class(y_rec_o[:, d - 1::d], 'input')
+    if not test_data:
+        y_rec_h, y_pred_h, y_rec_o, y_pred_o = (y[:, d - 1::d] for y in (y_rec_h, y_pred_h, y_rec_o, y_pred_o))
+    y_seg_h = segmentation_from_output_class(y_rec_h, 'output')
+    y_seg_o = segmentation_from_output_class(y_rec_o, 'output')
+    if sigma:
+        y_seg_h = ignore_last_step_end_flag(y_seg_h)
+        y_seg_o = ignore_last_step_end_flag_general(y_seg_o)
+    y_seg_h = smooth_segmentation(y_seg_h, sigma)
+    y_seg_o = smooth_segmentation(y_seg_o, sigma)
+    # distances (:1019-1040, :1132-1153): objects are NOT divided by the image size there, the skeleton is
+    cad_dims = np.array([640, 480], dtype=np.float32)
+    ho, oo = [], []
+    for _, _, sbb, obb, _, _ in data:
+        co = compute_centroid(_ds(obb, d))
+        cs = compute_centroid(_ds(sbb, d)) / cad_dims
+        ho.append(np.linalg.norm(co - cs[:, None], ord=2, axis=-1)[:, None, :])
+        oo.append(np.linalg.norm(co[:, None, :, :] - co[:, :, None, :], ord=2, axis=-1))
+    x_ho = _pad_stack(ho, [T, 1, O])
+    x_oo = _pad_stack(oo, [T, O, O])
+    ex = lambda a: np.expand_dims(a, axis=2)  # "fake" human dimension (:474-477)
+    xs = [ex(x_human), x_objects, mask, ex(x_seg_h), x_seg_o, x_ho, x_oo, assemble_num_steps(data, d)]
+    ys = [ex(y_seg_h), y_seg_o, ex(y_seg_h), y_seg_o, ex(y_rec_h), ex(y_pred_h), y_rec_o, y_pred_o,
+          ex(y_rec_h), ex(y_pred_h), y_rec_o, y_pred_o]
+    return xs, ys
+
+
+def assemble_cad120_segmentations_from_frame_level_features(data):
+    """(start, end) frame pairs per video (:389-400; the reference forgets the return statement there)."""
+    out = []
+    for item in data:
+        out.append([(s.start_frame - 1, s.end_frame - 1) for s in item[5]
+                    if s.start_frame is not None and s.end_frame is not None])
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------------
+def scale_array(x, scaler=None, scaling_strategy='standard'):
+    from sklearn.preprocessing import StandardScaler
+    shape = x.shape
+    x = x.reshape(-1, shape[-1])
+    if scaler is None:
+        if scaling_strategy != 'standard':
+            raise ValueError(f'scaling_strategy must be standard and not {scaling_strategy}.')
+        scaler = StandardScaler().fit(x)
+    return scaler.transform(x).reshape(*shape), scaler
+
+
+def maybe_scale_input_tensors(x, model_name, scaling_strategy=None, scalers=None):
+    if not scalers:
+        scalers = {}
+        if scaling_strategy is None:
+            return x, scalers
+    xh, hs = scale_array(x[0], scaler=scalers.get('human_scaler'), scaling_strategy=scaling_strategy)
+    xo, os_ = scale_array(x[1], scaler=scalers.get('object_scaler'), scaling_strategy=scaling_strategy)
+    return [xh, xo] + x[2:], {'human_scaler': hs, 'object_scaler': os_}
+
+
+def create_data_loader(data, model_name: str, model_input_type: str, dataset_name: str, batch_size: int, shuffle: bool,
+                       scaling_strategy: Optional[str] = None, scalers: Optional[dict] = None, sigma: float = 0.0,
+                       downsampling: int = 1, test_data: bool = False, pin_memory: bool = False):
+    """vhoi/data_loading.py:362-379 (plus an opt-in pinned-memory dataset for asynchronous H2D copies)."""
+    name = dataset_name.lower()
+    if name == 'cad120':
+        x, y = assemble_tensors(data, model_name, model_input_type, sigma, downsampling, test_data)
+    elif name == 'mphoi':
+        x, y = assemble_mphoi_tensors(data, model_name, sigma, downsampling, test_data)
+    else:
+        x, y = assemble_bimanual_tensors(data, model_name, sigma, downsampling, test_data)
+    x, scalers = maybe_scale_input_tensors(x, model_name, scaling_strategy=scaling_strategy, scalers=scalers)
+    x = [np.nan_to_num(ix, copy=False, nan=0.0) for ix in x]
+    tensors = [torch.from_numpy(np.ascontiguousarray(a)) for a in x + y]
+    if pin_memory and torch.cuda.is_available():
+        tensors = [t.pin_memory() for t in tensors]
+    loader = DataLoader(TensorDataset(*tensors), batch_size=batch_size, shuffle=shuffle, num_workers=0,
+                        pin_memory=False, drop_last=False)
+    segmentations = assemble_cad120_segmentations_from_frame_level_features(data) if name == 'cad120' else None
+    return loader, scalers, segmentations
+
+
+def gcn_fetcher(dataset, device, non_blocking: bool = False, **kwargs):
+    """:1282-1315: moves only the tensors the configuration needs; the others stay on the host."""
+    to = lambda t: t.to(device, non_blocking=non_blocking)
+    data = [to(dataset[0]), to(dataset[1]), to(dataset[2])]
+    data.append(to(dataset[3]) if kwargs.get('input_human_segmentation', False) else dataset[3])
+    dist = kwargs.get('make_attention_distance_based', False)
+    if kwargs.get('dataset_name', 'cad120') == 'cad120':
+        data.append(to(dataset[4]) if kwargs.get('input_object_segmentation', False) else dataset[4])
+        data += [to(dataset[5]), to(dataset[6])] if dist else [dataset[5], dataset[6]]
+    else:
+        data += [to(dataset[4]), to(dataset[5]), to(dataset[6])] if dist else [dataset[4], dataset[5], dataset[6]]
+    targets = [to(t) for t in dataset[8:]]
+    data.append(to(dataset[7]))
+    return data, targets
+
+
+def gcn_forward(model, data, **kwargs):
+    """:1233-1279: maps tuple slots to forward() keywords."""
+    pattern = kwargs.get('impose_segmentation_pattern', 0)
+    if pattern not in (0, 1):
+        raise ValueError(f'Segmentation pattern can only be 1, not {pattern}')
+    if pattern:
+        human_seg = torch.ones(data[0].size()[:-1], dtype=data[0].dtype, device=data[0].device)
+    elif kwargs.get('input_human_segmentation', False):
+        human_seg = data[3]
+    else:
+        human_seg = None
+    mk = dict(x_human=data[0], x_objects=data[1], objects_mask=data[2], human_segmentation=human_seg)
+    hh = ho = oo = None
+    if kwargs.get('dataset_name', 'cad120') == 'cad120':
+        if pattern:
+            obj_seg = torch.ones(data[1].size()[:-1], dtype=data[1].dtype, device=data[1].device)
+        elif kwargs.get('input_object_segmentation', False):
+            obj_seg = data[4]
+        else:
+            obj_seg = None
+        mk['objects_segmentation'] = obj_seg
+        if kwargs.get('make_attention_distance_based', False):
+            ho, oo = data[5], data[6]
+    elif kwargs.get('make_attention_distance_based', False):
+        hh, ho, oo = data[4], data[5], data[6]
+    mk.update(human_human_distances=hh, human_object_distances=ho, object_object_distances=oo,
+              steps_per_example=data[7], inspect_model=kwargs.get('inspect_model', False))
+    return model(**mk)
+
+
+def select_model_data_fetcher(model_name: str, model_input_type: str, **kwargs):
+    return {'2G-GCN': partial(gcn_fetcher, **kwargs)}[model_name]
+
+
+def select_model_data_feeder(model_name: str, model_input_type: str, **kwargs):
+    return {'2G-GCN': partial(gcn_forward, **kwargs)}[model_name]
+
+
+def determine_num_classes(model_name: str, model_input_type: str, dataset_name: str):
+    if dataset_name.lower() == 'bimanual':
+        return 14, None
+    if dataset_name.lower() == 'mphoi':
+        return 13, None
+    return 10, 12
+
+
+def input_size_from_data_loader(data_loader: DataLoader, model_name: str, model_input_type: str):
+    if model_name != '2G-GCN':
+        raise ValueError(f'{model_name} is not an option for model name.')
+    return data_loader.dataset[0][0].size(-1), data_loader.dataset[0][1].size(-1)

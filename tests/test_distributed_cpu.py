@@ -1,0 +1,92 @@
+"""CPU, 2 processes over gloo: the data-parallel wrapper (flat parameter/gradient buffers, chunked gradient all-reduce,
+1/W folded into the fused Adam) gives every rank the SAME parameters as a single process that sees the whole batch,
+for a model whose loss is a mean over clips. Uses the torch test double of the kernel interface (no GPU here)."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _tiny_model(seed=0):
+    import twog_gcn_amd  # noqa: F401
+    from twog_gcn_amd.models import TGGCN
+    torch.manual_seed(seed)
+    return TGGCN(input_size=(2048 + 4 * 26, 2048), num_classes=(13, None), hidden_size=8, gcn_node=26,
+                 attention_style='v3', discrete_optimization_strategy='gs', message_segment=True, message_type='v2',
+                 message_granularity='v1', message_aggregation='att', object_segment_update_strategy='ind')
+
+
+def _batch(bs, T=4, H=2, O=3, N=26, seed=1):
+    g = torch.Generator().manual_seed(seed)
+    xh = torch.rand(bs, T, H, 2048 + 4 * N, generator=g)
+    xo = torch.rand(bs, T, O, 2048, generator=g)
+    mask = torch.ones(bs, O)
+    tgt = torch.randint(0, 13, (bs, T, H), generator=g)
+    noise = torch.distributions.gumbel.Gumbel(0.0, 1.0).sample((T * O, bs, 2))
+    return xh, xo, mask, tgt, noise
+
+
+def _loss(model, xh, xo, mask, tgt, noise):
+    model._gumbel_noise_override = noise
+    model.eval()  # running-stat BatchNorm: no cross-clip coupling, so the sharded and the full batch are comparable
+    out = model(xh, xo, mask, human_segmentation=torch.ones(xh.shape[:3]))
+    return torch.nn.functional.nll_loss(out[4], tgt) + torch.nn.functional.nll_loss(out[5], tgt)
+
+
+def _worker(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import twog_gcn_amd  # noqa: F401
+    from twog_gcn_amd import kernels
+    from twog_gcn_amd.distributed import DataParallel, FusedAdam
+    from tests.fake_kernels import FakeKernels
+    kernels._set_backend_for_tests(FakeKernels())
+    torch.set_num_threads(2)
+    model = _tiny_model(seed=rank)  # different init per rank: the wrapper must broadcast rank 0's parameters
+    dp = DataParallel(model, bucket_mb=1)
+    opt = FusedAdam(dp.flat, lr=1e-2)
+    xh, xo, mask, tgt, noise = _batch(4)
+    sl = slice(rank * 2, rank * 2 + 2)
+    init = dp.flat.flat.clone()
+    dp.zero_grad()
+    _loss(model, xh[sl], xo[sl], mask[sl], tgt[sl], noise[:, sl]).backward()
+    dp.all_reduce_gradients()
+    grad = dp.flat.grad.clone() * dp.grad_scale
+    opt.step(dp.grad_scale)
+    ret[rank] = (init, grad, dp.flat.flat.clone())
+    dist.destroy_process_group()
+
+
+def test_two_rank_data_parallel_matches_single_process():
+    import twog_gcn_amd  # noqa: F401
+    from twog_gcn_amd import kernels
+    from twog_gcn_amd.distributed import DataParallel, FusedAdam
+    from tests.fake_kernels import FakeKernels
+    port = 29500 + os.getpid() % 2000
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(2, port, ret), nprocs=2, join=True)
+    for a, b in zip(ret[0], ret[1]):
+        assert torch.equal(a, b), 'ranks diverged'  # same broadcast init, same reduced gradient, same update
+    # single-process reference on the full batch
+    kernels._set_backend_for_tests(FakeKernels())
+    try:
+        model = _tiny_model(seed=0)
+        dp = DataParallel(model)
+        opt = FusedAdam(dp.flat, lr=1e-2)
+        xh, xo, mask, tgt, noise = _batch(4)
+        assert torch.equal(ret[0][0], dp.flat.flat), 'rank-0 parameters were not broadcast'
+        dp.zero_grad()
+        _loss(model, xh, xo, mask, tgt, noise).backward()
+        ref = dp.flat.grad
+        err = (ret[0][1] - ref).abs().max().item()
+        assert err < 1e-5 * max(1.0, ref.abs().max().item()), err  # mean of shard means == mean over the full batch
+        assert not torch.equal(ret[0][2], ret[0][0])  # the fused Adam step moved the parameters
+    finally:
+        kernels._set_backend_for_tests(None)

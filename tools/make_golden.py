@@ -282,6 +282,88 @@ def g7_losses():
     print('g7: ', len(out), 'arrays')
 
 
+def _raw_videos(kind, seed):
+    """Synthetic raw per-video arrays in the layout the reference's readers produce (small feature width)."""
+    rng = np.random.RandomState(seed)
+    vids = []
+    F = 16
+    if kind in ('mphoi', 'bimanual'):
+        J = 32 if kind == 'mphoi' else 21
+        n_obj_max = 4 if kind == 'mphoi' else 9
+        keys = ('Human1', 'Human2') if kind == 'mphoi' else ('left_hand', 'right_hand')
+        for L, n in ((20, n_obj_max), (14, n_obj_max - 1), (17, 2)):
+            gt = {}
+            for k in keys:
+                y, cur = [], 0
+                while len(y) < L:
+                    y += [int(rng.randint(0, 5))] * int(rng.randint(2, 6))
+                gt[k] = y[:L]
+            vids.append([rng.randn(L, F).astype(np.float32), rng.randn(L, F).astype(np.float32),
+                         rng.randn(L, n, F).astype(np.float32), gt,
+                         rng.rand(L, 4) * 1000, rng.rand(L, 4) * 1000, rng.rand(L, n, 4) * 1000,
+                         rng.rand(L, J, 2) * 1000, rng.rand(L, J, 2) * 1000])
+    else:
+        from vhoi.cad120classes import CAD120VideoSegment
+        for L, n in ((21, 5), (15, 3), (18, 4)):
+            segs, start = [], 1
+            while start <= L:
+                end = min(L, start + int(rng.randint(2, 6)))
+                s = CAD120VideoSegment()
+                s.start_frame, s.end_frame = start, end
+                s.subactivity = int(rng.randint(1, 11))
+                s.object_affordance = {o + 1: int(rng.randint(1, 13)) for o in range(n)}
+                segs.append(s)
+                start = end + 1
+            for a, b in zip(segs[:-1], segs[1:]):
+                a.next_subactivity = b.subactivity
+                a.next_object_affordance = dict(b.object_affordance)
+            vids.append([rng.randn(L, F).astype(np.float32), rng.randn(L, n, F).astype(np.float32),
+                         rng.rand(L, 4) * 400, rng.rand(L, n, 4) * 400, rng.rand(L, 9, 2) * 300, segs])
+    return vids
+
+
+def g6_batching():
+    """G6: the reference's create_data_loader on synthetic raw videos (mphoi / bimanual / cad120), the fetcher's device
+    placement decisions and the feeder's forward kwargs."""
+    import types
+    sys.modules.setdefault('zarr', types.ModuleType('zarr'))
+    tb = types.ModuleType('torch.utils.tensorboard')
+    tb.SummaryWriter = object
+    sys.modules.setdefault('torch.utils.tensorboard', tb)
+    import vhoi.data_loading as ref_dl
+    out = {}
+    for kind in ('mphoi', 'bimanual', 'cad120'):
+        for sigma, test_data in ((0.0, False), (2.0, False), (0.0, True)):
+            vids = _raw_videos(kind, seed=60)
+            loader, _, _ = ref_dl.create_data_loader(vids, '2G-GCN', 'multiple', kind, batch_size=2, shuffle=False,
+                                                     sigma=sigma, downsampling=3, test_data=test_data)
+            for i, t in enumerate(loader.dataset.tensors):
+                out[f'{kind}_s{sigma}_t{int(test_data)}_{i}'] = t.numpy()
+        loader, _, _ = ref_dl.create_data_loader(_raw_videos(kind, seed=60), '2G-GCN', 'multiple', kind, batch_size=2,
+                                                 shuffle=False, downsampling=3)
+        batch = next(iter(loader))
+
+        class Rec:
+            def __call__(self, **kw):
+                self.kw = kw
+                return 'out'
+
+        for tag, kwargs in (('plain', dict(dataset_name=kind, impose_segmentation_pattern=1)),
+                            ('input', dict(dataset_name=kind, input_human_segmentation=True,
+                                           input_object_segmentation=True, make_attention_distance_based=True))):
+            data, targets = ref_dl.gcn_fetcher(batch, 'cpu', **kwargs)
+            rec = Rec()
+            ref_dl.gcn_forward(rec, data, **kwargs)
+            out[f'{kind}_{tag}_n_targets'] = np.array(len(targets))
+            for k, v in rec.kw.items():
+                if torch.is_tensor(v):
+                    out[f'{kind}_{tag}_kw_{k}'] = v.numpy()
+                else:
+                    out[f'{kind}_{tag}_kwnone_{k}'] = np.array(v is None or v is False)
+    np.savez_compressed(os.path.join(OUT, 'g6_batching.npz'), **out)
+    print('g6: ', len(out), 'arrays')
+
+
 if __name__ == '__main__':
     torch.set_num_threads(8)
     os.makedirs(OUT, exist_ok=True)
@@ -290,3 +372,4 @@ if __name__ == '__main__':
     g5_reorder_filter()
     g4_full()
     g7_losses()
+    g6_batching()
