@@ -27,6 +27,7 @@ def _batch(bs, T=4, H=2, O=3, N=26, seed=1):
     xo = torch.rand(bs, T, O, 2048, generator=g)
     mask = torch.ones(bs, O)
     tgt = torch.randint(0, 13, (bs, T, H), generator=g)
+    torch.manual_seed(1234)  # the Gumbel draw uses the global generator: make it identical in every process
     noise = torch.distributions.gumbel.Gumbel(0.0, 1.0).sample((T * O, bs, 2))
     return xh, xo, mask, tgt, noise
 
