@@ -15,8 +15,24 @@ namespace {
 
 constexpr int MAX_H = 4, MAX_O = 12, MAX_E = MAX_H + MAX_O;
 constexpr int MAXG = 4;
-struct FwdGroup { twog_attn_t a[MAXG]; };
-struct BwdGroup { twog_attn_bwd_t a[MAXG]; };
+struct FwdGroup { twog_attn_t a[MAXG]; int staged; };
+struct BwdGroup { twog_attn_bwd_t a[MAXG]; int staged; };
+
+// Latency-bound calls (few instances, e.g. one per clip inside the segment-level time loop) first copy every message /
+// gradient row of the instance into LDS with one burst of 16-byte loads, so the rest of the kernel never waits on HBM/L2
+// again; the relation descriptor is re-pointed at the LDS copy. Throughput-bound calls (one instance per (clip, frame))
+// keep streaming from global memory at high occupancy.
+__device__ __forceinline__ void stage_rows_lds(twog_rows_t& rel, int first_row, int n_rows, int width, float*& cursor) {
+    if (!rel.ptr) return;
+    const int w4 = width >> 2;
+    for (int i = threadIdx.x; i < n_rows * w4; i += blockDim.x) {
+        const int r = i / w4, c = (i - r * w4) * 4;
+        *reinterpret_cast<float4*>(cursor + r * width + c) =
+            *reinterpret_cast<const float4*>(twog_row_ptr(rel, first_row + r) + c);
+    }
+    rel.ptr = cursor; rel.inner = 1; rel.ld_outer = width; rel.ld_inner = width;
+    cursor += n_rows * width;
+}
 
 // layout of the saved attention weights of one instance
 __device__ __forceinline__ int att_off_hh(int, int) { return 0; }
@@ -96,7 +112,7 @@ __device__ __forceinline__ void stage_features(const twog_attn_t& A, int inst, f
 
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const FwdGroup g) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    const twog_attn_t& A = g.a[blockIdx.y];
+    twog_attn_t A = g.a[blockIdx.y];
     const int inst = blockIdx.x;
     if (inst >= A.n_inst) return;
     const int H = A.H, O = A.O, E = H + O, D = A.D, hid = A.hidden;
@@ -104,7 +120,19 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const FwdGroup g) {
     float* sG = sF + E * D;         // [E][E]
     float* sW = sG + MAX_E * MAX_E; // [H*H + 2*H*O + O*O]
     float* sMask = sW + (MAX_H * MAX_H + 2 * MAX_H * MAX_O + MAX_O * MAX_O);
+    int ih = inst * H, io = inst * O, ig = inst;  // first message row of this instance per sender type
     stage_features(A, inst, sF);
+    if (g.staged) {
+        float* cur = sMask + MAX_O + 4;
+        cur = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(cur) + 15) & ~uintptr_t(15));
+        stage_rows_lds(A.msg_hh, ih, H, hid, cur);
+        stage_rows_lds(A.msg_ho, ih, H, hid, cur);
+        stage_rows_lds(A.msg_oh, io, O, hid, cur);
+        stage_rows_lds(A.msg_oo, io, O, hid, cur);
+        stage_rows_lds(A.msg_so, ig, 1, hid, cur);
+        stage_rows_lds(A.msg_sh, ig, 1, hid, cur);
+        ih = io = ig = 0;
+    }
     __syncthreads();
     compute_weights(A, sF, inst, sG, sW, sMask);
     const int natt = H * H + 2 * H * O + O * O;
@@ -114,7 +142,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const FwdGroup g) {
     for (int j = threadIdx.x; j < hid; j += blockDim.x) {
         float m[MAX_O];
         if (A.msg_hh.ptr) {
-            for (int s = 0; s < H; ++s) m[s] = twog_row_ptr(A.msg_hh, inst * H + s)[j];
+            for (int s = 0; s < H; ++s) m[s] = twog_row_ptr(A.msg_hh, ih + s)[j];
             for (int h = 0; h < H; ++h) {
                 float acc = 0.f;
                 for (int s = 0; s < H; ++s) acc = fmaf(sW[att_off_hh(H, O) + h * H + s], m[s], acc);
@@ -122,7 +150,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const FwdGroup g) {
             }
         }
         if (A.msg_oh.ptr) {
-            for (int s = 0; s < O; ++s) m[s] = twog_row_ptr(A.msg_oh, inst * O + s)[j];
+            for (int s = 0; s < O; ++s) m[s] = twog_row_ptr(A.msg_oh, io + s)[j];
             for (int h = 0; h < H; ++h) {
                 float acc = 0.f;
                 for (int s = 0; s < O; ++s) acc = fmaf(sW[att_off_oh(H, O) + h * O + s], m[s], acc);
@@ -130,11 +158,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const FwdGroup g) {
             }
         }
         if (A.msg_sh.ptr) {
-            const float v = twog_row_ptr(A.msg_sh, inst)[j];
+            const float v = twog_row_ptr(A.msg_sh, ig)[j];
             for (int h = 0; h < H; ++h) twog_row_ptr(A.out_sh, inst * H + h)[j] = v;
         }
         if (A.msg_ho.ptr) {
-            for (int s = 0; s < H; ++s) m[s] = twog_row_ptr(A.msg_ho, inst * H + s)[j];
+            for (int s = 0; s < H; ++s) m[s] = twog_row_ptr(A.msg_ho, ih + s)[j];
             for (int k = 0; k < O; ++k) {
                 float acc = 0.f;
                 for (int s = 0; s < H; ++s) acc = fmaf(sW[att_off_ho(H, O) + k * H + s], m[s], acc);
@@ -142,11 +170,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const FwdGroup g) {
             }
         }
         if (A.msg_so.ptr) {
-            const float v = twog_row_ptr(A.msg_so, inst)[j];
+            const float v = twog_row_ptr(A.msg_so, ig)[j];
             for (int k = 0; k < O; ++k) twog_row_ptr(A.out_so, inst * O + k)[j] = A.recv_mask_ho ? v * sMask[k] : v;
         }
         if (A.msg_oo.ptr) {
-            for (int s = 0; s < O; ++s) m[s] = twog_row_ptr(A.msg_oo, inst * O + s)[j];
+            for (int s = 0; s < O; ++s) m[s] = twog_row_ptr(A.msg_oo, io + s)[j];
             for (int k = 0; k < O; ++k) {
                 float acc = 0.f;
                 for (int s = 0; s < O; ++s) acc = fmaf(sW[att_off_oo(H, O) + k * O + s], m[s], acc);
@@ -165,23 +193,41 @@ __device__ __forceinline__ float wave_dot(const float* a, const float* b, int n,
 
 __global__ __launch_bounds__(256) void attn_bwd_kernel(const BwdGroup g) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    const twog_attn_bwd_t& B = g.a[blockIdx.y];
-    const twog_attn_t& A = B.f;
+    twog_attn_bwd_t B = g.a[blockIdx.y];
+    twog_attn_t& A = B.f;
     const int inst = blockIdx.x;
     if (inst >= A.n_inst) return;
     const int H = A.H, O = A.O, E = H + O, D = A.D, hid = A.hidden;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const int natt = H * H + 2 * H * O + O * O;
-    float* sF = sm;                  // [E][D]
-    float* sW = sF + E * D;          // saved weights [natt]
-    float* sdW = sW + (MAX_H * MAX_H + 2 * MAX_H * MAX_O + MAX_O * MAX_O);  // dL/dw then dscore [natt]
-    float* sC = sdW + (MAX_H * MAX_H + 2 * MAX_H * MAX_O + MAX_O * MAX_O);  // [E][E] coefficients of dF
+    constexpr int NATT_MAX = MAX_H * MAX_H + 2 * MAX_H * MAX_O + MAX_O * MAX_O;
+    float* sW = sm;               // saved weights [natt]
+    float* sdW = sW + NATT_MAX;   // dL/dw then dscore [natt]
+    float* sC = sdW + NATT_MAX;   // [E][E] coefficients of dF
     float* sMask = sC + MAX_E * MAX_E;
     const int clip = inst / A.inst_per_clip;
-    stage_features(A, inst, sF);
+    // first rows of this instance: sender messages (mh/mo/mg) and incoming gradients (rh/ro)
+    int mh = inst * H, mo = inst * O, mg = inst, rh = inst * H, ro = inst * O;
     for (int i = threadIdx.x; i < natt; i += blockDim.x) sW[i] = A.att[(int64_t)inst * natt + i];
     if (threadIdx.x < O) sMask[threadIdx.x] = A.obj_mask ? A.obj_mask[(int64_t)clip * O + threadIdx.x] : 1.f;
     for (int i = threadIdx.x; i < MAX_E * MAX_E; i += blockDim.x) sC[i] = 0.f;
+    if (g.staged) {
+        float* cur = sMask + MAX_O + 4;
+        cur = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(cur) + 15) & ~uintptr_t(15));
+        stage_rows_lds(A.msg_hh, mh, H, hid, cur);
+        stage_rows_lds(A.msg_ho, mh, H, hid, cur);
+        stage_rows_lds(A.msg_oh, mo, O, hid, cur);
+        stage_rows_lds(A.msg_oo, mo, O, hid, cur);
+        stage_rows_lds(A.msg_so, mg, 1, hid, cur);
+        stage_rows_lds(A.msg_sh, mg, 1, hid, cur);
+        if (A.msg_hh.ptr) stage_rows_lds(B.dout_hh, rh, H, hid, cur);
+        if (A.msg_oh.ptr) stage_rows_lds(B.dout_oh, rh, H, hid, cur);
+        if (A.msg_sh.ptr) stage_rows_lds(B.dout_sh, rh, H, hid, cur);
+        if (A.msg_ho.ptr) stage_rows_lds(B.dout_ho, ro, O, hid, cur);
+        if (A.msg_so.ptr) stage_rows_lds(B.dout_so, ro, O, hid, cur);
+        if (A.msg_oo.ptr) stage_rows_lds(B.dout_oo, ro, O, hid, cur);
+        mh = mo = mg = rh = ro = 0;
+    }
     __syncthreads();
     // dL/dw[r][s] = recv_mask_r * <dout[r], msg[s]>   (one wave per pair)
     for (int p = wv; p < natt; p += nw) {
@@ -189,20 +235,20 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const BwdGroup g) {
         if (p < H * H) {
             const int r = p / H, s = p - r * H;
             if (A.msg_hh.ptr && r != s)
-                v = wave_dot(twog_row_ptr(B.dout_hh, inst * H + r), twog_row_ptr(A.msg_hh, inst * H + s), hid, lane);
+                v = wave_dot(twog_row_ptr(B.dout_hh, rh + r), twog_row_ptr(A.msg_hh, mh + s), hid, lane);
         } else if (p < H * H + H * O) {
             const int q = p - H * H, r = q / O, s = q - r * O;
             if (A.msg_oh.ptr)
-                v = wave_dot(twog_row_ptr(B.dout_oh, inst * H + r), twog_row_ptr(A.msg_oh, inst * O + s), hid, lane);
+                v = wave_dot(twog_row_ptr(B.dout_oh, rh + r), twog_row_ptr(A.msg_oh, mo + s), hid, lane);
         } else if (p < H * H + 2 * H * O) {
             const int q = p - H * H - H * O, r = q / H, s = q - r * H;
             if (A.msg_ho.ptr)
                 v = (A.recv_mask_ho ? sMask[r] : 1.f) *
-                    wave_dot(twog_row_ptr(B.dout_ho, inst * O + r), twog_row_ptr(A.msg_ho, inst * H + s), hid, lane);
+                    wave_dot(twog_row_ptr(B.dout_ho, ro + r), twog_row_ptr(A.msg_ho, mh + s), hid, lane);
         } else {
             const int q = p - H * H - 2 * H * O, r = q / O, s = q - r * O;
             if (A.msg_oo.ptr && r != s)
-                v = wave_dot(twog_row_ptr(B.dout_oo, inst * O + r), twog_row_ptr(A.msg_oo, inst * O + s), hid, lane);
+                v = wave_dot(twog_row_ptr(B.dout_oo, ro + r), twog_row_ptr(A.msg_oo, mo + s), hid, lane);
         }
         if (lane == 0) sdW[p] = v;
     }
@@ -247,56 +293,64 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const BwdGroup g) {
             }
     }
     __syncthreads();
-    // gradient wrt sender messages: dmsg[s] = sum_r w[r][s] * recv_mask_r * dout[r]
+    // gradient wrt sender messages: dmsg[s] = sum_r w[r][s] * recv_mask_r * dout[r]  (optionally times ReLU'(msg))
     for (int j = threadIdx.x; j < hid; j += blockDim.x) {
         float gr[MAX_O];
         if (A.msg_hh.ptr) {
-            for (int r = 0; r < H; ++r) gr[r] = twog_row_ptr(B.dout_hh, inst * H + r)[j];
+            for (int r = 0; r < H; ++r) gr[r] = twog_row_ptr(B.dout_hh, rh + r)[j];
             for (int s = 0; s < H; ++s) {
                 float acc = 0.f;
                 for (int r = 0; r < H; ++r) acc = fmaf(sW[att_off_hh(H, O) + r * H + s], gr[r], acc);
-                twog_row_ptr(B.dmsg_hh, inst * H + s)[j] = (B.relu_mask_dmsg && !(twog_row_ptr(A.msg_hh, inst * H + s)[j] > 0.f)) ? 0.f : acc;
+                if (B.relu_mask_dmsg && !(twog_row_ptr(A.msg_hh, mh + s)[j] > 0.f)) acc = 0.f;
+                twog_row_ptr(B.dmsg_hh, inst * H + s)[j] = acc;
             }
         }
         if (A.msg_oh.ptr) {
-            for (int r = 0; r < H; ++r) gr[r] = twog_row_ptr(B.dout_oh, inst * H + r)[j];
+            for (int r = 0; r < H; ++r) gr[r] = twog_row_ptr(B.dout_oh, rh + r)[j];
             for (int s = 0; s < O; ++s) {
                 float acc = 0.f;
                 for (int r = 0; r < H; ++r) acc = fmaf(sW[att_off_oh(H, O) + r * O + s], gr[r], acc);
-                twog_row_ptr(B.dmsg_oh, inst * O + s)[j] = (B.relu_mask_dmsg && !(twog_row_ptr(A.msg_oh, inst * O + s)[j] > 0.f)) ? 0.f : acc;
+                if (B.relu_mask_dmsg && !(twog_row_ptr(A.msg_oh, mo + s)[j] > 0.f)) acc = 0.f;
+                twog_row_ptr(B.dmsg_oh, inst * O + s)[j] = acc;
             }
         }
         if (A.msg_sh.ptr) {
             float acc = 0.f;
-            for (int r = 0; r < H; ++r) acc += twog_row_ptr(B.dout_sh, inst * H + r)[j];
-            twog_row_ptr(B.dmsg_sh, inst)[j] = (B.relu_mask_dmsg && !(twog_row_ptr(A.msg_sh, inst)[j] > 0.f)) ? 0.f : acc;
+            for (int r = 0; r < H; ++r) acc += twog_row_ptr(B.dout_sh, rh + r)[j];
+            if (B.relu_mask_dmsg && !(twog_row_ptr(A.msg_sh, mg)[j] > 0.f)) acc = 0.f;
+            twog_row_ptr(B.dmsg_sh, inst)[j] = acc;
         }
         if (A.msg_ho.ptr) {
-            for (int r = 0; r < O; ++r) gr[r] = (A.recv_mask_ho ? sMask[r] : 1.f) * twog_row_ptr(B.dout_ho, inst * O + r)[j];
+            for (int r = 0; r < O; ++r) gr[r] = (A.recv_mask_ho ? sMask[r] : 1.f) * twog_row_ptr(B.dout_ho, ro + r)[j];
             for (int s = 0; s < H; ++s) {
                 float acc = 0.f;
                 for (int r = 0; r < O; ++r) acc = fmaf(sW[att_off_ho(H, O) + r * H + s], gr[r], acc);
-                twog_row_ptr(B.dmsg_ho, inst * H + s)[j] = (B.relu_mask_dmsg && !(twog_row_ptr(A.msg_ho, inst * H + s)[j] > 0.f)) ? 0.f : acc;
+                if (B.relu_mask_dmsg && !(twog_row_ptr(A.msg_ho, mh + s)[j] > 0.f)) acc = 0.f;
+                twog_row_ptr(B.dmsg_ho, inst * H + s)[j] = acc;
             }
         }
         if (A.msg_so.ptr) {
             float acc = 0.f;
-            for (int r = 0; r < O; ++r) acc = fmaf(A.recv_mask_ho ? sMask[r] : 1.f, twog_row_ptr(B.dout_so, inst * O + r)[j], acc);
-            twog_row_ptr(B.dmsg_so, inst)[j] = (B.relu_mask_dmsg && !(twog_row_ptr(A.msg_so, inst)[j] > 0.f)) ? 0.f : acc;
+            for (int r = 0; r < O; ++r) acc = fmaf(A.recv_mask_ho ? sMask[r] : 1.f, twog_row_ptr(B.dout_so, ro + r)[j], acc);
+            if (B.relu_mask_dmsg && !(twog_row_ptr(A.msg_so, mg)[j] > 0.f)) acc = 0.f;
+            twog_row_ptr(B.dmsg_so, inst)[j] = acc;
         }
         if (A.msg_oo.ptr) {
-            for (int r = 0; r < O; ++r) gr[r] = twog_row_ptr(B.dout_oo, inst * O + r)[j];
+            for (int r = 0; r < O; ++r) gr[r] = twog_row_ptr(B.dout_oo, ro + r)[j];
             for (int s = 0; s < O; ++s) {
                 float acc = 0.f;
                 for (int r = 0; r < O; ++r) acc = fmaf(sW[att_off_oo(H, O) + r * O + s], gr[r], acc);
-                twog_row_ptr(B.dmsg_oo, inst * O + s)[j] = (B.relu_mask_dmsg && !(twog_row_ptr(A.msg_oo, inst * O + s)[j] > 0.f)) ? 0.f : acc;
+                if (B.relu_mask_dmsg && !(twog_row_ptr(A.msg_oo, mo + s)[j] > 0.f)) acc = 0.f;
+                twog_row_ptr(B.dmsg_oo, inst * O + s)[j] = acc;
             }
         }
     }
-    // gradient wrt the features: dF[a] = sum_b C[a][b] F[b]
+    // gradient wrt the features: dF[a] = sum_b C[a][b] F[b]; F is read straight from global memory (one burst of E
+    // independent lane-contiguous loads per column), so the backward kernel keeps no LDS copy of the features
     for (int d = threadIdx.x; d < D; d += blockDim.x) {
         float f[MAX_E];
-        for (int b = 0; b < E; ++b) f[b] = sF[b * D + d];
+        for (int b = 0; b < E; ++b)
+            f[b] = (b < H ? twog_row_ptr(A.feat_h, inst * H + b) : twog_row_ptr(A.feat_o, inst * O + (b - H)))[d];
         for (int a = 0; a < E; ++a) {
             float acc = 0.f;
             for (int b = 0; b < E; ++b) acc = fmaf(sC[a * MAX_E + b], f[b], acc);
@@ -306,13 +360,27 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const BwdGroup g) {
     }
 }
 
-inline size_t lds_fwd(int E, int D) {
-    return sizeof(float) * ((size_t)E * D + MAX_E * MAX_E + (MAX_H * MAX_H + 2 * MAX_H * MAX_O + MAX_O * MAX_O) + MAX_O);
+constexpr int STAGE_MAX_INST = 1024;  // calls with at most this many instances use the LDS-staged (latency) path
+inline size_t n_msg_rows(const twog_attn_t& a) {
+    return (size_t)(a.msg_hh.ptr ? a.H : 0) + (a.msg_ho.ptr ? a.H : 0) + (a.msg_oh.ptr ? a.O : 0) +
+           (a.msg_oo.ptr ? a.O : 0) + (a.msg_so.ptr ? 1 : 0) + (a.msg_sh.ptr ? 1 : 0);
 }
-inline size_t lds_bwd(int E, int D) {
-    return sizeof(float) *
-           ((size_t)E * D + 2 * (MAX_H * MAX_H + 2 * MAX_H * MAX_O + MAX_O * MAX_O) + MAX_E * MAX_E + MAX_O);
+inline size_t n_dout_rows(const twog_attn_t& a) {
+    return (size_t)(a.msg_hh.ptr ? a.H : 0) + (a.msg_oh.ptr ? a.H : 0) + (a.msg_sh.ptr ? a.H : 0) +
+           (a.msg_ho.ptr ? a.O : 0) + (a.msg_so.ptr ? a.O : 0) + (a.msg_oo.ptr ? a.O : 0);
 }
+constexpr int NATT_MAX_H = MAX_H * MAX_H + 2 * MAX_H * MAX_O + MAX_O * MAX_O;
+inline size_t lds_fwd(const twog_attn_t& a, bool staged) {
+    size_t f = (size_t)(a.H + a.O) * a.D + MAX_E * MAX_E + NATT_MAX_H + MAX_O + 8;
+    if (staged) f += n_msg_rows(a) * a.hidden;
+    return sizeof(float) * f;
+}
+inline size_t lds_bwd(const twog_attn_t& a, bool staged) {
+    size_t f = 2 * (size_t)NATT_MAX_H + MAX_E * MAX_E + MAX_O + 8;
+    if (staged) f += (n_msg_rows(a) + n_dout_rows(a)) * a.hidden;
+    return sizeof(float) * f;
+}
+constexpr size_t LDS_LIMIT = 160 * 1024;
 
 }  // namespace
 
@@ -326,15 +394,27 @@ extern "C" int twog_attn_fwd(const twog_attn_t* a, int n, void* stream) {
     if (n > MAXG) return -1;
     FwdGroup g;
     int maxinst = 0;
-    size_t lds = 0;
     for (int i = 0; i < n; ++i) {
         g.a[i] = a[i];
-        if (a[i].H > MAX_H || a[i].O > MAX_O || a[i].H < 0 || a[i].O < 0 || (a[i].D & 3)) return -2;
+        if (a[i].H > MAX_H || a[i].O > MAX_O || a[i].H < 0 || a[i].O < 0 || (a[i].D & 3) || (a[i].hidden & 3)) return -2;
         if (a[i].n_inst > maxinst) maxinst = a[i].n_inst;
-        const size_t l = lds_fwd(a[i].H + a[i].O, a[i].D);
-        if (l > lds) lds = l;
     }
     if (maxinst == 0) return 0;
+    bool staged = maxinst <= STAGE_MAX_INST;
+    size_t lds = 0;
+    for (int pass = 0; pass < 2; ++pass) {
+        lds = 0;
+        for (int i = 0; i < n; ++i) lds = lds_fwd(a[i], staged) > lds ? lds_fwd(a[i], staged) : lds;
+        if (lds <= LDS_LIMIT) break;
+        staged = false;
+    }
+    g.staged = staged ? 1 : 0;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)LDS_LIMIT);
+        attr_set = true;
+    }
     hipLaunchKernelGGL(attn_fwd_kernel, dim3(maxinst, n), dim3(256), lds, (hipStream_t)stream, g);
     TWOG_CHECK_LAUNCH();
     return 0;
@@ -344,15 +424,27 @@ extern "C" int twog_attn_bwd(const twog_attn_bwd_t* a, int n, void* stream) {
     if (n > MAXG) return -1;
     BwdGroup g;
     int maxinst = 0;
-    size_t lds = 0;
     for (int i = 0; i < n; ++i) {
         g.a[i] = a[i];
-        if (a[i].f.H > MAX_H || a[i].f.O > MAX_O || (a[i].f.D & 3)) return -2;
+        if (a[i].f.H > MAX_H || a[i].f.O > MAX_O || (a[i].f.D & 3) || (a[i].f.hidden & 3)) return -2;
         if (a[i].f.n_inst > maxinst) maxinst = a[i].f.n_inst;
-        const size_t l = lds_bwd(a[i].f.H + a[i].f.O, a[i].f.D);
-        if (l > lds) lds = l;
     }
     if (maxinst == 0) return 0;
+    bool staged = maxinst <= STAGE_MAX_INST;
+    size_t lds = 0;
+    for (int pass = 0; pass < 2; ++pass) {
+        lds = 0;
+        for (int i = 0; i < n; ++i) lds = lds_bwd(a[i].f, staged) > lds ? lds_bwd(a[i].f, staged) : lds;
+        if (lds <= LDS_LIMIT) break;
+        staged = false;
+    }
+    g.staged = staged ? 1 : 0;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)LDS_LIMIT);
+        attr_set = true;
+    }
     hipLaunchKernelGGL(attn_bwd_kernel, dim3(maxinst, n), dim3(256), lds, (hipStream_t)stream, g);
     TWOG_CHECK_LAUNCH();
     return 0;

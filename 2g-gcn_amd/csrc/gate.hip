@@ -82,29 +82,75 @@ __global__ __launch_bounds__(256) void rank1_kernel(twog_rows_t dst, const float
     }
 }
 
-// partial sums of s[r] * x[r][c] over row slabs (s may be NULL -> 1)
+// partial sums of s[r] * x[r][c] over row slabs (s may be NULL -> 1).
+// VEC: every lane owns 4 consecutive columns (one 16-byte load per row: 1 KiB per wave instruction) and 4 independent
+// row streams are kept in flight; block = 64 column-quads x 4 row lanes.
+template <bool VEC>
 __global__ __launch_bounds__(256) void wcolsum_partial_kernel(twog_rows_t x, const float* s, int rows, int cols,
                                                               float* partials) {
-    __shared__ float red[4][64];
+    constexpr int CW = VEC ? 4 : 1;
+    __shared__ float red[4][64 * CW];
     const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + cl;
+    const int c = (blockIdx.x * 64 + cl) * CW;
     const int per = (rows + gridDim.y - 1) / gridDim.y;
     const int r0 = blockIdx.y * per, r1 = min(rows, r0 + per);
-    float acc = 0.f;
-    if (c < cols)
-        for (int r = r0 + rl; r < r1; r += 4) acc = fmaf(s ? s[r] : 1.f, twog_row_ptr(x, r)[c], acc);
-    red[rl][cl] = acc;
+    float acc[CW];
+#pragma unroll
+    for (int i = 0; i < CW; ++i) acc[i] = 0.f;
+    if (c < cols) {
+        if constexpr (VEC) {
+            float4 a0 = make_float4(0, 0, 0, 0), a1 = a0, a2 = a0, a3 = a0;
+            int r = r0 + rl;
+            for (; r + 12 < r1; r += 16) {
+                const float4 v0 = *reinterpret_cast<const float4*>(twog_row_ptr(x, r) + c);
+                const float4 v1 = *reinterpret_cast<const float4*>(twog_row_ptr(x, r + 4) + c);
+                const float4 v2 = *reinterpret_cast<const float4*>(twog_row_ptr(x, r + 8) + c);
+                const float4 v3 = *reinterpret_cast<const float4*>(twog_row_ptr(x, r + 12) + c);
+                const float s0 = s ? s[r] : 1.f, s1 = s ? s[r + 4] : 1.f, s2 = s ? s[r + 8] : 1.f, s3 = s ? s[r + 12] : 1.f;
+                a0.x = fmaf(s0, v0.x, a0.x); a0.y = fmaf(s0, v0.y, a0.y); a0.z = fmaf(s0, v0.z, a0.z); a0.w = fmaf(s0, v0.w, a0.w);
+                a1.x = fmaf(s1, v1.x, a1.x); a1.y = fmaf(s1, v1.y, a1.y); a1.z = fmaf(s1, v1.z, a1.z); a1.w = fmaf(s1, v1.w, a1.w);
+                a2.x = fmaf(s2, v2.x, a2.x); a2.y = fmaf(s2, v2.y, a2.y); a2.z = fmaf(s2, v2.z, a2.z); a2.w = fmaf(s2, v2.w, a2.w);
+                a3.x = fmaf(s3, v3.x, a3.x); a3.y = fmaf(s3, v3.y, a3.y); a3.z = fmaf(s3, v3.z, a3.z); a3.w = fmaf(s3, v3.w, a3.w);
+            }
+            for (; r < r1; r += 4) {
+                const float4 v0 = *reinterpret_cast<const float4*>(twog_row_ptr(x, r) + c);
+                const float s0 = s ? s[r] : 1.f;
+                a0.x = fmaf(s0, v0.x, a0.x); a0.y = fmaf(s0, v0.y, a0.y); a0.z = fmaf(s0, v0.z, a0.z); a0.w = fmaf(s0, v0.w, a0.w);
+            }
+            acc[0] = (a0.x + a1.x) + (a2.x + a3.x);
+            acc[1 % CW] = (a0.y + a1.y) + (a2.y + a3.y);
+            acc[2 % CW] = (a0.z + a1.z) + (a2.z + a3.z);
+            acc[3 % CW] = (a0.w + a1.w) + (a2.w + a3.w);
+        } else {
+            for (int r = r0 + rl; r < r1; r += 4) acc[0] = fmaf(s ? s[r] : 1.f, twog_row_ptr(x, r)[c], acc[0]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < CW; ++i) red[rl][cl * CW + i] = acc[i];
     __syncthreads();
-    if (rl == 0 && c < cols) partials[(int64_t)blockIdx.y * cols + c] = red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl];
+    if (rl == 0 && c < cols) {
+#pragma unroll
+        for (int i = 0; i < CW; ++i)
+            partials[(int64_t)blockIdx.y * cols + c + i] =
+                (red[0][cl * CW + i] + red[1][cl * CW + i]) + (red[2][cl * CW + i] + red[3][cl * CW + i]);
+    }
 }
 
 __global__ __launch_bounds__(256) void wcolsum_final_kernel(const float* partials, int n_blocks, int cols, float* out,
                                                             int accumulate) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= cols) return;
+    // 64 columns x 4 lanes over the partial rows, then an ordered LDS reduction (deterministic)
+    __shared__ float red[4][64];
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
     float acc = 0.f;
-    for (int b = 0; b < n_blocks; ++b) acc += partials[(int64_t)b * cols + c];
-    out[c] = accumulate ? out[c] + acc : acc;
+    if (c < cols)
+        for (int b = rl; b < n_blocks; b += 4) acc += partials[(int64_t)b * cols + c];
+    red[rl][cl] = acc;
+    __syncthreads();
+    if (rl == 0 && c < cols) {
+        const float t = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
+        out[c] = accumulate ? out[c] + t : t;
+    }
 }
 
 }  // namespace
@@ -142,10 +188,16 @@ extern "C" int twog_colsum(twog_rows_t x, const float* rowscale, int rows, int c
     if (cols <= 0) return 0;
     if (n_blocks < 1) n_blocks = 1;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(wcolsum_partial_kernel, dim3((cols + 63) / 64, n_blocks), dim3(256), 0, st, x, rowscale, rows,
-                       cols, partials);
+    const bool vec = (cols % 4 == 0) && (reinterpret_cast<uintptr_t>(x.ptr) % 16 == 0) && (x.ld_outer % 4 == 0) &&
+                     (x.inner <= 1 || x.ld_inner % 4 == 0);
+    if (vec)
+        hipLaunchKernelGGL(wcolsum_partial_kernel<true>, dim3((cols + 255) / 256, n_blocks), dim3(256), 0, st, x,
+                           rowscale, rows, cols, partials);
+    else
+        hipLaunchKernelGGL(wcolsum_partial_kernel<false>, dim3((cols + 63) / 64, n_blocks), dim3(256), 0, st, x,
+                           rowscale, rows, cols, partials);
     TWOG_CHECK_LAUNCH();
-    hipLaunchKernelGGL(wcolsum_final_kernel, dim3((cols + 255) / 256), dim3(256), 0, st, partials, n_blocks, cols, out,
+    hipLaunchKernelGGL(wcolsum_final_kernel, dim3((cols + 63) / 64), dim3(256), 0, st, partials, n_blocks, cols, out,
                        accumulate);
     TWOG_CHECK_LAUNCH();
     return 0;

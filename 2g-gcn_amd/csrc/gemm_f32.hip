@@ -400,11 +400,19 @@ extern "C" int twog_gemm_f32(const twog_gemm_t* problems, int n_problems, int a_
         g.k_per_split = ((kmax + BK - 1) / BK) * BK;
         g.slabs = nullptr;
         // deterministic split-K when the grid would leave CUs idle and the reduction is long
-        if (t < 384 && kmax >= 1024 && workspace) {
-            int want = (768 + t - 1) / t;
-            const int max_by_k = kmax / 512;
-            if (want > max_by_k) want = max_by_k;
-            if (want > 64) want = 64;
+        if (t < 4096 && kmax >= 1024 && workspace) {
+            // pick the split that fills whole "rounds" of resident workgroups (2 per CU for 128-tiles, 4 for 64-tiles)
+            const int slots = big ? 512 : 1024;
+            const int max_by_k = kmax / 256;
+            int want = 1;
+            double best = 0.0;
+            const int max_split = t < 384 ? 64 : 16;
+            for (int sft = 1; sft <= max_split && sft <= max_by_k; ++sft) {
+                const int64_t wg = (int64_t)t * sft;
+                if (wg > (t < 384 ? 2 : 8) * slots && sft > 1) break;
+                const double eff = (double)wg / (double)(((wg + slots - 1) / slots) * slots);
+                if (eff > best + 0.03) { best = eff; want = sft; }
+            }
             if (force_split > 0) want = force_split;
             const size_t need = (size_t)want * t * BMN * BMN * sizeof(float);
             if (want > 1 && need <= workspace_bytes) {

@@ -119,7 +119,7 @@ class HipKernels:
                 g.batch, g.a_batch_stride, g.b_batch_stride, g.c_batch_stride = b
         ws_ptr, ws_bytes = 0, 0
         if split_k_workspace:
-            ws = self.workspace(64 << 20, dev, 'splitk')
+            ws = self.workspace(320 << 20, dev, 'splitk')
             ws_ptr, ws_bytes = ws.data_ptr(), ws.numel() * 4
         rc = self.lib.twog_gemm_f32(arr, n, int(a_kmajor), int(b_kmajor), ws_ptr, ws_bytes, self._stream())
         self._check(rc, 'twog_gemm_f32')
@@ -376,7 +376,7 @@ class HipKernels:
         if out is None:
             out = torch.empty(cols, dtype=torch.float32, device=x.device)
             accumulate = False
-        nblk = max(1, min(256, rows // 64))
+        nblk = max(1, min(128, rows // 128))
         partials = self.workspace(nblk * cols * 4, x.device, 'colsum')
         self._check(self.lib.twog_colsum(rows_of(x), _ptr(rowscale), rows, cols, out.data_ptr(), int(accumulate),
                                          partials.data_ptr(), nblk, self._stream()), 'twog_colsum')

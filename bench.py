@@ -60,7 +60,7 @@ class GemmProfiler:
     def __enter__(self):
         def gemm(problems, a_kmajor=False, b_kmajor=False, split_k_workspace=True):
             from twog_gcn_amd.kernels import n_rows
-            flops, tiles128 = 0.0, 0
+            flops, tiles128, kmax, wide = 0.0, 0, 0, True
             for p in problems:
                 A, Cm = p['A'], p['C']
                 M, Nn = n_rows(Cm), Cm.shape[-1]
@@ -68,11 +68,16 @@ class GemmProfiler:
                 nb = p['batch'][0] if p.get('batch') else 1
                 flops += 2.0 * M * Nn * Kk * nb
                 tiles128 += nb * math.ceil(M / 128) * math.ceil(Nn / 128)
+                kmax = max(kmax, Kk)
+                wide = wide and M >= 96 and Nn >= 96
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             self.orig(problems, a_kmajor, b_kmajor, split_k_workspace)
             e1.record()
-            self.records.append(('128x128' if tiles128 >= 384 else '64x64', flops, e0, e1))
+            # same rule as twog_gemm_f32 (gemm_f32.hip): 128x128 tiles when wide and the chip can be filled
+            reach = tiles128 * (kmax // 512 if kmax >= 1024 else 1)
+            big = wide and (tiles128 >= 256 or reach >= 256)
+            self.records.append(('128x128' if big else '64x64', flops, e0, e1))
         self.K.gemm = gemm
         return self
 
