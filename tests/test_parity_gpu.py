@@ -187,3 +187,54 @@ def test_full_size_determinism_and_batch_independence():
     for a, b in zip(full[1:], part[1:]):
         err = (a[3:5] - b).abs().max().item()
         assert err < REL * max(1.0, b.abs().max().item()), err
+
+
+# ------------------------------------------------------------------------------------------------- edge cases
+@pytest.mark.parametrize('bs,T,H,O,N,h,mask_mode', [
+    (1, 1, 2, 4, 26, 32, 'all'),        # single clip, single frame (chain start == chain end, forced last gate)
+    (2, 3, 1, 5, 19, 32, 'none_real'),  # CAD-120 layout (H=1, no human-human relation), every object virtual
+    (2, 4, 2, 12, 34, 16, 'ragged'),    # maximum supported object count, ragged object sets
+])
+def test_edge_cases_vs_oracle(bs, T, H, O, N, h, mask_mode):
+    cfg = dict(STAGE1)
+    if H == 1:
+        cfg['message_humans_to_human'] = False
+    torch.manual_seed(11)
+    n_aff = 12 if H == 1 else None
+    m = TGGCN(input_size=(2048 + 4 * N, 2048), num_classes=(10 if H == 1 else 13, n_aff), hidden_size=h, gcn_node=N, **cfg)
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    g = torch.Generator().manual_seed(5)
+    x_human = torch.rand(bs, T, H, 2048 + 4 * N, generator=g)
+    x_objects = torch.rand(bs, T, O, 2048, generator=g)
+    mask = torch.ones(bs, O)
+    if mask_mode == 'none_real':
+        mask.zero_()
+    elif mask_mode == 'ragged':
+        mask[0, 3:] = 0
+        mask[1, 7:] = 0
+    x_objects = x_objects * mask[:, None, :, None]
+    n_gated = H + O
+    noise = torch.distributions.gumbel.Gumbel(0.0, 1.0).sample((T * n_gated, bs, 2))
+    ref = cpu_ref.tggcn_forward(sd, dict(m.cfg), x_human, x_objects, mask, training=True, gumbel_noise=noise)
+    m = m.to(DEV).train()
+    m._gumbel_noise_override = noise
+    out = m(x_human.to(DEV), x_objects.to(DEV), mask.to(DEV))
+    assert len(out) == len(ref) == (12 if n_aff else 6)
+    for i, (o, r) in enumerate(zip(out, ref)):
+        got, want = o.detach().cpu(), r.detach()
+        assert got.shape == want.shape
+        assert not torch.isnan(got).any(), i
+        assert (got - want).abs().max().item() < REL * max(1.0, want.abs().max().item()), i
+    sum(o.sum() for o in out if o.requires_grad).backward()
+    assert all(torch.isfinite(p.grad).all() for p in m.parameters() if p.grad is not None)
+
+
+def test_limits_fail_loudly():
+    """More objects than the attention kernel supports must raise, not silently fall back."""
+    N, h, O = 26, 16, 13
+    m = TGGCN(input_size=(2048 + 4 * N, 2048), num_classes=(13, None), hidden_size=h, gcn_node=N, **STAGE1).to(DEV)
+    with pytest.raises(RuntimeError):
+        m(torch.rand(1, 2, 2, 2048 + 4 * N, device=DEV), torch.rand(1, 2, O, 2048, device=DEV), torch.ones(1, O, device=DEV),
+          human_segmentation=torch.ones(1, 2, 2, device=DEV))
+    with pytest.raises(ValueError):  # feature width inconsistent with gcn_node
+        m(torch.rand(1, 2, 2, 2048 + 4 * 19, device=DEV), torch.rand(1, 2, 4, 2048, device=DEV), torch.ones(1, 4, device=DEV))
