@@ -4,34 +4,53 @@
 // compute_attention_weights (:1721-1754) for message_type 'v2', granularity 'v1' (the sender's message does not
 // depend on the receiver), aggregation 'att', attention style 'v2'/'v3' (dot / scaled dot product).
 // The reference runs this per time step, per receiver, per sender in Python; here ONE workgroup handles ONE instance
-// (a (clip, frame) at frame level, a clip at segment level): all entity feature vectors of the instance are staged
-// in LDS once, every needed pairwise score is a wave-level dot product (shuffle reduction), the masked softmax
-// (-inf on virtual senders, NaN -> 0 when every sender is virtual, :1750-1753) runs on a handful of lanes, and the
-// weighted message sums are written lane-contiguously straight into the caller's concatenated entity rows.
-// Sender messages are computed once per (sender, relation) by the MFMA GEMM, not once per receiver.
+// (a (clip, frame) at frame level, a clip at segment level): the entity feature vectors are staged in LDS once, every
+// pairwise score is a wave-level dot product (shuffle reduction), the masked softmax (-inf on virtual senders, NaN -> 0
+// when every sender is virtual, :1750-1753) is done in place in LDS, and the weighted message sums are written
+// lane-contiguously straight into the caller's concatenated entity rows. Sender messages are computed once per
+// (sender, relation) by the MFMA GEMM, not once per receiver.
+//
+// Two launch regimes: throughput (frame level: thousands of instances, 256-thread workgroups streaming from global
+// memory at high occupancy) and latency (segment level: one instance per clip inside the time loop; 1024-thread
+// workgroups so 4 waves per SIMD interleave the dependent chains, all message / gradient rows staged in LDS up front).
+// The rows of one instance are always equally strided, so every row set is resolved ONCE to (base, step): no integer
+// division and no descriptor re-read inside the loops (that instruction overhead dominated the first version).
 #include "twog_common.h"
 
 namespace {
 
 constexpr int MAX_H = 4, MAX_O = 12, MAX_E = MAX_H + MAX_O;
+constexpr int NATT_MAX = MAX_H * MAX_H + 2 * MAX_H * MAX_O + MAX_O * MAX_O;
 constexpr int MAXG = 4;
 struct FwdGroup { twog_attn_t a[MAXG]; int staged; };
 struct BwdGroup { twog_attn_bwd_t a[MAXG]; int staged; };
 
-// Latency-bound calls (few instances, e.g. one per clip inside the segment-level time loop) first copy every message /
-// gradient row of the instance into LDS with one burst of 16-byte loads, so the rest of the kernel never waits on HBM/L2
-// again; the relation descriptor is re-pointed at the LDS copy. Throughput-bound calls (one instance per (clip, frame))
-// keep streaming from global memory at high occupancy.
-__device__ __forceinline__ void stage_rows_lds(twog_rows_t& rel, int first_row, int n_rows, int width, float*& cursor) {
-    if (!rel.ptr) return;
+// the n rows (inst*n .. inst*n+n-1) of a twog_rows_t resolved to base + e*step  (host guarantees inner <= 1 or == n)
+struct RowSet {
+    float* base;
+    int64_t step;
+    __device__ __forceinline__ float* row(int e) const { return base + e * step; }
+    __device__ __forceinline__ bool on() const { return base != nullptr; }
+};
+__device__ __forceinline__ RowSet rowset(const twog_rows_t& m, int inst, int n) {
+    RowSet r;
+    if (!m.ptr) { r.base = nullptr; r.step = 0; return r; }
+    if (m.inner <= 1) { r.base = m.ptr + (int64_t)inst * n * m.ld_outer; r.step = m.ld_outer; }
+    else { r.base = m.ptr + (int64_t)inst * m.ld_outer; r.step = m.ld_inner; }
+    return r;
+}
+
+// copies the n x width floats of a row set into LDS (16-byte accesses) and re-points the set at the copy
+__device__ __forceinline__ void stage_rowset(RowSet& rs, int n, int width, float*& cursor) {
+    if (!rs.on()) return;
     const int w4 = width >> 2;
-    for (int i = threadIdx.x; i < n_rows * w4; i += blockDim.x) {
+    for (int i = threadIdx.x; i < n * w4; i += blockDim.x) {
         const int r = i / w4, c = (i - r * w4) * 4;
-        *reinterpret_cast<float4*>(cursor + r * width + c) =
-            *reinterpret_cast<const float4*>(twog_row_ptr(rel, first_row + r) + c);
+        *reinterpret_cast<float4*>(cursor + r * width + c) = *reinterpret_cast<const float4*>(rs.row(r) + c);
     }
-    rel.ptr = cursor; rel.inner = 1; rel.ld_outer = width; rel.ld_inner = width;
-    cursor += n_rows * width;
+    rs.base = cursor;
+    rs.step = width;
+    cursor += n * width;
 }
 
 // layout of the saved attention weights of one instance
@@ -40,193 +59,238 @@ __device__ __forceinline__ int att_off_oh(int H, int) { return H * H; }
 __device__ __forceinline__ int att_off_ho(int H, int O) { return H * H + H * O; }
 __device__ __forceinline__ int att_off_oo(int H, int O) { return H * H + 2 * H * O; }
 
-// softmax over senders for one receiver: score[s] valid where ok(s). NaN->0 semantics when nothing is valid.
-__device__ __forceinline__ void masked_softmax(const float* score, const bool* ok, int S, float* w) {
+// masked softmax of one receiver's scores straight from / to LDS: w[0..S) <- softmax over the valid senders, 0 elsewhere
+// (no valid sender -> all zeros: the reference's NaN -> 0 replacement)
+template <typename Ok>
+__device__ __forceinline__ void softmax_row(const float* score, float* w, int S, bool relation_on, Ok ok) {
     float m = -INFINITY;
     for (int s = 0; s < S; ++s)
-        if (ok[s]) m = fmaxf(m, score[s]);
+        if (ok(s)) m = fmaxf(m, score[s]);
     float sum = 0.f;
     for (int s = 0; s < S; ++s) {
-        w[s] = ok[s] ? expf(score[s] - m) : 0.f;
-        sum += w[s];
+        const float e = ok(s) ? expf(score[s] - m) : 0.f;
+        w[s] = e;
+        sum += e;
     }
-    for (int s = 0; s < S; ++s) w[s] = ok[s] ? w[s] / sum : 0.f;
+    for (int s = 0; s < S; ++s) w[s] = (relation_on && ok(s)) ? w[s] / sum : 0.f;
 }
 
-__device__ void compute_weights(const twog_attn_t& A, const float* sF, int inst, float* sG, float* sW, float* sMask) {
+// pairwise scores + the four masked softmaxes. sF: [E][D] features in LDS; sG: [E][E] scratch; sW: weights out.
+__device__ __forceinline__ void compute_weights(const twog_attn_t& A, const float* sF, float* sG, float* sW,
+                                                const float* sMask) {
     const int H = A.H, O = A.O, E = H + O, D = A.D;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    const int clip = inst / A.inst_per_clip;
-    if (threadIdx.x < O) sMask[threadIdx.x] = A.obj_mask ? A.obj_mask[(int64_t)clip * O + threadIdx.x] : 1.f;
-    // Gram matrix of the entity features (upper triangle incl. diagonal unused entries are cheap to skip)
+    const float scale = A.scale;
+    // Gram matrix of the entity features: one wave per (a <= b) pair
     for (int p = wv; p < E * E; p += nw) {
         const int a = p / E, b = p - a * E;
         if (b < a) continue;
+        const float4* fa = reinterpret_cast<const float4*>(sF + a * D);
+        const float4* fb = reinterpret_cast<const float4*>(sF + b * D);
         float acc = 0.f;
-        for (int d = lane; d < D; d += 64) acc = fmaf(sF[a * D + d], sF[b * D + d], acc);
-        acc = wave_sum(acc);
+        for (int d = lane; d < (D >> 2); d += 64) {
+            const float4 x = fa[d], y = fb[d];
+            acc = fmaf(x.x, y.x, acc);
+            acc = fmaf(x.y, y.y, acc);
+            acc = fmaf(x.z, y.z, acc);
+            acc = fmaf(x.w, y.w, acc);
+        }
+        acc = wave_sum(acc) * scale;
         if (lane == 0) {
-            sG[a * E + b] = acc * A.scale;
-            sG[b * E + a] = acc * A.scale;
+            sG[a * E + b] = acc;
+            sG[b * E + a] = acc;
         }
     }
     __syncthreads();
-    // one thread per (relation, receiver)
-    const int nrec = 2 * H + 2 * O;
-    for (int i = threadIdx.x; i < nrec; i += blockDim.x) {
-        float sc[MAX_E], w[MAX_E];
-        bool ok[MAX_E];
-        if (i < H) {  // hh: receiver human i, senders humans != i
-            const int h = i;
-            for (int s = 0; s < H; ++s) { sc[s] = sG[h * E + s]; ok[s] = (s != h); }
-            masked_softmax(sc, ok, H, w);
-            for (int s = 0; s < H; ++s) sW[att_off_hh(H, O) + h * H + s] = A.msg_hh.ptr ? w[s] : 0.f;
-        } else if (i < 2 * H) {  // oh: receiver human, senders objects (masked)
-            const int h = i - H;
-            for (int s = 0; s < O; ++s) { sc[s] = sG[h * E + H + s]; ok[s] = sMask[s] != 0.f; }
-            masked_softmax(sc, ok, O, w);
-            for (int s = 0; s < O; ++s) sW[att_off_oh(H, O) + h * O + s] = A.msg_oh.ptr ? w[s] : 0.f;
-        } else if (i < 2 * H + O) {  // ho: receiver object, senders humans
-            const int k = i - 2 * H;
-            for (int s = 0; s < H; ++s) { sc[s] = sG[(H + k) * E + s]; ok[s] = true; }
-            masked_softmax(sc, ok, H, w);
-            for (int s = 0; s < H; ++s) sW[att_off_ho(H, O) + k * H + s] = A.msg_ho.ptr ? w[s] : 0.f;
-        } else {  // oo: receiver object k, senders objects != k (masked)
-            const int k = i - 2 * H - O;
-            for (int s = 0; s < O; ++s) { sc[s] = sG[(H + k) * E + H + s]; ok[s] = (s != k) && sMask[s] != 0.f; }
-            masked_softmax(sc, ok, O, w);
-            for (int s = 0; s < O; ++s) sW[att_off_oo(H, O) + k * O + s] = A.msg_oo.ptr ? w[s] : 0.f;
-        }
+    // one thread per (relation, receiver): scores are row pieces of sG, weights go to sW
+    const int i = threadIdx.x;
+    if (i < H) {  // hh: receiver human i, senders humans != i
+        softmax_row(sG + i * E, sW + att_off_hh(H, O) + i * H, H, A.msg_hh.ptr != nullptr,
+                    [&](int s) { return s != i; });
+    } else if (i < 2 * H) {  // oh: receiver human, senders objects (masked)
+        const int h = i - H;
+        softmax_row(sG + h * E + H, sW + att_off_oh(H, O) + h * O, O, A.msg_oh.ptr != nullptr,
+                    [&](int s) { return sMask[s] != 0.f; });
+    } else if (i < 2 * H + O) {  // ho: receiver object, senders humans
+        const int k = i - 2 * H;
+        softmax_row(sG + (H + k) * E, sW + att_off_ho(H, O) + k * H, H, A.msg_ho.ptr != nullptr,
+                    [&](int) { return true; });
+    } else if (i < 2 * H + 2 * O) {  // oo: receiver object k, senders objects != k (masked)
+        const int k = i - 2 * H - O;
+        softmax_row(sG + (H + k) * E + H, sW + att_off_oo(H, O) + k * O, O, A.msg_oo.ptr != nullptr,
+                    [&](int s) { return s != k && sMask[s] != 0.f; });
     }
     __syncthreads();
 }
 
-__device__ __forceinline__ void stage_features(const twog_attn_t& A, int inst, float* sF) {
-    const int H = A.H, O = A.O, D = A.D, d4 = D >> 2;
-    for (int i = threadIdx.x; i < (H + O) * d4; i += blockDim.x) {
-        const int e = i / d4, c = (i - e * d4) * 4;
-        const float* src = e < H ? twog_row_ptr(A.feat_h, inst * H + e) : twog_row_ptr(A.feat_o, inst * O + (e - H));
-        *reinterpret_cast<float4*>(sF + e * D + c) = *reinterpret_cast<const float4*>(src + c);
-    }
-}
-
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const FwdGroup g) {
+__global__ __launch_bounds__(1024) void attn_fwd_kernel(const FwdGroup g) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    twog_attn_t A = g.a[blockIdx.y];
+    const twog_attn_t& A = g.a[blockIdx.y];
     const int inst = blockIdx.x;
     if (inst >= A.n_inst) return;
     const int H = A.H, O = A.O, E = H + O, D = A.D, hid = A.hidden;
-    float* sF = sm;                 // [E][D]
-    float* sG = sF + E * D;         // [E][E]
-    float* sW = sG + MAX_E * MAX_E; // [H*H + 2*H*O + O*O]
-    float* sMask = sW + (MAX_H * MAX_H + 2 * MAX_H * MAX_O + MAX_O * MAX_O);
-    int ih = inst * H, io = inst * O, ig = inst;  // first message row of this instance per sender type
-    stage_features(A, inst, sF);
+    float* sF = sm;            // [E][D]
+    float* sG = sF + E * D;    // [E][E]
+    float* sW = sG + MAX_E * MAX_E;
+    float* sMask = sW + NATT_MAX;
+    const int clip = inst / A.inst_per_clip;
+    const RowSet fh = rowset(A.feat_h, inst, H), fo = rowset(A.feat_o, inst, O);
+    RowSet m_hh = rowset(A.msg_hh, inst, H), m_ho = rowset(A.msg_ho, inst, H);
+    RowSet m_oh = rowset(A.msg_oh, inst, O), m_oo = rowset(A.msg_oo, inst, O);
+    RowSet m_so = rowset(A.msg_so, inst, 1), m_sh = rowset(A.msg_sh, inst, 1);
+    const RowSet o_hh = rowset(A.out_hh, inst, H), o_oh = rowset(A.out_oh, inst, H), o_sh = rowset(A.out_sh, inst, H);
+    const RowSet o_ho = rowset(A.out_ho, inst, O), o_so = rowset(A.out_so, inst, O), o_oo = rowset(A.out_oo, inst, O);
+    if (threadIdx.x < O) sMask[threadIdx.x] = A.obj_mask ? A.obj_mask[(int64_t)clip * O + threadIdx.x] : 1.f;
+    {   // features -> LDS
+        const int d4 = D >> 2;
+        for (int i = threadIdx.x; i < E * d4; i += blockDim.x) {
+            const int e = i / d4, c = (i - e * d4) * 4;
+            const float* src = e < H ? fh.row(e) : fo.row(e - H);
+            *reinterpret_cast<float4*>(sF + e * D + c) = *reinterpret_cast<const float4*>(src + c);
+        }
+    }
     if (g.staged) {
         float* cur = sMask + MAX_O + 4;
         cur = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(cur) + 15) & ~uintptr_t(15));
-        stage_rows_lds(A.msg_hh, ih, H, hid, cur);
-        stage_rows_lds(A.msg_ho, ih, H, hid, cur);
-        stage_rows_lds(A.msg_oh, io, O, hid, cur);
-        stage_rows_lds(A.msg_oo, io, O, hid, cur);
-        stage_rows_lds(A.msg_so, ig, 1, hid, cur);
-        stage_rows_lds(A.msg_sh, ig, 1, hid, cur);
-        ih = io = ig = 0;
+        stage_rowset(m_hh, H, hid, cur);
+        stage_rowset(m_ho, H, hid, cur);
+        stage_rowset(m_oh, O, hid, cur);
+        stage_rowset(m_oo, O, hid, cur);
+        stage_rowset(m_so, 1, hid, cur);
+        stage_rowset(m_sh, 1, hid, cur);
     }
     __syncthreads();
-    compute_weights(A, sF, inst, sG, sW, sMask);
+    compute_weights(A, sF, sG, sW, sMask);
     const int natt = H * H + 2 * H * O + O * O;
     if (A.att)
         for (int i = threadIdx.x; i < natt; i += blockDim.x) A.att[(int64_t)inst * natt + i] = sW[i];
-    // weighted sums, one output column per thread (lane-contiguous loads/stores)
-    for (int j = threadIdx.x; j < hid; j += blockDim.x) {
+    // weighted sums: one (group, column) item per thread, lane-contiguous loads/stores. Groups are independent pieces of
+    // work of similar size -- 0: messages to humans (hh, oh, sh); 1: human/geometry messages to objects (ho, so);
+    // 2, 3: object->object messages for the first / second half of the receivers.
+    const int o_half = (O + 1) / 2;
+    const bool rmask = A.recv_mask_ho != 0;
+    for (int idx = threadIdx.x; idx < 4 * hid; idx += blockDim.x) {
+        const int grp = idx / hid, j = idx - grp * hid;
         float m[MAX_O];
-        if (A.msg_hh.ptr) {
-            for (int s = 0; s < H; ++s) m[s] = twog_row_ptr(A.msg_hh, ih + s)[j];
-            for (int h = 0; h < H; ++h) {
-                float acc = 0.f;
-                for (int s = 0; s < H; ++s) acc = fmaf(sW[att_off_hh(H, O) + h * H + s], m[s], acc);
-                twog_row_ptr(A.out_hh, inst * H + h)[j] = acc;
+        if (grp == 0) {
+            if (m_hh.on()) {
+#pragma unroll
+                for (int s = 0; s < MAX_H; ++s) m[s] = s < H ? m_hh.row(s)[j] : 0.f;
+                for (int h = 0; h < H; ++h) {
+                    const float* w = sW + att_off_hh(H, O) + h * H;
+                    float acc = 0.f;
+#pragma unroll
+                    for (int s = 0; s < MAX_H; ++s)
+                        if (s < H) acc = fmaf(w[s], m[s], acc);
+                    o_hh.row(h)[j] = acc;
+                }
             }
-        }
-        if (A.msg_oh.ptr) {
-            for (int s = 0; s < O; ++s) m[s] = twog_row_ptr(A.msg_oh, io + s)[j];
-            for (int h = 0; h < H; ++h) {
-                float acc = 0.f;
-                for (int s = 0; s < O; ++s) acc = fmaf(sW[att_off_oh(H, O) + h * O + s], m[s], acc);
-                twog_row_ptr(A.out_oh, inst * H + h)[j] = acc;
+            if (m_oh.on()) {
+#pragma unroll
+                for (int s = 0; s < MAX_O; ++s) m[s] = s < O ? m_oh.row(s)[j] : 0.f;
+                for (int h = 0; h < H; ++h) {
+                    const float* w = sW + att_off_oh(H, O) + h * O;
+                    float acc = 0.f;
+#pragma unroll
+                    for (int s = 0; s < MAX_O; ++s)
+                        if (s < O) acc = fmaf(w[s], m[s], acc);
+                    o_oh.row(h)[j] = acc;
+                }
             }
-        }
-        if (A.msg_sh.ptr) {
-            const float v = twog_row_ptr(A.msg_sh, ig)[j];
-            for (int h = 0; h < H; ++h) twog_row_ptr(A.out_sh, inst * H + h)[j] = v;
-        }
-        if (A.msg_ho.ptr) {
-            for (int s = 0; s < H; ++s) m[s] = twog_row_ptr(A.msg_ho, ih + s)[j];
-            for (int k = 0; k < O; ++k) {
-                float acc = 0.f;
-                for (int s = 0; s < H; ++s) acc = fmaf(sW[att_off_ho(H, O) + k * H + s], m[s], acc);
-                twog_row_ptr(A.out_ho, inst * O + k)[j] = A.recv_mask_ho ? acc * sMask[k] : acc;
+            if (m_sh.on()) {
+                const float v = m_sh.row(0)[j];
+                for (int h = 0; h < H; ++h) o_sh.row(h)[j] = v;
             }
-        }
-        if (A.msg_so.ptr) {
-            const float v = twog_row_ptr(A.msg_so, ig)[j];
-            for (int k = 0; k < O; ++k) twog_row_ptr(A.out_so, inst * O + k)[j] = A.recv_mask_ho ? v * sMask[k] : v;
-        }
-        if (A.msg_oo.ptr) {
-            for (int s = 0; s < O; ++s) m[s] = twog_row_ptr(A.msg_oo, io + s)[j];
-            for (int k = 0; k < O; ++k) {
+        } else if (grp == 1) {
+            if (m_ho.on()) {
+#pragma unroll
+                for (int s = 0; s < MAX_H; ++s) m[s] = s < H ? m_ho.row(s)[j] : 0.f;
+                for (int k = 0; k < O; ++k) {
+                    const float* w = sW + att_off_ho(H, O) + k * H;
+                    float acc = 0.f;
+#pragma unroll
+                    for (int s = 0; s < MAX_H; ++s)
+                        if (s < H) acc = fmaf(w[s], m[s], acc);
+                    o_ho.row(k)[j] = rmask ? acc * sMask[k] : acc;
+                }
+            }
+            if (m_so.on()) {
+                const float v = m_so.row(0)[j];
+                for (int k = 0; k < O; ++k) o_so.row(k)[j] = rmask ? v * sMask[k] : v;
+            }
+        } else if (m_oo.on()) {
+            const int k0 = grp == 2 ? 0 : o_half, k1 = grp == 2 ? o_half : O;
+#pragma unroll
+            for (int s = 0; s < MAX_O; ++s) m[s] = s < O ? m_oo.row(s)[j] : 0.f;
+            for (int k = k0; k < k1; ++k) {
+                const float* w = sW + att_off_oo(H, O) + k * O;
                 float acc = 0.f;
-                for (int s = 0; s < O; ++s) acc = fmaf(sW[att_off_oo(H, O) + k * O + s], m[s], acc);
-                twog_row_ptr(A.out_oo, inst * O + k)[j] = acc;
+#pragma unroll
+                for (int s = 0; s < MAX_O; ++s)
+                    if (s < O) acc = fmaf(w[s], m[s], acc);
+                o_oo.row(k)[j] = acc;
             }
         }
     }
 }
 
-// wave-level dot product of two global rows of length n
+// wave-level dot product of two rows of length n (n % 4 == 0, 16-byte aligned)
 __device__ __forceinline__ float wave_dot(const float* a, const float* b, int n, int lane) {
+    const float4* a4 = reinterpret_cast<const float4*>(a);
+    const float4* b4 = reinterpret_cast<const float4*>(b);
     float acc = 0.f;
-    for (int j = lane; j < n; j += 64) acc = fmaf(a[j], b[j], acc);
+    for (int j = lane; j < (n >> 2); j += 64) {
+        const float4 x = a4[j], y = b4[j];
+        acc = fmaf(x.x, y.x, acc);
+        acc = fmaf(x.y, y.y, acc);
+        acc = fmaf(x.z, y.z, acc);
+        acc = fmaf(x.w, y.w, acc);
+    }
     return wave_sum(acc);
 }
 
-__global__ __launch_bounds__(256) void attn_bwd_kernel(const BwdGroup g) {
+__global__ __launch_bounds__(1024) void attn_bwd_kernel(const BwdGroup g) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    twog_attn_bwd_t B = g.a[blockIdx.y];
-    twog_attn_t& A = B.f;
+    const twog_attn_bwd_t& B = g.a[blockIdx.y];
+    const twog_attn_t& A = B.f;
     const int inst = blockIdx.x;
     if (inst >= A.n_inst) return;
     const int H = A.H, O = A.O, E = H + O, D = A.D, hid = A.hidden;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const int natt = H * H + 2 * H * O + O * O;
-    constexpr int NATT_MAX = MAX_H * MAX_H + 2 * MAX_H * MAX_O + MAX_O * MAX_O;
     float* sW = sm;               // saved weights [natt]
     float* sdW = sW + NATT_MAX;   // dL/dw then dscore [natt]
     float* sC = sdW + NATT_MAX;   // [E][E] coefficients of dF
     float* sMask = sC + MAX_E * MAX_E;
     const int clip = inst / A.inst_per_clip;
-    // first rows of this instance: sender messages (mh/mo/mg) and incoming gradients (rh/ro)
-    int mh = inst * H, mo = inst * O, mg = inst, rh = inst * H, ro = inst * O;
+    const RowSet fh = rowset(A.feat_h, inst, H), fo = rowset(A.feat_o, inst, O);
+    RowSet m_hh = rowset(A.msg_hh, inst, H), m_ho = rowset(A.msg_ho, inst, H);
+    RowSet m_oh = rowset(A.msg_oh, inst, O), m_oo = rowset(A.msg_oo, inst, O);
+    RowSet m_so = rowset(A.msg_so, inst, 1), m_sh = rowset(A.msg_sh, inst, 1);
+    RowSet d_hh = rowset(B.dout_hh, inst, H), d_oh = rowset(B.dout_oh, inst, H), d_sh = rowset(B.dout_sh, inst, H);
+    RowSet d_ho = rowset(B.dout_ho, inst, O), d_so = rowset(B.dout_so, inst, O), d_oo = rowset(B.dout_oo, inst, O);
+    const RowSet g_hh = rowset(B.dmsg_hh, inst, H), g_ho = rowset(B.dmsg_ho, inst, H);
+    const RowSet g_oh = rowset(B.dmsg_oh, inst, O), g_oo = rowset(B.dmsg_oo, inst, O);
+    const RowSet g_so = rowset(B.dmsg_so, inst, 1), g_sh = rowset(B.dmsg_sh, inst, 1);
+    const RowSet df_h = rowset(B.dfeat_h, inst, H), df_o = rowset(B.dfeat_o, inst, O);
+    const bool rmask = A.recv_mask_ho != 0, relu_mask = B.relu_mask_dmsg != 0;
     for (int i = threadIdx.x; i < natt; i += blockDim.x) sW[i] = A.att[(int64_t)inst * natt + i];
     if (threadIdx.x < O) sMask[threadIdx.x] = A.obj_mask ? A.obj_mask[(int64_t)clip * O + threadIdx.x] : 1.f;
-    for (int i = threadIdx.x; i < MAX_E * MAX_E; i += blockDim.x) sC[i] = 0.f;
     if (g.staged) {
         float* cur = sMask + MAX_O + 4;
         cur = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(cur) + 15) & ~uintptr_t(15));
-        stage_rows_lds(A.msg_hh, mh, H, hid, cur);
-        stage_rows_lds(A.msg_ho, mh, H, hid, cur);
-        stage_rows_lds(A.msg_oh, mo, O, hid, cur);
-        stage_rows_lds(A.msg_oo, mo, O, hid, cur);
-        stage_rows_lds(A.msg_so, mg, 1, hid, cur);
-        stage_rows_lds(A.msg_sh, mg, 1, hid, cur);
-        if (A.msg_hh.ptr) stage_rows_lds(B.dout_hh, rh, H, hid, cur);
-        if (A.msg_oh.ptr) stage_rows_lds(B.dout_oh, rh, H, hid, cur);
-        if (A.msg_sh.ptr) stage_rows_lds(B.dout_sh, rh, H, hid, cur);
-        if (A.msg_ho.ptr) stage_rows_lds(B.dout_ho, ro, O, hid, cur);
-        if (A.msg_so.ptr) stage_rows_lds(B.dout_so, ro, O, hid, cur);
-        if (A.msg_oo.ptr) stage_rows_lds(B.dout_oo, ro, O, hid, cur);
-        mh = mo = mg = rh = ro = 0;
+        stage_rowset(m_hh, H, hid, cur);
+        stage_rowset(m_ho, H, hid, cur);
+        stage_rowset(m_oh, O, hid, cur);
+        stage_rowset(m_oo, O, hid, cur);
+        stage_rowset(m_so, 1, hid, cur);
+        stage_rowset(m_sh, 1, hid, cur);
+        if (m_hh.on()) stage_rowset(d_hh, H, hid, cur);
+        if (m_oh.on()) stage_rowset(d_oh, H, hid, cur);
+        if (m_sh.on()) stage_rowset(d_sh, H, hid, cur);
+        if (m_ho.on()) stage_rowset(d_ho, O, hid, cur);
+        if (m_so.on()) stage_rowset(d_so, O, hid, cur);
+        if (m_oo.on()) stage_rowset(d_oo, O, hid, cur);
     }
     __syncthreads();
     // dL/dw[r][s] = recv_mask_r * <dout[r], msg[s]>   (one wave per pair)
@@ -234,26 +298,21 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const BwdGroup g) {
         float v = 0.f;
         if (p < H * H) {
             const int r = p / H, s = p - r * H;
-            if (A.msg_hh.ptr && r != s)
-                v = wave_dot(twog_row_ptr(B.dout_hh, rh + r), twog_row_ptr(A.msg_hh, mh + s), hid, lane);
+            if (m_hh.on() && r != s) v = wave_dot(d_hh.row(r), m_hh.row(s), hid, lane);
         } else if (p < H * H + H * O) {
             const int q = p - H * H, r = q / O, s = q - r * O;
-            if (A.msg_oh.ptr)
-                v = wave_dot(twog_row_ptr(B.dout_oh, rh + r), twog_row_ptr(A.msg_oh, mo + s), hid, lane);
+            if (m_oh.on()) v = wave_dot(d_oh.row(r), m_oh.row(s), hid, lane);
         } else if (p < H * H + 2 * H * O) {
             const int q = p - H * H - H * O, r = q / H, s = q - r * H;
-            if (A.msg_ho.ptr)
-                v = (A.recv_mask_ho ? sMask[r] : 1.f) *
-                    wave_dot(twog_row_ptr(B.dout_ho, ro + r), twog_row_ptr(A.msg_ho, mh + s), hid, lane);
+            if (m_ho.on()) v = (rmask ? sMask[r] : 1.f) * wave_dot(d_ho.row(r), m_ho.row(s), hid, lane);
         } else {
             const int q = p - H * H - 2 * H * O, r = q / O, s = q - r * O;
-            if (A.msg_oo.ptr && r != s)
-                v = wave_dot(twog_row_ptr(B.dout_oo, ro + r), twog_row_ptr(A.msg_oo, mo + s), hid, lane);
+            if (m_oo.on() && r != s) v = wave_dot(d_oo.row(r), m_oo.row(s), hid, lane);
         }
         if (lane == 0) sdW[p] = v;
     }
     __syncthreads();
-    // softmax backward per receiver: dscore = w * (dw - sum_s w dw) * scale ; scatter into the dF coefficient matrix
+    // softmax backward per receiver: dscore = w * (dw - sum_s w dw) * scale
     if (threadIdx.x < 2 * H + 2 * O) {
         const int i = threadIdx.x;
         int off, S;
@@ -266,96 +325,107 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const BwdGroup g) {
         for (int s = 0; s < S; ++s) sdW[off + s] = sW[off + s] * (sdW[off + s] - t) * A.scale;
     }
     __syncthreads();
-    if (threadIdx.x == 0) {  // tiny (<= ~100 entries): serial, deterministic
-        for (int r = 0; r < H; ++r)
-            for (int s = 0; s < H; ++s) {
-                const float v = sdW[att_off_hh(H, O) + r * H + s];
-                sC[r * MAX_E + s] += v;
-                sC[s * MAX_E + r] += v;
-            }
-        for (int r = 0; r < H; ++r)
-            for (int s = 0; s < O; ++s) {
-                const float v = sdW[att_off_oh(H, O) + r * O + s];
-                sC[r * MAX_E + H + s] += v;
-                sC[(H + s) * MAX_E + r] += v;
-            }
-        for (int r = 0; r < O; ++r)
-            for (int s = 0; s < H; ++s) {
-                const float v = sdW[att_off_ho(H, O) + r * H + s];
-                sC[(H + r) * MAX_E + s] += v;
-                sC[s * MAX_E + H + r] += v;
-            }
-        for (int r = 0; r < O; ++r)
-            for (int s = 0; s < O; ++s) {
-                const float v = sdW[att_off_oo(H, O) + r * O + s];
-                sC[(H + r) * MAX_E + H + s] += v;
-                sC[(H + s) * MAX_E + H + r] += v;
-            }
+    // coefficient of F[b] in dF[a]: every score <F_r, F_s> sends its dscore to both its receiver and its sender.
+    // Fixed order of the (at most 4) terms per entry -> deterministic.
+    for (int i = threadIdx.x; i < E * E; i += blockDim.x) {
+        const int a = i / E, b = i - a * E;
+        float v;
+        if (a < H && b < H) v = sdW[att_off_hh(H, O) + a * H + b] + sdW[att_off_hh(H, O) + b * H + a];
+        else if (a < H) v = sdW[att_off_oh(H, O) + a * O + (b - H)] + sdW[att_off_ho(H, O) + (b - H) * H + a];
+        else if (b < H) v = sdW[att_off_ho(H, O) + (a - H) * H + b] + sdW[att_off_oh(H, O) + b * O + (a - H)];
+        else v = sdW[att_off_oo(H, O) + (a - H) * O + (b - H)] + sdW[att_off_oo(H, O) + (b - H) * O + (a - H)];
+        sC[a * MAX_E + b] = v;
     }
     __syncthreads();
-    // gradient wrt sender messages: dmsg[s] = sum_r w[r][s] * recv_mask_r * dout[r]  (optionally times ReLU'(msg))
-    for (int j = threadIdx.x; j < hid; j += blockDim.x) {
+    // gradient wrt sender messages: dmsg[s] = sum_r w[r][s] * recv_mask_r * dout[r]  (optionally times ReLU'(msg)),
+    // one (group, column) item per thread; groups: 0: hh, oh, sh; 1: ho, so; 2, 3: oo senders first / second half
+    const int o_half = (O + 1) / 2;
+    for (int idx = threadIdx.x; idx < 4 * hid; idx += blockDim.x) {
+        const int grp = idx / hid, j = idx - grp * hid;
         float gr[MAX_O];
-        if (A.msg_hh.ptr) {
-            for (int r = 0; r < H; ++r) gr[r] = twog_row_ptr(B.dout_hh, rh + r)[j];
-            for (int s = 0; s < H; ++s) {
-                float acc = 0.f;
-                for (int r = 0; r < H; ++r) acc = fmaf(sW[att_off_hh(H, O) + r * H + s], gr[r], acc);
-                if (B.relu_mask_dmsg && !(twog_row_ptr(A.msg_hh, mh + s)[j] > 0.f)) acc = 0.f;
-                twog_row_ptr(B.dmsg_hh, inst * H + s)[j] = acc;
+        if (grp == 0) {
+            if (m_hh.on()) {
+#pragma unroll
+                for (int r = 0; r < MAX_H; ++r) gr[r] = r < H ? d_hh.row(r)[j] : 0.f;
+                for (int s = 0; s < H; ++s) {
+                    float acc = 0.f;
+#pragma unroll
+                    for (int r = 0; r < MAX_H; ++r)
+                        if (r < H) acc = fmaf(sW[att_off_hh(H, O) + r * H + s], gr[r], acc);
+                    if (relu_mask && !(m_hh.row(s)[j] > 0.f)) acc = 0.f;
+                    g_hh.row(s)[j] = acc;
+                }
             }
-        }
-        if (A.msg_oh.ptr) {
-            for (int r = 0; r < H; ++r) gr[r] = twog_row_ptr(B.dout_oh, rh + r)[j];
-            for (int s = 0; s < O; ++s) {
-                float acc = 0.f;
-                for (int r = 0; r < H; ++r) acc = fmaf(sW[att_off_oh(H, O) + r * O + s], gr[r], acc);
-                if (B.relu_mask_dmsg && !(twog_row_ptr(A.msg_oh, mo + s)[j] > 0.f)) acc = 0.f;
-                twog_row_ptr(B.dmsg_oh, inst * O + s)[j] = acc;
+            if (m_oh.on()) {
+#pragma unroll
+                for (int r = 0; r < MAX_H; ++r) gr[r] = r < H ? d_oh.row(r)[j] : 0.f;
+                for (int s = 0; s < O; ++s) {
+                    float acc = 0.f;
+#pragma unroll
+                    for (int r = 0; r < MAX_H; ++r)
+                        if (r < H) acc = fmaf(sW[att_off_oh(H, O) + r * O + s], gr[r], acc);
+                    if (relu_mask && !(m_oh.row(s)[j] > 0.f)) acc = 0.f;
+                    g_oh.row(s)[j] = acc;
+                }
             }
-        }
-        if (A.msg_sh.ptr) {
-            float acc = 0.f;
-            for (int r = 0; r < H; ++r) acc += twog_row_ptr(B.dout_sh, rh + r)[j];
-            if (B.relu_mask_dmsg && !(twog_row_ptr(A.msg_sh, mg)[j] > 0.f)) acc = 0.f;
-            twog_row_ptr(B.dmsg_sh, inst)[j] = acc;
-        }
-        if (A.msg_ho.ptr) {
-            for (int r = 0; r < O; ++r) gr[r] = (A.recv_mask_ho ? sMask[r] : 1.f) * twog_row_ptr(B.dout_ho, ro + r)[j];
-            for (int s = 0; s < H; ++s) {
+            if (m_sh.on()) {
                 float acc = 0.f;
-                for (int r = 0; r < O; ++r) acc = fmaf(sW[att_off_ho(H, O) + r * H + s], gr[r], acc);
-                if (B.relu_mask_dmsg && !(twog_row_ptr(A.msg_ho, mh + s)[j] > 0.f)) acc = 0.f;
-                twog_row_ptr(B.dmsg_ho, inst * H + s)[j] = acc;
+                for (int r = 0; r < H; ++r) acc += d_sh.row(r)[j];
+                if (relu_mask && !(m_sh.row(0)[j] > 0.f)) acc = 0.f;
+                g_sh.row(0)[j] = acc;
             }
-        }
-        if (A.msg_so.ptr) {
-            float acc = 0.f;
-            for (int r = 0; r < O; ++r) acc = fmaf(A.recv_mask_ho ? sMask[r] : 1.f, twog_row_ptr(B.dout_so, ro + r)[j], acc);
-            if (B.relu_mask_dmsg && !(twog_row_ptr(A.msg_so, mg)[j] > 0.f)) acc = 0.f;
-            twog_row_ptr(B.dmsg_so, inst)[j] = acc;
-        }
-        if (A.msg_oo.ptr) {
-            for (int r = 0; r < O; ++r) gr[r] = twog_row_ptr(B.dout_oo, ro + r)[j];
-            for (int s = 0; s < O; ++s) {
+        } else if (grp == 1) {
+            if (m_ho.on()) {
+#pragma unroll
+                for (int r = 0; r < MAX_O; ++r) gr[r] = r < O ? (rmask ? sMask[r] : 1.f) * d_ho.row(r)[j] : 0.f;
+                for (int s = 0; s < H; ++s) {
+                    float acc = 0.f;
+#pragma unroll
+                    for (int r = 0; r < MAX_O; ++r)
+                        if (r < O) acc = fmaf(sW[att_off_ho(H, O) + r * H + s], gr[r], acc);
+                    if (relu_mask && !(m_ho.row(s)[j] > 0.f)) acc = 0.f;
+                    g_ho.row(s)[j] = acc;
+                }
+            }
+            if (m_so.on()) {
                 float acc = 0.f;
-                for (int r = 0; r < O; ++r) acc = fmaf(sW[att_off_oo(H, O) + r * O + s], gr[r], acc);
-                if (B.relu_mask_dmsg && !(twog_row_ptr(A.msg_oo, mo + s)[j] > 0.f)) acc = 0.f;
-                twog_row_ptr(B.dmsg_oo, inst * O + s)[j] = acc;
+                for (int r = 0; r < O; ++r) acc = fmaf(rmask ? sMask[r] : 1.f, d_so.row(r)[j], acc);
+                if (relu_mask && !(m_so.row(0)[j] > 0.f)) acc = 0.f;
+                g_so.row(0)[j] = acc;
+            }
+        } else if (m_oo.on()) {
+            const int s0 = grp == 2 ? 0 : o_half, s1 = grp == 2 ? o_half : O;
+#pragma unroll
+            for (int r = 0; r < MAX_O; ++r) gr[r] = r < O ? d_oo.row(r)[j] : 0.f;
+            for (int s = s0; s < s1; ++s) {
+                float acc = 0.f;
+#pragma unroll
+                for (int r = 0; r < MAX_O; ++r)
+                    if (r < O) acc = fmaf(sW[att_off_oo(H, O) + r * O + s], gr[r], acc);
+                if (relu_mask && !(m_oo.row(s)[j] > 0.f)) acc = 0.f;
+                g_oo.row(s)[j] = acc;
             }
         }
     }
     // gradient wrt the features: dF[a] = sum_b C[a][b] F[b]; F is read straight from global memory (one burst of E
-    // independent lane-contiguous loads per column), so the backward kernel keeps no LDS copy of the features
-    for (int d = threadIdx.x; d < D; d += blockDim.x) {
+    // independent lane-contiguous loads per column), so the backward kernel keeps no LDS copy of the features.
+    // Two (group, column) items per column: first / second half of the entities.
+    const int e_half = (E + 1) / 2;
+    const bool accum = B.dfeat_accumulate != 0;
+    for (int idx = threadIdx.x; idx < 2 * D; idx += blockDim.x) {
+        const int grp = idx / D, d = idx - grp * D;
         float f[MAX_E];
-        for (int b = 0; b < E; ++b)
-            f[b] = (b < H ? twog_row_ptr(A.feat_h, inst * H + b) : twog_row_ptr(A.feat_o, inst * O + (b - H)))[d];
-        for (int a = 0; a < E; ++a) {
+#pragma unroll
+        for (int b = 0; b < MAX_E; ++b) f[b] = b < E ? (b < H ? fh.row(b) : fo.row(b - H))[d] : 0.f;
+        const int a0 = grp == 0 ? 0 : e_half, a1 = grp == 0 ? e_half : E;
+        for (int a = a0; a < a1; ++a) {
+            const float* c = sC + a * MAX_E;
             float acc = 0.f;
-            for (int b = 0; b < E; ++b) acc = fmaf(sC[a * MAX_E + b], f[b], acc);
-            float* dst = a < H ? twog_row_ptr(B.dfeat_h, inst * H + a) : twog_row_ptr(B.dfeat_o, inst * O + (a - H));
-            dst[d] = B.dfeat_accumulate ? dst[d] + acc : acc;
+#pragma unroll
+            for (int b = 0; b < MAX_E; ++b)
+                if (b < E) acc = fmaf(c[b], f[b], acc);
+            float* dst = (a < H ? df_h.row(a) : df_o.row(a - H)) + d;
+            *dst = accum ? *dst + acc : acc;
         }
     }
 }
@@ -369,18 +439,34 @@ inline size_t n_dout_rows(const twog_attn_t& a) {
     return (size_t)(a.msg_hh.ptr ? a.H : 0) + (a.msg_oh.ptr ? a.H : 0) + (a.msg_sh.ptr ? a.H : 0) +
            (a.msg_ho.ptr ? a.O : 0) + (a.msg_so.ptr ? a.O : 0) + (a.msg_oo.ptr ? a.O : 0);
 }
-constexpr int NATT_MAX_H = MAX_H * MAX_H + 2 * MAX_H * MAX_O + MAX_O * MAX_O;
 inline size_t lds_fwd(const twog_attn_t& a, bool staged) {
-    size_t f = (size_t)(a.H + a.O) * a.D + MAX_E * MAX_E + NATT_MAX_H + MAX_O + 8;
+    size_t f = (size_t)(a.H + a.O) * a.D + MAX_E * MAX_E + NATT_MAX + MAX_O + 8;
     if (staged) f += n_msg_rows(a) * a.hidden;
     return sizeof(float) * f;
 }
 inline size_t lds_bwd(const twog_attn_t& a, bool staged) {
-    size_t f = 2 * (size_t)NATT_MAX_H + MAX_E * MAX_E + MAX_O + 8;
+    size_t f = 2 * (size_t)NATT_MAX + MAX_E * MAX_E + MAX_O + 8;
     if (staged) f += (n_msg_rows(a) + n_dout_rows(a)) * a.hidden;
     return sizeof(float) * f;
 }
 constexpr size_t LDS_LIMIT = 160 * 1024;
+
+// the rows of one instance must be equally strided: plain rows (inner <= 1) or exactly one outer group per instance
+inline bool rows_ok(const twog_rows_t& m, int n) { return !m.ptr || m.inner <= 1 || m.inner == n; }
+inline bool desc_ok(const twog_attn_t& a) {
+    if (a.H > MAX_H || a.O > MAX_O || a.H < 0 || a.O < 0 || (a.D & 3) || (a.hidden & 3)) return false;
+    return rows_ok(a.feat_h, a.H) && rows_ok(a.feat_o, a.O) && rows_ok(a.msg_hh, a.H) && rows_ok(a.msg_ho, a.H) &&
+           rows_ok(a.msg_oh, a.O) && rows_ok(a.msg_oo, a.O) && rows_ok(a.msg_so, 1) && rows_ok(a.msg_sh, 1) &&
+           rows_ok(a.out_hh, a.H) && rows_ok(a.out_oh, a.H) && rows_ok(a.out_sh, a.H) && rows_ok(a.out_ho, a.O) &&
+           rows_ok(a.out_so, a.O) && rows_ok(a.out_oo, a.O);
+}
+inline bool bdesc_ok(const twog_attn_bwd_t& b) {
+    const twog_attn_t& a = b.f;
+    return rows_ok(b.dout_hh, a.H) && rows_ok(b.dout_oh, a.H) && rows_ok(b.dout_sh, a.H) && rows_ok(b.dout_ho, a.O) &&
+           rows_ok(b.dout_so, a.O) && rows_ok(b.dout_oo, a.O) && rows_ok(b.dmsg_hh, a.H) && rows_ok(b.dmsg_ho, a.H) &&
+           rows_ok(b.dmsg_oh, a.O) && rows_ok(b.dmsg_oo, a.O) && rows_ok(b.dmsg_so, 1) && rows_ok(b.dmsg_sh, 1) &&
+           rows_ok(b.dfeat_h, a.H) && rows_ok(b.dfeat_o, a.O);
+}
 
 }  // namespace
 
@@ -396,7 +482,7 @@ extern "C" int twog_attn_fwd(const twog_attn_t* a, int n, void* stream) {
     int maxinst = 0;
     for (int i = 0; i < n; ++i) {
         g.a[i] = a[i];
-        if (a[i].H > MAX_H || a[i].O > MAX_O || a[i].H < 0 || a[i].O < 0 || (a[i].D & 3) || (a[i].hidden & 3)) return -2;
+        if (!desc_ok(a[i])) return -2;
         if (a[i].n_inst > maxinst) maxinst = a[i].n_inst;
     }
     if (maxinst == 0) return 0;
@@ -408,14 +494,15 @@ extern "C" int twog_attn_fwd(const twog_attn_t* a, int n, void* stream) {
         if (lds <= LDS_LIMIT) break;
         staged = false;
     }
+    if (lds > LDS_LIMIT) return -3;
     g.staged = staged ? 1 : 0;
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)LDS_LIMIT);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT);
         attr_set = true;
     }
-    hipLaunchKernelGGL(attn_fwd_kernel, dim3(maxinst, n), dim3(256), lds, (hipStream_t)stream, g);
+    hipLaunchKernelGGL(attn_fwd_kernel, dim3(maxinst, n), dim3(staged ? 1024 : 256), lds, (hipStream_t)stream, g);
     TWOG_CHECK_LAUNCH();
     return 0;
 }
@@ -426,7 +513,7 @@ extern "C" int twog_attn_bwd(const twog_attn_bwd_t* a, int n, void* stream) {
     int maxinst = 0;
     for (int i = 0; i < n; ++i) {
         g.a[i] = a[i];
-        if (a[i].f.H > MAX_H || a[i].f.O > MAX_O || (a[i].f.D & 3) || (a[i].f.hidden & 3)) return -2;
+        if (!desc_ok(a[i].f) || !bdesc_ok(a[i])) return -2;
         if (a[i].f.n_inst > maxinst) maxinst = a[i].f.n_inst;
     }
     if (maxinst == 0) return 0;
@@ -438,14 +525,15 @@ extern "C" int twog_attn_bwd(const twog_attn_bwd_t* a, int n, void* stream) {
         if (lds <= LDS_LIMIT) break;
         staged = false;
     }
+    if (lds > LDS_LIMIT) return -3;
     g.staged = staged ? 1 : 0;
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)LDS_LIMIT);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT);
         attr_set = true;
     }
-    hipLaunchKernelGGL(attn_bwd_kernel, dim3(maxinst, n), dim3(256), lds, (hipStream_t)stream, g);
+    hipLaunchKernelGGL(attn_bwd_kernel, dim3(maxinst, n), dim3(staged ? 1024 : 256), lds, (hipStream_t)stream, g);
     TWOG_CHECK_LAUNCH();
     return 0;
 }
