@@ -33,6 +33,7 @@ struct Prob {
     int act, accumulate;
     int tiles_m, tiles_n, tile_start;
     int a_vec, b_vec;  // 16-byte vector loads legal for this operand
+    int n_major;       // logical tile order: consecutive tiles share the B column panel (weights larger than activations)
     int batch;         // independent problems sharing shapes; operand b of batch i = ptr + i * *_bs
     int64_t a_bs, b_bs, c_bs;
 };
@@ -41,6 +42,8 @@ struct Group {
     Prob p[MAXP];
     int n;
     int total_tiles;
+    int n_cls;       // classes of equal K: tiles [cls_start, cls_start + cls_ntiles), remainder ring offset cls_rot
+    int cls_start[MAXP], cls_ntiles[MAXP], cls_rot[MAXP];
     int splitk;      // >= 1
     int k_per_split; // multiple of BK
     float* slabs;    // split-K partials: [problem-tile-major] see below
@@ -94,7 +97,7 @@ __device__ __forceinline__ void store_tile(const TileRegs<ROWS, COLS>& t, float*
     }
 }
 
-template <int BM, int BN, bool AKM, bool BKM, bool FAST, int TM, int TN>
+template <int BM, int BN, bool AKM, bool BKM, bool FAST, int TM, int TN, int D>
 __device__ __forceinline__ void gemm_mainloop(const twog_rows_t A, const twog_rows_t B, int M, int N, int a_vec,
                                               int b_vec, int m0, int n0, int k_begin, int k_end, float* smem,
                                               f32x16 (&acc)[TM][TN]) {
@@ -107,42 +110,56 @@ __device__ __forceinline__ void gemm_mainloop(const twog_rows_t A, const twog_ro
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int li = lane & 31, kh = lane >> 5;
     const int wm = (wave >> 1) * WM, wn = (wave & 1) * WN;
+    const int tid = threadIdx.x;
 
     using ARegs = TileRegs<(AKM ? BK : BM), (AKM ? BM : BK)>;
     using BRegs = TileRegs<(BKM ? BK : BN), (BKM ? BN : BK)>;
-    ARegs ra;
-    BRegs rb;
     // FAST: 16-byte aligned operands and only whole k-tiles -> every lane issues unconditional global_load_dwordx4
     // (row / column indices beyond the matrix are clamped: they only feed outputs that are never stored), so the
-    // loads of k-tile t+1 stay in flight under the MFMAs of tile t.
-    const int tid = threadIdx.x;
-    auto gload = [&](int k0) {
+    // loads stay in flight under the MFMAs. All row addressing is resolved before the loop: per pass one pointer
+    // (row-major operand: the tile row; k-major operand with plain rows: row 0 of the pass, advanced by k0 * ld).
+    const float* pa[ARegs::PASSES];
+    const float* pb[BRegs::PASSES];
+    const bool a_plain = A.inner <= 1, b_plain = B.inner <= 1;
+    if constexpr (FAST) {
+#pragma unroll
+        for (int i = 0; i < ARegs::PASSES; ++i) {
+            const int rr = tid / ARegs::F4_PER_ROW + i * ARegs::ROWS_PER_PASS, cc = (tid % ARegs::F4_PER_ROW) * 4;
+            if constexpr (AKM) pa[i] = A.ptr + (int64_t)rr * A.ld_outer + min(m0 + cc, M - 4);
+            else pa[i] = A.ptr + twog_row_off(A, min(m0 + rr, M - 1)) + cc;
+        }
+#pragma unroll
+        for (int i = 0; i < BRegs::PASSES; ++i) {
+            const int rr = tid / BRegs::F4_PER_ROW + i * BRegs::ROWS_PER_PASS, cc = (tid % BRegs::F4_PER_ROW) * 4;
+            if constexpr (BKM) pb[i] = B.ptr + (int64_t)rr * B.ld_outer + min(n0 + cc, N - 4);
+            else pb[i] = B.ptr + twog_row_off(B, min(n0 + rr, N - 1)) + cc;
+        }
+    }
+    auto gload = [&](ARegs& ra, BRegs& rb, int k0) {
         if constexpr (FAST) {
-            if constexpr (AKM) {
-                const int c = min(m0 + (tid % ARegs::F4_PER_ROW) * 4, M - 4);
 #pragma unroll
-                for (int i = 0; i < ARegs::PASSES; ++i)
-                    ra.v[i] = *reinterpret_cast<const f32x4*>(
-                        A.ptr + twog_row_off(A, k0 + tid / ARegs::F4_PER_ROW + i * ARegs::ROWS_PER_PASS) + c);
-            } else {
-#pragma unroll
-                for (int i = 0; i < ARegs::PASSES; ++i) {
-                    const int row = min(m0 + tid / ARegs::F4_PER_ROW + i * ARegs::ROWS_PER_PASS, M - 1);
-                    ra.v[i] = *reinterpret_cast<const f32x4*>(A.ptr + twog_row_off(A, row) + (tid % ARegs::F4_PER_ROW) * 4 + k0);
+            for (int i = 0; i < ARegs::PASSES; ++i) {
+                const float* p;
+                if constexpr (AKM) {
+                    if (a_plain) p = pa[i] + (int64_t)k0 * A.ld_outer;
+                    else p = A.ptr + twog_row_off(A, k0 + tid / ARegs::F4_PER_ROW + i * ARegs::ROWS_PER_PASS) +
+                             min(m0 + (tid % ARegs::F4_PER_ROW) * 4, M - 4);
+                } else {
+                    p = pa[i] + k0;
                 }
+                ra.v[i] = *reinterpret_cast<const f32x4*>(p);
             }
-            if constexpr (BKM) {
-                const int c = min(n0 + (tid % BRegs::F4_PER_ROW) * 4, N - 4);
 #pragma unroll
-                for (int i = 0; i < BRegs::PASSES; ++i)
-                    rb.v[i] = *reinterpret_cast<const f32x4*>(
-                        B.ptr + twog_row_off(B, k0 + tid / BRegs::F4_PER_ROW + i * BRegs::ROWS_PER_PASS) + c);
-            } else {
-#pragma unroll
-                for (int i = 0; i < BRegs::PASSES; ++i) {
-                    const int row = min(n0 + tid / BRegs::F4_PER_ROW + i * BRegs::ROWS_PER_PASS, N - 1);
-                    rb.v[i] = *reinterpret_cast<const f32x4*>(B.ptr + twog_row_off(B, row) + (tid % BRegs::F4_PER_ROW) * 4 + k0);
+            for (int i = 0; i < BRegs::PASSES; ++i) {
+                const float* p;
+                if constexpr (BKM) {
+                    if (b_plain) p = pb[i] + (int64_t)k0 * B.ld_outer;
+                    else p = B.ptr + twog_row_off(B, k0 + tid / BRegs::F4_PER_ROW + i * BRegs::ROWS_PER_PASS) +
+                             min(n0 + (tid % BRegs::F4_PER_ROW) * 4, N - 4);
+                } else {
+                    p = pb[i] + k0;
                 }
+                rb.v[i] = *reinterpret_cast<const f32x4*>(p);
             }
         } else {
             if constexpr (AKM) load_tile(ra, A, k0, m0, k_end, M, a_vec);
@@ -151,19 +168,12 @@ __device__ __forceinline__ void gemm_mainloop(const twog_rows_t A, const twog_ro
             else               load_tile(rb, B, n0, k0, N, k_end, b_vec);
         }
     };
-
-    const int nkt = (k_end > k_begin) ? (k_end - k_begin + BK - 1) / BK : 0;
-    if (nkt > 0) {
-        gload(k_begin);
-        store_tile<ARegs::R, ARegs::C, LDA>(ra, smem);
-        store_tile<BRegs::R, BRegs::C, LDB>(rb, smem + A_ELEMS);
-    }
-    __syncthreads();
-    for (int kt = 0; kt < nkt; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nkt) {
-            gload(k_begin + (kt + 1) * BK);
-        }
+    auto sstore = [&](const ARegs& ra, const BRegs& rb, int buf) {
+        float* dst = smem + buf * STAGE;
+        store_tile<ARegs::R, ARegs::C, LDA>(ra, dst);
+        store_tile<BRegs::R, BRegs::C, LDB>(rb, dst + A_ELEMS);
+    };
+    auto compute = [&](int buf) {
         const float* a_s = smem + buf * STAGE;
         const float* b_s = a_s + A_ELEMS;
 #pragma unroll
@@ -197,16 +207,53 @@ __device__ __forceinline__ void gemm_mainloop(const twog_rows_t A, const twog_ro
                     for (int b = 0; b < TN; ++b)
                         acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a][r], bf[b][r], acc[a][b], 0, 0, 0);
         }
-        if (kt + 1 < nkt) {
-            float* nxt = smem + (buf ^ 1) * STAGE;
-            store_tile<ARegs::R, ARegs::C, LDA>(ra, nxt);
-            store_tile<BRegs::R, BRegs::C, LDB>(rb, nxt + A_ELEMS);
-        }
+    };
+
+    const int nkt = (k_end > k_begin) ? (k_end - k_begin + BK - 1) / BK : 0;
+    if (nkt == 0) return;
+    ARegs ra0;
+    BRegs rb0;
+    // Loads and LDS stores past the last k-tile are clamped to it instead of branched around (FAST path): a branch
+    // makes the compiler merge its outstanding-load counters conservatively (s_waitcnt vmcnt(0) before the LDS
+    // stores), which would serialise the younger in-flight tile. The redundant tail tile is never read.
+    const int k_last = k_begin + (nkt - 1) * BK;
+    if constexpr (D == 1 || !FAST) {
+        // loads of k-tile t+1 in flight under the MFMAs of tile t
+        gload(ra0, rb0, k_begin);
+        sstore(ra0, rb0, 0);
         __syncthreads();
+        for (int kt = 0; kt < nkt; ++kt) {
+            const int buf = kt & 1;
+            if (FAST || kt + 1 < nkt) gload(ra0, rb0, min(k_begin + (kt + 1) * BK, k_last));
+            compute(buf);
+            if (FAST || kt + 1 < nkt) sstore(ra0, rb0, buf ^ 1);
+            __syncthreads();
+        }
+    } else {
+        // prefetch distance 2 (two register stages): the loads of tile t+2 are issued before the MFMAs of tile t and are
+        // consumed a whole iteration later, so short-k-tile kernels (64x64 tiles: 16 MFMAs per wave per k-tile) still
+        // cover the L2/HBM latency. Loop unrolled by two so the register stages keep static names.
+        ARegs ra1;
+        BRegs rb1;
+        gload(ra0, rb0, k_begin);
+        gload(ra1, rb1, min(k_begin + BK, k_last));
+        sstore(ra0, rb0, 0);
+        __syncthreads();
+        for (int kt = 0; kt < nkt; kt += 2) {
+            gload(ra0, rb0, min(k_begin + (kt + 2) * BK, k_last));
+            compute(0);
+            sstore(ra1, rb1, 1);
+            __syncthreads();
+            if (kt + 1 >= nkt) break;
+            gload(ra1, rb1, min(k_begin + (kt + 3) * BK, k_last));
+            compute(1);
+            sstore(ra0, rb0, 0);
+            __syncthreads();
+        }
     }
 }
 
-template <int BM, int BN, bool AKM, bool BKM>
+template <int BM, int BN, bool AKM, bool BKM, int D>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(const Group g) {
     constexpr int WM = BM / 2, WN = BN / 2;    // per-wave tile
     constexpr int TM = WM / 32, TN = WN / 32;  // 32x32 MFMA tiles per wave
@@ -216,11 +263,27 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const Group g) {
     constexpr int B_ELEMS = BKM ? BK * LDB : BN * LDB;
     __shared__ __attribute__((aligned(16))) float smem[2 * (A_ELEMS + B_ELEMS)];
 
-    // XCD-aware, bijective remap: consecutive logical tiles (same A row panel) land on the same XCD / L2
-    int bid = blockIdx.x;
+    // XCD-aware, bijective block -> (problem, tile) map. Blocks are dealt round-robin over the 8 XCDs (speed only:
+    // correctness never depends on it), so XCD x = blockIdx & 7 owns the blocks with local index l = blockIdx >> 3.
+    // Problems with the same reduction length form a class (the host sorts them adjacent, longest first); the tile list
+    // of every class is cut into 8 contiguous chunks, one per XCD (its L2 then serves the row / column panels the
+    // chunk shares), and each XCD walks the classes in order: all XCDs get the same share of long and short tiles, so
+    // heterogeneous groups stay balanced. Chunk sizes differ by at most one tile; the classes' remainders are dealt
+    // around the XCD ring one after the other (cls_rot), which makes the per-XCD totals match the hardware's deal.
+    int bid = 0;  // logical tile id
     {
-        const int nwg = gridDim.x, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+        const int x = blockIdx.x & 7;
+        int l = blockIdx.x >> 3;
+#pragma unroll 1
+        for (int c = 0; c < g.n_cls; ++c) {
+            const int nt = g.cls_ntiles[c], q = nt >> 3, r = nt & 7, o = (x - g.cls_rot[c]) & 7;
+            const int cnt = q + (o < r ? 1 : 0);
+            if (l < cnt) {
+                bid = g.cls_start[c] + o * q + min(o, r) + l;
+                break;
+            }
+            l -= cnt;
+        }
     }
     int pi = 0;
 #pragma unroll 1
@@ -236,8 +299,9 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const Group g) {
     C.ptr += bi * G.c_bs;
     const int M = G.M, N = G.N, K = G.K, a_vec = G.a_vec, b_vec = G.b_vec, act = G.act, accumulate = G.accumulate;
     const float* bias = G.bias;
-    const int tiles_n = G.tiles_n;
-    const int tm_idx = tile / tiles_n, tn_idx = tile - tm_idx * tiles_n;
+    int tm_idx, tn_idx;
+    if (G.n_major) { tn_idx = tile / G.tiles_m; tm_idx = tile - tn_idx * G.tiles_m; }
+    else { tm_idx = tile / G.tiles_n; tn_idx = tile - tm_idx * G.tiles_n; }
     const int m0 = tm_idx * BM, n0 = tn_idx * BN;
     const int split = blockIdx.y;
     const int k_begin = split * g.k_per_split;
@@ -258,9 +322,9 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const Group g) {
     // uniform per workgroup: aligned operands and a reduction range made of whole k-tiles -> branch-free staging
     const bool fast = a_vec && b_vec && ((k_end - k_begin) % BK == 0);
     if (fast)
-        gemm_mainloop<BM, BN, AKM, BKM, true, TM, TN>(A, B, M, N, a_vec, b_vec, m0, n0, k_begin, k_end, smem, acc);
+        gemm_mainloop<BM, BN, AKM, BKM, true, TM, TN, D>(A, B, M, N, a_vec, b_vec, m0, n0, k_begin, k_end, smem, acc);
     else
-        gemm_mainloop<BM, BN, AKM, BKM, false, TM, TN>(A, B, M, N, a_vec, b_vec, m0, n0, k_begin, k_end, smem, acc);
+        gemm_mainloop<BM, BN, AKM, BKM, false, TM, TN, 1>(A, B, M, N, a_vec, b_vec, m0, n0, k_begin, k_end, smem, acc);
 
     // epilogue. C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
     if (g.splitk > 1) {
@@ -312,7 +376,9 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const Group g) {
     tile -= bi * per_batch;
     twog_rows_t C = P.C;
     C.ptr += bi * P.c_bs;
-    const int tm_idx = tile / P.tiles_n, tn_idx = tile - tm_idx * P.tiles_n;
+    int tm_idx, tn_idx;
+    if (P.n_major) { tn_idx = tile / P.tiles_m; tm_idx = tile - tn_idx * P.tiles_m; }
+    else { tm_idx = tile / P.tiles_n; tn_idx = tile - tm_idx * P.tiles_n; }
     const int m0 = tm_idx * BM, n0 = tn_idx * BN;
     // grid.y slices the tile so that small-output / deep-split problems still spread over the chip
     const int chunk = (BM * BN) / gridDim.y;
@@ -335,13 +401,15 @@ inline int vec_ok(const twog_rows_t& m, int64_t batch_stride, int contiguous_ext
     return (aligned && ld_ok && contiguous_extent >= 4 && contiguous_extent % 4 == 0) ? 1 : 0;
 }
 
-template <int BM, int BN>
+template <int BM, int BN, int D>
 int launch(Group& g, int akm, int bkm, hipStream_t st) {
     dim3 grid(g.total_tiles, g.splitk), block(256);
-    if (!akm && !bkm) hipLaunchKernelGGL((gemm_kernel<BM, BN, false, false>), grid, block, 0, st, g);
-    else if (!akm && bkm) hipLaunchKernelGGL((gemm_kernel<BM, BN, false, true>), grid, block, 0, st, g);
-    else if (akm && bkm) hipLaunchKernelGGL((gemm_kernel<BM, BN, true, true>), grid, block, 0, st, g);
-    else hipLaunchKernelGGL((gemm_kernel<BM, BN, true, false>), grid, block, 0, st, g);
+    static const int lds_pad = getenv("TWOG_GEMM_LDSPAD") ? atoi(getenv("TWOG_GEMM_LDSPAD")) : 0;  // occupancy experiments
+    const int dyn = BM == 64 ? lds_pad : 0;
+    if (!akm && !bkm) hipLaunchKernelGGL((gemm_kernel<BM, BN, false, false, D>), grid, block, dyn, st, g);
+    else if (!akm && bkm) hipLaunchKernelGGL((gemm_kernel<BM, BN, false, true, D>), grid, block, dyn, st, g);
+    else if (akm && bkm) hipLaunchKernelGGL((gemm_kernel<BM, BN, true, true, D>), grid, block, dyn, st, g);
+    else hipLaunchKernelGGL((gemm_kernel<BM, BN, true, false, D>), grid, block, dyn, st, g);
     TWOG_CHECK_LAUNCH();
     if (g.splitk > 1) {
         hipLaunchKernelGGL((splitk_reduce_kernel<BM, BN>), dim3(g.total_tiles, (BM * BN) / 1024), block, 0, st, g);
@@ -380,20 +448,40 @@ extern "C" int twog_gemm_f32(const twog_gemm_t* problems, int n_problems, int a_
         const int BMN = big ? 128 : 64;
         Group g;
         g.n = n;
+        // longest reductions first, equal K adjacent (stable: the caller's order within a class is kept)
+        int order[MAXP];
+        for (int i = 0; i < n; ++i) order[i] = i;
+        for (int i = 1; i < n; ++i)
+            for (int j = i; j > 0 && pr[order[j]].K > pr[order[j - 1]].K; --j) { const int tmp = order[j]; order[j] = order[j - 1]; order[j - 1] = tmp; }
         int t = 0;
+        g.n_cls = 0;
         for (int i = 0; i < n; ++i) {
             Prob& P = g.p[i];
-            P.A = pr[i].A; P.B = pr[i].B; P.C = pr[i].C; P.bias = pr[i].bias;
-            P.M = pr[i].M; P.N = pr[i].N; P.K = pr[i].K;
-            P.act = pr[i].act; P.accumulate = pr[i].accumulate;
+            const twog_gemm_t& q = pr[order[i]];
+            P.A = q.A; P.B = q.B; P.C = q.C; P.bias = q.bias;
+            P.M = q.M; P.N = q.N; P.K = q.K;
+            P.act = q.act; P.accumulate = q.accumulate;
             P.tiles_m = (P.M + BMN - 1) / BMN;
             P.tiles_n = (P.N + BMN - 1) / BMN;
             P.tile_start = t;
-            P.batch = pr[i].batch > 0 ? pr[i].batch : 1;
-            P.a_bs = pr[i].a_batch_stride; P.b_bs = pr[i].b_batch_stride; P.c_bs = pr[i].c_batch_stride;
-            t += P.batch * P.tiles_m * P.tiles_n;
-            P.a_vec = vec_ok(P.A, pr[i].a_batch_stride, a_kmajor ? P.M : P.K);
-            P.b_vec = vec_ok(P.B, pr[i].b_batch_stride, b_kmajor ? P.N : P.K);
+            P.batch = q.batch > 0 ? q.batch : 1;
+            static const int force_nmajor = getenv("TWOG_GEMM_NMAJOR") ? atoi(getenv("TWOG_GEMM_NMAJOR")) : -1;
+            P.n_major = force_nmajor >= 0 ? force_nmajor : (P.N > P.M ? 1 : 0);
+            P.a_bs = q.a_batch_stride; P.b_bs = q.b_batch_stride; P.c_bs = q.c_batch_stride;
+            const int ntiles = P.batch * P.tiles_m * P.tiles_n;
+            if (i == 0 || P.K != g.p[i - 1].K) {
+                g.cls_start[g.n_cls] = t;
+                g.cls_ntiles[g.n_cls] = 0;
+                ++g.n_cls;
+            }
+            g.cls_ntiles[g.n_cls - 1] += ntiles;
+            t += ntiles;
+            P.a_vec = vec_ok(P.A, q.a_batch_stride, a_kmajor ? P.M : P.K);
+            P.b_vec = vec_ok(P.B, q.b_batch_stride, b_kmajor ? P.N : P.K);
+        }
+        for (int c = 0, rot = 0; c < g.n_cls; ++c) {
+            g.cls_rot[c] = rot & 7;
+            rot += g.cls_ntiles[c] & 7;
         }
         g.total_tiles = t;
         g.splitk = 1;
@@ -422,7 +510,11 @@ extern "C" int twog_gemm_f32(const twog_gemm_t* problems, int n_problems, int a_
                 g.slabs = reinterpret_cast<float*>(workspace);
             }
         }
-        const int rc = big ? launch<128, 128>(g, a_kmajor, b_kmajor, st) : launch<64, 64>(g, a_kmajor, b_kmajor, st);
+        static const int depth = getenv("TWOG_GEMM_DEPTH") ? atoi(getenv("TWOG_GEMM_DEPTH")) : 0;  // tuning knob
+        const int d128 = depth ? (depth & 3) : 2, d64 = depth ? ((depth >> 2) & 3) : 2;
+        int rc;
+        if (big) rc = d128 == 2 ? launch<128, 128, 2>(g, a_kmajor, b_kmajor, st) : launch<128, 128, 1>(g, a_kmajor, b_kmajor, st);
+        else rc = d64 == 2 ? launch<64, 64, 2>(g, a_kmajor, b_kmajor, st) : launch<64, 64, 1>(g, a_kmajor, b_kmajor, st);
         if (rc) return rc;
         done += n;
     }
