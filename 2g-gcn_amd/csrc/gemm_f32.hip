@@ -173,39 +173,45 @@ __device__ __forceinline__ void gemm_mainloop(const twog_rows_t A, const twog_ro
         store_tile<ARegs::R, ARegs::C, LDA>(ra, dst);
         store_tile<BRegs::R, BRegs::C, LDB>(rb, dst + A_ELEMS);
     };
+    // fragments of 8 k-steps: lane (li, kh) holds k = 4kh..4kh+3 of the chunk for its row / column
+    auto frag_load = [&](const float* a_s, const float* b_s, int kk, float (&af)[TM][4], float (&bf)[TN][4]) {
+#pragma unroll
+        for (int a = 0; a < TM; ++a) {
+            if constexpr (AKM) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) af[a][r] = a_s[(kk * 8 + kh * 4 + r) * LDA + wm + a * 32 + li];
+            } else {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(a_s + (wm + a * 32 + li) * LDA + kk * 8 + kh * 4);
+                af[a][0] = v.x; af[a][1] = v.y; af[a][2] = v.z; af[a][3] = v.w;
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+            if constexpr (BKM) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) bf[b][r] = b_s[(kk * 8 + kh * 4 + r) * LDB + wn + b * 32 + li];
+            } else {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(b_s + (wn + b * 32 + li) * LDB + kk * 8 + kh * 4);
+                bf[b][0] = v.x; bf[b][1] = v.y; bf[b][2] = v.z; bf[b][3] = v.w;
+            }
+        }
+    };
+    // the fragments of chunk kk+1 are read from LDS while the MFMAs of chunk kk run (two register sets)
     auto compute = [&](int buf) {
         const float* a_s = smem + buf * STAGE;
         const float* b_s = a_s + A_ELEMS;
+        float af[2][TM][4], bf[2][TN][4];
+        frag_load(a_s, b_s, 0, af[0], bf[0]);
 #pragma unroll
         for (int kk = 0; kk < BK / 8; ++kk) {
-            float af[TM][4], bf[TN][4];
-#pragma unroll
-            for (int a = 0; a < TM; ++a) {
-                if constexpr (AKM) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) af[a][r] = a_s[(kk * 8 + kh * 4 + r) * LDA + wm + a * 32 + li];
-                } else {
-                    const f32x4 v = *reinterpret_cast<const f32x4*>(a_s + (wm + a * 32 + li) * LDA + kk * 8 + kh * 4);
-                    af[a][0] = v.x; af[a][1] = v.y; af[a][2] = v.z; af[a][3] = v.w;
-                }
-            }
-#pragma unroll
-            for (int b = 0; b < TN; ++b) {
-                if constexpr (BKM) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) bf[b][r] = b_s[(kk * 8 + kh * 4 + r) * LDB + wn + b * 32 + li];
-                } else {
-                    const f32x4 v = *reinterpret_cast<const f32x4*>(b_s + (wn + b * 32 + li) * LDB + kk * 8 + kh * 4);
-                    bf[b][0] = v.x; bf[b][1] = v.y; bf[b][2] = v.z; bf[b][3] = v.w;
-                }
-            }
+            if (kk + 1 < BK / 8) frag_load(a_s, b_s, kk + 1, af[(kk + 1) & 1], bf[(kk + 1) & 1]);
 #pragma unroll
             for (int r = 0; r < 4; ++r)
 #pragma unroll
                 for (int a = 0; a < TM; ++a)
 #pragma unroll
                     for (int b = 0; b < TN; ++b)
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a][r], bf[b][r], acc[a][b], 0, 0, 0);
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk & 1][a][r], bf[kk & 1][b][r], acc[a][b], 0, 0, 0);
         }
     };
 
