@@ -60,13 +60,14 @@ class GemmProfiler:
     def __enter__(self):
         def gemm(problems, a_kmajor=False, b_kmajor=False, split_k_workspace=True):
             from twog_gcn_amd.kernels import n_rows
-            flops, tiles128, kmax, wide = 0.0, 0, 0, True
+            flops, abytes, tiles128, kmax, wide = 0.0, 0.0, 0, 0, True
             for p in problems:
                 A, Cm = p['A'], p['C']
                 M, Nn = n_rows(Cm), Cm.shape[-1]
                 Kk = n_rows(A) if a_kmajor else A.shape[-1]
                 nb = p['batch'][0] if p.get('batch') else 1
                 flops += 2.0 * M * Nn * Kk * nb
+                abytes += 4.0 * (M * Kk + Nn * Kk + M * Nn) * nb  # each operand once
                 tiles128 += nb * math.ceil(M / 128) * math.ceil(Nn / 128)
                 kmax = max(kmax, Kk)
                 wide = wide and M >= 96 and Nn >= 96
@@ -77,7 +78,7 @@ class GemmProfiler:
             # same rule as twog_gemm_f32 (gemm_f32.hip): 128x128 tiles when wide and the chip can be filled
             reach = tiles128 * (kmax // 512 if kmax >= 1024 else 1)
             big = wide and (tiles128 >= 256 or reach >= 256)
-            self.records.append(('128x128' if big else '64x64', flops, e0, e1))
+            self.records.append(('128x128' if big else '64x64', flops, e0, e1, abytes))
         self.K.gemm = gemm
         return self
 
@@ -87,11 +88,12 @@ class GemmProfiler:
     def summary(self):
         torch.cuda.synchronize()
         agg = {}
-        for kind, flops, e0, e1 in self.records:
-            a = agg.setdefault(kind, [0.0, 0.0, 0])
+        for kind, flops, e0, e1, abytes in self.records:
+            a = agg.setdefault(kind, [0.0, 0.0, 0, 0.0])
             a[0] += flops
             a[1] += e0.elapsed_time(e1) * 1e-3
             a[2] += 1
+            a[3] += abytes
         return agg
 
 
@@ -237,8 +239,15 @@ def main():
     if rank == 0:
         total_gemm_s = sum(v[1] for v in agg.values())
         dom = max(agg.items(), key=lambda kv: kv[1][1])
-        kind, (flops, secs, calls) = dom
+        kind, (flops, secs, calls, bytes_alg) = dom
         achieved = flops / secs / 1e12 if secs > 0 else 0.0
+        # HBM-side bytes per launch of the dominant kernel come from the committed rocprofv3 PMC passes of this same
+        # command (tools/bench_pmc.sh -> profiles/): counters cannot be read from inside the process.
+        traffic, traffic_src = None, None
+        tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_gemm128_hbm_traffic.json')
+        if kind == '128x128' and os.path.exists(tpath):
+            tj = json.load(open(tpath))
+            traffic, traffic_src = tj['hbm_bytes_per_launch'], 'profiles/r01_gemm128_hbm_traffic.json: ' + tj['source']
         result = {
             'metric': 'clips/sec fwd+bwd, T=120 N=34 C=512', 'value': bs * world * args.steps / dt, 'unit': 'clips/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
@@ -250,7 +259,10 @@ def main():
                        'loss_last': float(loss.detach())},
             'roofline': {'bound': 'mfma', 'kernel': f'gemm_kernel<{kind.replace("x", ",")},*> (fp32 v_mfma_f32_32x32x2_f32)',
                          'achieved': achieved, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': achieved / PEAK_FP32_MFMA_TFLOPS, 'traffic': None,
+                         'frac': achieved / PEAK_FP32_MFMA_TFLOPS, 'traffic': traffic,
+                         'traffic_unit': 'bytes per launch (L2<->fabric, Infinity-Cache hits included)',
+                         'traffic_source': traffic_src,
+                         'algorithmic_bytes_per_launch': bytes_alg / max(calls, 1),
                          'launches_per_step': calls / args.steps, 'avg_launch_ms': secs / max(calls, 1) * 1e3,
                          'algorithmic_gflop_per_step': flops / args.steps / 1e9,
                          'share_of_step_time': secs / dt},

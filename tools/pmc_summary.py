@@ -1,0 +1,77 @@
+#!/usr/bin/env python3
+"""Per-kernel summary of the rocprofv3 --pmc passes written by tools/bench_pmc.sh.
+
+HBM bytes follow MI355X_MICROARCH.md (HBM section): FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports half
+of the bytes of wide coalesced reads, so read bytes = 2 * FETCH_SIZE * 1024; write bytes = WRITE_SIZE * 1024.
+MFMA utilisation = SQ_VALU_MFMA_BUSY_CYCLES / ((GRBM_GUI_ACTIVE / 8) * 256 CUs * 4 SIMDs): rocprofv3 sums GRBM_GUI_ACTIVE over
+the 8 XCDs (checked: GUI_ACTIVE / 8 / kernel duration = 2.16 GHz), the MFMA busy cycles over all 1024 SIMDs.
+Durations under --pmc are serialised / inflated and are NOT used; pair the bytes with the kernel-trace durations."""
+import collections
+import csv
+import glob
+import re
+import sys
+
+csv.field_size_limit(1 << 30)
+
+
+def short(name):
+    name = re.sub(r'\(anonymous namespace\)::', '', name)
+    m = re.match(r'(void )?([A-Za-z0-9_:]+(<[^(]*>)?)', name)
+    s = m.group(2) if m else name
+    return s[:70]
+
+
+def load(d):
+    out = collections.defaultdict(lambda: collections.defaultdict(float))
+    cnt = collections.Counter()
+    for f in glob.glob(d + '/*/*_counter_collection.csv'):
+        seen = set()
+        for r in csv.DictReader(open(f)):
+            k = short(r['Kernel_Name'])
+            out[k][r['Counter_Name']] += float(r['Counter_Value'])
+            if r['Dispatch_Id'] not in seen:
+                seen.add(r['Dispatch_Id'])
+                cnt[k] += 1
+    return out, cnt
+
+
+def main():
+    root, dst = sys.argv[1], sys.argv[2]
+    f, nf = load(root + '/f')
+    w, _ = load(root + '/w')
+    s, _ = load(root + '/s')
+    rows = []
+    for k in nf:
+        rd = 2.0 * f[k].get('FETCH_SIZE', 0.0) * 1024
+        wr = w.get(k, {}).get('WRITE_SIZE', 0.0) * 1024
+        sq = s.get(k, {})
+        gui = sq.get('GRBM_GUI_ACTIVE', 0.0)
+        mfma = sq.get('SQ_VALU_MFMA_BUSY_CYCLES', 0.0)
+        rows.append(dict(kernel=k, dispatches=nf[k], hbm_read_bytes=int(rd), hbm_write_bytes=int(wr),
+                         hbm_bytes_per_dispatch=int((rd + wr) / max(nf[k], 1)),
+                         mfma_util_pct=round(100.0 * mfma / (gui / 8 * 256 * 4), 2) if gui else 0.0,
+                         sq_wait_any_frac=round(sq.get('SQ_WAIT_ANY', 0.0) / sq['SQ_WAVE_CYCLES'], 3) if sq.get('SQ_WAVE_CYCLES') else 0.0,
+                         sq_wait_inst_frac=round(sq.get('SQ_WAIT_INST_ANY', 0.0) / sq['SQ_WAVE_CYCLES'], 3) if sq.get('SQ_WAVE_CYCLES') else 0.0))
+    rows.sort(key=lambda r: -(r['hbm_read_bytes'] + r['hbm_write_bytes']))
+    with open(dst, 'w', newline='') as fo:
+        wri = csv.DictWriter(fo, fieldnames=list(rows[0].keys()))
+        wri.writeheader()
+        wri.writerows(rows)
+    big = [r for r in rows if r['kernel'].startswith('gemm_kernel<128, 128')]
+    if big and len(sys.argv) > 3:
+        import json
+        nd = sum(r['dispatches'] for r in big)
+        by = sum(r['hbm_read_bytes'] + r['hbm_write_bytes'] for r in big)
+        json.dump(dict(kernel='gemm_kernel<128,128,*>', dispatches=nd, hbm_bytes_total=by, hbm_bytes_per_launch=by / nd,
+                       source='rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `python3 bench.py --steps 1 --warmup 1`'
+                              ' (tools/bench_pmc.sh); read bytes = 2 * FETCH_SIZE KiB (gfx950 correction)'),
+                  open(sys.argv[3], 'w'), indent=1)
+    tot = sum(r['hbm_read_bytes'] + r['hbm_write_bytes'] for r in rows)
+    print('total HBM bytes (2 bench steps incl. warmup + setup):', tot)
+    for r in rows[:14]:
+        print(r)
+
+
+if __name__ == '__main__':
+    main()
