@@ -11,5 +11,6 @@ The directory name is not a Python identifier, so import it through the repo-roo
   csrc/            the HIP kernels
 """
 from .models import TGGCN, select_model, build_mlp  # noqa: F401
+from .losses import select_loss, multi_task_loss  # noqa: F401
 
-__all__ = ['TGGCN', 'select_model', 'build_mlp']
+__all__ = ['TGGCN', 'select_model', 'build_mlp', 'select_loss', 'multi_task_loss']

@@ -97,6 +97,14 @@ class Gate(C.Structure):  # twog_gate_t
                 ('threshold', C.c_float), ('pad_', C.c_int32)]
 
 
+class Loss(C.Structure):  # twog_loss_t
+    _fields_ = [('kind', C.c_int32), ('n_classes', C.c_int32), ('outer', C.c_int64), ('inner', C.c_int64),
+                ('input', C.c_void_p), ('target', C.c_void_p), ('dinput', C.c_void_p), ('weight', C.c_float),
+                ('ignore_value', C.c_float)]
+
+
+LOSS_MAX_TERMS, LOSS_BLOCKS = 16, 64  # TWOG_LOSS_MAX_TERMS, TWOG_LOSS_BLOCKS
+
 # name -> (argtypes) ; every function returns int except twog_version
 _I, _L, _F, _P = C.c_int, C.c_int64, C.c_float, C.c_void_p
 SIGNATURES = {
@@ -129,6 +137,8 @@ SIGNATURES = {
     'twog_relu_bwd': [Rows, Rows, Rows, _I, _I, _P],
     'twog_add_rows': [Rows, Rows, _I, _I, _P],
     'twog_adam_step': [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _F, _P],
+    'twog_multitask_loss_fwd': [C.POINTER(Loss), _I, _P, _P, _P, _P],
+    'twog_multitask_loss_bwd': [C.POINTER(Loss), _I, _P, _P, _P],
 }
 
 _lib = None

@@ -438,6 +438,47 @@ class HipKernels:
                                             step, grad_scale, self._stream()), 'twog_adam_step')
 
 
+    # ---------------------------------------------------------------- multi-task loss
+    def _loss_terms(self, terms, dinputs=None):
+        """terms: list of dict(kind 0 NLL / 1 BCE / 2 budget, input, target, weight, ignore). input/target contiguous."""
+        arr = (L.Loss * len(terms))()
+        for i, (t, a) in enumerate(zip(terms, arr)):
+            x, y = t['input'], t['target']
+            assert x.is_contiguous() and y.is_contiguous() and x.dtype == torch.float32
+            a.kind = t['kind']
+            if t['kind'] == 0:
+                assert y.dtype == torch.int64 and x.dim() >= 2 and y.numel() * x.shape[1] == x.numel()
+                a.n_classes, a.outer = x.shape[1], x.shape[0]
+                a.inner = x.numel() // max(x.shape[0] * x.shape[1], 1)
+            else:
+                assert y.dtype == torch.float32 and y.numel() == x.numel()
+                a.n_classes, a.outer, a.inner = 1, 1, x.numel()
+            a.input, a.target = x.data_ptr(), y.data_ptr()
+            a.dinput = None if dinputs is None or dinputs[i] is None else dinputs[i].data_ptr()
+            a.weight, a.ignore_value = float(t['weight']), float(t['ignore'])
+        return arr
+
+    def multitask_loss_fwd(self, terms):
+        """All loss terms in one launch. Returns (losses [n] fp32, stats [n][2] fp64 = sum, count)."""
+        n, dev = len(terms), terms[0]['input'].device
+        if n > L.LOSS_MAX_TERMS:
+            raise ValueError(f'at most {L.LOSS_MAX_TERMS} loss terms per call')
+        losses = torch.empty(n, dtype=torch.float32, device=dev)
+        stats = torch.empty(n, 2, dtype=torch.float64, device=dev)
+        partials = self.workspace(n * L.LOSS_BLOCKS * 2 * 8, dev, 'loss')
+        self._check(self.lib.twog_multitask_loss_fwd(self._loss_terms(terms), n, partials.data_ptr(), stats.data_ptr(),
+                                                     losses.data_ptr(), self._stream()), 'twog_multitask_loss_fwd')
+        return losses, stats
+
+    def multitask_loss_bwd(self, terms, stats, dlosses, need):
+        """d(input) of every term with need[i] (others None), scaled by the upstream gradient dlosses [n]."""
+        dins = [torch.empty_like(t['input']) if nd else None for t, nd in zip(terms, need)]
+        self._check(self.lib.twog_multitask_loss_bwd(self._loss_terms(terms, dins), len(terms), stats.data_ptr(),
+                                                     dlosses.contiguous().data_ptr(), self._stream()),
+                    'twog_multitask_loss_bwd')
+        return dins
+
+
 _backend = None
 
 

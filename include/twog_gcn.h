@@ -315,6 +315,38 @@ int twog_add_rows(twog_rows_t src, twog_rows_t dst, int rows, int cols, void* st
 int twog_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
                    float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale, void* stream);
 
+/* ===============================================================================================================
+ * Multi-task loss: the criterion the training loop applies to the model's output list
+ * (vhoi/losses.py:8-70 select_loss; pyrutils/torch/losses.py:7-51 multi_task_loss, binary_cross_entropy_loss,
+ * budget_loss; F.nll_loss with ignore_index, reduction 'mean'). All terms of the list run in ONE forward and ONE
+ * backward launch; sums are fp64 and ordered (deterministic); nothing syncs with the host (the reference calls
+ * mask.sum().item() per term).
+ *   kind 0  NLL:    input [outer][C][inner] log-probabilities, target int64 [outer][inner];
+ *                   loss = w * sum_{target != ignore} -input[o][target][i] / count            (count 0 -> NaN, as torch)
+ *   kind 1  BCE:    input, target float [inner] (outer = C = 1); m = target != ignore;
+ *                   loss = w * sum_m -(t*max(log x,-100) + (1-t)*max(log(1-x),-100)) / count   (count 0 -> 0)
+ *   kind 2  budget: loss = w * sum_m x / count                                                 (count 0 -> 0)
+ * stats[term] = {sum, count} is written by the forward call and read by the backward call, which stores
+ * d(loss_total)/d(input) = dlosses[term] * d(loss_term)/d(input) into terms[i].dinput (skipped where dinput is NULL).
+ * =============================================================================================================== */
+typedef struct {
+    int32_t kind;
+    int32_t n_classes;
+    int64_t outer, inner;
+    const float* input;
+    const void* target;
+    float* dinput;
+    float weight;
+    float ignore_value;
+} twog_loss_t;
+#define TWOG_LOSS_MAX_TERMS 16
+#define TWOG_LOSS_BLOCKS 64
+/* partials: workspace of n_terms * TWOG_LOSS_BLOCKS * 2 doubles; losses: [n_terms] floats. */
+int twog_multitask_loss_fwd(const twog_loss_t* terms, int n_terms, double* partials, double* stats, float* losses,
+                            void* stream);
+int twog_multitask_loss_bwd(const twog_loss_t* terms, int n_terms, const double* stats, const float* dlosses,
+                            void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -518,3 +518,46 @@ class FakeKernels:
         exp_avg_sq.mul_(beta2).addcmul_(g, g, value=1 - beta2)
         bc1, bc2 = 1 - beta1 ** step, 1 - beta2 ** step
         param.addcdiv_(exp_avg, exp_avg_sq.sqrt() / math.sqrt(bc2) + eps, value=-lr / bc1)
+
+    # ---------------------------------------------------------------- multi-task loss (executable spec of loss.hip)
+    @staticmethod
+    def _loss_stats(t):
+        x, y, ig = t['input'], t['target'], t['ignore']
+        if t['kind'] == 0:
+            valid = (y != int(ig)) & (y >= 0) & (y < x.shape[1])
+            picked = torch.gather(x, 1, y.clamp(0, x.shape[1] - 1).unsqueeze(1)).squeeze(1)
+            return -(picked.double() * valid).sum(), valid.double().sum()
+        m = y != ig
+        if t['kind'] == 1:
+            el = -(y * torch.log(x).clamp(min=-100.0) + (1 - y) * torch.log(1 - x).clamp(min=-100.0))
+        else:
+            el = x
+        return torch.where(m, el, torch.zeros_like(el)).double().sum(), m.double().sum()
+
+    def multitask_loss_fwd(self, terms):
+        stats = torch.stack([torch.stack(self._loss_stats(t)) for t in terms])
+        vals = []
+        for t, (s, c) in zip(terms, stats):
+            v = s / c if t['kind'] == 0 else (s / c if c > 0 else torch.zeros((), dtype=torch.float64))
+            vals.append(t['weight'] * v.float())
+        return torch.stack(vals).float(), stats
+
+    def multitask_loss_bwd(self, terms, stats, dlosses, need):
+        out = []
+        for i, (t, nd) in enumerate(zip(terms, need)):
+            if not nd:
+                out.append(None)
+                continue
+            x, y, ig, c = t['input'], t['target'], t['ignore'], stats[i, 1]
+            g = (t['weight'] * dlosses[i] / c.float()) if c > 0 else torch.zeros(())
+            if t['kind'] == 0:
+                valid = (y != int(ig)) & (y >= 0) & (y < x.shape[1])
+                d = torch.zeros_like(x)
+                d.scatter_(1, y.clamp(0, x.shape[1] - 1).unsqueeze(1), (-g * valid.float()).unsqueeze(1))
+            elif t['kind'] == 1:
+                d = torch.where(y != ig, g * (x - y) / ((1 - x) * x).clamp(min=1e-12), torch.zeros_like(x))
+            else:
+                d = torch.where(y != ig, g.expand_as(x), torch.zeros_like(x)).clone()
+            out.append(d)
+        return out
+
