@@ -7,7 +7,8 @@
 
 Same outputs as the reference (tuple slot order of SURVEY.md Appendix B, NaN padding to the split maximum then
 ``nan_to_num``, float32 / int64 dtypes), but assembled with whole-video numpy operations instead of the reference's
-per-frame Python loops, and with an optional pinned-memory + non-blocking fetcher for the GPU.
+per-frame Python loops, and with a double-buffered pinned / HBM-resident input pipeline (``DevicePrefetcher``,
+SURVEY.md section 8f row 2) in place of the reference's synchronous pageable copies.
 """
 from functools import partial
 from itertools import groupby
@@ -344,6 +345,128 @@ def gcn_fetcher(dataset, device, non_blocking: bool = False, **kwargs):
     targets = [to(t) for t in dataset[8:]]
     data.append(to(dataset[7]))
     return data, targets
+
+
+class DevicePrefetcher:
+    """Double-buffered host -> HBM input pipeline around a DataLoader and a fetcher.
+
+    The reference copies every batch synchronously from pageable memory inside the step (vhoi/data_loading.py:376,
+    :1284-1314: ``tensor.to(device)`` per slot). Here batch i+1 is staged while batch i computes: each host tensor
+    the fetcher would move is first copied into one of two persistent PINNED staging slots, then sent with a
+    non-blocking copy on a side HIP stream; the consumer's stream waits on the copy's event only when it receives the
+    batch, and the device tensors are tied to the consumer stream (``record_stream``) so the allocator cannot recycle
+    them early. With ``resident=True`` the whole split is moved to HBM once (the real datasets are a few GB; 288 GB
+    of HBM3E) and batches become device-side index selections: no per-step PCIe traffic at all.
+
+    Iterating yields exactly what ``fetch(batch, device=...)`` yields for every batch of ``loader``, in loader order.
+    On a CPU device it degenerates to that plain loop (used by the CPU tests of the host logic)."""
+
+    def __init__(self, loader, fetch, device, resident: bool = False, **fetch_kwargs):
+        self.loader, self.fetch, self.device, self.kw = loader, fetch, torch.device(device), fetch_kwargs
+        self.on_gpu = self.device.type == 'cuda'
+        self.copy_stream = torch.cuda.Stream(self.device) if self.on_gpu else None
+        self._slots = [{}, {}]  # pinned staging buffers of the two in-flight batches, keyed by tuple position
+        self._slot_events = [None, None]
+        self._resident = None
+        if resident:
+            ds = loader.dataset
+            if not isinstance(ds, TensorDataset):
+                raise TypeError('resident=True needs a TensorDataset (create_data_loader builds one)')
+            self._resident = TensorDataset(*[t.to(self.device) for t in ds.tensors])
+
+    def __len__(self):
+        return len(self.loader)
+
+    def _slot_view(self, slot, i, shape, dtype):
+        n = 1
+        for d in shape:
+            n *= d
+        buf = self._slots[slot].get(i)
+        if buf is None or buf.dtype != dtype or buf.numel() < n:
+            buf = torch.empty(max(n, 1), dtype=dtype).pin_memory()
+            self._slots[slot][i] = buf
+        return buf[:n].view(shape)
+
+    def _host_batches(self):
+        """Host-side batches. For a TensorDataset the rows of a batch are gathered straight into the pinned staging
+        slot (one host copy; DataLoader's collate + pin would make two); otherwise the loader's own batches are
+        copied into the slot."""
+        ds = self.loader.dataset
+        if self.on_gpu and isinstance(ds, TensorDataset) and self.loader.batch_sampler is not None:
+            for k, idx in enumerate(self._batch_indices()):
+                slot = k & 1
+                self._wait_slot_free(slot)
+                idx = torch.as_tensor(idx, dtype=torch.int64)
+                yield [torch.index_select(t, 0, idx, out=self._slot_view(slot, i, (len(idx),) + tuple(t.shape[1:]), t.dtype))
+                       for i, t in enumerate(ds.tensors)]
+        else:
+            for k, batch in enumerate(self.loader):
+                if self.on_gpu:
+                    slot = k & 1
+                    self._wait_slot_free(slot)
+                    staged = []
+                    for i, t in enumerate(batch):
+                        if isinstance(t, torch.Tensor) and not t.is_cuda and not t.is_pinned():
+                            v = self._slot_view(slot, i, tuple(t.shape), t.dtype)
+                            v.copy_(t)
+                            t = v
+                        staged.append(t)
+                    batch = staged
+                yield batch
+
+    def _batch_indices(self):
+        """The loader's own batch order (shuffled or sequential, drop_last honoured). A DataLoader iterator draws its
+        worker base seed from the loader's generator before the sampler draws the permutation; the same draw is made
+        here so that a seeded shuffling loader visits the clips in the same order with and without the prefetcher."""
+        torch.empty((), dtype=torch.int64).random_(generator=self.loader.generator)
+        return iter(self.loader.batch_sampler)
+
+    def _wait_slot_free(self, slot):
+        """A pinned slot is rewritten two batches after the copy that read it was issued: wait for that copy."""
+        ev = self._slot_events[slot]
+        if ev is not None:
+            ev.synchronize()
+
+    def _stage(self, batch, k):
+        if not self.on_gpu:
+            return self.fetch(batch, device=self.device, **self.kw), None
+        with torch.cuda.stream(self.copy_stream):
+            out = self.fetch(batch, device=self.device, non_blocking=True, **self.kw)
+            ev = torch.cuda.Event()
+            ev.record(self.copy_stream)
+        self._slot_events[k & 1] = ev
+        return out, ev
+
+    def _hand_over(self, staged):
+        out, ev = staged
+        if ev is not None:
+            cur = torch.cuda.current_stream(self.device)
+            cur.wait_event(ev)
+            for group in out:
+                for t in group:
+                    if isinstance(t, torch.Tensor) and t.is_cuda:
+                        t.record_stream(cur)
+        return out
+
+    def _resident_batches(self):
+        ds, bs = self._resident, self.loader.batch_size
+        for idx in self._batch_indices():
+            idx = torch.as_tensor(idx, dtype=torch.int64, device=self.device)
+            yield self.fetch([t.index_select(0, idx) for t in ds.tensors], device=self.device, **self.kw)
+
+    def __iter__(self):
+        if self._resident is not None:
+            yield from self._resident_batches()
+            return
+        self._slot_events = [None, None]
+        staged = None
+        for k, batch in enumerate(self._host_batches()):
+            upcoming = self._stage(batch, k)  # batch k is on its way while the consumer still works on batch k-1
+            if staged is not None:
+                yield self._hand_over(staged)
+            staged = upcoming
+        if staged is not None:
+            yield self._hand_over(staged)
 
 
 def gcn_forward(model, data, **kwargs):
