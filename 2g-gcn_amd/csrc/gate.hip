@@ -136,19 +136,21 @@ __global__ __launch_bounds__(256) void wcolsum_partial_kernel(twog_rows_t x, con
     }
 }
 
-__global__ __launch_bounds__(256) void wcolsum_final_kernel(const float* partials, int n_blocks, int cols, float* out,
-                                                            int accumulate) {
-    // 64 columns x 4 lanes over the partial rows, then an ordered LDS reduction (deterministic)
-    __shared__ float red[4][64];
+__global__ __launch_bounds__(1024) void wcolsum_final_kernel(const float* partials, int n_blocks, int cols, float* out,
+                                                             int accumulate) {
+    // 64 columns x 16 lanes over the partial rows, then an ordered LDS reduction (deterministic)
+    __shared__ float red[16][64];
     const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + cl;
     float acc = 0.f;
     if (c < cols)
-        for (int b = rl; b < n_blocks; b += 4) acc += partials[(int64_t)b * cols + c];
+        for (int b = rl; b < n_blocks; b += 16) acc += partials[(int64_t)b * cols + c];
     red[rl][cl] = acc;
     __syncthreads();
     if (rl == 0 && c < cols) {
-        const float t = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) t += red[i][cl];
         out[c] = accumulate ? out[c] + t : t;
     }
 }
@@ -197,7 +199,7 @@ extern "C" int twog_colsum(twog_rows_t x, const float* rowscale, int rows, int c
         hipLaunchKernelGGL(wcolsum_partial_kernel<false>, dim3((cols + 63) / 64, n_blocks), dim3(256), 0, st, x,
                            rowscale, rows, cols, partials);
     TWOG_CHECK_LAUNCH();
-    hipLaunchKernelGGL(wcolsum_final_kernel, dim3((cols + 63) / 64), dim3(256), 0, st, partials, n_blocks, cols, out,
+    hipLaunchKernelGGL(wcolsum_final_kernel, dim3((cols + 63) / 64), dim3(1024), 0, st, partials, n_blocks, cols, out,
                        accumulate);
     TWOG_CHECK_LAUNCH();
     return 0;

@@ -146,24 +146,37 @@ __global__ __launch_bounds__(256) void embed1_bwd_kernel(const float* x, int64_t
 // reduce embed1 partials over blocks; convert (da, db) to (dgamma, dbeta):
 //   dgamma = invstd * (da - mean * db') ... with x^ = a x + b, a = gamma*invstd, b = beta - mean*a:
 //   dL/dgamma = invstd * (dL/da - mean * dL/db), dL/dbeta = dL/db        (mean/invstd constant wrt the parameters)
-__global__ __launch_bounds__(256) void embed1_bwd_final_kernel(const float* partials, int n_blocks, int nch,
-                                                               const float* mean_invstd, float* dw1, float* db1,
-                                                               float* dgamma, float* dbeta) {
+__global__ __launch_bounds__(1024) void embed1_bwd_final_kernel(const float* partials, int n_blocks, int nch,
+                                                                const float* mean_invstd, float* dw1, float* db1,
+                                                                float* dgamma, float* dbeta) {
+    // 64 outputs x 16 lanes over the per-block partial rows; ordered LDS reduction (deterministic)
+    __shared__ float red[2][16][64];
     const int stride = 320 + 2 * nch;
-    for (int i = threadIdx.x; i < 320 + nch; i += blockDim.x) {
-        if (i < 320) {
-            float s = 0.f;
-            for (int b = 0; b < n_blocks; ++b) s += partials[(int64_t)b * stride + i];
-            if (i < 256) dw1[i] = s; else db1[i - 256] = s;
-        } else {
+    const int ol = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + ol;
+    float sa = 0.f, sb = 0.f;
+    if (i < 320) {
+        for (int b = rl; b < n_blocks; b += 16) sa += partials[(int64_t)b * stride + i];
+    } else if (i < 320 + nch) {
+        const int ch = i - 320;
+        for (int b = rl; b < n_blocks; b += 16) {
+            sa += partials[(int64_t)b * stride + 320 + ch];
+            sb += partials[(int64_t)b * stride + 320 + nch + ch];
+        }
+    }
+    red[0][rl][ol] = sa;
+    red[1][rl][ol] = sb;
+    __syncthreads();
+    if (rl == 0 && i < 320 + nch) {
+        float ta = 0.f, tb = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { ta += red[0][k][ol]; tb += red[1][k][ol]; }
+        if (i < 256) dw1[i] = ta;
+        else if (i < 320) db1[i - 256] = ta;
+        else {
             const int ch = i - 320;
-            float sa = 0.f, sb = 0.f;
-            for (int b = 0; b < n_blocks; ++b) {
-                sa += partials[(int64_t)b * stride + 320 + ch];
-                sb += partials[(int64_t)b * stride + 320 + nch + ch];
-            }
-            dgamma[ch] = mean_invstd[nch + ch] * (sa - mean_invstd[ch] * sb);
-            dbeta[ch] = sb;
+            dgamma[ch] = mean_invstd[nch + ch] * (ta - mean_invstd[ch] * tb);
+            dbeta[ch] = tb;
         }
     }
 }
@@ -342,7 +355,7 @@ extern "C" int twog_gcn_embed1_bwd(const float* x_geo, int64_t frame_stride, int
     hipLaunchKernelGGL(embed1_bwd_kernel, dim3(n_blocks), dim3(256), 0, st, x_geo, frame_stride, n_frames, n_nodes, ab,
                        w1, de1, partials);
     TWOG_CHECK_LAUNCH();
-    hipLaunchKernelGGL(embed1_bwd_final_kernel, dim3(1), dim3(256), 0, st, partials, n_blocks, 4 * n_nodes,
+    hipLaunchKernelGGL(embed1_bwd_final_kernel, dim3((320 + 4 * n_nodes + 63) / 64), dim3(1024), 0, st, partials, n_blocks, 4 * n_nodes,
                        mean_invstd, dw1, db1, dgamma, dbeta);
     TWOG_CHECK_LAUNCH();
     return 0;

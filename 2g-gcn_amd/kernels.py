@@ -158,7 +158,7 @@ class HipKernels:
     def gcn_embed1_bwd(self, x_human, n_nodes, ab, mean_invstd, w1, de1):
         ptr, fstride, nf = self._geo(x_human)
         dev = x_human.device
-        nblk = 128
+        nblk = max(1, min(2048, (nf * n_nodes + 31) // 32))  # 4 waves per block, >= 8 rows per wave
         partials = torch.empty(nblk * (320 + 8 * n_nodes), dtype=torch.float32, device=dev)
         dw1 = torch.empty(64, 4, dtype=torch.float32, device=dev)
         db1 = torch.empty(64, dtype=torch.float32, device=dev)
@@ -376,7 +376,8 @@ class HipKernels:
         if out is None:
             out = torch.empty(cols, dtype=torch.float32, device=x.device)
             accumulate = False
-        nblk = max(1, min(128, rows // 128))
+        # enough row slices to fill the chip (~1024 workgroups over column blocks x row slices), >= 64 rows per slice
+        nblk = max(1, min(rows // 64, max(1, 1024 // ((cols + 255) // 256))))
         partials = self.workspace(nblk * cols * 4, x.device, 'colsum')
         self._check(self.lib.twog_colsum(rows_of(x), _ptr(rowscale), rows, cols, out.data_ptr(), int(accumulate),
                                          partials.data_ptr(), nblk, self._stream()), 'twog_colsum')
