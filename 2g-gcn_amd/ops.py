@@ -139,14 +139,25 @@ def used_parameter_names(plan: Plan):
 
 
 class _Grads:
-    """Accumulates parameter gradients by name (several stages can contribute to one parameter)."""
+    """Accumulates parameter gradients by name (several stages can contribute to one parameter).
 
-    def __init__(self, K):
-        self.K, self.g = K, {}
+    `sinks`: name -> the parameter's existing, contiguous ``.grad`` buffer (e.g. a view of the flat gradient buffer of
+    ``distributed.FlatParameters``). A gradient with a sink is ADDED into it by the producing kernel itself (GEMM /
+    column-sum epilogue with accumulate) -- the same ``grad += g`` autograd's AccumulateGrad would do, without the
+    temporary and the extra elementwise launch per parameter -- and is then reported to autograd as None."""
+
+    def __init__(self, K, sinks=None):
+        self.K, self.g, self.sinks = K, {}, sinks or {}
+
+    def sink(self, name):
+        return self.sinks.get(name)
 
     def add(self, name, t):
-        if name in self.g:
-            self.K.add_rows(_v2(t.reshape(1, -1)), _v2(self.g[name].view(1, -1)))
+        dst = self.sinks.get(name)
+        if dst is None:
+            dst = self.g.get(name)
+        if dst is not None:
+            self.K.add_rows(_v2(t.reshape(1, -1)), _v2(dst.view(1, -1)))
         else:
             self.g[name] = t
 
@@ -154,11 +165,19 @@ class _Grads:
 def _lin_w_grads(K, G, wname, bname, dY, X):
     """dW = dY^T X (tall reduction -> k-major x k-major GEMM with split-K), db = column sums of dY."""
     N, Kin = dY.shape[-1], X.shape[-1]
-    dW = torch.empty(N, Kin, dtype=torch.float32, device=dY.device)
-    K.gemm([dict(A=dY, B=X, C=dW)], a_kmajor=True, b_kmajor=True)
-    G.add(wname, dW)
+    dst = G.sink(wname)
+    if dst is not None:
+        K.gemm([dict(A=dY, B=X, C=dst.view(N, Kin), accumulate=True)], a_kmajor=True, b_kmajor=True)
+    else:
+        dW = torch.empty(N, Kin, dtype=torch.float32, device=dY.device)
+        K.gemm([dict(A=dY, B=X, C=dW)], a_kmajor=True, b_kmajor=True)
+        G.add(wname, dW)
     if bname is not None:
-        G.add(bname, K.colsum(dY))
+        dstb = G.sink(bname)
+        if dstb is not None:
+            K.colsum(dY, out=dstb.view(-1), accumulate=True)
+        else:
+            G.add(bname, K.colsum(dY))
 
 
 def tggcn_forward(K, plan: Plan, P, x_human, x_objects, objects_mask, human_seg, object_seg, noise, training, bn_bufs):
@@ -336,14 +355,15 @@ def tggcn_forward(K, plan: Plan, P, x_human, x_objects, objects_mask, human_seg,
     return outputs, S
 
 
-def tggcn_backward(K, plan: Plan, P, S, x_human, x_objects, objects_mask, d_outputs):
+def tggcn_backward(K, plan: Plan, P, S, x_human, x_objects, objects_mask, d_outputs, sinks=None):
     """Hand-derived backward pass. d_outputs: list aligned with the forward outputs (None = no gradient).
-    Returns dict name -> gradient for every parameter used by the forward."""
+    Returns dict name -> gradient for every parameter used by the forward that has no entry in `sinks`
+    (see _Grads: gradients with a sink have been added into it)."""
     p = plan
     bs, T, H, O, N, h = p.bs, p.T, p.H, p.O, p.N, p.h
     dev = x_human.device
     nF = bs * T
-    G = _Grads(K)
+    G = _Grads(K, sinks)
 
     def empty(*shape):
         return torch.empty(*shape, dtype=torch.float32, device=dev)
@@ -633,7 +653,17 @@ class TGGCNFunction(torch.autograd.Function):
         for i in range(n_gate):
             if not gates[kinds[i]]['learned']:
                 d_outputs[i] = None
-        grads = tggcn_backward(K, plan, ctx.P, ctx.S, x_human, x_objects, objects_mask, d_outputs)
+        # parameters that already own a contiguous fp32 .grad buffer receive their gradient in place (grad += g inside
+        # the producing kernels); autograd gets None for them, so no AccumulateGrad add runs. Parameter hooks do not
+        # fire on this route -- twog_gcn_amd.distributed.DataParallel reduces the flat buffer itself.
+        sinks = {}
+        for i, n in enumerate(ctx.names):
+            prm = ctx.P[n]
+            g = getattr(prm, 'grad', None)
+            if (ctx.needs_input_grad[10 + i] and g is not None and g.is_contiguous() and g.dtype == torch.float32
+                    and g.device == prm.device and not getattr(prm, '_backward_hooks', None)):
+                sinks[n] = g
+        grads = tggcn_backward(K, plan, ctx.P, ctx.S, x_human, x_objects, objects_mask, d_outputs, sinks)
         out = [None] * 10
         for n in ctx.names:
             g = grads.get(n)

@@ -95,3 +95,31 @@ def test_eval_mode_uses_running_stats(fake_backend):
         out = m(**g4_inputs(z))
     assert torch.equal(bn.running_mean, rm)
     assert len(out) == 6
+
+
+def test_in_place_gradient_route_equals_autograd_accumulation(fake_backend):
+    """Parameters that already own a .grad buffer get `grad += g` from the producing kernels (ops._Grads sinks); the
+    result must equal autograd's own accumulation, including across two backward passes."""
+    z, meta = load_g4('c2_stage1')
+    noise = torch.from_numpy(z['gumbel_noise'])
+
+    def run(prealloc, passes):
+        m = build_model(meta)
+        m.train()
+        m._gumbel_noise_override = noise if len(noise) else None
+        if prealloc:
+            for p in m.parameters():
+                p.grad = torch.zeros_like(p)
+        for _ in range(passes):
+            out = m(**g4_inputs(z))
+            sum((o * o).sum() for o in out if o.requires_grad).backward()
+        return {n: (None if p.grad is None else p.grad.clone()) for n, p in m.named_parameters()}
+
+    ref1, got1, got2 = run(False, 1), run(True, 1), run(True, 2)
+    for n, g in ref1.items():
+        if g is None:
+            assert float(got1[n].abs().max()) == 0.0, n      # dead parameter: the preallocated buffer stays zero
+            continue
+        scale = float(g.abs().max()) + 1e-12
+        assert float((got1[n] - g).abs().max()) <= 1e-6 * scale, n
+        assert float((got2[n] - 2 * g).abs().max()) <= 1e-5 * scale, n
