@@ -116,6 +116,9 @@ SIGNATURES = {
     'twog_gcn_embed1_bwd': [_P, _L, _I, _I, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P],
     'twog_gcn_attn_fwd': [_P, _P, _I, _I, _P, _P, _P],
     'twog_gcn_attn_bwd': [_P, _P, _P, _P, _I, _I, _P, _P, _P],
+    'twog_gcn_attn2_fwd': [_P, _P, _I, _I, _P, _P, _P],
+    'twog_gcn_attn2_bwd_blocks': [_I],
+    'twog_gcn_attn2_bwd': [_P, _P, _P, _P, _I, _I, _P, _P, _I, _P],
     'twog_gru_step_fwd': [C.POINTER(GruStep), _I, _P],
     'twog_gru_step_bwd': [C.POINTER(GruStepBwd), _I, _P],
     'twog_bigru_fwd': [C.POINTER(BiGru), _I, _I, _I, _I, _P],

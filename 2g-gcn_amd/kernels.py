@@ -177,6 +177,24 @@ class HipKernels:
                                                z.data_ptr(), self._stream()), 'twog_gcn_attn_fwd')
         return s, z
 
+    def gcn_attn2_fwd(self, x, md, n_frames, n_nodes):
+        """Folded-projection adjacency attention on MFMA: returns (adj [nF,N,N], z [nF*N,64])."""
+        s = torch.empty(n_frames, n_nodes, n_nodes, dtype=torch.float32, device=x.device)
+        z = torch.empty(n_frames * n_nodes, 64, dtype=torch.float32, device=x.device)
+        self._check(self.lib.twog_gcn_attn2_fwd(x.data_ptr(), md.data_ptr(), n_frames, n_nodes, s.data_ptr(),
+                                                z.data_ptr(), self._stream()), 'twog_gcn_attn2_fwd')
+        return s, z
+
+    def gcn_attn2_bwd(self, x, md, s, dz, n_frames, n_nodes):
+        """Returns (dx_att [nF*N,64], dmd [65,64] = gradient wrt (Mt | d))."""
+        dx = torch.empty(n_frames * n_nodes, 64, dtype=torch.float32, device=x.device)
+        nblk = self.lib.twog_gcn_attn2_bwd_blocks(n_frames)
+        partials = torch.empty(nblk, 65 * 64, dtype=torch.float32, device=x.device)
+        self._check(self.lib.twog_gcn_attn2_bwd(x.data_ptr(), md.data_ptr(), s.data_ptr(), dz.data_ptr(), n_frames,
+                                                n_nodes, dx.data_ptr(), partials.data_ptr(), nblk, self._stream()),
+                    'twog_gcn_attn2_bwd')
+        return dx, self.colsum(partials).view(65, 64)
+
     def gcn_attn_bwd(self, qk, x, s, dz, n_frames, n_nodes):
         dx = torch.empty(n_frames * n_nodes, 64, dtype=torch.float32, device=qk.device)
         dqk = torch.empty(n_frames * n_nodes, 256, dtype=torch.float32, device=qk.device)

@@ -200,17 +200,19 @@ def tggcn_forward(K, plan: Plan, P, x_human, x_objects, objects_mask, human_seg,
     w2 = P[g + 'joint_embed.cnn.3.cnn.weight'].view(64, 64)
     X = empty(nF * N, 64)
     K.gemm([dict(A=e1, B=w2, C=X, bias=P[g + 'joint_embed.cnn.3.cnn.bias'], act=1)])
-    QK = empty(nF * N, 256)
+    # compute_similarity folded (geo_attn_mfma.hip): theta_i . phi_j = x_i^T (Wq^T Wk) x_j + (Wk^T bq) . x_j + terms constant
+    # in j, which the softmax over j cancels. md = [Mt | d], Mt[n][k] = sum_o Wk[o][n] Wq[o][k], d = Wk^T bq
     wq, wk = P[g + 'get_s.s1.cnn.weight'].view(128, 64), P[g + 'get_s.s2.cnn.weight'].view(128, 64)
-    K.gemm([dict(A=X, B=wq, C=QK[:, :128], bias=P[g + 'get_s.s1.cnn.bias']),
-            dict(A=X, B=wk, C=QK[:, 128:], bias=P[g + 'get_s.s2.cnn.bias'])])
-    adj, Z = K.gcn_attn_fwd(QK, X, nF, N)
+    md = empty(65, 64)
+    K.gemm([dict(A=wk, B=wq, C=md[:64])], a_kmajor=True, b_kmajor=True)
+    K.colsum(wk, rowscale=P[g + 'get_s.s1.cnn.bias'], out=md[64])
+    adj, Z = K.gcn_attn2_fwd(X, md, nF, N)
     # Y = Z W, stored (bs, 128, N, T) with T fastest so that the reference's raw .view (models.py:644-645) is free
     Gout = empty(bs, 128, N, T)
     Zv = Z.view(bs, T, N, 64).permute(0, 2, 1, 3)  # (bs, N, T, 64) view
     K.gemm([dict(A=P[g + 'weight'], B=Zv[0], C=Gout[0].view(128, N * T), batch=(bs, 0, T * N * 64, 128 * N * T))],
            a_kmajor=True, b_kmajor=False)
-    S.update(ab=ab, mi=mi, e1=e1, X=X, QK=QK, adj=adj, Z=Z)
+    S.update(ab=ab, mi=mi, e1=e1, X=X, md=md, adj=adj, Z=Z)
     geo_in = Gout.view(nF, 128 * N)  # raw reinterpretation of the (c, n, t)-ordered block
 
     # ------------------------------------------------------------------ B. embeddings (models.py:646)
@@ -583,7 +585,7 @@ def tggcn_backward(K, plan: Plan, P, S, x_human, x_objects, objects_mask, d_outp
 
     # ---- A. GCN backward
     g = 'geometry_embedding_gcn.'
-    Z, X, QK, e1 = S['Z'], S['X'], S['QK'], S['e1']
+    Z, X, e1 = S['Z'], S['X'], S['e1']
     dZ = empty(nF * N, 64)
     dZv = dZ.view(bs, T, N, 64).permute(0, 2, 1, 3)
     K.gemm([dict(A=dGout[0].view(128, N * T), B=P[g + 'weight'], C=dZv[0], batch=(bs, 128 * N * T, 0, T * N * 64))],
@@ -593,16 +595,21 @@ def tggcn_backward(K, plan: Plan, P, S, x_human, x_objects, objects_mask, d_outp
     K.gemm([dict(A=Zv[0], B=dGout[0].view(128, N * T), C=dWp[0], batch=(bs, T * N * 64, 128 * N * T, 64 * 128))],
            a_kmajor=True, b_kmajor=False)
     G.add(g + 'weight', K.colsum(dWp.view(bs, 64 * 128)).view(64, 128))
-    dX, dQK = K.gcn_attn_bwd(QK, X, S['adj'], dZ, nF, N)
+    # dX through adjacency and aggregation, plus the gradient of the folded similarity parameters (Mt | d)
+    dX, dmd = K.gcn_attn2_bwd(X, S['md'], S['adj'], dZ, nF, N)
     wq, wk = P[g + 'get_s.s1.cnn.weight'].view(128, 64), P[g + 'get_s.s2.cnn.weight'].view(128, 64)
-    K.gemm([dict(A=dQK[:, :128], B=wq, C=dX, accumulate=True)], b_kmajor=True)
-    K.gemm([dict(A=dQK[:, 128:], B=wk, C=dX, accumulate=True)], b_kmajor=True)
-    dwq, dwk = empty(128, 64), empty(128, 64)
-    K.gemm([dict(A=dQK[:, :128], B=X, C=dwq), dict(A=dQK[:, 128:], B=X, C=dwk)], a_kmajor=True, b_kmajor=True)
+    bq = P[g + 'get_s.s1.cnn.bias']
+    dMt, dd = dmd[:64], dmd[64]
+    # Mt = Wk^T Wq, d = Wk^T bq  =>  dWq = Wk dMt, dWk = Wq dMt^T + bq dd^T, dbq = Wk dd, dbk = 0 (the key bias only adds
+    # terms constant along the softmax axis: its gradient is identically zero in the reference too)
+    dwq, dwk, dbq = empty(128, 64), empty(128, 64), empty(128, 1)
+    K.gemm([dict(A=wk, B=dMt, C=dwq)], b_kmajor=True)
+    K.gemm([dict(A=wq, B=dMt, C=dwk), dict(A=wk, B=dd.view(1, 64), C=dbq)])
+    K.rank1_update(dwk, bq, dd)
     G.add(g + 'get_s.s1.cnn.weight', dwq.view(128, 64, 1, 1))
     G.add(g + 'get_s.s2.cnn.weight', dwk.view(128, 64, 1, 1))
-    G.add(g + 'get_s.s1.cnn.bias', K.colsum(dQK[:, :128]))
-    G.add(g + 'get_s.s2.cnn.bias', K.colsum(dQK[:, 128:]))
+    G.add(g + 'get_s.s1.cnn.bias', dbq.view(128))
+    G.add(g + 'get_s.s2.cnn.bias', zeros(128))
     K.relu_bwd(dX, X, dX)
     w2 = P[g + 'joint_embed.cnn.3.cnn.weight'].view(64, 64)
     dw2 = empty(64, 64)

@@ -315,6 +315,17 @@ int twog_add_rows(twog_rows_t src, twog_rows_t dst, int rows, int cols, void* st
 int twog_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
                    float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale, void* stream);
 
+/* Adjacency attention of Geo_gcn (compute_similarity + s.matmul(x), pyrutils/torch/models_gcn.py:86-100, :30-34) on the
+ * matrix cores with the theta / phi projections folded: md = [65][64] = Mt (Mt[n][k] = sum_o Wk[o][n] Wq[o][k]) followed
+ * by d = Wk^T bq; per frame P = X M + d, adj = softmax_j(P X^T), z = adj X (identical to softmax(theta phi^T) X: the
+ * dropped terms are constant along j). x: [n_frames*N][64], adj: [n_frames][N][N], z: [n_frames*N][64].
+ * Backward: dx_att = d/dX through adj and z (X's own ReLU/W2 path excluded), partials[n_blocks][65*64] = per-workgroup
+ * sums of (dMt | dd), n_blocks = twog_gcn_attn2_bwd_blocks(n_frames); the caller column-sums them (twog_colsum). */
+int twog_gcn_attn2_fwd(const float* x, const float* md, int n_frames, int n_nodes, float* adj, float* z, void* stream);
+int twog_gcn_attn2_bwd_blocks(int n_frames);
+int twog_gcn_attn2_bwd(const float* x, const float* md, const float* adj, const float* dz, int n_frames, int n_nodes,
+                       float* dx_att, float* partials, int n_blocks, void* stream);
+
 /* ===============================================================================================================
  * Multi-task loss: the criterion the training loop applies to the model's output list
  * (vhoi/losses.py:8-70 select_loss; pyrutils/torch/losses.py:7-51 multi_task_loss, binary_cross_entropy_loss,

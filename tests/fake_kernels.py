@@ -120,6 +120,26 @@ class FakeKernels:
         dk = dP.transpose(1, 2) @ q
         return dx.reshape(-1, 64), torch.cat([dq, dk], -1).reshape(-1, 256)
 
+    def gcn_attn2_fwd(self, x, md, n_frames, n_nodes):
+        """Executable spec of geo_attn_mfma.hip: P = X M + d, adj = softmax(P X^T), Z = adj X (md = [Mt | d])."""
+        xs = x.view(n_frames, n_nodes, 64)
+        p = xs @ md[:64].t() + md[64]
+        s = torch.softmax(p @ xs.transpose(1, 2), dim=-1)
+        return s.contiguous(), (s @ xs).reshape(-1, 64)
+
+    def gcn_attn2_bwd(self, x, md, s, dz, n_frames, n_nodes):
+        xs = x.view(n_frames, n_nodes, 64)
+        dzs = dz.view(n_frames, n_nodes, 64)
+        Mt, d = md[:64], md[64]
+        p = xs @ Mt.t() + d
+        dA = dzs @ xs.transpose(1, 2)
+        dS = s * (dA - (dA * s).sum(-1, keepdim=True))
+        dP = dS @ xs
+        dx = s.transpose(1, 2) @ dzs + dS.transpose(1, 2) @ p + dP @ Mt
+        dMt = (dP.transpose(1, 2) @ xs).sum(0)
+        dd = dP.sum((0, 1))
+        return dx.reshape(-1, 64), torch.cat([dMt, dd.view(1, 64)], 0)
+
     # ------------------------------------------------------------------ GRU
     @staticmethod
     def _gates(gi, gh, hp, h):

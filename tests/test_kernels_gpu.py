@@ -173,6 +173,16 @@ def test_gcn_kernels(K, N):
     dx_g, dqk_g = K.gcn_attn_bwd(qk.to(DEV), x.to(DEV), s_c.to(DEV), dz.to(DEV), nF, N)
     close(dx_g, dx_c, rtol=1e-4, atol=1e-5, what='gcn attn dX')
     close(dqk_g, dqk_c, rtol=1e-4, atol=1e-5, what='gcn attn dQK')
+    # folded-projection MFMA kernels
+    md = torch.cat([rnd(64, 64, seed=11, scale=0.05), rnd(1, 64, seed=12, scale=0.3)], 0)
+    s2_c, z2_c = F.gcn_attn2_fwd(x, md, nF, N)
+    s2_g, z2_g = K.gcn_attn2_fwd(x.to(DEV), md.to(DEV), nF, N)
+    close(s2_g, s2_c, rtol=1e-4, atol=1e-6, what='gcn attn2 S')
+    close(z2_g, z2_c, rtol=1e-4, atol=1e-5, what='gcn attn2 Z')
+    dx2_c, dmd_c = F.gcn_attn2_bwd(x, md, s2_c, dz, nF, N)
+    dx2_g, dmd_g = K.gcn_attn2_bwd(x.to(DEV), md.to(DEV), s2_c.to(DEV), dz.to(DEV), nF, N)
+    close(dx2_g, dx2_c, rtol=1e-4, atol=1e-5, what='gcn attn2 dX')
+    close(dmd_g, dmd_c, rtol=2e-4, atol=1e-4 * float(dmd_c.abs().max()), what='gcn attn2 dM|dd')
 
 
 # --------------------------------------------------------------------------------------------------------------- BiGRU
