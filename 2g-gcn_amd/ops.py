@@ -180,18 +180,14 @@ def _lin_w_grads(K, G, wname, bname, dY, X):
             G.add(bname, K.colsum(dY))
 
 
-def tggcn_forward(K, plan: Plan, P, x_human, x_objects, objects_mask, human_seg, object_seg, noise, training, bn_bufs):
-    """Returns (outputs list, saved dict). P: dict name -> parameter tensor."""
-    p = plan
-    bs, T, H, O, N, h = p.bs, p.T, p.H, p.O, p.N, p.h
-    dev = x_human.device
-    S = {}  # saved for backward
-    nF = bs * T
+def geo_gcn_forward(K, P, x_human, bs, T, N, training, bn_bufs, S):
+    """Geo_gcn.forward (pyrutils/torch/models_gcn.py:30-37) on the geometry block of x_human; returns the (bs, 128, N, T)
+    output and stores what the backward needs in S. Algorithmic HBM bytes: T*(16N + 512N) per clip."""
+    dev, nF = x_human.device, bs * T
 
     def empty(*shape):
         return torch.empty(*shape, dtype=torch.float32, device=dev)
 
-    # ------------------------------------------------------------------ A. geometric-level GCN (models_gcn.py:30-37)
     g = 'geometry_embedding_gcn.'
     ab, mi = K.bn_fold(x_human, N, P[g + 'joint_embed.cnn.0.bn.weight'], P[g + 'joint_embed.cnn.0.bn.bias'],
                        bn_bufs['running_mean'], bn_bufs['running_var'], bn_bufs['num_batches_tracked'], training)
@@ -213,6 +209,22 @@ def tggcn_forward(K, plan: Plan, P, x_human, x_objects, objects_mask, human_seg,
     K.gemm([dict(A=P[g + 'weight'], B=Zv[0], C=Gout[0].view(128, N * T), batch=(bs, 0, T * N * 64, 128 * N * T))],
            a_kmajor=True, b_kmajor=False)
     S.update(ab=ab, mi=mi, e1=e1, X=X, md=md, adj=adj, Z=Z)
+    return Gout
+
+
+def tggcn_forward(K, plan: Plan, P, x_human, x_objects, objects_mask, human_seg, object_seg, noise, training, bn_bufs):
+    """Returns (outputs list, saved dict). P: dict name -> parameter tensor."""
+    p = plan
+    bs, T, H, O, N, h = p.bs, p.T, p.H, p.O, p.N, p.h
+    dev = x_human.device
+    S = {}  # saved for backward
+    nF = bs * T
+
+    def empty(*shape):
+        return torch.empty(*shape, dtype=torch.float32, device=dev)
+
+    # ------------------------------------------------------------------ A. geometric-level GCN (models_gcn.py:30-37)
+    Gout = geo_gcn_forward(K, P, x_human, bs, T, N, training, bn_bufs, S)
     geo_in = Gout.view(nF, 128 * N)  # raw reinterpretation of the (c, n, t)-ordered block
 
     # ------------------------------------------------------------------ B. embeddings (models.py:646)

@@ -20,7 +20,24 @@ import os
 import sys
 import time
 
-import torch
+
+def _cpu_quota():
+    """Cores the cgroup really grants (the GPU boxes show 256 cores under a 16-core quota); see 2g-gcn_amd/hostcpu.py."""
+    n = os.cpu_count() or 1
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()[:2]
+        if quota != 'max':
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+# before torch creates its thread pools: oversubscribing the quota gets the whole cgroup throttled in 100 ms periods,
+# which stalls the thread that feeds the GPU (measured: sporadic +90 ms steps)
+os.environ.setdefault('OMP_NUM_THREADS', str(max(1, _cpu_quota() - 4)))
+
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -104,7 +121,9 @@ def cpu_baseline(sample_frames=12, sample_clips=8):
     from oracle import cpu_ref
     import twog_gcn_amd  # noqa: F401
     from twog_gcn_amd.models import TGGCN
-    cores = min(32, os.cpu_count() or 1)  # the reference's default resources.num_threads (conf/config.yaml:9)
+    from twog_gcn_amd.hostcpu import effective_cpu_count
+    # the reference's default resources.num_threads is 32 (conf/config.yaml:9); never more than the cgroup grants
+    cores = min(32, effective_cpu_count())
     torch.set_num_threads(cores)
     torch.manual_seed(0)
     m = TGGCN(input_size=(2048 + 4 * N_NODES, 2048), num_classes=(N_CLASSES, None), **CFG)
@@ -175,6 +194,8 @@ def main():
     from twog_gcn_amd.models import TGGCN
     from twog_gcn_amd.kernels import get_kernels
     from twog_gcn_amd.distributed import DataParallel, FusedAdam
+    from twog_gcn_amd.hostcpu import limit_host_threads
+    limit_host_threads()  # thread pools sized from the cgroup quota, not from the node's core count (hostcpu.py)
     K = get_kernels()
     assert K.name == 'hip'
 
@@ -229,6 +250,25 @@ def main():
     agg = prof.summary()
     log(f'timed region done: {dt / args.steps * 1e3:.1f} ms/step')
 
+    # secondary roofline: the geometric-level GCN forward alone (the kernel group the north star's HBM-roofline target
+    # names), HIP events around its launches; algorithmic bytes T*(16N + 512N) per clip
+    from twog_gcn_amd import ops as _ops
+    with torch.no_grad():
+        Pd = {n: p_ for n, p_ in model.named_parameters()}
+        bn = model.geometry_embedding_gcn.joint_embed.cnn[0].bn  # cloned: the measurement must not touch the statistics
+        bn_bufs = dict(running_mean=bn.running_mean.clone(), running_var=bn.running_var.clone(),
+                       num_batches_tracked=bn.num_batches_tracked.clone())
+        for _ in range(2):
+            _ops.geo_gcn_forward(K, Pd, x_human, bs, T, N_NODES, True, bn_bufs, {})
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            _ops.geo_gcn_forward(K, Pd, x_human, bs, T, N_NODES, True, bn_bufs, {})
+        e1.record()
+        torch.cuda.synchronize()
+        gcn_ms = e0.elapsed_time(e1) / 10
+    gcn_bytes = bs * T * (16 * N_NODES + 512 * N_NODES)
+
     fwd_only = None
     if args.forward_only:
         with torch.no_grad():
@@ -270,6 +310,12 @@ def main():
                          'launches_per_step': calls / args.steps, 'avg_launch_ms': secs / max(calls, 1) * 1e3,
                          'algorithmic_gflop_per_step': flops / args.steps / 1e9,
                          'share_of_step_time': secs / dt},
+            'roofline_gcn': {'bound': 'hbm', 'kernel': 'geo_gcn forward (bn_stats..gcn_attn2_fwd..projection)',
+                             'achieved': gcn_bytes / (gcn_ms * 1e-3) / 1e9, 'peak': 8000.0, 'unit': 'GB/s',
+                             'frac': gcn_bytes / (gcn_ms * 1e-3) / 8e12, 'ms_per_batch': gcn_ms,
+                             'algorithmic_bytes_per_batch': gcn_bytes,
+                             'note': 'fp32 MFMA floor of this block (2.41 MFLOP/frame at 157.3 TFLOP/s) = 0.118 ms per bs64 '
+                                     'batch, above its HBM floor (0.017 ms)'},
             'gemm_classes': {k: {'tflops': (v[0] / v[1] / 1e12 if v[1] else 0.0), 'ms_per_step': v[1] / args.steps * 1e3,
                                  'launches_per_step': v[2] / args.steps} for k, v in agg.items()},
             'host_gemm_share_of_step': total_gemm_s / dt,

@@ -12,6 +12,9 @@ GOLDEN = os.path.join(ROOT, 'tests', 'golden')
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+    import twog_gcn_amd  # noqa: F401
+    from twog_gcn_amd.hostcpu import limit_host_threads
+    limit_host_threads()  # the GPU boxes report 256 cores under a 16-core cgroup quota
 
 
 @pytest.fixture(scope='session')
