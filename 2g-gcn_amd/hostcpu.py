@@ -26,11 +26,11 @@ def effective_cpu_count() -> int:
     return n
 
 
-def limit_host_threads(reserve: int = 4) -> int:
-    """Caps torch's CPU thread pools at the cgroup quota minus `reserve` cores (kept for the launch thread and the HIP
-    runtime's helper threads). Returns the cap."""
+def limit_host_threads(reserve: int = 4, share: int = 1) -> int:
+    """Caps torch's CPU thread pools at this process's share (1/`share`: ranks on the node) of the cgroup quota minus
+    `reserve` cores (kept for the launch thread and the HIP runtime's helper threads). Returns the cap."""
     import torch
-    cap = max(1, effective_cpu_count() - reserve)
+    cap = max(1, effective_cpu_count() // max(1, share) - reserve)
     if torch.get_num_threads() > cap:
         torch.set_num_threads(cap)
     os.environ.setdefault('OMP_NUM_THREADS', str(cap))

@@ -35,7 +35,7 @@ def _cpu_quota():
 
 # before torch creates its thread pools: oversubscribing the quota gets the whole cgroup throttled in 100 ms periods,
 # which stalls the thread that feeds the GPU (measured: sporadic +90 ms steps)
-os.environ.setdefault('OMP_NUM_THREADS', str(max(1, _cpu_quota() - 4)))
+os.environ.setdefault('OMP_NUM_THREADS', str(max(1, _cpu_quota() // int(os.environ.get('LOCAL_WORLD_SIZE', '1')) - 4)))
 
 import torch  # noqa: E402
 
@@ -195,7 +195,8 @@ def main():
     from twog_gcn_amd.kernels import get_kernels
     from twog_gcn_amd.distributed import DataParallel, FusedAdam
     from twog_gcn_amd.hostcpu import limit_host_threads
-    limit_host_threads()  # thread pools sized from the cgroup quota, not from the node's core count (hostcpu.py)
+    # thread pools sized from this rank's share of the cgroup quota, not from the node's core count (hostcpu.py)
+    limit_host_threads(share=int(os.environ.get('LOCAL_WORLD_SIZE', '1')))
     K = get_kernels()
     assert K.name == 'hip'
 
