@@ -325,6 +325,29 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const Group g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
+    // epilogue operands are fetched BEFORE the reduction loop so their latency hides under it (it is a visible share of
+    // the short recurrent launches: 16 k-tiles): the bias of this lane's columns and, for the single-accumulator
+    // 64x64 class, the previous C values of accumulate launches
+    constexpr bool PREFETCH_C = (TM * TN == 1);
+    float bv[TN];
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+        bv[b] = (PREFETCH_C && bias && g.splitk == 1) ? bias[min(n0 + wn + b * 32 + li, N - 1)] : 0.f;
+    float cprev[PREFETCH_C ? 16 : 1];
+    if constexpr (PREFETCH_C) {
+        if (accumulate && g.splitk == 1) {
+            const int col = min(n0 + wn + li, N - 1);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = min(m0 + wm + (r & 3) + 8 * (r >> 2) + 4 * kh, M - 1);
+                cprev[r] = C.ptr[twog_row_off(C, row) + col];
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) cprev[r] = 0.f;
+        }
+    }
+
     // uniform per workgroup: aligned operands and a reduction range made of whole k-tiles -> branch-free staging
     const bool fast = a_vec && b_vec && ((k_end - k_begin) % BK == 0);
     if (fast)
@@ -360,8 +383,12 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const Group g) {
                 const int col = n0 + wn + b * 32 + li;
                 if (col >= N) continue;
                 float v = acc[a][b][r];
-                if (bias) v += bias[col];
-                if (accumulate) v += crow[col];
+                if constexpr (PREFETCH_C) {
+                    v += bv[b] + cprev[r];
+                } else {  // 128x128 class: registers are full, and its long reduction makes the epilogue latency immaterial
+                    if (bias) v += bias[col];
+                    if (accumulate) v += crow[col];
+                }
                 if (act == 1) v = fmaxf(v, 0.f);
                 crow[col] = v;
             }
