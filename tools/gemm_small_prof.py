@@ -14,8 +14,8 @@ K = get_kernels()
 dev = 'cuda:0'
 REPS = 10
 configs = []
-for groups, M, N in ((1, 512, 2048), (2, 512, 2048), (3, 512, 2048), (4, 512, 2048), (8, 512, 2048), (4, 128, 1536), (4, 512, 1536)):
-    for Kk in (512, 1024, 2048):
+for groups, M, N in ((1, 512, 2048), (2, 512, 2048), (4, 512, 2048)):
+    for Kk in (32, 64, 128, 256, 512, 1024):
         configs.append((groups, M, N, Kk, False))
 configs.append((4, 512, 512, 1536, True))
 out = []
