@@ -142,6 +142,8 @@ SIGNATURES = {
     'twog_adam_step': [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _F, _P],
     'twog_multitask_loss_fwd': [C.POINTER(Loss), _I, _P, _P, _P, _P],
     'twog_multitask_loss_bwd': [C.POINTER(Loss), _I, _P, _P, _P],
+    'twog_predict_labels': [_P, _I, _I, _I, _I, _I, _I, _P, _P],
+    'twog_f1_at_k': [_P, _P, _I, _I, _I, C.c_double, _L, _I, _P, _P, _P, _P],
 }
 
 _lib = None

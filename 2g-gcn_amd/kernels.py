@@ -498,6 +498,32 @@ class HipKernels:
         return dins
 
 
+    # ---------------------------------------------------------------- inference post-processing
+    def predict_labels(self, logp, downsampling, target_steps):
+        """(bs, C, T, E) log-probabilities -> int64 labels (bs, target_steps, E) (upsample, match_shape, argmax)."""
+        assert logp.dim() == 4 and logp.dtype == torch.float32
+        logp = logp.contiguous()
+        bs, Cn, T, E = logp.shape
+        labels = torch.empty(bs, target_steps, E, dtype=torch.int64, device=logp.device)
+        self._check(self.lib.twog_predict_labels(logp.data_ptr(), bs, Cn, T, E, int(downsampling), int(target_steps),
+                                                 labels.data_ptr(), self._stream()), 'twog_predict_labels')
+        return labels
+
+    def f1_at_k(self, y_true, y_pred, num_classes, overlap, ignore_value=None):
+        """Per-sequence F1@k and validity flags for int64 (n_seq, n_steps) label matrices."""
+        y_true, y_pred = y_true.to(torch.int64).contiguous(), y_pred.to(torch.int64).contiguous()
+        n_seq, n_steps = y_true.shape
+        dev = y_true.device
+        f1 = torch.zeros(n_seq, dtype=torch.float32, device=dev)
+        valid = torch.zeros(n_seq, dtype=torch.float32, device=dev)
+        scratch = torch.empty(max(n_seq * n_steps, 1), dtype=torch.uint8, device=dev)
+        self._check(self.lib.twog_f1_at_k(y_true.data_ptr(), y_pred.data_ptr(), n_seq, n_steps, int(num_classes),
+                                          float(overlap), int(ignore_value) if ignore_value is not None else 0,
+                                          int(ignore_value is not None), scratch.data_ptr(), f1.data_ptr(),
+                                          valid.data_ptr(), self._stream()), 'twog_f1_at_k')
+        return f1, valid
+
+
 _backend = None
 
 

@@ -358,6 +358,20 @@ int twog_multitask_loss_fwd(const twog_loss_t* terms, int n_terms, double* parti
 int twog_multitask_loss_bwd(const twog_loss_t* terms, int n_terms, const double* stats, const float* dlosses,
                             void* stream);
 
+/* ===============================================================================================================
+ * Inference post-processing on the device.
+ * twog_predict_labels: predict.py:64-70 (repeat_interleave by `downsampling` along time, match_shape :95-116 to T_out
+ *   steps) + :195-201 (argmax over classes; ties -> first index): logp [bs][C][T][E] -> labels int64 [bs][T_out][E],
+ *   labels[b][t][e] = argmax_c logp[b][c][min(t / downsampling, T - 1)][e].
+ * twog_f1_at_k: pyrutils/metrics.py:7-81. y_true / y_pred int64 [n_seq][n_steps]; steps with y_true == ignore_value
+ *   are dropped from both (use_ignore); f1[s] = F1@overlap of sequence s, valid[s] = 0 for sequences left empty (the
+ *   reference skips them); the batch metric is sum(f1) / sum(valid). scratch: n_seq * n_steps bytes.
+ * =============================================================================================================== */
+int twog_predict_labels(const float* logp, int bs, int n_classes, int T, int E, int downsampling, int T_out,
+                        int64_t* labels, void* stream);
+int twog_f1_at_k(const int64_t* y_true, const int64_t* y_pred, int n_seq, int n_steps, int num_classes, double overlap,
+                 int64_t ignore_value, int use_ignore, unsigned char* scratch, float* f1, float* valid, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

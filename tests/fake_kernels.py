@@ -581,3 +581,20 @@ class FakeKernels:
             out.append(d)
         return out
 
+    # ---------------------------------------------------------------- inference post-processing (spec of postprocess.hip)
+    def predict_labels(self, logp, downsampling, target_steps):
+        bs, Cn, T, E = logp.shape
+        t = torch.clamp(torch.arange(target_steps) // max(1, int(downsampling)), max=T - 1)
+        return torch.from_numpy(logp[:, :, t].numpy().argmax(1).astype('int64'))
+
+    def f1_at_k(self, y_true, y_pred, num_classes, overlap, ignore_value=None):
+        from oracle import postprocess_ref as R  # the test double may lean on the oracle; the product never does
+        f1, valid = [], []
+        for yt, yp in zip(y_true.numpy(), y_pred.numpy()):
+            if ignore_value is not None:
+                keep = yt != ignore_value
+                yt, yp = yt[keep], yp[keep]
+            valid.append(float(yt.size > 0))
+            f1.append(R.f1_at_k_single_example(yt, yp, num_classes, overlap) if yt.size else 0.0)
+        return torch.tensor(f1, dtype=torch.float32), torch.tensor(valid, dtype=torch.float32)
+

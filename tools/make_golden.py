@@ -364,6 +364,63 @@ def g6_batching():
     print('g6: ', len(out), 'arrays')
 
 
+def g8_postprocess():
+    """G8: inference post-processing of predict.py (:64-70 repeat_interleave + match_shape, :195-201 argmax) and the
+    segmental metric pyrutils.metrics.f1_at_k (:68-81) on seeded label sequences with ignored padding."""
+    import importlib.util
+    from pyrutils.metrics import f1_at_k
+    # predict.py imports omegaconf / sklearn at module level (absent here); match_shape is self-contained: load it alone
+    src = open(os.path.join(REF, 'predict.py')).read()
+    start = src.index('def match_shape(out, tgt):')
+    end = src.index('def match_att_shape')
+    ns = {'torch': torch}
+    exec(compile(src[start:end], 'predict_match_shape', 'exec'), ns)
+    match_shape = ns['match_shape']
+    out = {}
+    rng = np.random.RandomState(8)
+    cases = []
+    for ci, (bs, C, T, E, ds, T_tgt) in enumerate(((3, 13, 10, 2, 1, 10), (2, 10, 7, 5, 3, 19), (2, 12, 6, 3, 4, 26),
+                                                   (1, 4, 5, 1, 2, 7))):
+        logp = torch.log_softmax(torch.from_numpy(rng.randn(bs, C, T, E).astype(np.float32)), 1)
+        logp[0, 1, 0, 0] = logp[0, 2, 0, 0] = logp[0].max() + 1.0     # a tie: np.argmax takes the first index
+        tgt = torch.zeros(bs, T_tgt, E, dtype=torch.int64)
+        o = logp
+        if ds > 1:
+            o = torch.repeat_interleave(o, repeats=ds, dim=-2)
+            o = match_shape(o, tgt)
+        labels = np.argmax(o.numpy(), axis=1)
+        out[f'pl{ci}_logp'], out[f'pl{ci}_labels'] = logp.numpy(), labels.astype(np.int64)
+        out[f'pl{ci}_cfg'] = np.array([ds, T_tgt if ds > 1 else T])
+        cases.append(ci)
+    out['pl_cases'] = np.array(cases)
+    # F1@k: sequences built from runs, predictions = noisy copies; trailing padding -1 and a fully padded row
+    for fi, (n_seq, n_steps, ncls) in enumerate(((6, 40, 5), (4, 25, 3), (3, 8, 2))):
+        yt = np.zeros((n_seq, n_steps), dtype=np.int64)
+        yp = np.zeros((n_seq, n_steps), dtype=np.int64)
+        for r in range(n_seq):
+            seq, pred = [], []
+            while len(seq) < n_steps:
+                run = int(rng.randint(1, 7))
+                lab = int(rng.randint(0, ncls + 1))          # label ncls is "ignored class" (>= num_classes)
+                seq += [lab] * run
+                shift = int(rng.randint(-2, 3))
+                plab = lab if rng.rand() < 0.7 else int(rng.randint(0, ncls + 1))
+                pred += [plab] * max(1, run + shift)
+            yt[r] = seq[:n_steps]
+            yp[r] = (pred + [pred[-1]] * n_steps)[:n_steps]
+            pad = int(rng.randint(0, 6))
+            if pad:
+                yt[r, n_steps - pad:] = -1
+        yt[-1, :] = -1 if fi == 0 else yt[-1, :]
+        out[f'f1_{fi}_true'], out[f'f1_{fi}_pred'] = yt, yp
+        vals = [f1_at_k(yt, yp, ncls, overlap=ov, ignore_value=-1.0)
+                for ov in (0.1, 0.25, 0.5)]
+        out[f'f1_{fi}_values'] = np.array(vals, dtype=np.float64)
+        out[f'f1_{fi}_ncls'] = np.array(ncls)
+    np.savez_compressed(os.path.join(OUT, 'g8_postprocess.npz'), **out)
+    print('g8: ', len(out), 'arrays')
+
+
 if __name__ == '__main__':
     torch.set_num_threads(8)
     os.makedirs(OUT, exist_ok=True)
@@ -373,3 +430,4 @@ if __name__ == '__main__':
     g4_full()
     g7_losses()
     g6_batching()
+    g8_postprocess()
