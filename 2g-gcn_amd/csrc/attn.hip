@@ -149,27 +149,34 @@ __global__ __launch_bounds__(1024) void attn_fwd_kernel(const FwdGroup g) {
             *reinterpret_cast<float4*>(sF + e * D + c) = *reinterpret_cast<const float4*>(src + c);
         }
     }
+    // latency regime: the instance is shared by gridDim.z = 2 workgroups -- both compute the (cheap) weights, half 0
+    // produces the messages to humans and the human / geometry messages to objects, half 1 the object -> object ones
+    const int half = blockIdx.z, nhalf = gridDim.z;
+    const bool do01 = nhalf == 1 || half == 0, do23 = nhalf == 1 || half == 1;
     if (g.staged) {
         float* cur = sMask + MAX_O + 4;
         cur = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(cur) + 15) & ~uintptr_t(15));
-        stage_rowset(m_hh, H, hid, cur);
-        stage_rowset(m_ho, H, hid, cur);
-        stage_rowset(m_oh, O, hid, cur);
-        stage_rowset(m_oo, O, hid, cur);
-        stage_rowset(m_so, 1, hid, cur);
-        stage_rowset(m_sh, 1, hid, cur);
+        if (do01) {
+            stage_rowset(m_hh, H, hid, cur);
+            stage_rowset(m_ho, H, hid, cur);
+            stage_rowset(m_oh, O, hid, cur);
+            stage_rowset(m_so, 1, hid, cur);
+            stage_rowset(m_sh, 1, hid, cur);
+        }
+        if (do23) stage_rowset(m_oo, O, hid, cur);
     }
     __syncthreads();
     compute_weights(A, sF, sG, sW, sMask);
     const int natt = H * H + 2 * H * O + O * O;
-    if (A.att)
+    if (A.att && half == 0)
         for (int i = threadIdx.x; i < natt; i += blockDim.x) A.att[(int64_t)inst * natt + i] = sW[i];
     // weighted sums: one (group, column) item per thread, lane-contiguous loads/stores. Groups are independent pieces of
     // work of similar size -- 0: messages to humans (hh, oh, sh); 1: human/geometry messages to objects (ho, so);
     // 2, 3: object->object messages for the first / second half of the receivers.
     const int o_half = (O + 1) / 2;
     const bool rmask = A.recv_mask_ho != 0;
-    for (int idx = threadIdx.x; idx < 4 * hid; idx += blockDim.x) {
+    const int idx_lo = do01 ? 0 : 2 * hid, idx_hi = do23 ? 4 * hid : 2 * hid;
+    for (int idx = idx_lo + threadIdx.x; idx < idx_hi; idx += blockDim.x) {
         const int grp = idx / hid, j = idx - grp * hid;
         float m[MAX_O];
         if (grp == 0) {
@@ -293,7 +300,11 @@ __global__ __launch_bounds__(1024) void attn_bwd_kernel(const BwdGroup g) {
         if (m_oo.on()) stage_rowset(d_oo, O, hid, cur);
     }
     __syncthreads();
+    // latency regime (gridDim.z = 2): half 0 produces the sender-message gradients, half 1 the feature gradients
+    const int half = blockIdx.z, nhalf = gridDim.z;
+    const bool do_feat = nhalf == 1 || half == 1, do_msg = nhalf == 1 || half == 0;
     // dL/dw[r][s] = recv_mask_r * <dout[r], msg[s]>   (one wave per pair)
+    if (do_feat)
     for (int p = wv; p < natt; p += nw) {
         float v = 0.f;
         if (p < H * H) {
@@ -313,7 +324,7 @@ __global__ __launch_bounds__(1024) void attn_bwd_kernel(const BwdGroup g) {
     }
     __syncthreads();
     // softmax backward per receiver: dscore = w * (dw - sum_s w dw) * scale
-    if (threadIdx.x < 2 * H + 2 * O) {
+    if (do_feat && threadIdx.x < 2 * H + 2 * O) {
         const int i = threadIdx.x;
         int off, S;
         if (i < H) { off = att_off_hh(H, O) + i * H; S = H; }
@@ -327,6 +338,7 @@ __global__ __launch_bounds__(1024) void attn_bwd_kernel(const BwdGroup g) {
     __syncthreads();
     // coefficient of F[b] in dF[a]: every score <F_r, F_s> sends its dscore to both its receiver and its sender.
     // Fixed order of the (at most 4) terms per entry -> deterministic.
+    if (do_feat)
     for (int i = threadIdx.x; i < E * E; i += blockDim.x) {
         const int a = i / E, b = i - a * E;
         float v;
@@ -340,6 +352,7 @@ __global__ __launch_bounds__(1024) void attn_bwd_kernel(const BwdGroup g) {
     // gradient wrt sender messages: dmsg[s] = sum_r w[r][s] * recv_mask_r * dout[r]  (optionally times ReLU'(msg)),
     // one (group, column) item per thread; groups: 0: hh, oh, sh; 1: ho, so; 2, 3: oo senders first / second half
     const int o_half = (O + 1) / 2;
+    if (do_msg)
     for (int idx = threadIdx.x; idx < 4 * hid; idx += blockDim.x) {
         const int grp = idx / hid, j = idx - grp * hid;
         float gr[MAX_O];
@@ -412,6 +425,7 @@ __global__ __launch_bounds__(1024) void attn_bwd_kernel(const BwdGroup g) {
     // Two (group, column) items per column: first / second half of the entities.
     const int e_half = (E + 1) / 2;
     const bool accum = B.dfeat_accumulate != 0;
+    if (do_feat)
     for (int idx = threadIdx.x; idx < 2 * D; idx += blockDim.x) {
         const int grp = idx / D, d = idx - grp * D;
         float f[MAX_E];
@@ -502,7 +516,7 @@ extern "C" int twog_attn_fwd(const twog_attn_t* a, int n, void* stream) {
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT);
         attr_set = true;
     }
-    hipLaunchKernelGGL(attn_fwd_kernel, dim3(maxinst, n), dim3(staged ? 1024 : 256), lds, (hipStream_t)stream, g);
+    hipLaunchKernelGGL(attn_fwd_kernel, dim3(maxinst, n, staged ? 2 : 1), dim3(staged ? 1024 : 256), lds, (hipStream_t)stream, g);
     TWOG_CHECK_LAUNCH();
     return 0;
 }
@@ -533,7 +547,7 @@ extern "C" int twog_attn_bwd(const twog_attn_bwd_t* a, int n, void* stream) {
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT);
         attr_set = true;
     }
-    hipLaunchKernelGGL(attn_bwd_kernel, dim3(maxinst, n), dim3(staged ? 1024 : 256), lds, (hipStream_t)stream, g);
+    hipLaunchKernelGGL(attn_bwd_kernel, dim3(maxinst, n, staged ? 2 : 1), dim3(staged ? 1024 : 256), lds, (hipStream_t)stream, g);
     TWOG_CHECK_LAUNCH();
     return 0;
 }
