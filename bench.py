@@ -72,7 +72,7 @@ class GemmProfiler:
     stream the kernels are enqueued on). Launches are classed by the tile variant the library picks."""
 
     def __init__(self, K):
-        self.K, self.orig, self.records = K, K.gemm, []
+        self.K, self.orig, self.records, self.shapes = K, K.gemm, [], []
 
     def __enter__(self):
         def gemm(problems, a_kmajor=False, b_kmajor=False, split_k_workspace=True):
@@ -96,11 +96,25 @@ class GemmProfiler:
             reach = tiles128 * (kmax // 512 if kmax >= 1024 else 1)
             big = wide and (tiles128 >= 256 or reach >= 256)
             self.records.append(('128x128' if big else '64x64', flops, e0, e1, abytes))
+            self.shapes.append((a_kmajor, b_kmajor, [(n_rows(p['C']), p['C'].shape[-1], (n_rows(p['A']) if a_kmajor else p['A'].shape[-1]), (p['batch'][0] if p.get('batch') else 1)) for p in problems]))
         self.K.gemm = gemm
         return self
 
     def __exit__(self, *a):
         self.K.gemm = self.orig
+
+    def detail(self, steps):
+        """Per distinct launch signature: calls per step, average time, TFLOP/s (TWOG_BENCH_GEMM_DETAIL=1)."""
+        torch.cuda.synchronize()
+        agg = {}
+        for (kind, flops, e0, e1, _), (akm, bkm, shp) in zip(self.records, self.shapes):
+            a = agg.setdefault((kind, akm, bkm, tuple(shp)), [0.0, 0.0, 0])
+            a[0] += flops
+            a[1] += e0.elapsed_time(e1) * 1e-3
+            a[2] += 1
+        rows = sorted(agg.items(), key=lambda kv: -kv[1][1])
+        for (kind, akm, bkm, shp), (fl, sec, n) in rows:
+            log(f'{kind} {"T" if akm else "N"}{"T" if bkm else "N"} {n / steps:5.1f}/step {sec / n * 1e3:8.3f} ms {fl / sec / 1e12:6.1f} TF  {list(shp)[:4]}')
 
     def summary(self):
         torch.cuda.synchronize()
@@ -249,6 +263,8 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     agg = prof.summary()
+    if os.environ.get('TWOG_BENCH_GEMM_DETAIL') and rank == 0:
+        prof.detail(args.steps)
     log(f'timed region done: {dt / args.steps * 1e3:.1f} ms/step')
 
     # secondary roofline: the geometric-level GCN forward alone (the kernel group the north star's HBM-roofline target
