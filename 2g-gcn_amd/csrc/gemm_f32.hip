@@ -97,7 +97,7 @@ __device__ __forceinline__ void store_tile(const TileRegs<ROWS, COLS>& t, float*
     }
 }
 
-template <int BM, int BN, bool AKM, bool BKM, bool FAST, int TM, int TN, int D>
+template <int BM, int BN, bool AKM, bool BKM, bool FAST, int TM, int TN, int D, bool KG>
 __device__ __forceinline__ void gemm_mainloop(const twog_rows_t A, const twog_rows_t B, int M, int N, int a_vec,
                                               int b_vec, int m0, int n0, int k_begin, int k_end, float* smem,
                                               f32x16 (&acc)[TM][TN]) {
@@ -135,8 +135,63 @@ __device__ __forceinline__ void gemm_mainloop(const twog_rows_t A, const twog_ro
             else pb[i] = B.ptr + twog_row_off(B, min(n0 + rr, N - 1)) + cc;
         }
     }
+    // KG kernels (k-major operand whose rows are (outer, inner) grouped, e.g. "all but the first time step of every
+    // clip"): the row pointer of every pass is carried from k-tile to k-tile (k only moves forward): no division in the
+    // loop. Kept out of the plain kernels, whose registers are full.
+    const float* qa[KG ? ARegs::PASSES : 1];
+    const float* qb[KG ? BRegs::PASSES : 1];
+    int qa_i[KG ? ARegs::PASSES : 1], qb_i[KG ? BRegs::PASSES : 1], qa_k = k_begin, qb_k = k_begin;
+    const int a_inner = A.inner <= 1 ? 0x7fffffff : A.inner, b_inner = B.inner <= 1 ? 0x7fffffff : B.inner;
+    const int64_t a_step = A.inner <= 1 ? A.ld_outer : A.ld_inner, b_step = B.inner <= 1 ? B.ld_outer : B.ld_inner;
+    if constexpr (FAST && KG && AKM) {
+#pragma unroll
+        for (int i = 0; i < ARegs::PASSES; ++i) {
+            const int row = k_begin + tid / ARegs::F4_PER_ROW + i * ARegs::ROWS_PER_PASS;
+            const int o = A.inner <= 1 ? 0 : row / A.inner;
+            qa_i[i] = A.inner <= 1 ? 0 : row - o * A.inner;
+            qa[i] = A.ptr + twog_row_off(A, row) + min(m0 + (tid % ARegs::F4_PER_ROW) * 4, M - 4);
+        }
+    }
+    if constexpr (FAST && KG && BKM) {
+#pragma unroll
+        for (int i = 0; i < BRegs::PASSES; ++i) {
+            const int row = k_begin + tid / BRegs::F4_PER_ROW + i * BRegs::ROWS_PER_PASS;
+            const int o = B.inner <= 1 ? 0 : row / B.inner;
+            qb_i[i] = B.inner <= 1 ? 0 : row - o * B.inner;
+            qb[i] = B.ptr + twog_row_off(B, row) + min(n0 + (tid % BRegs::F4_PER_ROW) * 4, N - 4);
+        }
+    }
     auto gload = [&](ARegs& ra, BRegs& rb, int k0) {
-        if constexpr (FAST) {
+        if constexpr (FAST && KG) {
+            if constexpr (AKM) {
+                const int delta = k0 - qa_k;  // >= 0: tiles are visited in order (the clamped tail repeats the last one)
+                qa_k = k0;
+                const int64_t wrap = A.ld_outer - (int64_t)A.inner * A.ld_inner;
+#pragma unroll
+                for (int i = 0; i < ARegs::PASSES; ++i) {
+                    qa_i[i] += delta;
+                    qa[i] += (int64_t)delta * a_step;
+                    while (qa_i[i] >= a_inner) { qa_i[i] -= a_inner; qa[i] += wrap; }
+                }
+            }
+            if constexpr (BKM) {
+                const int delta = k0 - qb_k;
+                qb_k = k0;
+                const int64_t wrap = B.ld_outer - (int64_t)B.inner * B.ld_inner;
+#pragma unroll
+                for (int i = 0; i < BRegs::PASSES; ++i) {
+                    qb_i[i] += delta;
+                    qb[i] += (int64_t)delta * b_step;
+                    while (qb_i[i] >= b_inner) { qb_i[i] -= b_inner; qb[i] += wrap; }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < ARegs::PASSES; ++i)
+                ra.v[i] = *reinterpret_cast<const f32x4*>(AKM ? qa[i] : pa[i] + k0);
+#pragma unroll
+            for (int i = 0; i < BRegs::PASSES; ++i)
+                rb.v[i] = *reinterpret_cast<const f32x4*>(BKM ? qb[i] : pb[i] + k0);
+        } else if constexpr (FAST) {
 #pragma unroll
             for (int i = 0; i < ARegs::PASSES; ++i) {
                 const float* p;
@@ -259,7 +314,7 @@ __device__ __forceinline__ void gemm_mainloop(const twog_rows_t A, const twog_ro
     }
 }
 
-template <int BM, int BN, bool AKM, bool BKM, int D>
+template <int BM, int BN, bool AKM, bool BKM, int D, bool KG>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(const Group g) {
     constexpr int WM = BM / 2, WN = BN / 2;    // per-wave tile
     constexpr int TM = WM / 32, TN = WN / 32;  // 32x32 MFMA tiles per wave
@@ -351,9 +406,9 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const Group g) {
     // uniform per workgroup: aligned operands and a reduction range made of whole k-tiles -> branch-free staging
     const bool fast = a_vec && b_vec && ((k_end - k_begin) % BK == 0);
     if (fast)
-        gemm_mainloop<BM, BN, AKM, BKM, true, TM, TN, D>(A, B, M, N, a_vec, b_vec, m0, n0, k_begin, k_end, smem, acc);
+        gemm_mainloop<BM, BN, AKM, BKM, true, TM, TN, D, KG>(A, B, M, N, a_vec, b_vec, m0, n0, k_begin, k_end, smem, acc);
     else
-        gemm_mainloop<BM, BN, AKM, BKM, false, TM, TN, 1>(A, B, M, N, a_vec, b_vec, m0, n0, k_begin, k_end, smem, acc);
+        gemm_mainloop<BM, BN, AKM, BKM, false, TM, TN, 1, false>(A, B, M, N, a_vec, b_vec, m0, n0, k_begin, k_end, smem, acc);
 
     // epilogue. C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
     if (g.splitk > 1) {
@@ -437,12 +492,16 @@ inline int vec_ok(const twog_rows_t& m, int64_t batch_stride, int contiguous_ext
 template <int BM, int BN, int D>
 int launch(Group& g, int akm, int bkm, hipStream_t st) {
     dim3 grid(g.total_tiles, g.splitk), block(256);
-    static const int lds_pad = getenv("TWOG_GEMM_LDSPAD") ? atoi(getenv("TWOG_GEMM_LDSPAD")) : 0;  // occupancy experiments
-    const int dyn = BM == 64 ? lds_pad : 0;
-    if (!akm && !bkm) hipLaunchKernelGGL((gemm_kernel<BM, BN, false, false, D>), grid, block, dyn, st, g);
-    else if (!akm && bkm) hipLaunchKernelGGL((gemm_kernel<BM, BN, false, true, D>), grid, block, dyn, st, g);
-    else if (akm && bkm) hipLaunchKernelGGL((gemm_kernel<BM, BN, true, true, D>), grid, block, dyn, st, g);
-    else hipLaunchKernelGGL((gemm_kernel<BM, BN, true, false, D>), grid, block, dyn, st, g);
+    // KG variant: some k-major operand has (outer, inner) grouped rows
+    bool kg = false;
+    for (int i = 0; i < g.n; ++i) kg = kg || (akm && g.p[i].A.inner > 1) || (bkm && g.p[i].B.inner > 1);
+    if (!akm && !bkm) hipLaunchKernelGGL((gemm_kernel<BM, BN, false, false, D, false>), grid, block, 0, st, g);
+    else if (!akm && bkm && !kg) hipLaunchKernelGGL((gemm_kernel<BM, BN, false, true, D, false>), grid, block, 0, st, g);
+    else if (!akm && bkm) hipLaunchKernelGGL((gemm_kernel<BM, BN, false, true, D, true>), grid, block, 0, st, g);
+    else if (akm && bkm && !kg) hipLaunchKernelGGL((gemm_kernel<BM, BN, true, true, D, false>), grid, block, 0, st, g);
+    else if (akm && bkm) hipLaunchKernelGGL((gemm_kernel<BM, BN, true, true, D, true>), grid, block, 0, st, g);
+    else if (!kg) hipLaunchKernelGGL((gemm_kernel<BM, BN, true, false, D, false>), grid, block, 0, st, g);
+    else hipLaunchKernelGGL((gemm_kernel<BM, BN, true, false, D, true>), grid, block, 0, st, g);
     TWOG_CHECK_LAUNCH();
     if (g.splitk > 1) {
         hipLaunchKernelGGL((splitk_reduce_kernel<BM, BN>), dim3(g.total_tiles, (BM * BN) / 1024), block, 0, st, g);
