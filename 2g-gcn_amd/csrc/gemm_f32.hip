@@ -59,6 +59,13 @@ struct TileRegs {
     f32x4 v[PASSES];
 };
 
+// a wave-uniform pointer pinned to scalar registers, so that loads can use the scalar-base + 32-bit vector-offset form
+__device__ __forceinline__ const char* uniform_ptr(const float* p) {
+    const uint64_t v = reinterpret_cast<uint64_t>(p);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return reinterpret_cast<const char*>(((uint64_t)hi << 32) | lo);
+}
+
 // guarded load (edge tiles / unaligned operands): out-of-range elements read as 0
 template <int ROWS, int COLS>
 __device__ __forceinline__ void load_tile(TileRegs<ROWS, COLS>& t, const twog_rows_t& m, int r0, int c0, int rmax,
@@ -118,21 +125,24 @@ __device__ __forceinline__ void gemm_mainloop(const twog_rows_t A, const twog_ro
     // (row / column indices beyond the matrix are clamped: they only feed outputs that are never stored), so the
     // loads stay in flight under the MFMAs. All row addressing is resolved before the loop: per pass one pointer
     // (row-major operand: the tile row; k-major operand with plain rows: row 0 of the pass, advanced by k0 * ld).
-    const float* pa[ARegs::PASSES];
-    const float* pb[BRegs::PASSES];
-    const bool a_plain = A.inner <= 1, b_plain = B.inner <= 1;
+    // per pass ONE 32-bit BYTE offset from a wave-uniform base (the operand pointer advanced by the k-tile): the loads
+    // take the scalar-base + vector-offset form, no 64-bit address arithmetic and no extra registers inside the loop
+    // (the host only enables FAST for operands smaller than 2^30 elements)
+    uint32_t oa[ARegs::PASSES], ob[BRegs::PASSES];
+    const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(A.ptr, 0, 0xffffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc(B.ptr, 0, 0xffffffff, 0x00020000);
     if constexpr (FAST) {
 #pragma unroll
         for (int i = 0; i < ARegs::PASSES; ++i) {
             const int rr = tid / ARegs::F4_PER_ROW + i * ARegs::ROWS_PER_PASS, cc = (tid % ARegs::F4_PER_ROW) * 4;
-            if constexpr (AKM) pa[i] = A.ptr + (int64_t)rr * A.ld_outer + min(m0 + cc, M - 4);
-            else pa[i] = A.ptr + twog_row_off(A, min(m0 + rr, M - 1)) + cc;
+            if constexpr (AKM) oa[i] = 4u * (uint32_t)((int64_t)rr * A.ld_outer + min(m0 + cc, M - 4));
+            else oa[i] = 4u * (uint32_t)(twog_row_off(A, min(m0 + rr, M - 1)) + cc);
         }
 #pragma unroll
         for (int i = 0; i < BRegs::PASSES; ++i) {
             const int rr = tid / BRegs::F4_PER_ROW + i * BRegs::ROWS_PER_PASS, cc = (tid % BRegs::F4_PER_ROW) * 4;
-            if constexpr (BKM) pb[i] = B.ptr + (int64_t)rr * B.ld_outer + min(n0 + cc, N - 4);
-            else pb[i] = B.ptr + twog_row_off(B, min(n0 + rr, N - 1)) + cc;
+            if constexpr (BKM) ob[i] = 4u * (uint32_t)((int64_t)rr * B.ld_outer + min(n0 + cc, N - 4));
+            else ob[i] = 4u * (uint32_t)(twog_row_off(B, min(n0 + rr, N - 1)) + cc);
         }
     }
     // KG kernels (k-major operand whose rows are (outer, inner) grouped, e.g. "all but the first time step of every
@@ -187,35 +197,20 @@ __device__ __forceinline__ void gemm_mainloop(const twog_rows_t A, const twog_ro
             }
 #pragma unroll
             for (int i = 0; i < ARegs::PASSES; ++i)
-                ra.v[i] = *reinterpret_cast<const f32x4*>(AKM ? qa[i] : pa[i] + k0);
+                ra.v[i] = *reinterpret_cast<const f32x4*>(AKM ? reinterpret_cast<const char*>(qa[i]) : reinterpret_cast<const char*>(A.ptr + k0) + oa[i]);
 #pragma unroll
             for (int i = 0; i < BRegs::PASSES; ++i)
-                rb.v[i] = *reinterpret_cast<const f32x4*>(BKM ? qb[i] : pb[i] + k0);
+                rb.v[i] = *reinterpret_cast<const f32x4*>(BKM ? reinterpret_cast<const char*>(qb[i]) : reinterpret_cast<const char*>(B.ptr + k0) + ob[i]);
         } else if constexpr (FAST) {
+            // buffer loads: 128-bit scalar descriptor + scalar k-tile offset + per-lane 32-bit offset (no address VALU)
+            const int sa = (int)(AKM ? (uint32_t)k0 * (uint32_t)A.ld_outer * 4u : (uint32_t)k0 * 4u);
+            const int sb = (int)(BKM ? (uint32_t)k0 * (uint32_t)B.ld_outer * 4u : (uint32_t)k0 * 4u);
 #pragma unroll
-            for (int i = 0; i < ARegs::PASSES; ++i) {
-                const float* p;
-                if constexpr (AKM) {
-                    if (a_plain) p = pa[i] + (int64_t)k0 * A.ld_outer;
-                    else p = A.ptr + twog_row_off(A, k0 + tid / ARegs::F4_PER_ROW + i * ARegs::ROWS_PER_PASS) +
-                             min(m0 + (tid % ARegs::F4_PER_ROW) * 4, M - 4);
-                } else {
-                    p = pa[i] + k0;
-                }
-                ra.v[i] = *reinterpret_cast<const f32x4*>(p);
-            }
+            for (int i = 0; i < ARegs::PASSES; ++i)
+                ra.v[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, (int)oa[i], sa, 0));
 #pragma unroll
-            for (int i = 0; i < BRegs::PASSES; ++i) {
-                const float* p;
-                if constexpr (BKM) {
-                    if (b_plain) p = pb[i] + (int64_t)k0 * B.ld_outer;
-                    else p = B.ptr + twog_row_off(B, k0 + tid / BRegs::F4_PER_ROW + i * BRegs::ROWS_PER_PASS) +
-                             min(n0 + (tid % BRegs::F4_PER_ROW) * 4, N - 4);
-                } else {
-                    p = pb[i] + k0;
-                }
-                rb.v[i] = *reinterpret_cast<const f32x4*>(p);
-            }
+            for (int i = 0; i < BRegs::PASSES; ++i)
+                rb.v[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_b, (int)ob[i], sb, 0));
         } else {
             if constexpr (AKM) load_tile(ra, A, k0, m0, k_end, M, a_vec);
             else               load_tile(ra, A, m0, k0, M, k_end, a_vec);
@@ -483,7 +478,11 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const Group g) {
     }
 }
 
-inline int vec_ok(const twog_rows_t& m, int64_t batch_stride, int contiguous_extent) {
+inline int vec_ok(const twog_rows_t& m, int64_t batch_stride, int contiguous_extent, int64_t n_rows) {
+    // 32-bit element offsets inside the kernel: the operand must span fewer than 2^30 elements
+    const int64_t groups = m.inner > 1 ? (n_rows + m.inner - 1) / m.inner : n_rows;
+    const int64_t extent = groups * (m.ld_outer < 0 ? -m.ld_outer : m.ld_outer) + (m.inner > 1 ? (int64_t)m.inner * m.ld_inner : 0);
+    if (extent >= (int64_t(1) << 30)) return 0;
     const bool aligned = (reinterpret_cast<uintptr_t>(m.ptr) % 16) == 0;
     const bool ld_ok = (m.ld_outer % 4 == 0) && (m.inner <= 1 || m.ld_inner % 4 == 0) && (batch_stride % 4 == 0);
     return (aligned && ld_ok && contiguous_extent >= 4 && contiguous_extent % 4 == 0) ? 1 : 0;
@@ -568,8 +567,8 @@ extern "C" int twog_gemm_f32(const twog_gemm_t* problems, int n_problems, int a_
             }
             g.cls_ntiles[g.n_cls - 1] += ntiles;
             t += ntiles;
-            P.a_vec = vec_ok(P.A, q.a_batch_stride, a_kmajor ? P.M : P.K);
-            P.b_vec = vec_ok(P.B, q.b_batch_stride, b_kmajor ? P.N : P.K);
+            P.a_vec = vec_ok(P.A, q.a_batch_stride, a_kmajor ? P.M : P.K, a_kmajor ? P.K : P.M);
+            P.b_vec = vec_ok(P.B, q.b_batch_stride, b_kmajor ? P.N : P.K, b_kmajor ? P.K : P.N);
         }
         for (int c = 0, rot = 0; c < g.n_cls; ++c) {
             g.cls_rot[c] = rot & 7;
