@@ -295,17 +295,19 @@ __device__ __forceinline__ void gemm_mainloop(const twog_rows_t A, const twog_ro
         gload(ra1, rb1, min(k_begin + BK, k_last));
         sstore(ra0, rb0, 0);
         __syncthreads();
-        for (int kt = 0; kt < nkt; kt += 2) {
+        // whole pairs of k-tiles in the loop (no exit in the middle of the body: the accumulators keep one register
+        // assignment), a possible odd last tile after it -- it already sits in LDS buffer 0
+        for (int kt = 0; kt + 1 < nkt; kt += 2) {
             gload(ra0, rb0, min(k_begin + (kt + 2) * BK, k_last));
             compute(0);
             sstore(ra1, rb1, 1);
             __syncthreads();
-            if (kt + 1 >= nkt) break;
             gload(ra1, rb1, min(k_begin + (kt + 3) * BK, k_last));
             compute(1);
             sstore(ra0, rb0, 0);
             __syncthreads();
         }
+        if (nkt & 1) compute(0);
     }
 }
 
