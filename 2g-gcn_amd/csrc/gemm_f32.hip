@@ -246,6 +246,12 @@ __device__ __forceinline__ void gemm_mainloop(const twog_rows_t A, const twog_ro
             }
         }
     };
+    // single-accumulator waves (64x64 class): a second accumulator takes the odd k-steps, so consecutive MFMAs never
+    // wait on each other's result; the two are summed once after the reduction loop
+    constexpr bool SPLIT_ACC = (TM * TN == 1);
+    f32x16 acc_odd;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc_odd[r] = 0.f;
     // the fragments of chunk kk+1 are read from LDS while the MFMAs of chunk kk run (two register sets)
     auto compute = [&](int buf) {
         const float* a_s = smem + buf * STAGE;
@@ -260,8 +266,18 @@ __device__ __forceinline__ void gemm_mainloop(const twog_rows_t A, const twog_ro
 #pragma unroll
                 for (int a = 0; a < TM; ++a)
 #pragma unroll
-                    for (int b = 0; b < TN; ++b)
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk & 1][a][r], bf[kk & 1][b][r], acc[a][b], 0, 0, 0);
+                    for (int b = 0; b < TN; ++b) {
+                        if (SPLIT_ACC && (r & 1))
+                            acc_odd = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk & 1][a][r], bf[kk & 1][b][r], acc_odd, 0, 0, 0);
+                        else
+                            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk & 1][a][r], bf[kk & 1][b][r], acc[a][b], 0, 0, 0);
+                    }
+        }
+    };
+    auto fold = [&]() {
+        if constexpr (SPLIT_ACC) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[0][0][r] += acc_odd[r];
         }
     };
 
@@ -285,6 +301,7 @@ __device__ __forceinline__ void gemm_mainloop(const twog_rows_t A, const twog_ro
             if (FAST || kt + 1 < nkt) sstore(ra0, rb0, buf ^ 1);
             __syncthreads();
         }
+        fold();
     } else {
         // prefetch distance 2 (two register stages): the loads of tile t+2 are issued before the MFMAs of tile t and are
         // consumed a whole iteration later, so short-k-tile kernels (64x64 tiles: 16 MFMAs per wave per k-tile) still
@@ -308,6 +325,7 @@ __device__ __forceinline__ void gemm_mainloop(const twog_rows_t A, const twog_ro
             __syncthreads();
         }
         if (nkt & 1) compute(0);
+        fold();
     }
 }
 
