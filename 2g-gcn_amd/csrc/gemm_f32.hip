@@ -485,6 +485,24 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const Group g) {
     const int m0 = tm_idx * BM, n0 = tn_idx * BN;
     // grid.y slices the tile so that small-output / deep-split problems still spread over the chip
     const int chunk = (BM * BN) / gridDim.y;
+    // 16-byte path: four columns per lane when the output rows allow it (whole column quads inside N, aligned rows)
+    const bool vec = (P.N % 4 == 0) && (reinterpret_cast<uintptr_t>(C.ptr) % 16 == 0) && (C.ld_outer % 4 == 0) &&
+                     (C.inner <= 1 || C.ld_inner % 4 == 0) && (!P.bias || reinterpret_cast<uintptr_t>(P.bias) % 16 == 0);
+    if (vec) {
+        for (int e = blockIdx.y * chunk + threadIdx.x * 4; e < (blockIdx.y + 1) * chunk; e += 1024) {
+            const int row = e / BN, col = e - row * BN;
+            if (m0 + row >= P.M || n0 + col >= P.N) continue;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            for (int s = 0; s < g.splitk; ++s)
+                v += *reinterpret_cast<const f32x4*>(g.slabs + ((int64_t)s * g.total_tiles + bid) * (BM * BN) + e);
+            float* c = C.ptr + twog_row_off(C, m0 + row) + n0 + col;
+            if (P.bias) v += *reinterpret_cast<const f32x4*>(P.bias + n0 + col);
+            if (P.accumulate) v += *reinterpret_cast<const f32x4*>(c);
+            if (P.act == 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            *reinterpret_cast<f32x4*>(c) = v;
+        }
+        return;
+    }
     for (int e = blockIdx.y * chunk + threadIdx.x; e < (blockIdx.y + 1) * chunk; e += 256) {
         const int row = e / BN, col = e - row * BN;
         if (m0 + row >= P.M || n0 + col >= P.N) continue;
