@@ -73,12 +73,15 @@ __global__ __launch_bounds__(256) void lsm_permute_bwd_kernel(const float* out, 
 // reorder_hidden_states (vhoi/models.py:1567-1586): one block per (clip, entity); idx[t] = first end frame >= t
 __global__ __launch_bounds__(256) void reorder_kernel(const float* src, const float* gate, float* dst, int T, int E,
                                                       int cols, int backward) {
-    extern __shared__ int idx[];
+    extern __shared__ int idx[];  // [T] end-frame index, preceded in time by the staged gate flags
     const int b = blockIdx.x / E, e = blockIdx.x - b * E;
+    // all gate values of this (clip, entity) in one parallel load, then a serial suffix scan over LDS
+    for (int t = threadIdx.x; t < T; t += blockDim.x) idx[t] = gate[((int64_t)b * T + t) * E + e] != 0.f ? 1 : 0;
+    __syncthreads();
     if (threadIdx.x == 0) {
         int nxt = -1;
         for (int t = T - 1; t >= 0; --t) {
-            if (gate[((int64_t)b * T + t) * E + e] != 0.f) nxt = t;
+            if (idx[t]) nxt = t;
             idx[t] = nxt >= 0 ? nxt : t;
         }
     }
@@ -87,9 +90,17 @@ __global__ __launch_bounds__(256) void reorder_kernel(const float* src, const fl
     const float* s = src + ((int64_t)b * T * E + e) * cols;
     float* d = dst + ((int64_t)b * T * E + e) * cols;
     if (!backward) {
-        for (int i = threadIdx.x; i < T * cols; i += blockDim.x) {
-            const int t = i / cols, c = i - t * cols;
-            d[t * rs + c] = s[idx[t] * rs + c];
+        if ((cols & 3) == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0 && (reinterpret_cast<uintptr_t>(dst) & 15) == 0) {
+            const int c4 = cols >> 2;
+            for (int i = threadIdx.x; i < T * c4; i += blockDim.x) {
+                const int t = i / c4, c = (i - t * c4) * 4;
+                *reinterpret_cast<float4*>(d + t * rs + c) = *reinterpret_cast<const float4*>(s + idx[t] * rs + c);
+            }
+        } else {
+            for (int i = threadIdx.x; i < T * cols; i += blockDim.x) {
+                const int t = i / cols, c = i - t * cols;
+                d[t * rs + c] = s[idx[t] * rs + c];
+            }
         }
     } else {
         // dhx[s] = sum of dout[t] over the frames t mapped to s (a contiguous run ending at s)
