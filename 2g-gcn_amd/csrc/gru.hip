@@ -36,6 +36,7 @@ __global__ __launch_bounds__(256) void gru_step_fwd_kernel(const FwdGroup g) {
     float* ho = twog_row_ptr(S.h_out, r);
     float* sv = S.save.ptr ? twog_row_ptr(S.save, r) : nullptr;
     const float uu = gate_u(S.u, S.u_ld_outer, S.u_ld_inner, S.u_inner, r);
+#pragma unroll 2
     for (int j = threadIdx.x; j < H; j += blockDim.x) {
         float ir = gi[j], iz = gi[H + j], in_ = gi[2 * H + j];
         if (gi2) {
@@ -74,6 +75,7 @@ __global__ __launch_bounds__(256) void gru_step_bwd_kernel(const BwdGroup g) {
     float* dhp = twog_row_ptr(S.dh_prev, r);
     const float uu = gate_u(S.u, S.u_ld_outer, S.u_ld_inner, S.u_inner, r);
     float du = 0.f;
+#pragma unroll 2
     for (int j = threadIdx.x; j < H; j += blockDim.x) {
         float d = dh[j];
         if (dh2) d += dh2[j];
