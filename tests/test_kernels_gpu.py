@@ -137,7 +137,7 @@ def test_gemm_grouped_batched_splitk(K):
 
 
 # ----------------------------------------------------------------------------------------------------------------- GCN
-@pytest.mark.parametrize('N', [19, 34])
+@pytest.mark.parametrize('N', [1, 16, 19, 34, 50, 64])   # 50 / 64: the backward kernel's reduced-LDS path (no M copy)
 def test_gcn_kernels(K, N):
     bs, T, H = 3, 6, 2
     xh = rnd(bs, T, H, 2048 + 4 * N)
