@@ -49,6 +49,20 @@ CFG = dict(hidden_size=512, gcn_node=34, attention_style='v3', bias=True, discre
            message_granularity='v1', message_aggregation='att', object_segment_update_strategy='ind',
            update_segment_threshold=0.5)  # conf/models/2G-GCN_stage1.yaml:5-29 with gcn_node=34
 T, H, O, N_NODES, BS, N_CLASSES = 120, 2, 8, 34, 64, 13
+# the other single-GPU shapes of BASELINE.json.configs, selectable with --workload (informational: NOT the headline metric)
+WORKLOADS = {
+    'c3': dict(H=2, O=8, N=34, h=512, bs=64, classes=13, name='Synthetic T=120 N=34 C=512 (BASELINE configs[2])'),
+    'c2': dict(H=2, O=4, N=26, h=512, bs=8, classes=13, name='MPHOI-72 layout hs512 bs8 (BASELINE configs[1])'),
+    'c5': dict(H=2, O=9, N=30, h=64, bs=16, classes=14, name='Bimanual layout h=64, 16 clips per GPU (BASELINE configs[4])'),
+}
+
+
+def select_workload(name):
+    global H, O, N_NODES, BS, N_CLASSES
+    w = WORKLOADS[name]
+    H, O, N_NODES, BS, N_CLASSES = w['H'], w['O'], w['N'], w['bs'], w['classes']
+    CFG['hidden_size'], CFG['gcn_node'] = w['h'], w['N']
+    return w
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 FLOP/clk/CU
 PEAK_HBM_GBS = 8000.0
 
@@ -157,16 +171,16 @@ def cpu_baseline(sample_frames=12, sample_clips=8):
     dt = time.perf_counter() - t0
     clips = nb * Ts / T
     return dict(value=clips / dt, unit='clips/s', cores=cores, kind='port',
-                sample=f'{nb} clips (reference batch size) x first {Ts} of {T} frames (H=2,O=8,N=34,h=512), one '
+                sample=f'{nb} clips (reference batch size) x first {Ts} of {T} frames (H={H},O={O},N={N_NODES},h={CFG["hidden_size"]}), one '
                        f'forward+backward in {dt:.1f} s, scaled linearly in frames',
                 forward_clips_per_s=clips / t_fwd)
 
 
-def cpu_baseline_in_child(timeout_s=240):
+def cpu_baseline_in_child(workload='c3', timeout_s=240):
     """Runs the CPU leg in a child process (bounded by a timeout) so it can never take the bench line down."""
     import subprocess
     try:
-        r = subprocess.run([sys.executable, os.path.abspath(__file__), '--cpu-baseline-only'], capture_output=True,
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), '--cpu-baseline-only', '--workload', workload], capture_output=True,
                            text=True, timeout=timeout_s, env=dict(os.environ, HIP_VISIBLE_DEVICES='', CUDA_VISIBLE_DEVICES=''))
         for line in reversed(r.stdout.strip().splitlines()):
             if line.startswith('{'):
@@ -185,11 +199,16 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--batch', type=int, default=BS, help='clips per GPU per step')
+    ap.add_argument('--batch', type=int, default=None, help='clips per GPU per step (default: the workload\'s)')
+    ap.add_argument('--workload', choices=sorted(WORKLOADS), default='c3',
+                    help='c3 = the headline configuration; c2 / c5 = the other single-GPU shapes (informational)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-baseline-only', action='store_true', help=argparse.SUPPRESS)
     ap.add_argument('--forward-only', action='store_true', help='additionally report forward-only clips/s')
     args = ap.parse_args()
+    wl = select_workload(args.workload)
+    if args.batch is None:
+        args.batch = BS
     if args.cpu_baseline_only:
         print(json.dumps(cpu_baseline()), flush=True)
         return
@@ -310,11 +329,11 @@ def main():
             tj = json.load(open(tpath))
             traffic, traffic_src = tj['hbm_bytes_per_launch'], 'profiles/r01_gemm128_hbm_traffic.json: ' + tj['source']
         result = {
-            'metric': 'clips/sec fwd+bwd, T=120 N=34 C=512', 'value': bs * world * args.steps / dt, 'unit': 'clips/s',
+            'metric': 'clips/sec fwd+bwd, T=120 N=34 C=512' if args.workload == 'c3' else f'clips/sec fwd+bwd, {wl["name"]} (informational)', 'value': bs * world * args.steps / dt, 'unit': 'clips/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'fp32', 'data': 'synthetic',
-            'config': {'workload': f'Synthetic T=120 N=34 C=512 bs{bs} per GPU (BASELINE configs[2]; H=2, O=8, '
-                                   f'classes 13, 2G-GCN_stage1 parameters)',
+            'config': {'workload': f'{wl["name"]}: bs{bs} per GPU, T={T}, H={H}, O={O}, N={N_NODES}, h={CFG["hidden_size"]}, '
+                                   f'classes {N_CLASSES}, 2G-GCN_stage1 parameters',
                        'global_batch': bs * world, 'per_gpu_batch': bs, 'parallelism': f'dp{world}',
                        'step': 'forward + multi-task loss (fused HIP criterion) + backward + gradient all-reduce + fused Adam',
                        'loss_last': float(loss.detach())},
@@ -341,7 +360,7 @@ def main():
             result['forward_only_clips_per_s'] = fwd_only
         if world == 1 and not args.no_cpu_baseline:
             log('cpu baseline ...')
-            result['cpu_baseline'] = cpu_baseline_in_child()
+            result['cpu_baseline'] = cpu_baseline_in_child(args.workload)
             log('cpu baseline done')
         print(json.dumps(result), flush=True)
     if world > 1:
