@@ -1,0 +1,80 @@
+// hipGraph cache for the launch-bound time loops (frame-level BiGRU and segment-level recurrence, forward and
+// backward: 240-720 dependent launches per call).
+//
+// The loops are enqueued by host code in this library; at small batch the kernels are shorter than the host's launch
+// cost and the step becomes host-bound. A loop is therefore captured once into a hipGraph (stream capture of exactly the
+// launches the loop issues) and replayed with one hipGraphLaunch while its descriptor -- every pointer, shape and stride,
+// hashed -- stays the same, which is the steady state of a training loop under a caching allocator. A changed descriptor
+// is a different key (re-capture); the cache is small and flushed when full. TWOG_NO_GRAPHS=1 turns it off.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <unordered_map>
+
+namespace twog_graph {
+
+inline uint64_t fnv1a(const void* data, size_t n, uint64_t h = 1469598103934665603ull) {
+    const unsigned char* p = static_cast<const unsigned char*>(data);
+    for (size_t i = 0; i < n; ++i) { h ^= p[i]; h *= 1099511628211ull; }
+    return h;
+}
+
+struct Entry { hipGraphExec_t exec; int uses; };
+
+// enqueue(stream): issues the loop's launches on `stream`, returns 0 on success. key: hash of everything it reads.
+// Graphs are captured and replayed on a stream owned by the library (the caller's stream may be the legacy default
+// stream, which cannot be captured), fenced against the caller's stream with two events.
+template <class F>
+int run(uint64_t key, hipStream_t user, F enqueue) {
+    static const bool off = getenv("TWOG_NO_GRAPHS") != nullptr;
+    static std::unordered_map<uint64_t, Entry> cache;
+    static std::unordered_map<uint64_t, int> seen;  // a key is captured the second time it shows up
+    static hipStream_t side = nullptr;
+    static hipEvent_t ev_in = nullptr, ev_out = nullptr;
+    if (off) return enqueue(user);
+    if (!side) {
+        if (hipStreamCreateWithFlags(&side, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&ev_in, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&ev_out, hipEventDisableTiming) != hipSuccess) {
+            (void)hipGetLastError();
+            side = nullptr;
+            return enqueue(user);
+        }
+    }
+    auto it = cache.find(key);
+    if (it == cache.end()) {
+        if (seen[key]++ == 0) {
+            if (seen.size() > 256) seen.clear();
+            return enqueue(user);  // first sighting (also covers lazy one-time setup inside the launch paths)
+        }
+        hipGraph_t graph = nullptr;
+        if (hipStreamBeginCapture(side, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+            (void)hipGetLastError();
+            return enqueue(user);
+        }
+        const int rc = enqueue(side);
+        const hipError_t ec = hipStreamEndCapture(side, &graph);
+        hipGraphExec_t exec = nullptr;
+        if (rc != 0 || ec != hipSuccess || !graph ||
+            hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess || !exec) {
+            (void)hipGetLastError();
+            if (graph) (void)hipGraphDestroy(graph);
+            return rc != 0 ? rc : enqueue(user);  // nothing ran during the capture: issue the launches directly
+        }
+        (void)hipGraphDestroy(graph);
+        if (cache.size() >= 32) {
+            for (auto& kv : cache) (void)hipGraphExecDestroy(kv.second.exec);
+            cache.clear();
+        }
+        it = cache.emplace(key, Entry{exec, 0}).first;
+    }
+    ++it->second.uses;
+    if (hipEventRecord(ev_in, user) != hipSuccess || hipStreamWaitEvent(side, ev_in, 0) != hipSuccess) return -101;
+    if (hipGraphLaunch(it->second.exec, side) != hipSuccess) return -100;
+    if (hipEventRecord(ev_out, side) != hipSuccess || hipStreamWaitEvent(user, ev_out, 0) != hipSuccess) return -102;
+    return 0;
+}
+
+}  // namespace twog_graph

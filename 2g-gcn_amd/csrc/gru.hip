@@ -10,6 +10,7 @@
 // launch -- followed by one fused gate kernel (one workgroup per row, lane-contiguous along the hidden dimension).
 // r, z, n and W_hn h are saved for the backward pass, which walks the chain in reverse with the transposed GEMM.
 #include "twog_common.h"
+#include "graph_cache.h"
 
 namespace {
 
@@ -175,7 +176,7 @@ extern "C" int twog_gru_step_bwd(const twog_gru_step_bwd_t* steps, int n_steps, 
 // ---------------------------------------------------------------------------------------------------------------
 // Frame-level BiGRU recurrence for up to 4 entity types at once (humans, objects, geometry).
 // ---------------------------------------------------------------------------------------------------------------
-extern "C" int twog_bigru_fwd(const twog_bigru_t* types, int n_types, int bs, int T, int hidden, void* stream) {
+static int bigru_fwd_impl(const twog_bigru_t* types, int n_types, int bs, int T, int hidden, void* stream) {
     if (n_types > 4) return -1;
     const int h = hidden;
     for (int s = 0; s < T; ++s) {
@@ -221,7 +222,7 @@ extern "C" int twog_bigru_fwd(const twog_bigru_t* types, int n_types, int bs, in
 
 // Backward through time. d_out: gradient wrt `out` [bs][T][E][2h]; writes d_gi [bs][T][E][6h] and
 // d_gh [bs][T][E][6h] (the caller turns them into dX / dW_ih / dW_hh / biases with large GEMMs).
-extern "C" int twog_bigru_bwd(const twog_bigru_bwd_t* types, int n_types, int bs, int T, int hidden, void* stream) {
+static int bigru_bwd_impl(const twog_bigru_bwd_t* types, int n_types, int bs, int T, int hidden, void* stream) {
     if (n_types > 4) return -1;
     const int h = hidden;
     for (int s = T - 1; s >= 0; --s) {
@@ -267,4 +268,22 @@ extern "C" int twog_bigru_bwd(const twog_bigru_bwd_t* types, int n_types, int bs
         }
     }
     return 0;
+}
+
+extern "C" int twog_bigru_fwd(const twog_bigru_t* types, int n_types, int bs, int T, int hidden, void* stream) {
+    if (n_types > 4 || n_types < 0) return -1;
+    uint64_t key = twog_graph::fnv1a(types, sizeof(twog_bigru_t) * n_types);
+    const int dims[4] = {n_types, bs, T, hidden};
+    key = twog_graph::fnv1a(dims, sizeof(dims), key ^ 0x11);
+    return twog_graph::run(key, (hipStream_t)stream,
+                           [&](hipStream_t st) { return bigru_fwd_impl(types, n_types, bs, T, hidden, st); });
+}
+
+extern "C" int twog_bigru_bwd(const twog_bigru_bwd_t* types, int n_types, int bs, int T, int hidden, void* stream) {
+    if (n_types > 4 || n_types < 0) return -1;
+    uint64_t key = twog_graph::fnv1a(types, sizeof(twog_bigru_bwd_t) * n_types);
+    const int dims[4] = {n_types, bs, T, hidden};
+    key = twog_graph::fnv1a(dims, sizeof(dims), key ^ 0x22);
+    return twog_graph::run(key, (hipStream_t)stream,
+                           [&](hipStream_t st) { return bigru_bwd_impl(types, n_types, bs, T, hidden, st); });
 }

@@ -15,6 +15,7 @@
 // Everything the backward pass needs (gate activations, sender messages, aggregated messages, attention weights) is
 // written once into (clip, time, entity)-ordered buffers so the weight gradients become large GEMMs after the loop.
 #include "twog_common.h"
+#include "graph_cache.h"
 
 namespace {
 
@@ -82,7 +83,7 @@ inline void fill_attn(twog_attn_t& A, const twog_segrnn_t& S, const Dims& d, int
 
 }  // namespace
 
-extern "C" int twog_segrnn_fwd(const twog_segrnn_t* desc, void* stream) {
+static int segrnn_fwd_impl(const twog_segrnn_t* desc, void* stream) {
     const twog_segrnn_t& S = *desc;
     const Dims d = dims_of(S);
     const int h = d.h, T = d.T;
@@ -168,7 +169,7 @@ extern "C" int twog_segrnn_fwd(const twog_segrnn_t* desc, void* stream) {
     return 0;
 }
 
-extern "C" int twog_segrnn_bwd(const twog_segrnn_t* desc, const twog_segrnn_bwd_t* bdesc, void* stream) {
+static int segrnn_bwd_impl(const twog_segrnn_t* desc, const twog_segrnn_bwd_t* bdesc, void* stream) {
     const twog_segrnn_t& S = *desc;
     const twog_segrnn_bwd_t& B = *bdesc;
     const Dims d = dims_of(S);
@@ -288,4 +289,15 @@ extern "C" int twog_segrnn_bwd(const twog_segrnn_t* desc, const twog_segrnn_bwd_
         if (rc) return rc;
     }
     return 0;
+}
+
+extern "C" int twog_segrnn_fwd(const twog_segrnn_t* desc, void* stream) {
+    const uint64_t key = twog_graph::fnv1a(desc, sizeof(*desc)) ^ 0x33;
+    return twog_graph::run(key, (hipStream_t)stream, [&](hipStream_t st) { return segrnn_fwd_impl(desc, st); });
+}
+
+extern "C" int twog_segrnn_bwd(const twog_segrnn_t* desc, const twog_segrnn_bwd_t* bdesc, void* stream) {
+    const uint64_t key = twog_graph::fnv1a(bdesc, sizeof(*bdesc), twog_graph::fnv1a(desc, sizeof(*desc))) ^ 0x44;
+    return twog_graph::run(key, (hipStream_t)stream,
+                           [&](hipStream_t st) { return segrnn_bwd_impl(desc, bdesc, st); });
 }
