@@ -63,10 +63,24 @@ class DataParallel:
     """model + flat buffers + gradient all-reduce. Usage per step:
         dp.zero_grad(); loss = f(dp.model(...)); loss.backward(); dp.all_reduce_gradients(); opt.step(dp.grad_scale)"""
 
-    def __init__(self, model: torch.nn.Module, process_group=None, bucket_mb: int = 64, broadcast: bool = True):
+    def __init__(self, model: torch.nn.Module, process_group=None, bucket_mb: int = 64, broadcast: bool = True,
+                 sync_bn: bool = False, global_noise_seed: int = None):
+        """sync_bn: the geometric-level BatchNorm uses the statistics of the GLOBAL batch (one all-reduce of 2*4N fp64
+        sums per step). global_noise_seed: every rank draws the Gumbel noise of the global batch from a
+        generator seeded with this value and keeps its shard (8e (c)). With both (and equal shard sizes) W ranks compute
+        what one process computes on the whole batch; the throughput default keeps them off (standard DDP semantics)."""
         self.model = model
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
+        rank = dist.get_rank(process_group) if self.world > 1 else 0
+        if sync_bn:
+            def reduce_stats(sums, n_frames, world=self.world, group=process_group):
+                if world > 1:
+                    dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
+                return sums, n_frames * world
+            model._bn_stats_reduce = reduce_stats
+        if global_noise_seed is not None:
+            model._noise_shard = (rank, self.world, torch.Generator().manual_seed(int(global_noise_seed)))
         self.flat = FlatParameters(model)
         self.bucket = max(1, bucket_mb) * (1 << 20) // 4
         if self.world > 1 and broadcast:

@@ -132,7 +132,10 @@ class HipKernels:
         bs, T, H, Fh = x_human.shape
         return x_human.data_ptr() + 2048 * 4, H * Fh, bs * T
 
-    def bn_fold(self, x_human, n_nodes, gamma, beta, running_mean, running_var, num_batches_tracked, training):
+    def bn_fold(self, x_human, n_nodes, gamma, beta, running_mean, running_var, num_batches_tracked, training,
+                stats_reduce=None):
+        """stats_reduce (optional, sync-BN of distributed.DataParallel): callable (sums fp64 [2*4N], n_frames) ->
+        (sums reduced over the ranks, total frames); applied to the batch statistics before they are folded."""
         ptr, fstride, nf = self._geo(x_human)
         nch = 4 * n_nodes
         ab = torch.empty(2, nch, dtype=torch.float32, device=x_human.device)
@@ -142,6 +145,9 @@ class HipKernels:
         if training:
             self._check(self.lib.twog_bn_stats(ptr, fstride, nf, n_nodes, partials.data_ptr(), nblk, self._stream()),
                         'twog_bn_stats')
+            if stats_reduce is not None:
+                partials, nf = stats_reduce(partials.view(nblk, 2 * nch).sum(0), nf)
+                partials, nblk = partials.contiguous(), 1
         self._check(self.lib.twog_bn_finalize(partials.data_ptr(), nblk, nf, n_nodes, gamma.data_ptr(),
                                               beta.data_ptr(), running_mean.data_ptr(), running_var.data_ptr(),
                                               _ptr(num_batches_tracked), int(training), ab.data_ptr(), mi.data_ptr(),

@@ -277,6 +277,12 @@ class TGGCN(nn.Module):
         if plan.gs and n_gated:
             if self._gumbel_noise_override is not None:
                 noise = self._gumbel_noise_override
+            elif getattr(self, '_noise_shard', None) is not None:
+                # data-parallel equivalence mode (distributed.DataParallel(global_noise=True)): every rank draws the noise
+                # of the GLOBAL batch from an identically seeded generator and keeps its own clips
+                rank, world, gen = self._noise_shard
+                u = torch.rand(T * n_gated, world * bs, 2, generator=gen).clamp_(1e-10, 1.0 - 1e-7)
+                noise = (-torch.log(-torch.log(u)))[:, rank * bs:(rank + 1) * bs]
             else:
                 # drawn on the CPU default generator like the reference (pyrutils/torch/distributions.py:16);
                 # one (T*n_gated, bs, 2) draw equals the reference's T*n_gated sequential (bs, 2) draws
@@ -288,7 +294,7 @@ class TGGCN(nn.Module):
         params = [sd[n] for n in names]
         bn = self.geometry_embedding_gcn.joint_embed.cnn[0].bn
         bn_bufs = dict(running_mean=bn.running_mean, running_var=bn.running_var,
-                       num_batches_tracked=bn.num_batches_tracked)
+                       num_batches_tracked=bn.num_batches_tracked, stats_reduce=getattr(self, '_bn_stats_reduce', None))
         hs = human_segmentation.float() if human_segmentation is not None else None
         osg = objects_segmentation.float() if objects_segmentation is not None else None
         out = ops.TGGCNFunction.apply(plan, names, self.training, bn_bufs, x_human, x_objects, objects_mask, hs, osg,

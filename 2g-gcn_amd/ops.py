@@ -190,7 +190,8 @@ def geo_gcn_forward(K, P, x_human, bs, T, N, training, bn_bufs, S):
 
     g = 'geometry_embedding_gcn.'
     ab, mi = K.bn_fold(x_human, N, P[g + 'joint_embed.cnn.0.bn.weight'], P[g + 'joint_embed.cnn.0.bn.bias'],
-                       bn_bufs['running_mean'], bn_bufs['running_var'], bn_bufs['num_batches_tracked'], training)
+                       bn_bufs['running_mean'], bn_bufs['running_var'], bn_bufs['num_batches_tracked'], training,
+                       stats_reduce=bn_bufs.get('stats_reduce'))
     w1 = P[g + 'joint_embed.cnn.1.cnn.weight'].view(64, 4)
     e1 = K.gcn_embed1_fwd(x_human, N, ab, w1, P[g + 'joint_embed.cnn.1.cnn.bias'])
     w2 = P[g + 'joint_embed.cnn.3.cnn.weight'].view(64, 64)

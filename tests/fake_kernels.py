@@ -60,14 +60,18 @@ class FakeKernels:
         bs, T = x_human.shape[:2]
         return x_human[:, :, 0, 2048:].reshape(bs * T, N, 4)
 
-    def bn_fold(self, x_human, n_nodes, gamma, beta, running_mean, running_var, num_batches_tracked, training):
+    def bn_fold(self, x_human, n_nodes, gamma, beta, running_mean, running_var, num_batches_tracked, training,
+                stats_reduce=None):
         N = n_nodes
         x = self._geo(x_human, N).double()  # (F, N, 4)
         xc = x.permute(2, 1, 0).reshape(4 * N, -1)  # channel c*N+n
         nf = xc.shape[1]
         if training:
-            mean = xc.mean(1)
-            var = (xc * xc).mean(1) - mean * mean
+            sums = torch.cat([xc.sum(1), (xc * xc).sum(1)])
+            if stats_reduce is not None:
+                sums, nf = stats_reduce(sums, nf)
+            mean = sums[:4 * N] / nf
+            var = sums[4 * N:] / nf - mean * mean
             running_mean.mul_(0.9).add_(0.1 * mean.float())
             running_var.mul_(0.9).add_(0.1 * (var * nf / max(nf - 1, 1)).float())
             if num_batches_tracked is not None:

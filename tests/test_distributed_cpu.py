@@ -91,3 +91,59 @@ def test_two_rank_data_parallel_matches_single_process():
         assert not torch.equal(ret[0][2], ret[0][0])  # the fused Adam step moved the parameters
     finally:
         kernels._set_backend_for_tests(None)
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# exact equivalence mode: train-mode BatchNorm over the GLOBAL batch + global Gumbel noise
+def _loss_train(model, xh, xo, mask, tgt):
+    model.train()
+    out = model(xh, xo, mask)   # learned gates: Gumbel noise is drawn inside forward
+    return torch.nn.functional.nll_loss(out[4], tgt) + torch.nn.functional.nll_loss(out[5], tgt)
+
+
+def _worker_sync(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import twog_gcn_amd  # noqa: F401
+    from twog_gcn_amd import kernels
+    from twog_gcn_amd.distributed import DataParallel
+    from tests.fake_kernels import FakeKernels
+    kernels._set_backend_for_tests(FakeKernels())
+    torch.set_num_threads(2)
+    model = _tiny_model(seed=0)
+    dp = DataParallel(model, bucket_mb=1, sync_bn=True, global_noise_seed=77)
+    xh, xo, mask, tgt, _ = _batch(4)
+    sl = slice(rank * 2, rank * 2 + 2)
+    dp.zero_grad()
+    _loss_train(model, xh[sl], xo[sl], mask[sl], tgt[sl]).backward()
+    dp.all_reduce_gradients()
+    bn = model.geometry_embedding_gcn.joint_embed.cnn[0].bn
+    ret[rank] = (dp.flat.grad.clone() * dp.grad_scale, bn.running_mean.clone(), bn.running_var.clone())
+    dist.destroy_process_group()
+
+
+def test_sync_bn_and_global_noise_reproduce_the_full_batch_step():
+    import twog_gcn_amd  # noqa: F401
+    from twog_gcn_amd import kernels
+    from twog_gcn_amd.distributed import DataParallel
+    from tests.fake_kernels import FakeKernels
+    port = 31500 + os.getpid() % 2000
+    ret = mp.Manager().dict()
+    mp.spawn(_worker_sync, args=(2, port, ret), nprocs=2, join=True)
+    kernels._set_backend_for_tests(FakeKernels())
+    try:
+        model = _tiny_model(seed=0)
+        dp = DataParallel(model, sync_bn=True, global_noise_seed=77)   # world 1: same global noise, plain batch stats
+        xh, xo, mask, tgt, _ = _batch(4)
+        dp.zero_grad()
+        _loss_train(model, xh, xo, mask, tgt).backward()
+        ref = dp.flat.grad
+        bn = model.geometry_embedding_gcn.joint_embed.cnn[0].bn
+        for r in (0, 1):
+            err = (ret[r][0] - ref).abs().max().item()
+            assert err < 2e-5 * max(1.0, ref.abs().max().item()), (r, err)
+            assert torch.allclose(ret[r][1], bn.running_mean, rtol=1e-5, atol=1e-7)
+            assert torch.allclose(ret[r][2], bn.running_var, rtol=1e-5, atol=1e-7)
+    finally:
+        kernels._set_backend_for_tests(None)

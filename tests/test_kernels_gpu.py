@@ -408,3 +408,25 @@ def test_gates_filter_reorder_heads(K, gs):
         ref.grad = g0.clone()
         opt.step()
     close(pg, ref.data, rtol=1e-5, atol=1e-6, what='adam vs torch.optim.Adam')
+
+
+def test_bn_fold_with_stats_reduce_hook(K):
+    """sync-BN hook of distributed.DataParallel: reducing the (already complete) sums of one rank changes nothing, and
+    doubling sums and frame count (two identical ranks) gives the same statistics."""
+    N, bs, T, H = 26, 3, 5, 2
+    xh = rnd(bs, T, H, 2048 + 4 * N).to(DEV)
+    gamma, beta = (rnd(4 * N, seed=1).abs() + 0.5).to(DEV), rnd(4 * N, seed=2).to(DEV)
+
+    def run(hook):
+        rm, rv = torch.zeros(4 * N, device=DEV), torch.ones(4 * N, device=DEV)
+        nbt = torch.tensor(0, dtype=torch.int64, device=DEV)
+        ab, mi = K.bn_fold(xh, N, gamma, beta, rm, rv, nbt, True, stats_reduce=hook)
+        return ab.cpu(), mi.cpu(), rm.cpu(), rv.cpu()
+
+    base = run(None)
+    same = run(lambda s, n: (s, n))
+    two = run(lambda s, n: (s * 2, n * 2))
+    for a, b in zip(base, same):
+        close(b, a, rtol=1e-6, atol=1e-7, what='identity hook')
+    for a, b in zip(base[:3], two[:3]):
+        close(b, a, rtol=1e-6, atol=1e-7, what='two identical ranks')
