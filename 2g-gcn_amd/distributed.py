@@ -19,8 +19,13 @@ from .kernels import get_kernels
 class FlatParameters:
     """Re-homes every parameter of `module` as a view into one flat buffer; same for the gradients."""
 
-    def __init__(self, module: torch.nn.Module):
-        params = [p for p in module.parameters()]
+    def __init__(self, module: torch.nn.Module, stage_of=None):
+        """stage_of (optional): name -> int; parameters are laid out by ascending stage (stable), and
+        `stage_ranges[stage] = (begin, end)` gives each stage's slice of the flat buffers."""
+        named = list(module.named_parameters())
+        if stage_of is not None:
+            named.sort(key=lambda kv: stage_of(kv[0]))
+        params = [p for _, p in named]
         dev = params[0].device
         sizes = [(p.numel() + 3) // 4 * 4 for p in params]  # keep every view 16-byte aligned for the kernels
         total = sum(sizes)
@@ -36,6 +41,14 @@ class FlatParameters:
                 off += n
         self.params = params
         self.numel = total
+        self.stage_ranges = {}
+        if stage_of is not None:
+            off = 0
+            for (name, _), n in zip(named, sizes):
+                st = stage_of(name)
+                b, _e = self.stage_ranges.get(st, (off, off))
+                self.stage_ranges[st] = (b, off + n)
+                off += n
 
     def zero_grad(self):
         self.grad.zero_()
@@ -64,7 +77,7 @@ class DataParallel:
         dp.zero_grad(); loss = f(dp.model(...)); loss.backward(); dp.all_reduce_gradients(); opt.step(dp.grad_scale)"""
 
     def __init__(self, model: torch.nn.Module, process_group=None, bucket_mb: int = 64, broadcast: bool = True,
-                 sync_bn: bool = False, global_noise_seed: int = None):
+                 sync_bn: bool = False, global_noise_seed: int = None, overlap: bool = True):
         """sync_bn: the geometric-level BatchNorm uses the statistics of the GLOBAL batch (one all-reduce of 2*4N fp64
         sums per step). global_noise_seed: every rank draws the Gumbel noise of the global batch from a
         generator seeded with this value and keeps its shard (8e (c)). With both (and equal shard sizes) W ranks compute
@@ -73,6 +86,7 @@ class DataParallel:
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
         rank = dist.get_rank(process_group) if self.world > 1 else 0
+        self._works, self._launched = [], set()
         if sync_bn:
             def reduce_stats(sums, n_frames, world=self.world, group=process_group):
                 if world > 1:
@@ -81,8 +95,13 @@ class DataParallel:
             model._bn_stats_reduce = reduce_stats
         if global_noise_seed is not None:
             model._noise_shard = (rank, self.world, torch.Generator().manual_seed(int(global_noise_seed)))
-        self.flat = FlatParameters(model)
+        # gradients are laid out in the order the backward pass finishes them (ops.grad_ready_stage), so that each
+        # stage's all-reduce can start from inside the backward pass and overlap with the rest of it
+        from . import ops
+        self.flat = FlatParameters(model, stage_of=ops.grad_ready_stage if overlap else None)
         self.bucket = max(1, bucket_mb) * (1 << 20) // 4
+        if overlap and self.world > 1:
+            ops.set_grad_stage_hook(self._stage_ready)
         if self.world > 1 and broadcast:
             dist.broadcast(self.flat.flat, src=0, group=self.group)
             for b in model.buffers():
@@ -94,18 +113,35 @@ class DataParallel:
 
     def zero_grad(self):
         self.flat.zero_grad()
+        self._works, self._launched = [], set()
+
+    def _reduce_range(self, begin, end):
+        g = self.flat.grad
+        for off in range(begin, end, self.bucket):
+            self._works.append(dist.all_reduce(g[off:min(off + self.bucket, end)], op=dist.ReduceOp.SUM,
+                                               group=self.group, async_op=True))
+
+    def _stage_ready(self, stage):
+        """Called from inside the backward pass (ops.set_grad_stage_hook): every gradient of `stage` is final, start its
+        all-reduce now (a few large chunks; ring collectives over xGMI are per-link bound)."""
+        if stage in self._launched or stage not in self.flat.stage_ranges:
+            return
+        self._launched.add(stage)
+        self._reduce_range(*self.flat.stage_ranges[stage])
 
     def all_reduce_gradients(self):
-        """Sum-all-reduce of the flat gradient buffer in a few large chunks (launched back to back, then waited)."""
+        """Sum-all-reduce of the flat gradient buffer: whatever the backward pass has not started yet is launched here
+        (a few large chunks, back to back), then everything is waited for. One backward pass per call to zero_grad()."""
         if self.world == 1:
             return
-        works = []
-        g = self.flat.grad
-        for off in range(0, g.numel(), self.bucket):
-            works.append(dist.all_reduce(g[off:off + self.bucket], op=dist.ReduceOp.SUM, group=self.group,
-                                         async_op=True))
-        for w in works:
+        if self.flat.stage_ranges:
+            for stage in sorted(self.flat.stage_ranges):
+                self._stage_ready(stage)
+        else:
+            self._reduce_range(0, self.flat.grad.numel())
+        for w in self._works:
             w.wait()
+        self._works = []
 
     def shard(self, tensor, rank=None):
         """This rank's contiguous slice [r*bs/W, (r+1)*bs/W) of a global batch."""

@@ -138,6 +138,34 @@ def used_parameter_names(plan: Plan):
     return out
 
 
+# ---- gradient readiness (data-parallel overlap): the backward pass finishes the parameter gradients in three stages;
+# distributed.DataParallel lays its flat buffer out in this order and starts each stage's all-reduce from the hook
+_GRAD_STAGE_HOOK = None
+
+
+def set_grad_stage_hook(fn):
+    """fn(stage) is called from inside the backward pass as soon as every gradient of `stage` (see grad_ready_stage) is
+    final; None removes the hook."""
+    global _GRAD_STAGE_HOOK
+    _GRAD_STAGE_HOOK = fn
+
+
+def grad_ready_stage(name: str) -> int:
+    """0: label heads, segment-level cells / message MLPs / gate MLPs (final after the segment recurrence backward);
+    1: frame-level message MLPs, BiGRUs and their embeddings; 2: input embeddings and the geometric-level GCN (last)."""
+    if ('_segment_rnn_' in name or name.startswith('update_') or 'recognition_mlp' in name or 'prediction_mlp' in name
+            or any(name.startswith(v) for v in _SEG_MLP.values())):
+        return 0
+    if '_bd_rnn' in name or '_bd_embedding_mlp' in name or any(name.startswith(v) for v in _FRAME_MLP.values()):
+        return 1
+    return 2
+
+
+def _stage_done(stage):
+    if _GRAD_STAGE_HOOK is not None:
+        _GRAD_STAGE_HOOK(stage)
+
+
 class _Grads:
     """Accumulates parameter gradients by name (several stages can contribute to one parameter).
 
@@ -511,6 +539,8 @@ def tggcn_backward(K, plan: Plan, P, S, x_human, x_objects, objects_mask, d_outp
         if (mlp + '.0.bias') in P:
             G.add(mlp + '.0.bias', K.colsum(dlogit.view(-1, 1)))
 
+    _stage_done(0)
+
     # ---- D. frame-level attention + sender MLPs backward
     MSGH, MSGO, MSGS = S['MSGH'], S['MSGO'], S['MSGS']
     dMSGH, dMSGO, dMSGS = empty(*MSGH.shape), empty(*MSGO.shape), empty(*MSGS.shape)
@@ -576,6 +606,8 @@ def tggcn_backward(K, plan: Plan, P, S, x_human, x_objects, objects_mask, d_outp
             G.add(f'{name}_bd_rnn.weight_hh_l0{sfx}', dW_hh)
             G.add(f'{name}_bd_rnn.bias_hh_l0{sfx}', K.colsum(dghv[:, d * 3 * h:(d + 1) * 3 * h]))
             K.gemm([dict(A=dgi_d, B=P[f'{name}_bd_rnn.weight_ih_l0{sfx}'], C=dEv[:, :h], accumulate=True)], b_kmajor=True)
+
+    _stage_done(1)
 
     # ---- B. embeddings backward
     xh_in = x_human.view(nF * H, x_human.shape[-1])[:, :2048]

@@ -123,3 +123,34 @@ def test_in_place_gradient_route_equals_autograd_accumulation(fake_backend):
         scale = float(g.abs().max()) + 1e-12
         assert float((got1[n] - g).abs().max()) <= 1e-6 * scale, n
         assert float((got2[n] - 2 * g).abs().max()) <= 1e-5 * scale, n
+
+
+@pytest.mark.parametrize('case', ['c2_stage1', 'c1_stage2', 'c5_stage1'])
+def test_gradient_stages_are_final_when_the_hook_fires(case, fake_backend):
+    """distributed.DataParallel starts a stage's all-reduce from ops' stage hook: at that moment every gradient of the
+    stage must already have its final value (nothing may be added to it later in the backward pass)."""
+    from twog_gcn_amd import ops
+    from twog_gcn_amd.distributed import FlatParameters
+    z, meta = load_g4(case)
+    m = build_model(meta)
+    m.train()
+    noise = torch.from_numpy(z['gumbel_noise'])
+    m._gumbel_noise_override = noise if len(noise) else None
+    flat = FlatParameters(m, stage_of=ops.grad_ready_stage)
+    assert set(flat.stage_ranges) == {0, 1, 2}
+    assert sum(e - b for b, e in flat.stage_ranges.values()) == flat.numel
+    snaps = {}
+    ops.set_grad_stage_hook(lambda st: snaps.setdefault(st, flat.grad[slice(*flat.stage_ranges[st])].clone()))
+    try:
+        out = m(**g4_inputs(z))
+        sum((o * o).sum() for o in out if o.requires_grad).backward()
+    finally:
+        ops.set_grad_stage_hook(None)
+    assert set(snaps) == {0, 1}
+    for st, snap in snaps.items():
+        final = flat.grad[slice(*flat.stage_ranges[st])]
+        assert torch.equal(snap, final), f'stage {st} gradients changed after the hook'
+        assert float(final.abs().max()) > 0
+    # and the stage-2 block (embeddings, GCN) is what remains
+    b2, e2 = flat.stage_ranges[2]
+    assert float(flat.grad[b2:e2].abs().max()) > 0
