@@ -217,9 +217,17 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     import torch.distributed as dist
+    # TWOG_BENCH_BACKEND=gloo lets several ranks share one GPU (plumbing check of the N > 1 flow on a 1-GPU box);
+    # the measured configuration is always nccl (= RCCL), one rank per GPU
+    backend = os.environ.get('TWOG_BENCH_BACKEND', 'nccl')
+    if backend != 'nccl':
+        local_rank = local_rank % max(1, torch.cuda.device_count())
     if world > 1:
         torch.cuda.set_device(local_rank)
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        else:
+            dist.init_process_group(backend)
     device = torch.device('cuda', local_rank)
     torch.cuda.set_device(device)
 
