@@ -516,7 +516,8 @@ extern "C" int twog_attn_fwd(const twog_attn_t* a, int n, void* stream) {
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT);
         attr_set = true;
     }
-    hipLaunchKernelGGL(attn_fwd_kernel, dim3(maxinst, n, staged ? 2 : 1), dim3(staged ? 1024 : 256), lds, (hipStream_t)stream, g);
+    // throughput regime: 512 threads (the LDS feature tile limits a CU to 3 workgroups: 24 waves instead of 12)
+    hipLaunchKernelGGL(attn_fwd_kernel, dim3(maxinst, n, staged ? 2 : 1), dim3(staged ? 1024 : 512), lds, (hipStream_t)stream, g);
     TWOG_CHECK_LAUNCH();
     return 0;
 }
