@@ -60,7 +60,7 @@ __device__ __forceinline__ void stage_rows64(const float* src, int N, int NP, fl
     }
 }
 
-__global__ __launch_bounds__(256, 2) void gcn_attn2_fwd_kernel(const float* xin, const float* md, int n_frames, int N,
+__global__ __launch_bounds__(512, 1) void gcn_attn2_fwd_kernel(const float* xin, const float* md, int n_frames, int N,
                                                                float* adj, float* z) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int NP = (N + 15) & ~15, RT = NP >> 4, LDN = NP + 4;
@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256, 2) void gcn_attn2_fwd_kernel(const float* xin,
     float* sP = sX + NP * LDK;     // [NP][LDK]
     float* sXt = sP + NP * LDK;    // [64][LDN]
     float* sS = sXt + 64 * LDN;    // [NP][LDN]
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, i16 = lane & 15, g = lane >> 4;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6, i16 = lane & 15, g = lane >> 4;
     for (int i = threadIdx.x; i < 64 * 16; i += blockDim.x) {
         const int r = i >> 4, c = (i & 15) * 4;
         *reinterpret_cast<float4*>(sMt + r * LDK + c) = *reinterpret_cast<const float4*>(md + r * 64 + c);
@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256, 2) void gcn_attn2_fwd_kernel(const float* xin,
         stage_rows64(xin + r0 * 64, N, NP, sX, sXt, LDN);
         __syncthreads();
         // P = X M + d
-        for (int t = wv; t < RT * 4; t += 4) {
+        for (int t = wv; t < RT * 4; t += nw) {
             const int rt = t >> 2, ct = t & 3;
             f32x4m acc = {0.f, 0.f, 0.f, 0.f};
             acc = tile_mm(sX + rt * 16 * LDK, LDK, sMt + ct * 16 * LDK, LDK, 16, i16, g, acc);
@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256, 2) void gcn_attn2_fwd_kernel(const float* xin,
         }
         __syncthreads();
         // scores = P X^T
-        for (int t = wv; t < RT * RT; t += 4) {
+        for (int t = wv; t < RT * RT; t += nw) {
             const int rt = t / RT, ct = t - rt * RT;
             f32x4m acc = {0.f, 0.f, 0.f, 0.f};
             acc = tile_mm(sP + rt * 16 * LDK, LDK, sX + ct * 16 * LDK, LDK, 16, i16, g, acc);
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256, 2) void gcn_attn2_fwd_kernel(const float* xin,
         }
         __syncthreads();
         // row softmax over the N real columns; padding rows / columns become exact zeros
-        for (int i = wv; i < NP; i += 4) {
+        for (int i = wv; i < NP; i += nw) {
             const bool on = i < N && lane < N;
             const float p = on ? sS[i * LDN + lane] : -INFINITY;
             const float m = wave_max(p);
@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256, 2) void gcn_attn2_fwd_kernel(const float* xin,
         }
         __syncthreads();
         // Z = S X
-        for (int t = wv; t < RT * 4; t += 4) {
+        for (int t = wv; t < RT * 4; t += nw) {
             const int rt = t >> 2, ct = t & 3;
             f32x4m acc = {0.f, 0.f, 0.f, 0.f};
             acc = tile_mm(sS + rt * 16 * LDN, LDN, sXt + ct * 16 * LDN, LDN, RT * 4, i16, g, acc);
@@ -295,7 +295,7 @@ extern "C" int twog_gcn_attn2_fwd(const float* x, const float* md, int n_frames,
         attr_set = true;
     }
     const int grid = n_frames < 512 ? n_frames : 512;
-    hipLaunchKernelGGL(gcn_attn2_fwd_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, x, md, n_frames, n_nodes,
+    hipLaunchKernelGGL(gcn_attn2_fwd_kernel, dim3(grid), dim3(512), lds, (hipStream_t)stream, x, md, n_frames, n_nodes,
                        adj, z);
     TWOG_CHECK_LAUNCH();
     return 0;
