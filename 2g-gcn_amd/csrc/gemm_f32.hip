@@ -6,8 +6,8 @@
 // GRU / GRUCell input+hidden projections (vhoi/models.py:267-320), message MLPs (:323-520), label heads (:552-580)
 // and -- through the k-major operand forms -- their backward passes.
 //
-// Design (MI355X-first): 256-thread workgroups = 4 waves in a 2x2 grid, each wave owns (BM/2)x(BN/2) of the tile as
-// 32x32 MFMA accumulators. Operand tiles are staged global -> registers -> LDS with a 2-deep software pipeline
+// Design (MI355X-first): workgroups of 4 waves (2x2 grid; the 64x64 class) or 8 waves (4x2 grid; the 128x128 class), each
+// wave owning its share of the tile as 32x32 MFMA accumulators. Operand tiles are staged global -> registers -> LDS with a 2-deep software pipeline
 // (loads for k-tile t+1 are issued before the MFMAs of tile t, written to the other LDS buffer after them; one
 // barrier per k-tile). K-contiguous operands are kept [row][BK+4] in LDS and read as one ds_read_b128 per 4 k-steps
 // (the MFMA k order is arbitrary as long as A and B agree, so lane half kh takes k = 4kh..4kh+3 of each 8-chunk;
@@ -50,11 +50,11 @@ struct Group {
 };
 
 // tile of ROWS x COLS (COLS contiguous in memory) -> registers; out-of-range elements read as 0
-template <int ROWS, int COLS>
+template <int ROWS, int COLS, int NT>
 struct TileRegs {
     static constexpr int R = ROWS, C = COLS;
     static constexpr int F4_PER_ROW = COLS / 4;
-    static constexpr int ROWS_PER_PASS = 256 / F4_PER_ROW;
+    static constexpr int ROWS_PER_PASS = NT / F4_PER_ROW;
     static constexpr int PASSES = ROWS / ROWS_PER_PASS;
     f32x4 v[PASSES];
 };
@@ -67,10 +67,10 @@ __device__ __forceinline__ const char* uniform_ptr(const float* p) {
 }
 
 // guarded load (edge tiles / unaligned operands): out-of-range elements read as 0
-template <int ROWS, int COLS>
-__device__ __forceinline__ void load_tile(TileRegs<ROWS, COLS>& t, const twog_rows_t& m, int r0, int c0, int rmax,
+template <int ROWS, int COLS, int NT>
+__device__ __forceinline__ void load_tile(TileRegs<ROWS, COLS, NT>& t, const twog_rows_t& m, int r0, int c0, int rmax,
                                           int cmax, int vec_ok) {
-    using T = TileRegs<ROWS, COLS>;
+    using T = TileRegs<ROWS, COLS, NT>;
     const int tid = threadIdx.x;
     const int c = c0 + (tid % T::F4_PER_ROW) * 4;
 #pragma unroll
@@ -92,9 +92,9 @@ __device__ __forceinline__ void load_tile(TileRegs<ROWS, COLS>& t, const twog_ro
     }
 }
 
-template <int ROWS, int COLS, int LD>
-__device__ __forceinline__ void store_tile(const TileRegs<ROWS, COLS>& t, float* s) {
-    using T = TileRegs<ROWS, COLS>;
+template <int ROWS, int COLS, int LD, int NT>
+__device__ __forceinline__ void store_tile(const TileRegs<ROWS, COLS, NT>& t, float* s) {
+    using T = TileRegs<ROWS, COLS, NT>;
     const int tid = threadIdx.x;
     const int c = (tid % T::F4_PER_ROW) * 4;
 #pragma unroll
@@ -104,11 +104,11 @@ __device__ __forceinline__ void store_tile(const TileRegs<ROWS, COLS>& t, float*
     }
 }
 
-template <int BM, int BN, bool AKM, bool BKM, bool FAST, int TM, int TN, int D, bool KG>
+template <int BM, int BN, int NT, bool AKM, bool BKM, bool FAST, int TM, int TN, int D, bool KG>
 __device__ __forceinline__ void gemm_mainloop(const twog_rows_t A, const twog_rows_t B, int M, int N, int a_vec,
                                               int b_vec, int m0, int n0, int k_begin, int k_end, float* smem,
                                               f32x16 (&acc)[TM][TN]) {
-    constexpr int WM = BM / 2, WN = BN / 2;
+    constexpr int WM = BM / (NT / 128), WN = BN / 2;  // waves in a (NT/128) x 2 grid
     constexpr int LDA = AKM ? (BM + 4) : (BK + 4);
     constexpr int LDB = BKM ? (BN + 4) : (BK + 4);
     constexpr int A_ELEMS = AKM ? BK * LDA : BM * LDA;
@@ -119,8 +119,8 @@ __device__ __forceinline__ void gemm_mainloop(const twog_rows_t A, const twog_ro
     const int wm = (wave >> 1) * WM, wn = (wave & 1) * WN;
     const int tid = threadIdx.x;
 
-    using ARegs = TileRegs<(AKM ? BK : BM), (AKM ? BM : BK)>;
-    using BRegs = TileRegs<(BKM ? BK : BN), (BKM ? BN : BK)>;
+    using ARegs = TileRegs<(AKM ? BK : BM), (AKM ? BM : BK), NT>;
+    using BRegs = TileRegs<(BKM ? BK : BN), (BKM ? BN : BK), NT>;
     // FAST: 16-byte aligned operands and only whole k-tiles -> every lane issues unconditional global_load_dwordx4
     // (row / column indices beyond the matrix are clamped: they only feed outputs that are never stored), so the
     // loads stay in flight under the MFMAs. All row addressing is resolved before the loop: per pass one pointer
@@ -220,8 +220,8 @@ __device__ __forceinline__ void gemm_mainloop(const twog_rows_t A, const twog_ro
     };
     auto sstore = [&](const ARegs& ra, const BRegs& rb, int buf) {
         float* dst = smem + buf * STAGE;
-        store_tile<ARegs::R, ARegs::C, LDA>(ra, dst);
-        store_tile<BRegs::R, BRegs::C, LDB>(rb, dst + A_ELEMS);
+        store_tile<ARegs::R, ARegs::C, LDA, NT>(ra, dst);
+        store_tile<BRegs::R, BRegs::C, LDB, NT>(rb, dst + A_ELEMS);
     };
     // fragments of 8 k-steps: lane (li, kh) holds k = 4kh..4kh+3 of the chunk for its row / column
     auto frag_load = [&](const float* a_s, const float* b_s, int kk, float (&af)[TM][4], float (&bf)[TN][4]) {
@@ -329,9 +329,9 @@ __device__ __forceinline__ void gemm_mainloop(const twog_rows_t A, const twog_ro
     }
 }
 
-template <int BM, int BN, bool AKM, bool BKM, int D, bool KG>
-__global__ __launch_bounds__(256, 2) void gemm_kernel(const Group g) {
-    constexpr int WM = BM / 2, WN = BN / 2;    // per-wave tile
+template <int BM, int BN, int NT, bool AKM, bool BKM, int D, bool KG>
+__global__ __launch_bounds__(NT, 2) void gemm_kernel(const Group g) {
+    constexpr int WM = BM / (NT / 128), WN = BN / 2;  // per-wave tile; waves in a (NT/128) x 2 grid
     constexpr int TM = WM / 32, TN = WN / 32;  // 32x32 MFMA tiles per wave
     constexpr int LDA = AKM ? (BM + 4) : (BK + 4);
     constexpr int LDB = BKM ? (BN + 4) : (BK + 4);
@@ -421,9 +421,9 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const Group g) {
     // uniform per workgroup: aligned operands and a reduction range made of whole k-tiles -> branch-free staging
     const bool fast = a_vec && b_vec && ((k_end - k_begin) % BK == 0);
     if (fast)
-        gemm_mainloop<BM, BN, AKM, BKM, true, TM, TN, D, KG>(A, B, M, N, a_vec, b_vec, m0, n0, k_begin, k_end, smem, acc);
+        gemm_mainloop<BM, BN, NT, AKM, BKM, true, TM, TN, D, KG>(A, B, M, N, a_vec, b_vec, m0, n0, k_begin, k_end, smem, acc);
     else
-        gemm_mainloop<BM, BN, AKM, BKM, false, TM, TN, 1, false>(A, B, M, N, a_vec, b_vec, m0, n0, k_begin, k_end, smem, acc);
+        gemm_mainloop<BM, BN, NT, AKM, BKM, false, TM, TN, 1, false>(A, B, M, N, a_vec, b_vec, m0, n0, k_begin, k_end, smem, acc);
 
     // epilogue. C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
     if (g.splitk > 1) {
@@ -526,22 +526,22 @@ inline int vec_ok(const twog_rows_t& m, int64_t batch_stride, int contiguous_ext
     return (aligned && ld_ok && contiguous_extent >= 4 && contiguous_extent % 4 == 0) ? 1 : 0;
 }
 
-template <int BM, int BN, int D>
+template <int BM, int BN, int NT, int D>
 int launch(Group& g, int akm, int bkm, hipStream_t st) {
-    dim3 grid(g.total_tiles, g.splitk), block(256);
+    dim3 grid(g.total_tiles, g.splitk), block(NT);
     // KG variant: some k-major operand has (outer, inner) grouped rows
     bool kg = false;
     for (int i = 0; i < g.n; ++i) kg = kg || (akm && g.p[i].A.inner > 1) || (bkm && g.p[i].B.inner > 1);
-    if (!akm && !bkm) hipLaunchKernelGGL((gemm_kernel<BM, BN, false, false, D, false>), grid, block, 0, st, g);
-    else if (!akm && bkm && !kg) hipLaunchKernelGGL((gemm_kernel<BM, BN, false, true, D, false>), grid, block, 0, st, g);
-    else if (!akm && bkm) hipLaunchKernelGGL((gemm_kernel<BM, BN, false, true, D, true>), grid, block, 0, st, g);
-    else if (akm && bkm && !kg) hipLaunchKernelGGL((gemm_kernel<BM, BN, true, true, D, false>), grid, block, 0, st, g);
-    else if (akm && bkm) hipLaunchKernelGGL((gemm_kernel<BM, BN, true, true, D, true>), grid, block, 0, st, g);
-    else if (!kg) hipLaunchKernelGGL((gemm_kernel<BM, BN, true, false, D, false>), grid, block, 0, st, g);
-    else hipLaunchKernelGGL((gemm_kernel<BM, BN, true, false, D, true>), grid, block, 0, st, g);
+    if (!akm && !bkm) hipLaunchKernelGGL((gemm_kernel<BM, BN, NT, false, false, D, false>), grid, block, 0, st, g);
+    else if (!akm && bkm && !kg) hipLaunchKernelGGL((gemm_kernel<BM, BN, NT, false, true, D, false>), grid, block, 0, st, g);
+    else if (!akm && bkm) hipLaunchKernelGGL((gemm_kernel<BM, BN, NT, false, true, D, true>), grid, block, 0, st, g);
+    else if (akm && bkm && !kg) hipLaunchKernelGGL((gemm_kernel<BM, BN, NT, true, true, D, false>), grid, block, 0, st, g);
+    else if (akm && bkm) hipLaunchKernelGGL((gemm_kernel<BM, BN, NT, true, true, D, true>), grid, block, 0, st, g);
+    else if (!kg) hipLaunchKernelGGL((gemm_kernel<BM, BN, NT, true, false, D, false>), grid, block, 0, st, g);
+    else hipLaunchKernelGGL((gemm_kernel<BM, BN, NT, true, false, D, true>), grid, block, 0, st, g);
     TWOG_CHECK_LAUNCH();
     if (g.splitk > 1) {
-        hipLaunchKernelGGL((splitk_reduce_kernel<BM, BN>), dim3(g.total_tiles, (BM * BN) / 1024), block, 0, st, g);
+        hipLaunchKernelGGL((splitk_reduce_kernel<BM, BN>), dim3(g.total_tiles, (BM * BN) / 1024), dim3(256), 0, st, g);
         TWOG_CHECK_LAUNCH();
     }
     return 0;
@@ -642,8 +642,12 @@ extern "C" int twog_gemm_f32(const twog_gemm_t* problems, int n_problems, int a_
         static const int depth = getenv("TWOG_GEMM_DEPTH") ? atoi(getenv("TWOG_GEMM_DEPTH")) : 0;  // tuning knob
         const int d128 = depth ? (depth & 3) : 2, d64 = depth ? ((depth >> 2) & 3) : 2;
         int rc;
-        if (big) rc = d128 == 2 ? launch<128, 128, 2>(g, a_kmajor, b_kmajor, st) : launch<128, 128, 1>(g, a_kmajor, b_kmajor, st);
-        else rc = d64 == 2 ? launch<64, 64, 2>(g, a_kmajor, b_kmajor, st) : launch<64, 64, 1>(g, a_kmajor, b_kmajor, st);
+        // 128x128 tiles run with 8 waves (4 x 2 grid, 32x64 per wave): four waves per SIMD hide the LDS / barrier
+        // latencies that a 4-wave tile (two per SIMD) exposes: +5 % on every big shape (TWOG_GEMM_W8=0: 4 waves)
+        static const int w8 = getenv("TWOG_GEMM_W8") ? atoi(getenv("TWOG_GEMM_W8")) : 1;
+        if (big && w8) rc = launch<128, 128, 512, 2>(g, a_kmajor, b_kmajor, st);
+        else if (big) rc = d128 == 2 ? launch<128, 128, 256, 2>(g, a_kmajor, b_kmajor, st) : launch<128, 128, 256, 1>(g, a_kmajor, b_kmajor, st);
+        else rc = d64 == 2 ? launch<64, 64, 256, 2>(g, a_kmajor, b_kmajor, st) : launch<64, 64, 256, 1>(g, a_kmajor, b_kmajor, st);
         if (rc) return rc;
         done += n;
     }
