@@ -645,7 +645,10 @@ extern "C" int twog_gemm_f32(const twog_gemm_t* problems, int n_problems, int a_
         // 128x128 tiles run with 8 waves (4 x 2 grid, 32x64 per wave): four waves per SIMD hide the LDS / barrier
         // latencies that a 4-wave tile (two per SIMD) exposes: +5 % on every big shape (TWOG_GEMM_W8=0: 4 waves)
         static const int w8 = getenv("TWOG_GEMM_W8") ? atoi(getenv("TWOG_GEMM_W8")) : 1;
-        if (big && w8) rc = d128 == 2 ? launch<128, 128, 512, 2>(g, a_kmajor, b_kmajor, st) : launch<128, 128, 512, 1>(g, a_kmajor, b_kmajor, st);
+        bool grouped = false;  // grouped k-major rows keep the 4-wave tiles: their pointer-carrying 8-wave kernels exceed
+                               // 128 VGPRs (3 waves/SIMD) and measure 7 % slower
+        for (int i = 0; i < n; ++i) grouped = grouped || (a_kmajor && pr[i].A.inner > 1) || (b_kmajor && pr[i].B.inner > 1);
+        if (big && w8 && !grouped) rc = d128 == 2 ? launch<128, 128, 512, 2>(g, a_kmajor, b_kmajor, st) : launch<128, 128, 512, 1>(g, a_kmajor, b_kmajor, st);
         else if (big) rc = d128 == 2 ? launch<128, 128, 256, 2>(g, a_kmajor, b_kmajor, st) : launch<128, 128, 256, 1>(g, a_kmajor, b_kmajor, st);
         else rc = d64 == 2 ? launch<64, 64, 256, 2>(g, a_kmajor, b_kmajor, st) : launch<64, 64, 256, 1>(g, a_kmajor, b_kmajor, st);
         if (rc) return rc;
