@@ -510,12 +510,8 @@ extern "C" int twog_attn_fwd(const twog_attn_t* a, int n, void* stream) {
     }
     if (lds > LDS_LIMIT) return -3;
     g.staged = staged ? 1 : 0;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT);
-        attr_set = true;
-    }
+    static std::atomic<uint32_t> lds_attr_done{0};
+    twog_allow_dynamic_lds(attn_fwd_kernel, (int)LDS_LIMIT, lds_attr_done);
     // throughput regime: 512 threads (the LDS feature tile limits a CU to 3 workgroups: 24 waves instead of 12)
     hipLaunchKernelGGL(attn_fwd_kernel, dim3(maxinst, n, staged ? 2 : 1), dim3(staged ? 1024 : 512), lds, (hipStream_t)stream, g);
     TWOG_CHECK_LAUNCH();
@@ -542,12 +538,8 @@ extern "C" int twog_attn_bwd(const twog_attn_bwd_t* a, int n, void* stream) {
     }
     if (lds > LDS_LIMIT) return -3;
     g.staged = staged ? 1 : 0;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT);
-        attr_set = true;
-    }
+    static std::atomic<uint32_t> lds_attr_done{0};
+    twog_allow_dynamic_lds(attn_bwd_kernel, (int)LDS_LIMIT, lds_attr_done);
     hipLaunchKernelGGL(attn_bwd_kernel, dim3(maxinst, n, staged ? 2 : 1), dim3(staged ? 1024 : 256), lds, (hipStream_t)stream, g);
     TWOG_CHECK_LAUNCH();
     return 0;

@@ -288,12 +288,8 @@ extern "C" int twog_gcn_attn2_fwd(const float* x, const float* md, int n_frames,
     if (n_nodes > MAXN || n_nodes < 1) return -1;
     if (n_frames <= 0) return 0;
     const size_t lds = lds_fwd_bytes(n_nodes);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gcn_attn2_fwd_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
+    static std::atomic<uint32_t> lds_attr_done{0};
+    twog_allow_dynamic_lds(gcn_attn2_fwd_kernel, 160 * 1024, lds_attr_done);
     const int grid = n_frames < 512 ? n_frames : 512;
     hipLaunchKernelGGL(gcn_attn2_fwd_kernel, dim3(grid), dim3(512), lds, (hipStream_t)stream, x, md, n_frames, n_nodes,
                        adj, z);
@@ -311,12 +307,8 @@ extern "C" int twog_gcn_attn2_bwd(const float* x, const float* md, const float* 
     const bool with_m = lds_bwd_bytes(n_nodes, true) <= 160 * 1024;
     const size_t lds = lds_bwd_bytes(n_nodes, with_m);
     if (lds > 160 * 1024) return -3;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gcn_attn2_bwd_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
+    static std::atomic<uint32_t> lds_attr_done{0};
+    twog_allow_dynamic_lds(gcn_attn2_bwd_kernel, 160 * 1024, lds_attr_done);
     hipLaunchKernelGGL(gcn_attn2_bwd_kernel, dim3(n_blocks), dim3(512), lds, (hipStream_t)stream, x, md, adj, dz,
                        n_frames, n_nodes, dx_att, partials, with_m ? 1 : 0);
     TWOG_CHECK_LAUNCH();

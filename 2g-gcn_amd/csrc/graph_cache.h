@@ -5,12 +5,13 @@
 // cost and the step becomes host-bound. A loop is therefore captured once into a hipGraph (stream capture of exactly the
 // launches the loop issues) and replayed with one hipGraphLaunch while its descriptor -- every pointer, shape and stride,
 // hashed -- stays the same, which is the steady state of a training loop under a caching allocator. A changed descriptor
-// is a different key (re-capture); the cache is small and flushed when full. TWOG_NO_GRAPHS=1 turns it off.
+// is a different key (re-capture); the cache is small (64 loops) and flushed when full. TWOG_NO_GRAPHS=1 turns it off.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <unordered_map>
 
 namespace twog_graph {
@@ -23,17 +24,42 @@ inline uint64_t fnv1a(const void* data, size_t n, uint64_t h = 14695981039346656
 
 struct Entry { hipGraphExec_t exec; int uses; };
 
+// One instance per process (inline function static: shared by every translation unit of the library). The mutex makes
+// the entry points callable from several host threads (calls are serialised: capture is thread-local and a replay is
+// one launch); the per-device side stream and the device ordinal mixed into the key keep a process that drives more
+// than one GPU correct, although the intended deployment is one process per GPU.
+constexpr int MAX_DEVICES = 16;
+struct State {
+    std::mutex mu;
+    std::unordered_map<uint64_t, Entry> cache;
+    std::unordered_map<uint64_t, int> seen;  // a key is captured the second time it shows up
+    hipStream_t side[MAX_DEVICES] = {};
+    hipEvent_t ev_in[MAX_DEVICES] = {}, ev_out[MAX_DEVICES] = {};
+};
+inline State& state() {
+    static State s;
+    return s;
+}
+
 // enqueue(stream): issues the loop's launches on `stream`, returns 0 on success. key: hash of everything it reads.
 // Graphs are captured and replayed on a stream owned by the library (the caller's stream may be the legacy default
 // stream, which cannot be captured), fenced against the caller's stream with two events.
 template <class F>
 int run(uint64_t key, hipStream_t user, F enqueue) {
     static const bool off = getenv("TWOG_NO_GRAPHS") != nullptr;
-    static std::unordered_map<uint64_t, Entry> cache;
-    static std::unordered_map<uint64_t, int> seen;  // a key is captured the second time it shows up
-    static hipStream_t side = nullptr;
-    static hipEvent_t ev_in = nullptr, ev_out = nullptr;
     if (off) return enqueue(user);
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES) {
+        (void)hipGetLastError();
+        return enqueue(user);
+    }
+    State& S = state();
+    std::lock_guard<std::mutex> lock(S.mu);
+    key ^= 0x9e3779b97f4a7c15ull * (uint64_t)(dev + 1);
+    hipStream_t& side = S.side[dev];
+    hipEvent_t &ev_in = S.ev_in[dev], &ev_out = S.ev_out[dev];
+    auto& cache = S.cache;
+    auto& seen = S.seen;
     if (!side) {
         if (hipStreamCreateWithFlags(&side, hipStreamNonBlocking) != hipSuccess ||
             hipEventCreateWithFlags(&ev_in, hipEventDisableTiming) != hipSuccess ||
@@ -64,7 +90,10 @@ int run(uint64_t key, hipStream_t user, F enqueue) {
             return rc != 0 ? rc : enqueue(user);  // nothing ran during the capture: issue the launches directly
         }
         (void)hipGraphDestroy(graph);
-        if (cache.size() >= 32) {
+        if (cache.size() >= 64) {
+            // flush: wait for replays still in flight on the side streams before their executables go away
+            for (int i = 0; i < MAX_DEVICES; ++i)
+                if (S.side[i]) (void)hipStreamSynchronize(S.side[i]);
             for (auto& kv : cache) (void)hipGraphExecDestroy(kv.second.exec);
             cache.clear();
         }

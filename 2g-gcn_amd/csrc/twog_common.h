@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 #include "../../include/twog_gcn.h"
 
 #define TWOG_WAVE 64
@@ -11,6 +12,18 @@
         hipError_t e_ = hipGetLastError();          \
         if (e_ != hipSuccess) return -(int)e_;      \
     } while (0)
+
+// Raises a kernel's dynamic-LDS limit once per device (function attributes are per device; the flag word is one bit per
+// device ordinal, so a process that drives several GPUs -- or several host threads -- stays correct).
+template <class K>
+inline void twog_allow_dynamic_lds(K kernel, int bytes, std::atomic<uint32_t>& done) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = 0; }
+    const uint32_t bit = 1u << (dev & 31);
+    if (done.load(std::memory_order_acquire) & bit) return;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    done.fetch_or(bit, std::memory_order_release);
+}
 
 // address of row r in a twog_rows_t (see include/twog_gcn.h)
 __device__ __forceinline__ int64_t twog_row_off(const twog_rows_t& m, int r) {

@@ -2,14 +2,19 @@
 (``create_data_loader`` :362-379, ``assemble_tensors`` :436-471, ``assemble_bimanual_tensors`` :480-501,
 ``assemble_mphoi_tensors`` :504-522, the per-dataset human/object assemblers :562-982, distances :985-1203,
 ``assemble_num_steps`` :1206, fetcher/feeder :1215-1315, ``determine_num_classes`` :1318, ``input_size_from_data_loader``
-:1332). Dataset I/O (zarr/json/pickle readers, :23-350) is out of scope: the functions here start from the same in-memory
-``data`` lists those readers produce.
+:1332), and of the MPHOI-72 / Bimanual-Actions dataset readers (``load_mphoi_training_data`` :118-160,
+``load_mphoi_testing_data`` :285-309, ``load_bimanual_training_data`` :63-115, ``load_bimanual_testing_data`` :234-282,
+``split_train_test`` :353-359) over the zarr feature stores, read natively by ``featstore`` (no zarr dependency). The
+CAD-120 readers (:23-60, :201-231: pickled ``CAD120Video`` objects) are out of scope: start from the in-memory ``data``
+list they produce.
 
 Same outputs as the reference (tuple slot order of SURVEY.md Appendix B, NaN padding to the split maximum then
 ``nan_to_num``, float32 / int64 dtypes), but assembled with whole-video numpy operations instead of the reference's
 per-frame Python loops, and with a double-buffered pinned / HBM-resident input pipeline (``DevicePrefetcher``,
 SURVEY.md section 8f row 2) in place of the reference's synchronous pageable copies.
 """
+import json
+import random
 from functools import partial
 from itertools import groupby
 from typing import Optional
@@ -17,6 +22,8 @@ from typing import Optional
 import numpy as np
 import torch
 from torch.utils.data import DataLoader, TensorDataset
+
+from . import featstore
 
 # layout constants per dataset (reference lines in comments)
 _SPECS = {
@@ -329,6 +336,126 @@ def create_data_loader(data, model_name: str, model_input_type: str, dataset_nam
                         pin_memory=False, drop_last=False)
     segmentations = assemble_cad120_segmentations_from_frame_level_features(data) if name == 'cad120' else None
     return loader, scalers, segmentations
+
+
+def split_train_test(training_data: list, test_fraction: float = 0.2, seed: int = 42):
+    """:353-359 (seeds and uses the global ``random`` generator exactly as the reference does)."""
+    random.seed(seed)
+    random.shuffle(training_data)
+    n_test = round(len(training_data) * test_fraction)
+    return training_data[n_test:], training_data[:n_test]
+
+
+# per-video record layout of the two-entity datasets: [entity-1 features, entity-2 features, object features,
+# ground truth, entity-1 boxes, entity-2 boxes, object boxes, entity-1 pose, entity-2 pose]; (store, array) per slot
+_STORE_SLOTS = {
+    'mphoi': (('feat', 'Human1'), ('feat', 'Human2'), ('feat', 'objects'), None, ('hbb', 'Human1'), ('hbb', 'Human2'),
+              ('obb', 'objects'), ('hps', 'Human1'), ('hps', 'Human2')),                              # :134-143
+    'bimanual': (('feat', 'left_hand'), ('feat', 'right_hand'), ('feat', 'objects'), None, ('bbs', 'left_hand'),
+                 ('bbs', 'right_hand'), ('bbs', 'objects'), ('hps', 'left_hand'), ('hps', 'right_hand')),  # :80-87
+}
+
+
+def _read_videos(dataset, data_path, store_paths, keep, video_id_to_video_fps=None):
+    """Ground-truth JSON + feature stores -> list of per-video records (and their ids), in the JSON's order."""
+    with open(data_path, mode='rb') as f:
+        ground_truth = json.load(f)
+    roots = {k: featstore.open(p, mode='r') for k, p in store_paths.items()}
+    records, ids = [], []
+    for video_id, gt in ground_truth.items():
+        if not keep(video_id):
+            continue
+        rec = [gt if slot is None else roots[slot[0]][video_id][slot[1]][:] for slot in _STORE_SLOTS[dataset]]
+        if video_id_to_video_fps is not None and video_id_to_video_fps[video_id] == 15:
+            # some Bimanual videos were recorded at 15 FPS: every frame (and label) is doubled (:89-99)
+            rec = [r if i == 3 else np.repeat(r, repeats=2, axis=0) for i, r in enumerate(rec)]
+            for k in ('left_hand', 'right_hand'):
+                gt[k] = np.repeat(gt[k], repeats=2, axis=0)
+        records.append(rec)
+        ids.append(video_id)
+    return records, ids
+
+
+def _training_loaders(records, dataset, model_name, model_input_type, batch_size, val_fraction, seed, debug,
+                      scaling_strategy, sigma, downsampling):
+    training_data, val_data = split_train_test(records, test_fraction=val_fraction, seed=seed)
+    if debug:
+        training_data, val_data = training_data[:4], val_data[:1]
+    train_loader, scalers, _ = create_data_loader(training_data, model_name, model_input_type, dataset,
+                                                  batch_size=batch_size, shuffle=True,
+                                                  scaling_strategy=scaling_strategy, sigma=sigma,
+                                                  downsampling=downsampling, test_data=False)
+    val_loader, _, _ = create_data_loader(val_data, model_name, model_input_type, dataset, batch_size=len(val_data),
+                                          shuffle=False, scalers=scalers, sigma=sigma, downsampling=downsampling,
+                                          test_data=False)
+    data_info = {'input_size': input_size_from_data_loader(train_loader, model_name, model_input_type)}
+    return train_loader, val_loader, data_info, scalers
+
+
+def _testing_loader(records, ids, dataset, model_name, model_input_type, batch_size, scalers, downsampling):
+    test_loader, _, segmentations = create_data_loader(records, model_name, model_input_type, dataset,
+                                                       batch_size=batch_size, shuffle=False, scalers=scalers,
+                                                       downsampling=downsampling, test_data=True)
+    data_info = {'input_size': input_size_from_data_loader(test_loader, model_name, model_input_type)}
+    return test_loader, data_info, segmentations, ids
+
+
+def _mphoi_stores(data_path_zarr, data_path_obbs_zarr, data_path_hbbs_zarr, data_path_hps_zarr):
+    return {'feat': data_path_zarr, 'obb': data_path_obbs_zarr, 'hbb': data_path_hbbs_zarr, 'hps': data_path_hps_zarr}
+
+
+def load_mphoi_training_data(data_path, data_path_zarr, data_path_obbs_zarr, data_path_hbbs_zarr, data_path_hps_zarr,
+                             model_name: str, model_input_type: str, test_subject_id, batch_size: int = 8,
+                             val_fraction: float = 0.2, seed: int = 42, debug: bool = False, scaling_strategy=None,
+                             sigma: float = 0.0, downsampling: int = 1):
+    """:118-160. A video trains unless one of its two subjects is one of the two held-out subjects (the last two
+    digits of 'SubjectAB' name the pair)."""
+    test_pair = {int(test_subject_id[-2]), int(test_subject_id[-1])}
+
+    def keep(video_id):
+        subject = video_id.split(sep='-')[0]
+        return not ({int(subject[-2]), int(subject[-1])} & test_pair)
+
+    records, _ = _read_videos('mphoi', data_path, _mphoi_stores(data_path_zarr, data_path_obbs_zarr,
+                                                                data_path_hbbs_zarr, data_path_hps_zarr), keep)
+    return _training_loaders(records, 'mphoi', model_name, model_input_type, batch_size, val_fraction, seed, debug,
+                             scaling_strategy, sigma, downsampling)
+
+
+def load_mphoi_testing_data(data_path, data_path_zarr, data_path_obbs_zarr, data_path_hbbs_zarr, data_path_hps_zarr,
+                            model_name: str, model_input_type: str, test_subject_id, batch_size: int,
+                            scalers: Optional[dict] = None, downsampling: int = 1):
+    """:285-309: the videos whose subject field equals ``test_subject_id``."""
+    records, ids = _read_videos('mphoi', data_path, _mphoi_stores(data_path_zarr, data_path_obbs_zarr,
+                                                                  data_path_hbbs_zarr, data_path_hps_zarr),
+                                lambda video_id: video_id.split(sep='-')[0] == test_subject_id)
+    return _testing_loader(records, ids, 'mphoi', model_name, model_input_type, batch_size, scalers, downsampling)
+
+
+def _bimanual_subject(video_id):
+    return int(video_id.split(sep='-')[0].split(sep='_')[1])
+
+
+def load_bimanual_training_data(data_path, data_path_zarr, data_path_bbs_zarr, data_path_hps_zarr, model_name: str,
+                                model_input_type: str, test_subject_id: int, video_id_to_video_fps: dict,
+                                batch_size: int = 8, val_fraction: float = 0.2, seed: int = 42, debug: bool = False,
+                                scaling_strategy=None, sigma: float = 0.0, downsampling: int = 1):
+    """:63-115."""
+    stores = {'feat': data_path_zarr, 'bbs': data_path_bbs_zarr, 'hps': data_path_hps_zarr}
+    records, _ = _read_videos('bimanual', data_path, stores, lambda v: _bimanual_subject(v) != test_subject_id,
+                              video_id_to_video_fps)
+    return _training_loaders(records, 'bimanual', model_name, model_input_type, batch_size, val_fraction, seed, debug,
+                             scaling_strategy, sigma, downsampling)
+
+
+def load_bimanual_testing_data(data_path, data_path_zarr, data_path_bbs_zarr, data_path_hps_zarr, model_name: str,
+                               model_input_type: str, test_subject_id: int, video_id_to_video_fps: dict,
+                               batch_size: int, scalers: Optional[dict] = None, downsampling: int = 1):
+    """:234-282."""
+    stores = {'feat': data_path_zarr, 'bbs': data_path_bbs_zarr, 'hps': data_path_hps_zarr}
+    records, ids = _read_videos('bimanual', data_path, stores, lambda v: _bimanual_subject(v) == test_subject_id,
+                                video_id_to_video_fps)
+    return _testing_loader(records, ids, 'bimanual', model_name, model_input_type, batch_size, scalers, downsampling)
 
 
 def gcn_fetcher(dataset, device, non_blocking: bool = False, **kwargs):
