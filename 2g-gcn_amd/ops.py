@@ -327,7 +327,13 @@ def tggcn_forward(K, plan: Plan, P, x_human, x_objects, objects_mask, human_seg,
             ('h', p.learn_h, human_seg, HUMv, H, p.gate_cols_h(), 'update_human_segment_mlp', 0),
             ('o', p.learn_o, object_seg, OBJv, O, p.gate_cols_o(), 'update_object_segment_mlp', H if p.learn_h else 0)):
         if not learn:
-            gates[kind] = dict(hard=seg.contiguous(), soft=seg.contiguous(), learned=False)
+            seg = seg.contiguous()
+            hard = seg
+            if p.filter:
+                # the local-maximum filter also runs over a GIVEN segmentation (models.py:751-753 filters ux_hss /
+                # ux_oss, which hold the given values when no gate is learned)
+                hard, _ = K.filter_fwd(seg, p.thr)
+            gates[kind] = dict(hard=hard, soft=seg, learned=False)
             continue
         d = dict(x=Ev, seg_col=cols, hidden=h, w=P[mlp + '.0.weight'], b=P.get(mlp + '.0.bias'),
                  noise=noise if p.gs else None, bs=bs, T=T, E=E, noise_entities=n_gated, noise_offset=off,

@@ -154,3 +154,18 @@ def test_gradient_stages_are_final_when_the_hook_fires(case, fake_backend):
     # and the stage-2 block (embeddings, GCN) is what remains
     b2, e2 = flat.stage_ranges[2]
     assert float(flat.grad[b2:e2].abs().max()) > 0
+
+
+def test_randomised_layouts_vs_oracle(fake_backend):
+    """Host composition (kernel test double) against the oracle over random layouts / gate semantics / message switches
+    (the generator of tools/parity_fuzz.py; the same sweep runs on the HIP kernels in tests/test_parity_gpu.py).
+    Covers e.g. a GIVEN segmentation combined with filter_discrete_updates (the filter applies to it too)."""
+    import random
+    from tools.parity_fuzz import one_case
+    rng = random.Random(0)
+    seen = set()
+    for i in range(14):
+        d = one_case(rng, i, dev='cpu')
+        assert d['worst_output_rel'] < 1e-4, d     # (gradients: asserted per tensor inside one_case)
+        seen.add((d['given_seg'], d['filt']))
+    assert (True, True) in seen and (False, False) in seen

@@ -238,3 +238,16 @@ def test_limits_fail_loudly():
           human_segmentation=torch.ones(1, 2, 2, device=DEV))
     with pytest.raises(ValueError):  # feature width inconsistent with gcn_node
         m(torch.rand(1, 2, 2, 2048 + 4 * 19, device=DEV), torch.rand(1, 2, 4, 2048, device=DEV), torch.ones(1, 4, device=DEV))
+
+
+def test_randomised_layouts_vs_oracle():
+    """Random layouts (clips, frames, humans, objects, nodes, width, masks), gate semantics (given / learned
+    segmentation, local-maximum filter), message switches, train / eval: HIP vs oracle, outputs 1e-4, gradients 5e-4."""
+    import random
+    from tools.parity_fuzz import one_case
+    rng = random.Random(0)
+    worst_o = worst_g = 0.0
+    for i in range(30):
+        d = one_case(rng, i, dev=DEV)
+        worst_o, worst_g = max(worst_o, d['worst_output_rel']), max(worst_g, d['worst_grad_rel'])
+    print(f'30 random cases: worst output {worst_o:.2e}, worst gradient {worst_g:.2e}')

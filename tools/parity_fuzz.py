@@ -1,0 +1,136 @@
+#!/usr/bin/env python3
+"""Randomised parity sweep on the GPU box: the shipped HIP path vs the CPU oracle (oracle/cpu_ref.py) over random small
+layouts -- clips, frames, humans, objects, graph nodes, hidden width, object masks, gate semantics (given / learned
+segmentation), train / eval mode -- outputs at 1e-4 relative, parameter gradients at 5e-4 of each tensor's scale.
+usage: python3 tools/parity_fuzz.py [n_cases] [seed]     (writes gpurun_out/parity_fuzz.json)"""
+import json
+import os
+import random
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import twog_gcn_amd  # noqa: E402,F401
+from twog_gcn_amd.hostcpu import limit_host_threads  # noqa: E402
+limit_host_threads()
+from twog_gcn_amd import kernels  # noqa: E402
+from twog_gcn_amd.models import TGGCN  # noqa: E402
+from oracle import cpu_ref  # noqa: E402
+
+DEV = 'cuda:0'
+BASE = dict(attention_style='v3', discrete_optimization_strategy='gs', filter_discrete_updates=False,
+            message_humans_to_human=True, message_human_to_objects=True, message_objects_to_human=True,
+            message_objects_to_object=True, message_geometry_to_objects=True, message_geometry_to_human=False,
+            message_segment=True, message_type='v2', message_granularity='v1', message_aggregation='att',
+            object_segment_update_strategy='ind', update_segment_threshold=0.5)
+
+
+def one_case(rng, idx, dev=DEV):
+    H = rng.choice([1, 2, 2])
+    cfg = dict(BASE)
+    bs, T = rng.randint(1, 5), rng.randint(1, 9)
+    O, N = rng.randint(1, 12), rng.choice([19, 26, 30, 34, 21, 40])
+    h = rng.choice([16, 32, 48, 64, 80])
+    if H == 1:
+        cfg['message_humans_to_human'] = False
+    if O == 1:
+        cfg['message_objects_to_object'] = False   # the reference stacks an empty sender list otherwise
+    cfg['message_geometry_to_human'] = rng.random() < 0.3
+    cfg['message_geometry_to_objects'] = rng.random() < 0.8
+    cfg['message_segment'] = rng.random() < 0.85
+    cfg['filter_discrete_updates'] = rng.random() < 0.3
+    cad = H == 1 and rng.random() < 0.5
+    classes = (10, 12) if cad else (13, None)
+    training = rng.random() < 0.8
+    given_seg = rng.random() < 0.5
+    desc = dict(idx=idx, bs=bs, T=T, H=H, O=O, N=N, h=h, classes=classes, training=training, given_seg=given_seg,
+                geo2h=cfg['message_geometry_to_human'], geo2o=cfg['message_geometry_to_objects'],
+                seg_msg=cfg['message_segment'], filt=cfg['filter_discrete_updates'])
+    seed = rng.randint(0, 10 ** 6)
+    torch.manual_seed(seed)
+    m = TGGCN(input_size=(2048 + 4 * N, 2048), num_classes=classes, hidden_size=h, gcn_node=N, **cfg)
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    g = torch.Generator().manual_seed(seed + 1)
+    x_human = torch.rand(bs, T, H, 2048 + 4 * N, generator=g)
+    x_objects = torch.rand(bs, T, O, 2048, generator=g)
+    mask = (torch.rand(bs, O, generator=g) < 0.75).float()
+    if rng.random() < 0.15:
+        mask[rng.randrange(bs)] = 0            # a clip without any real object
+    x_objects = x_objects * mask[:, None, :, None]
+    kw = {}
+    if given_seg:
+        kw['human_segmentation'] = (torch.rand(bs, T, H, generator=g) < 0.6).float()
+        if cad:
+            kw['objects_segmentation'] = (torch.rand(bs, T, O, generator=g) < 0.6).float()
+    n_gated = (0 if given_seg else H) + (0 if (given_seg and cad) else O)
+    noise = torch.distributions.gumbel.Gumbel(0.0, 1.0).sample((T * max(n_gated, 1), bs, 2))
+    osd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and 'running' not in k else v.clone())
+           for k, v in sd.items()}
+    ref = cpu_ref.tggcn_forward(osd, dict(m.cfg), x_human, x_objects, mask, training=training, gumbel_noise=noise, **kw)
+    if os.environ.get('TWOG_FUZZ_ORACLE_ONLY'):   # dry run of the case generator + oracle (no GPU)
+        return dict(desc, worst_output_rel=0.0, worst_grad_rel=0.0)
+    m = m.to(dev)
+    m.train(training)
+    m._gumbel_noise_override = noise
+    out = m(x_human.to(dev), x_objects.to(dev), mask.to(dev), **{k: v.to(dev) for k, v in kw.items()})
+    assert len(out) == len(ref)
+    worst_out = 0.0
+    for i, (o, r) in enumerate(zip(out, ref)):
+        got, want = o.detach().cpu(), r.detach()
+        assert got.shape == want.shape, (i, got.shape, want.shape)
+        assert not torch.isnan(got).any(), ('nan', i)
+        err = (got - want).abs().max().item() / max(1.0, want.abs().max().item())
+        worst_out = max(worst_out, err)
+        assert err < 1e-4, ('output', i, err)
+    worst_g = 0.0
+    if training:
+        rs = [torch.randn(o.shape, generator=torch.Generator().manual_seed(i)) for i, o in enumerate(ref)]
+        sum((o * r).sum() for o, r in zip(ref, rs) if o.requires_grad).backward()
+        sum((o * r.to(dev)).sum() for o, r in zip(out, rs) if o.requires_grad).backward()
+        for pname, p in m.named_parameters():
+            g_ref = osd[pname].grad
+            if g_ref is None or float(g_ref.abs().max()) == 0.0:
+                assert p.grad is None or float(p.grad.abs().max()) < 1e-6, ('dead grad', pname)
+                continue
+            assert p.grad is not None, ('missing grad', pname)
+            scale = max(g_ref.abs().max().item(), 1e-6)
+            err = (p.grad.cpu() - g_ref).abs().max().item()
+            worst_g = max(worst_g, err / scale)
+            assert err < 5e-4 * scale + 5e-6, ('grad', pname, err, scale)
+    desc.update(worst_output_rel=worst_out, worst_grad_rel=worst_g)
+    return desc
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    if not os.environ.get('TWOG_FUZZ_ORACLE_ONLY'):
+        assert kernels.get_kernels().name == 'hip'
+    rng = random.Random(seed)
+    results, failures = [], []
+    t0 = time.time()
+    for i in range(n):
+        state = rng.getstate()
+        try:
+            results.append(one_case(rng, i))
+        except NotImplementedError as e:   # a configuration the gfx950 path declares unsupported: not a parity failure
+            results.append(dict(idx=i, skipped=str(e)[:200]))
+        except Exception as e:  # noqa: BLE001
+            failures.append(dict(idx=i, error=repr(e)[:500], rng_state_hash=hash(state) & 0xffffffff))
+            print('FAIL', i, repr(e)[:500], flush=True)
+    ok = [r for r in results if 'worst_output_rel' in r]
+    summary = dict(cases=n, passed=len(ok), skipped=len(results) - len(ok), failed=len(failures), seed=seed,
+                   worst_output_rel=max((r['worst_output_rel'] for r in ok), default=0.0),
+                   worst_grad_rel=max((r['worst_grad_rel'] for r in ok), default=0.0), seconds=time.time() - t0)
+    os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
+    json.dump(dict(summary=summary, failures=failures, results=results),
+              open(os.path.join(ROOT, 'gpurun_out', 'parity_fuzz.json'), 'w'), indent=1)
+    print(json.dumps(summary))
+    sys.exit(1 if failures else 0)
+
+
+if __name__ == '__main__':
+    main()
