@@ -242,6 +242,8 @@ class TGGCN(nn.Module):
                              f"{c['discrete_optimization_strategy']}.")
         if c['object_segment_update_strategy'] not in {'independent', 'ind'}:
             bad.append(f"object_segment_update_strategy={c['object_segment_update_strategy']!r}")
+        if not c['bias']:
+            bad.append('bias=False')
         for k in ('add_segment_length', 'add_time_position', 'cat_level_states', 'share_level_mlps'):
             if c[k]:
                 bad.append(k)

@@ -22,7 +22,7 @@ from .kernels import get_kernels
 SUPPORTED_NOTE = ("the HIP path implements message_type 'v2' + message_granularity 'v1' + message_aggregation 'att' "
                   "with attention_style 'v2'/'v3', discrete_networks_num_layers == 1, "
                   "object_segment_update_strategy 'ind', no time-position / segment-length features, "
-                  "cat_level_states off (every configuration shipped in the reference's conf/models/)")
+                  "cat_level_states off, bias=True (every configuration shipped in the reference's conf/models/)")
 
 
 def _v2(t, width=None):

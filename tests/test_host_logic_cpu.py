@@ -162,10 +162,11 @@ def test_randomised_layouts_vs_oracle(fake_backend):
     Covers e.g. a GIVEN segmentation combined with filter_discrete_updates (the filter applies to it too)."""
     import random
     from tools.parity_fuzz import one_case
-    rng = random.Random(0)
-    seen = set()
-    for i in range(14):
+    rng = random.Random(3)
+    seen, axes = set(), set()
+    for i in range(16):
         d = one_case(rng, i, dev='cpu')
         assert d['worst_output_rel'] < 1e-4, d     # (gradients: asserted per tensor inside one_case)
         seen.add((d['given_seg'], d['filt']))
-    assert (True, True) in seen and (False, False) in seen
+        axes.update([d['strat'], d['att']])
+    assert len(seen) == 4 and axes == {'gs', 'st', 'v2', 'v3'}
