@@ -430,3 +430,26 @@ def test_bn_fold_with_stats_reduce_hook(K):
         close(b, a, rtol=1e-6, atol=1e-7, what='identity hook')
     for a, b in zip(base[:3], two[:3]):
         close(b, a, rtol=1e-6, atol=1e-7, what='two identical ranks')
+
+
+def test_out_of_range_descriptors_are_rejected_before_any_launch(K):
+    """Size limits of the C ABI (include/twog_gcn.h) return a negative code instead of launching; the device stays usable.
+    Every call below fails its first range check, so the null data pointers are never dereferenced."""
+    from twog_gcn_amd import _lib
+    lib, st = K.lib, K._stream()
+    max_nodes = lib.twog_gcn_max_nodes()
+    assert max_nodes == 64
+    assert lib.twog_bn_stats(None, 0, 8, max_nodes + 1, None, 4, st) < 0
+    assert lib.twog_bn_stats(None, 0, 8, 0, None, 4, st) < 0
+    assert lib.twog_gcn_attn2_fwd(None, None, 8, max_nodes + 1, None, None, st) < 0
+    assert lib.twog_bigru_fwd(None, 5, 2, 3, 32, st) < 0
+    assert lib.twog_attn_fwd(None, 5, st) < 0                      # more descriptor groups than one launch carries
+    g = _lib.Gate()
+    g.bs, g.T, g.E, g.n_seg = 2, 3, 2, 9                             # more gate-input column segments than the struct holds
+    assert lib.twog_gate_fwd(g, st) < 0
+    # empty problems are no-ops, not errors
+    assert lib.twog_gemm_f32(None, 0, 0, 0, None, 0, st) == 0
+    assert lib.twog_gcn_attn2_fwd(None, None, 0, 34, None, None, st) == 0
+    torch.cuda.synchronize()
+    x = torch.ones(4, device=DEV)
+    assert float((x + 1).sum()) == 8.0
