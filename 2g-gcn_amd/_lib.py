@@ -86,7 +86,8 @@ class SegRnnBwd(C.Structure):  # twog_segrnn_bwd_t
     _fields_ = [('d_hs_h', C.c_void_p), ('d_hs_o', C.c_void_p), ('d_gi_h', C.c_void_p), ('d_gi_o', C.c_void_p),
                 ('d_gh_h', C.c_void_p), ('d_gh_o', C.c_void_p), ('d_u_h', C.c_void_p), ('d_u_o', C.c_void_p),
                 ('d_pre_h', C.c_void_p), ('d_pre_o', C.c_void_p), ('carry_h', C.c_void_p), ('carry_o', C.c_void_p),
-                ('tmp_dmg_h', C.c_void_p), ('tmp_dmg_o', C.c_void_p), ('trash', C.c_void_p)]
+                ('tmp_dmg_h', C.c_void_p), ('tmp_dmg_o', C.c_void_p), ('trash', C.c_void_p), ('du_part_h', C.c_void_p),
+                ('du_part_o', C.c_void_p)]
 
 
 class Gate(C.Structure):  # twog_gate_t

@@ -49,6 +49,15 @@ struct Group {
     float* slabs;    // split-K partials: [problem-tile-major] see below
 };
 
+// Fused "next gate step" epilogue of the recurrent backward chains (gru.hip / segrnn.hip): the launch that adds the last
+// contribution to the carried state gradient finishes, per output tile, the element-wise GRU gate backward of the NEXT
+// chain step from the tile still in its accumulators (no separate gate launch, no re-read of the carry).
+struct GateArgs {
+    twog_gru_step_bwd_t s[MAXP];
+    float* du_part[MAXP];  // [2 * tiles_n][rows] partial row sums of d * (gru - h_prev) for this step, or nullptr
+    int gate_of[MAXP];     // per (sorted) problem: index into s, -1 = plain epilogue
+};
+
 // tile of ROWS x COLS (COLS contiguous in memory) -> registers; out-of-range elements read as 0
 template <int ROWS, int COLS, int NT>
 struct TileRegs {
@@ -329,8 +338,8 @@ __device__ __forceinline__ void gemm_mainloop(const twog_rows_t A, const twog_ro
     }
 }
 
-template <int BM, int BN, int NT, bool AKM, bool BKM, int D, bool KG>
-__global__ __launch_bounds__(NT, 2) void gemm_kernel(const Group g) {
+template <int BM, int BN, int NT, bool AKM, bool BKM, int D, bool KG, bool GATE>
+__device__ __forceinline__ void gemm_tile(const Group& g, const GateArgs* ga) {
     constexpr int WM = BM / (NT / 128), WN = BN / 2;  // per-wave tile; waves in a (NT/128) x 2 grid
     constexpr int TM = WM / 32, TN = WN / 32;  // 32x32 MFMA tiles per wave
     constexpr int LDA = AKM ? (BM + 4) : (BK + 4);
@@ -418,6 +427,44 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(const Group g) {
         }
     }
 
+    // fused gate epilogue: its operands do not depend on this launch, so they are requested here, next to the first
+    // operand tiles, and arrive under the reduction loop (the tile has the registers: these launches run one or two
+    // workgroups per CU). Addressing as checked by the host (twog_internal_gemm_gate_bwd): dh, save, h_prev, dgi, dgh and
+    // u share one (outer, inner) row grouping, resolved per row with an exact float reciprocal (rows < 2^22); every
+    // offset fits 31 bits; absent operands are redirected to a valid address and masked afterwards: no branch and no
+    // division between the loads.
+    constexpr int GN = GATE ? 16 : 1;
+    float g_dh[GN], g_rg[GN], g_z[GN], g_n[GN], g_hn[GN], g_h0[GN], g_uu[GN];
+    int gidx = -1;
+    if constexpr (GATE) {
+        gidx = ga->gate_of[pi];
+        if (gidx >= 0) {
+            const twog_gru_step_bwd_t& S = ga->s[gidx];
+            const int H = S.hidden;
+            const int colc = min(n0 + wn + li, N - 1);
+            const bool has_u = S.u != nullptr, has_hp = S.h_prev.ptr != nullptr;
+            const int inner = S.dh.inner > 1 ? S.dh.inner : 1;
+            const float inv_inner = 1.0f / (float)inner;
+            const float* hp_ptr = has_hp ? S.h_prev.ptr : S.dh.ptr;
+            const int hp_lo = has_hp ? (int)S.h_prev.ld_outer : (int)S.dh.ld_outer, hp_li = has_hp ? (int)S.h_prev.ld_inner : (int)S.dh.ld_inner;
+            const float* u_ptr = has_u ? S.u : S.dh.ptr;
+            const int u_lo = has_u ? (int)S.u_ld_outer : 0, u_li = has_u ? (int)S.u_ld_inner : 0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rowc = min(m0 + wm + (r & 3) + 8 * (r >> 2) + 4 * kh, M - 1);
+                const int o = (int)(((float)rowc + 0.5f) * inv_inner), i = rowc - o * inner;
+                const float* sv = S.save.ptr + (o * (int)S.save.ld_outer + i * (int)S.save.ld_inner);
+                g_dh[r] = S.dh.ptr[o * (int)S.dh.ld_outer + i * (int)S.dh.ld_inner + colc];
+                g_rg[r] = sv[colc];
+                g_z[r] = sv[H + colc];
+                g_n[r] = sv[2 * H + colc];
+                g_hn[r] = sv[3 * H + colc];
+                g_h0[r] = hp_ptr[o * hp_lo + i * hp_li + colc];
+                g_uu[r] = u_ptr[o * u_lo + i * u_li];
+            }
+        }
+    }
+
     // uniform per workgroup: aligned operands and a reduction range made of whole k-tiles -> branch-free staging
     const bool fast = a_vec && b_vec && ((k_end - k_begin) % BK == 0);
     if (fast)
@@ -441,6 +488,65 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(const Group g) {
                 }
         return;
     }
+    if constexpr (GATE) {
+        static_assert(TM * TN == 1 && PREFETCH_C, "the fused gate epilogue is written for the 64x64 class");
+        if (gidx >= 0) {
+            // acc + cprev is the complete carried gradient of this (row, unit): run the gate backward of the next chain
+            // step on it (same arithmetic as gru_step_bwd_kernel, gru.hip) and leave the direct path in the carry
+            const twog_gru_step_bwd_t& S = ga->s[gidx];
+            const int H = S.hidden;
+            const int col = n0 + wn + li;
+            const bool has_u = S.u != nullptr, has_hp = S.h_prev.ptr != nullptr;
+            const int inner = S.dh.inner > 1 ? S.dh.inner : 1;
+            const float inv_inner = 1.0f / (float)inner;
+            float dul[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                const bool ok = row < M && col < N;
+                const float d = g_dh[r] + acc[0][0][r] + cprev[r];
+                const float rg = g_rg[r], z = g_z[r], n = g_n[r], hn = g_hn[r];
+                const float h0 = has_hp ? g_h0[r] : 0.f, uu = has_u ? g_uu[r] : 1.0f;
+                const float gnew = (1.0f - z) * n + z * h0;
+                dul[r] = ok ? d * (gnew - h0) : 0.f;
+                const float dg = has_u ? uu * d : d;
+                float dprev = has_u ? (1.0f - uu) * d : 0.f;
+                const float dn = dg * (1.0f - z);
+                const float dz = dg * (h0 - n);
+                dprev += dg * z;
+                const float dn_pre = dn * (1.0f - n * n);
+                const float dr_pre = dn_pre * hn * rg * (1.0f - rg);
+                const float dz_pre = dz * z * (1.0f - z);
+                if (ok) {
+                    const int o = (int)(((float)row + 0.5f) * inv_inner), i = row - o * inner;
+                    float* dgi = S.dgi.ptr + (o * (int)S.dgi.ld_outer + i * (int)S.dgi.ld_inner);
+                    float* dgh = S.dgh.ptr + (o * (int)S.dgh.ld_outer + i * (int)S.dgh.ld_inner);
+                    dgi[col] = dr_pre;
+                    dgi[H + col] = dz_pre;
+                    dgi[2 * H + col] = dn_pre;
+                    dgh[col] = dr_pre;
+                    dgh[H + col] = dz_pre;
+                    dgh[2 * H + col] = dn_pre * rg;
+                    S.dh_prev.ptr[row * (int)S.dh_prev.ld_outer + col] = dprev;
+                }
+            }
+            float* part = ga->du_part[gidx];
+            if (part) {
+                // row sums over this wave's 32 units (lanes of one half-wave share the rows); the 2 * tiles_n partials
+                // per row are added in fixed order by du_reduce_kernel: deterministic, unlike atomics
+                const int p = 2 * tn_idx + (wave & 1);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float v = dul[r];
+#pragma unroll
+                    for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+                    const int row = m0 + wm + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                    if (li == 0 && row < M) part[(int64_t)p * S.rows + row] = v;
+                }
+            }
+            return;
+        }
+    }
 #pragma unroll
     for (int a = 0; a < TM; ++a)
 #pragma unroll
@@ -463,6 +569,17 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(const Group g) {
                 crow[col] = v;
             }
         }
+}
+
+template <int BM, int BN, int NT, bool AKM, bool BKM, int D, bool KG>
+__global__ __launch_bounds__(NT, 2) void gemm_kernel(const Group g) {
+    gemm_tile<BM, BN, NT, AKM, BKM, D, KG, false>(g, nullptr);
+}
+
+// 64x64 class, A row-major, B k-major (dX = dY W): the only form the recurrent backward chains use
+template <int D>
+__global__ __launch_bounds__(256, 2) void gemm_gate_bwd_kernel(const Group g, const GateArgs ga) {
+    gemm_tile<64, 64, 256, false, true, D, false, true>(g, &ga);
 }
 
 // sums split-K slabs in fixed order and applies the epilogue
@@ -549,6 +666,92 @@ int launch(Group& g, int akm, int bkm, hipStream_t st) {
 
 }  // namespace
 
+// Builds the launch descriptor of one chunk (<= MAXP problems): tile class, class-sorted problem list (order[i] = index of
+// the caller's problem that became sorted problem i), XCD map, split-K. Shared by the plain and the gate-fused launch.
+static void prepare_group(const twog_gemm_t* pr, int n, int a_kmajor, int b_kmajor, void* workspace,
+                          size_t workspace_bytes, Group& g, int* order, bool& big) {
+    // tile choice: 128x128 tiles (4 MFMA tiles per wave, half the LDS traffic per FLOP) whenever the problems are
+    // at least one tile wide and -- possibly with split-K -- still fill the chip; 64x64 for the skinny ones.
+    int64_t tiles128 = 0;
+    int kmax = 0;
+    bool wide = true;
+    for (int i = 0; i < n; ++i) {
+        const int nb = pr[i].batch > 0 ? pr[i].batch : 1;
+        tiles128 += (int64_t)nb * ((pr[i].M + 127) / 128) * ((pr[i].N + 127) / 128);
+        if (pr[i].K > kmax) kmax = pr[i].K;
+        if (pr[i].M < 96 || pr[i].N < 96) wide = false;
+    }
+    static const int force_tile = getenv("TWOG_GEMM_TILE") ? atoi(getenv("TWOG_GEMM_TILE")) : 0;
+    static const int force_split = getenv("TWOG_GEMM_SPLITK") ? atoi(getenv("TWOG_GEMM_SPLITK")) : 0;
+    const int64_t reach128 = tiles128 * (workspace ? (kmax >= 1024 ? kmax / 512 : 1) : 1);
+    big = wide && (tiles128 >= 256 || reach128 >= 256);
+    if (force_tile == 128) big = true;
+    if (force_tile == 64) big = false;
+    const int BMN = big ? 128 : 64;
+    g.n = n;
+    // longest reductions first, equal K adjacent (stable: the caller's order within a class is kept)
+    for (int i = 0; i < n; ++i) order[i] = i;
+    for (int i = 1; i < n; ++i)
+        for (int j = i; j > 0 && pr[order[j]].K > pr[order[j - 1]].K; --j) { const int tmp = order[j]; order[j] = order[j - 1]; order[j - 1] = tmp; }
+    int t = 0;
+    g.n_cls = 0;
+    for (int i = 0; i < n; ++i) {
+        Prob& P = g.p[i];
+        const twog_gemm_t& q = pr[order[i]];
+        P.A = q.A; P.B = q.B; P.C = q.C; P.bias = q.bias;
+        P.M = q.M; P.N = q.N; P.K = q.K;
+        P.act = q.act; P.accumulate = q.accumulate;
+        P.tiles_m = (P.M + BMN - 1) / BMN;
+        P.tiles_n = (P.N + BMN - 1) / BMN;
+        P.tile_start = t;
+        P.batch = q.batch > 0 ? q.batch : 1;
+        static const int force_nmajor = getenv("TWOG_GEMM_NMAJOR") ? atoi(getenv("TWOG_GEMM_NMAJOR")) : -1;
+        P.n_major = force_nmajor >= 0 ? force_nmajor : (P.N > P.M ? 1 : 0);
+        P.a_bs = q.a_batch_stride; P.b_bs = q.b_batch_stride; P.c_bs = q.c_batch_stride;
+        const int ntiles = P.batch * P.tiles_m * P.tiles_n;
+        if (i == 0 || P.K != g.p[i - 1].K) {
+            g.cls_start[g.n_cls] = t;
+            g.cls_ntiles[g.n_cls] = 0;
+            ++g.n_cls;
+        }
+        g.cls_ntiles[g.n_cls - 1] += ntiles;
+        t += ntiles;
+        P.a_vec = vec_ok(P.A, q.a_batch_stride, a_kmajor ? P.M : P.K, a_kmajor ? P.K : P.M);
+        P.b_vec = vec_ok(P.B, q.b_batch_stride, b_kmajor ? P.N : P.K, b_kmajor ? P.K : P.N);
+    }
+    for (int c = 0, rot = 0; c < g.n_cls; ++c) {
+        g.cls_rot[c] = rot & 7;
+        rot += g.cls_ntiles[c] & 7;
+    }
+    g.total_tiles = t;
+    g.splitk = 1;
+    g.k_per_split = ((kmax + BK - 1) / BK) * BK;
+    g.slabs = nullptr;
+    // deterministic split-K when the grid would leave CUs idle and the reduction is long
+    if (t < 4096 && kmax >= 1024 && workspace) {
+        // pick the split that fills whole "rounds" of resident workgroups (2 per CU for 128-tiles, 4 for 64-tiles)
+        const int slots = big ? 512 : 1024;
+        const int max_by_k = kmax / 256;
+        int want = 1;
+        double best = 0.0;
+        const int max_split = t < 384 ? 64 : 16;
+        for (int sft = 1; sft <= max_split && sft <= max_by_k; ++sft) {
+            const int64_t wg = (int64_t)t * sft;
+            if (wg > (t < 384 ? 2 : 8) * slots && sft > 1) break;
+            const double eff = (double)wg / (double)(((wg + slots - 1) / slots) * slots);
+            if (eff > best + 0.03) { best = eff; want = sft; }
+        }
+        if (force_split > 0) want = force_split;
+        const size_t need = (size_t)want * t * BMN * BMN * sizeof(float);
+        if (want > 1 && need <= workspace_bytes) {
+            int kps = (kmax + want - 1) / want;
+            g.k_per_split = ((kps + BK - 1) / BK) * BK;
+            g.splitk = (kmax + g.k_per_split - 1) / g.k_per_split;
+            g.slabs = reinterpret_cast<float*>(workspace);
+        }
+    }
+}
+
 extern "C" int twog_gemm_f32(const twog_gemm_t* problems, int n_problems, int a_kmajor, int b_kmajor, void* workspace,
                              size_t workspace_bytes, void* stream) {
     if (n_problems <= 0) return 0;
@@ -557,88 +760,10 @@ extern "C" int twog_gemm_f32(const twog_gemm_t* problems, int n_problems, int a_
     while (done < n_problems) {
         const int n = (n_problems - done) < MAXP ? (n_problems - done) : MAXP;
         const twog_gemm_t* pr = problems + done;
-        // tile choice: 128x128 tiles (4 MFMA tiles per wave, half the LDS traffic per FLOP) whenever the problems are
-        // at least one tile wide and -- possibly with split-K -- still fill the chip; 64x64 for the skinny ones.
-        int64_t tiles128 = 0;
-        int kmax = 0;
-        bool wide = true;
-        for (int i = 0; i < n; ++i) {
-            const int nb = pr[i].batch > 0 ? pr[i].batch : 1;
-            tiles128 += (int64_t)nb * ((pr[i].M + 127) / 128) * ((pr[i].N + 127) / 128);
-            if (pr[i].K > kmax) kmax = pr[i].K;
-            if (pr[i].M < 96 || pr[i].N < 96) wide = false;
-        }
-        static const int force_tile = getenv("TWOG_GEMM_TILE") ? atoi(getenv("TWOG_GEMM_TILE")) : 0;
-        static const int force_split = getenv("TWOG_GEMM_SPLITK") ? atoi(getenv("TWOG_GEMM_SPLITK")) : 0;
-        const int64_t reach128 = tiles128 * (workspace ? (kmax >= 1024 ? kmax / 512 : 1) : 1);
-        bool big = wide && (tiles128 >= 256 || reach128 >= 256);
-        if (force_tile == 128) big = true;
-        if (force_tile == 64) big = false;
-        const int BMN = big ? 128 : 64;
         Group g;
-        g.n = n;
-        // longest reductions first, equal K adjacent (stable: the caller's order within a class is kept)
         int order[MAXP];
-        for (int i = 0; i < n; ++i) order[i] = i;
-        for (int i = 1; i < n; ++i)
-            for (int j = i; j > 0 && pr[order[j]].K > pr[order[j - 1]].K; --j) { const int tmp = order[j]; order[j] = order[j - 1]; order[j - 1] = tmp; }
-        int t = 0;
-        g.n_cls = 0;
-        for (int i = 0; i < n; ++i) {
-            Prob& P = g.p[i];
-            const twog_gemm_t& q = pr[order[i]];
-            P.A = q.A; P.B = q.B; P.C = q.C; P.bias = q.bias;
-            P.M = q.M; P.N = q.N; P.K = q.K;
-            P.act = q.act; P.accumulate = q.accumulate;
-            P.tiles_m = (P.M + BMN - 1) / BMN;
-            P.tiles_n = (P.N + BMN - 1) / BMN;
-            P.tile_start = t;
-            P.batch = q.batch > 0 ? q.batch : 1;
-            static const int force_nmajor = getenv("TWOG_GEMM_NMAJOR") ? atoi(getenv("TWOG_GEMM_NMAJOR")) : -1;
-            P.n_major = force_nmajor >= 0 ? force_nmajor : (P.N > P.M ? 1 : 0);
-            P.a_bs = q.a_batch_stride; P.b_bs = q.b_batch_stride; P.c_bs = q.c_batch_stride;
-            const int ntiles = P.batch * P.tiles_m * P.tiles_n;
-            if (i == 0 || P.K != g.p[i - 1].K) {
-                g.cls_start[g.n_cls] = t;
-                g.cls_ntiles[g.n_cls] = 0;
-                ++g.n_cls;
-            }
-            g.cls_ntiles[g.n_cls - 1] += ntiles;
-            t += ntiles;
-            P.a_vec = vec_ok(P.A, q.a_batch_stride, a_kmajor ? P.M : P.K, a_kmajor ? P.K : P.M);
-            P.b_vec = vec_ok(P.B, q.b_batch_stride, b_kmajor ? P.N : P.K, b_kmajor ? P.K : P.N);
-        }
-        for (int c = 0, rot = 0; c < g.n_cls; ++c) {
-            g.cls_rot[c] = rot & 7;
-            rot += g.cls_ntiles[c] & 7;
-        }
-        g.total_tiles = t;
-        g.splitk = 1;
-        g.k_per_split = ((kmax + BK - 1) / BK) * BK;
-        g.slabs = nullptr;
-        // deterministic split-K when the grid would leave CUs idle and the reduction is long
-        if (t < 4096 && kmax >= 1024 && workspace) {
-            // pick the split that fills whole "rounds" of resident workgroups (2 per CU for 128-tiles, 4 for 64-tiles)
-            const int slots = big ? 512 : 1024;
-            const int max_by_k = kmax / 256;
-            int want = 1;
-            double best = 0.0;
-            const int max_split = t < 384 ? 64 : 16;
-            for (int sft = 1; sft <= max_split && sft <= max_by_k; ++sft) {
-                const int64_t wg = (int64_t)t * sft;
-                if (wg > (t < 384 ? 2 : 8) * slots && sft > 1) break;
-                const double eff = (double)wg / (double)(((wg + slots - 1) / slots) * slots);
-                if (eff > best + 0.03) { best = eff; want = sft; }
-            }
-            if (force_split > 0) want = force_split;
-            const size_t need = (size_t)want * t * BMN * BMN * sizeof(float);
-            if (want > 1 && need <= workspace_bytes) {
-                int kps = (kmax + want - 1) / want;
-                g.k_per_split = ((kps + BK - 1) / BK) * BK;
-                g.splitk = (kmax + g.k_per_split - 1) / g.k_per_split;
-                g.slabs = reinterpret_cast<float*>(workspace);
-            }
-        }
+        bool big;
+        prepare_group(pr, n, a_kmajor, b_kmajor, workspace, workspace_bytes, g, order, big);
         static const int depth = getenv("TWOG_GEMM_DEPTH") ? atoi(getenv("TWOG_GEMM_DEPTH")) : 0;  // tuning knob
         const int d128 = depth ? (depth & 3) : 2, d64 = depth ? ((depth >> 2) & 3) : 2;
         int rc;
@@ -654,6 +779,60 @@ extern "C" int twog_gemm_f32(const twog_gemm_t* problems, int n_problems, int a_
         if (rc) return rc;
         done += n;
     }
+    return 0;
+}
+
+
+// Gate-fused launch for the recurrent backward chains (see GateArgs): problems are C += A B with A row-major and B k-major;
+// gates[i].rows > 0 asks for the gate backward `gates[i]` in the epilogue of problem i (its C must be the gate's dh_prev
+// buffer; the gate's dh2 is taken from the accumulators, not from memory). Returns 1 without launching when this chunk
+// is not served by the fused kernel (tile class, grouped rows, too many partial slots) -- dry_run only asks that.
+int twog_internal_gemm_gate_bwd(const twog_gemm_t* pr, int n, const twog_gru_step_bwd_t* gates, float* const* du_part,
+                                int dry_run, void* stream) {
+    if (n <= 0 || n > MAXP) return 1;
+    Group g;
+    int order[MAXP];
+    bool big;
+    prepare_group(pr, n, 0, 1, nullptr, 0, g, order, big);
+    if (big || g.splitk != 1) return 1;
+    auto span31 = [](const twog_rows_t& m, int rows, int64_t width) {  // largest element offset fits 31 bits
+        const int inner = m.inner > 1 ? m.inner : 1;
+        const int64_t last = (int64_t)((rows - 1) / inner) * m.ld_outer + (int64_t)((rows - 1) % inner) * (m.inner > 1 ? m.ld_inner : 0) + width;
+        return m.ld_outer >= 0 && m.ld_inner >= 0 && last < (int64_t(1) << 31);
+    };
+    for (int i = 0; i < n; ++i) {
+        if (pr[i].B.inner > 1 || pr[i].batch > 1 || pr[i].bias || pr[i].act) return 1;
+        const twog_gru_step_bwd_t& G = gates[i];
+        if (G.rows <= 0) continue;
+        if ((pr[i].N + 63) / 64 > 8 || G.rows != pr[i].M || G.hidden != pr[i].N || G.rows >= (1 << 22)) return 1;
+        const int inner = G.dh.inner > 1 ? G.dh.inner : 1;
+        auto same = [&](const twog_rows_t& m) { return (m.inner > 1 ? m.inner : 1) == inner; };
+        if (!same(G.save) || !same(G.dgi) || !same(G.dgh) || (G.h_prev.ptr && !same(G.h_prev))) return 1;
+        if (G.u && (G.u_inner > 1 ? G.u_inner : 1) != inner) return 1;
+        if (G.dh_prev.inner > 1 || G.dh_prev.ptr != pr[i].C.ptr || G.dh_prev_accumulate) return 1;
+        const int H3 = 3 * G.hidden;
+        if (!span31(G.dh, G.rows, G.hidden) || !span31(G.save, G.rows, 4 * G.hidden) || !span31(G.dgi, G.rows, H3) ||
+            !span31(G.dgh, G.rows, H3) || !span31(G.dh_prev, G.rows, G.hidden) ||
+            (G.h_prev.ptr && !span31(G.h_prev, G.rows, G.hidden)))
+            return 1;
+        if (G.u && ((int64_t)((G.rows - 1) / inner) * G.u_ld_outer + (int64_t)((G.rows - 1) % inner) * G.u_ld_inner >= (int64_t(1) << 31)))
+            return 1;
+    }
+    if (dry_run) return 0;
+    GateArgs ga;
+    for (int i = 0; i < n; ++i) {
+        const int src = order[i];
+        ga.gate_of[i] = gates[src].rows > 0 ? i : -1;
+        ga.s[i] = gates[src];
+        ga.du_part[i] = (gates[src].rows > 0 && gates[src].du && du_part) ? du_part[src] : nullptr;
+    }
+    for (int i = n; i < MAXP; ++i) { ga.gate_of[i] = -1; ga.du_part[i] = nullptr; }
+    static const int depth = getenv("TWOG_GEMM_DEPTH") ? atoi(getenv("TWOG_GEMM_DEPTH")) : 0;
+    const int d64 = depth ? ((depth >> 2) & 3) : 2;
+    dim3 grid(g.total_tiles, 1), block(256);
+    if (d64 == 2) hipLaunchKernelGGL(gemm_gate_bwd_kernel<2>, grid, block, 0, (hipStream_t)stream, g, ga);
+    else hipLaunchKernelGGL(gemm_gate_bwd_kernel<1>, grid, block, 0, (hipStream_t)stream, g, ga);
+    TWOG_CHECK_LAUNCH();
     return 0;
 }
 

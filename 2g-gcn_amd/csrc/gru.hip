@@ -225,9 +225,8 @@ static int bigru_fwd_impl(const twog_bigru_t* types, int n_types, int bs, int T,
 static int bigru_bwd_impl(const twog_bigru_bwd_t* types, int n_types, int bs, int T, int hidden, void* stream) {
     if (n_types > 4) return -1;
     const int h = hidden;
-    for (int s = T - 1; s >= 0; --s) {
-        twog_gemm_t gm[8];
-        twog_gru_step_bwd_t st[8];
+    // gate descriptors + the carry GEMM of chain step s, one pair per (type, direction)
+    auto make_step = [&](int s, twog_gru_step_bwd_t* st, twog_gemm_t* gm) {
         int n = 0;
         for (int k = 0; k < n_types; ++k) {
             const twog_bigru_bwd_t& Y = types[k];
@@ -250,20 +249,44 @@ static int bigru_bwd_impl(const twog_bigru_bwd_t* types, int n_types, int bs, in
                 S.u = nullptr; S.du = nullptr; S.u_ld_outer = S.u_ld_inner = 0; S.u_inner = 1;
                 S.rows = rows; S.hidden = h; S.dh_prev_accumulate = 0;
                 // carried gradient: carry += d_gh W_hh   (reduction over the 3h gate rows of W_hh: k-major B)
-                twog_gemm_t& G = gm[n];
-                G.A = S.dgh;
-                G.B = rows_plain((dir == 0 ? Y.w_hh_f : Y.w_hh_r), h);
-                G.C = rows_plain(carry, h);
-                G.bias = nullptr;
-                G.M = rows; G.N = h; G.K = 3 * h; G.act = 0; G.accumulate = 1; G.batch = 1;
-                G.a_batch_stride = G.b_batch_stride = G.c_batch_stride = 0;
+                if (gm) {
+                    twog_gemm_t& G = gm[n];
+                    G.A = S.dgh;
+                    G.B = rows_plain((dir == 0 ? Y.w_hh_f : Y.w_hh_r), h);
+                    G.C = rows_plain(carry, h);
+                    G.bias = nullptr;
+                    G.M = rows; G.N = h; G.K = 3 * h; G.act = 0; G.accumulate = 1; G.batch = 1;
+                    G.a_batch_stride = G.b_batch_stride = G.c_batch_stride = 0;
+                }
                 ++n;
             }
         }
-        int rc = twog_gru_step_bwd(st, n, stream);
-        if (rc) return rc;
+        return n;
+    };
+    // The carry GEMM of step s is the only writer of the carried gradient, so the gate backward of step s-1 runs in its
+    // epilogue (gemm_f32.hip, GateArgs) instead of in a launch of its own; the first step has no GEMM before it.
+    bool fuse = T > 1 && (h + 63) / 64 <= 8 && getenv("TWOG_NO_GATE_FUSION") == nullptr;
+    for (int s = T - 1; s >= 0; --s) {
+        twog_gemm_t gm[8];
+        twog_gru_step_bwd_t st[8], nxt[8];
+        const int n = make_step(s, st, gm);
+        int rc;
+        if (!fuse || s == T - 1) {
+            rc = twog_gru_step_bwd(st, n, stream);
+            if (rc) return rc;
+        }
         if (s > 0) {
-            rc = twog_gemm_f32(gm, n, 0, 1, nullptr, 0, stream);
+            rc = 1;
+            if (fuse) {
+                make_step(s - 1, nxt, nullptr);
+                rc = twog_internal_gemm_gate_bwd(gm, n, nxt, nullptr, 0, stream);
+                if (rc < 0) return rc;
+                if (rc == 1) {  // shape not served by the fused kernel: decided at the first step
+                    if (s != T - 1) return -120;
+                    fuse = false;
+                }
+            }
+            if (rc == 1) rc = twog_gemm_f32(gm, n, 0, 1, nullptr, 0, stream);
             if (rc) return rc;
         }
     }

@@ -169,17 +169,31 @@ static int segrnn_fwd_impl(const twog_segrnn_t* desc, void* stream) {
     return 0;
 }
 
+// adds the parked d_u partials (fused gate epilogues) into d_u in fixed order: one thread per (clip, time, entity)
+__global__ __launch_bounds__(256) void du_reduce_kernel(const float* part, float* du, int bs, int T, int E, int P) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= bs * T * E) return;
+    const int e = i % E, t = (i / E) % T, b = i / (E * T);
+    const int rows = bs * E, row = b * E + e;
+    float acc = 0.f;
+    for (int dir = 0; dir < 2; ++dir) {
+        // the first step of each chain (t = T-1 forward in time, t = 0 backward) ran as a separate launch
+        if ((dir == 0 && t == T - 1) || (dir == 1 && t == 0)) continue;
+        const float* p = part + ((int64_t)(dir * T + t) * 16) * rows + row;
+        for (int k = 0; k < P; ++k) acc += p[(int64_t)k * rows];
+    }
+    du[i] += acc;
+}
+
 static int segrnn_bwd_impl(const twog_segrnn_t* desc, const twog_segrnn_bwd_t* bdesc, void* stream) {
     const twog_segrnn_t& S = *desc;
     const twog_segrnn_bwd_t& B = *bdesc;
     const Dims d = dims_of(S);
     const int h = d.h, T = d.T;
     const bool msg = S.msg_segment && (d.nmh + d.nmo) > 0;
-    for (int s = T - 1; s >= 0; --s) {
+    // gate backward descriptors of chain step s, order (dir, kind) like the GEMM problem lists below
+    auto make_gates = [&](int s, twog_gru_step_bwd_t* st, float** du_part) {
         const bool first = (s == 0), last = (s == T - 1);
-        int rc;
-        // (a) gate backward
-        twog_gru_step_bwd_t st[4];
         int ns = 0;
         for (int dir = 0; dir < 2; ++dir) {
             const int t = dir == 0 ? s : T - 1 - s, tp = dir == 0 ? t - 1 : t + 1;
@@ -190,7 +204,7 @@ static int segrnn_bwd_impl(const twog_segrnn_t* desc, const twog_segrnn_bwd_t* b
                 const float* hs = kind == 0 ? S.hs_h : S.hs_o;
                 const float* dhs = kind == 0 ? B.d_hs_h : B.d_hs_o;
                 float* carry = (kind == 0 ? B.carry_h : B.carry_o) + (int64_t)dir * rows * h;
-                twog_gru_step_bwd_t& G = st[ns++];
+                twog_gru_step_bwd_t& G = st[ns];
                 G.dh = rows_be(dhs + (int64_t)t * E * 2 * h + dir * h, E, 2 * h, T);
                 G.dh2 = last ? rows_null() : rows_plain(carry, h);
                 const float* sv = kind == 0 ? S.save_h : S.save_o;
@@ -205,10 +219,37 @@ static int segrnn_bwd_impl(const twog_segrnn_t* desc, const twog_segrnn_bwd_t* b
                 G.du = (kind == 0 ? B.d_u_h : B.d_u_o) + (int64_t)t * E;
                 G.u_ld_outer = (int64_t)T * E; G.u_ld_inner = 1; G.u_inner = E;
                 G.rows = rows; G.hidden = h; G.dh_prev_accumulate = 0;
+                if (du_part) {
+                    float* base = kind == 0 ? B.du_part_h : B.du_part_o;
+                    du_part[ns] = base ? base + ((int64_t)(dir * T + t) * 16) * rows : nullptr;
+                }
+                ++ns;
             }
         }
-        rc = twog_gru_step_bwd(st, ns, stream);
-        if (rc) return rc;
+        return ns;
+    };
+    // Which launch adds the LAST contribution to the carried state gradients of a step? With messages from both kinds
+    // of senders it is the sender-MLP GEMM (e); without segment-level messages the W_hh GEMM (b). In those two layouts
+    // the gate backward of the next chain step is fused into that launch's epilogue (gemm_f32.hip, GateArgs); any other
+    // layout (a sender kind missing) keeps the separate gate launches.
+    const bool both = d.H > 0 && d.O > 0;
+    const bool fuse_e = msg && both && d.nsh > 0 && d.nso > 0;
+    const bool fuse_b = !msg && both;
+    bool fuse = (fuse_e || fuse_b) && B.du_part_h && B.du_part_o && T > 1 && (h + 63) / 64 <= 8 &&
+                getenv("TWOG_NO_GATE_FUSION") == nullptr;
+    for (int s = T - 1; s >= 0; --s) {
+        const bool first = (s == 0);
+        int rc;
+        // (a) gate backward (separate launch: always for the first step of the chain, else only when not fused)
+        twog_gru_step_bwd_t st[4];
+        if (!fuse || s == T - 1) {
+            const int ns = make_gates(s, st, nullptr);
+            rc = twog_gru_step_bwd(st, ns, stream);
+            if (rc) return rc;
+        }
+        twog_gru_step_bwd_t nxt[4];  // gates of step s-1, aligned with the problems of the fused launch
+        float* nxt_part[4];
+        if (fuse && !first) make_gates(s - 1, nxt, nxt_part);
         // (b) through the projections: d_mg = d_gi W_ih[:, msg] ; carry += d_gh W_hh
         twog_gemm_t gm[8];
         int n = 0;
@@ -236,7 +277,16 @@ static int segrnn_bwd_impl(const twog_segrnn_t* desc, const twog_segrnn_bwd_t* b
             }
         }
         if (n) {
-            rc = twog_gemm_f32(gm, n, 0, 1, nullptr, 0, stream);
+            rc = 1;
+            if (fuse && fuse_b && !first) {  // problems are exactly the four W_hh GEMMs, in (dir, kind) order
+                rc = twog_internal_gemm_gate_bwd(gm, n, nxt, nxt_part, 0, stream);
+                if (rc < 0) return rc;
+                if (rc == 1) {  // shape not served by the fused kernel: decided at the first step, cannot change later
+                    if (s != T - 1) return -120;
+                    fuse = false;
+                }
+            }
+            if (rc == 1) rc = twog_gemm_f32(gm, n, 0, 1, nullptr, 0, stream);
             if (rc) return rc;
         }
         if (!msg) continue;
@@ -285,8 +335,25 @@ static int segrnn_bwd_impl(const twog_segrnn_t* desc, const twog_segrnn_bwd_t* b
                          rows_plain(B.carry_o + (int64_t)dir * d.bs * d.O * h, h), nullptr, d.bs * d.O, h, d.nso * h, 0, 1);
             }
         }
-        rc = twog_gemm_f32(gm, n, 0, 1, nullptr, 0, stream);
+        rc = 1;
+        if (fuse && fuse_e) {  // problems are exactly (dir, kind) = the order of make_gates
+            rc = twog_internal_gemm_gate_bwd(gm, n, nxt, nxt_part, 0, stream);
+            if (rc < 0) return rc;
+            if (rc == 1) {
+                if (s != T - 1) return -122;
+                fuse = false;
+            }
+        }
+        if (rc == 1) rc = twog_gemm_f32(gm, n, 0, 1, nullptr, 0, stream);
         if (rc) return rc;
+    }
+    if (fuse) {
+        const int P = 2 * ((h + 63) / 64);
+        if (d.H) hipLaunchKernelGGL(du_reduce_kernel, dim3((d.bs * T * d.H + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                                    B.du_part_h, B.d_u_h, d.bs, T, d.H, P);
+        if (d.O) hipLaunchKernelGGL(du_reduce_kernel, dim3((d.bs * T * d.O + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                                    B.du_part_o, B.d_u_o, d.bs, T, d.O, P);
+        TWOG_CHECK_LAUNCH();
     }
     return 0;
 }

@@ -25,6 +25,10 @@ inline void twog_allow_dynamic_lds(K kernel, int bytes, std::atomic<uint32_t>& d
     done.fetch_or(bit, std::memory_order_release);
 }
 
+// library-internal (gemm_f32.hip): grouped C += A B launch whose epilogue runs the GRU gate backward of the next chain step
+int twog_internal_gemm_gate_bwd(const twog_gemm_t* problems, int n, const twog_gru_step_bwd_t* gates,
+                                float* const* du_part, int dry_run, void* stream);
+
 // address of row r in a twog_rows_t (see include/twog_gcn.h)
 __device__ __forceinline__ int64_t twog_row_off(const twog_rows_t& m, int r) {
     if (m.inner <= 1) return (int64_t)r * m.ld_outer;

@@ -350,7 +350,8 @@ class HipKernels:
                    d_u_o=torch.zeros(bs, T, O, dtype=torch.float32, device=dev),
                    d_pre_h=e(2, bs, T, H, nsh * h), d_pre_o=e(2, bs, T, O, nso * h))
         scratch = dict(carry_h=e(2, bs * H, h), carry_o=e(2, bs * O, h), tmp_dmg_h=e(2, bs * H, nmh * h),
-                       tmp_dmg_o=e(2, bs * O, nmo * h), trash=e(bs * max(H, O, 1), h))
+                       tmp_dmg_o=e(2, bs * O, nmo * h), trash=e(bs * max(H, O, 1), h),
+                       du_part_h=e(2, T, 16, bs * H), du_part_o=e(2, T, 16, bs * O))
         s = L.SegRnn()
         self._fill_seg(s, p, bufs)
         b = L.SegRnnBwd()

@@ -253,6 +253,11 @@ typedef struct {
     float* tmp_dmg_h; /* scratch [2][bs*H][nmh*h] */
     float* tmp_dmg_o; /* scratch [2][bs*O][nmo*h] */
     float* trash;     /* scratch [bs*max(H,O)][h] */
+    /* scratch [2][T][16][bs*H] / [2][T][16][bs*O] or NULL. When both are given, the gate backward of chain step s-1 runs
+     * in the epilogue of the last GEMM of step s (no separate gate launches) and parks its per-row partial sums of
+     * d_u here; they are added into d_u_* in fixed order after the loop (bit-reproducible). NULL: separate launches. */
+    float* du_part_h;
+    float* du_part_o;
 } twog_segrnn_bwd_t;
 int twog_segrnn_bwd(const twog_segrnn_t* desc, const twog_segrnn_bwd_t* bdesc, void* stream);
 
