@@ -9,7 +9,6 @@ Row-strided views: a matrix operand may be a 2-D view (rows, cols) or a 3-D view
 stride on cols -- it maps onto twog_rows_t without a copy.
 """
 import ctypes as C
-import math
 
 import torch
 

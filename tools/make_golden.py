@@ -367,7 +367,6 @@ def g6_batching():
 def g8_postprocess():
     """G8: inference post-processing of predict.py (:64-70 repeat_interleave + match_shape, :195-201 argmax) and the
     segmental metric pyrutils.metrics.f1_at_k (:68-81) on seeded label sequences with ignored padding."""
-    import importlib.util
     from pyrutils.metrics import f1_at_k
     # predict.py imports omegaconf / sklearn at module level (absent here); match_shape is self-contained: load it alone
     src = open(os.path.join(REF, 'predict.py')).read()
