@@ -186,9 +186,9 @@ def test_gcn_kernels(K, N):
 
 
 # --------------------------------------------------------------------------------------------------------------- BiGRU
-@pytest.mark.parametrize('h', [16, 72])
-def test_bigru(K, h):
-    bs, T = 3, 5
+@pytest.mark.parametrize('h,bs', [(16, 3), (72, 3), (512, 40)])
+def test_bigru(K, h, bs):
+    T = 5 if h < 512 else 3
     types_c, types_g = [], []
     for i, E in enumerate((2, 3, 1)):
         d = dict(gi=rnd(bs, T, E, 6 * h, seed=i), w_hh_f=rnd(3 * h, h, seed=10 + i, scale=0.2), b_hh_f=rnd(3 * h, seed=20 + i),
@@ -269,7 +269,8 @@ def test_entity_attention(K, H, O, D, h, ipc, geo, rm):
 
 # ---------------------------------------------------------------------------------------------- segment-level recurrence
 def _seg_params(dev, bs, T, H, O, h, rels, msg_segment=True, seed=0):
-    t = lambda *s, sd=0, sc=0.3: rnd(*s, seed=seed + sd, scale=sc).to(dev)
+    w_sc = 0.3 if h <= 64 else 0.3 * math.sqrt(64.0 / h)   # keep pre-activations O(1) at full width
+    t = lambda *s, sd=0, sc=None: rnd(*s, seed=seed + sd, scale=w_sc if sc is None else sc).to(dev)
     rel_hh, rel_ho, rel_oh, rel_oo = rels
     nmh, nmo = int(rel_hh) + int(rel_oh), int(rel_ho) + int(rel_oo)
     nsh, nso = int(rel_hh) + int(rel_ho), int(rel_oh) + int(rel_oo)
@@ -297,7 +298,11 @@ def _seg_params(dev, bs, T, H, O, h, rels, msg_segment=True, seed=0):
 @pytest.mark.parametrize('bs,T,H,O,h,rels,msg', [(3, 5, 2, 4, 16, (True, True, True, True), True),
                                                  (2, 4, 1, 5, 32, (False, True, True, True), True),
                                                  (2, 3, 2, 3, 16, (True, True, True, True), False),
-                                                 (4, 6, 2, 8, 64, (True, True, True, True), True)])
+                                                 (4, 6, 2, 8, 64, (True, True, True, True), True),
+                                                 # full width: 8 column tiles, several row tiles -- every partial slot of
+                                                 # the fused gate-backward epilogue (with and without segment messages)
+                                                 (24, 3, 2, 8, 512, (True, True, True, True), True),
+                                                 (24, 3, 2, 8, 512, (True, True, True, True), False)])
 def test_segment_recurrence(K, bs, T, H, O, h, rels, msg):
     pc = _seg_params('cpu', bs, T, H, O, h, rels, msg)
     pg = _seg_params(DEV, bs, T, H, O, h, rels, msg)

@@ -34,7 +34,7 @@ def one_case(rng, idx, dev=DEV):
     cfg = dict(BASE)
     bs, T = rng.randint(1, 5), rng.randint(1, 9)
     O, N = rng.randint(1, 12), rng.choice([19, 26, 30, 34, 21, 40])
-    h = rng.choice([16, 32, 48, 64, 80])
+    h = rng.choice([16, 32, 48, 64, 80, 16, 32, 48, 64, 80, 256])   # 256: four column tiles per GEMM problem
     if H == 1:
         cfg['message_humans_to_human'] = False
     if O == 1:
