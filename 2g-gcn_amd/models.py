@@ -231,9 +231,10 @@ class TGGCN(nn.Module):
             bad.append(f"message_type={c['message_type']!r}")
         if c['message_granularity'] not in {'v1', 'generic'}:
             bad.append(f"message_granularity={c['message_granularity']!r}")
-        if c['message_aggregation'] not in {'att', 'attention'}:
+        mean_pool = c['message_aggregation'] in {'mp', 'mean_pooling'}
+        if not mean_pool and c['message_aggregation'] not in {'att', 'attention'}:
             bad.append(f"message_aggregation={c['message_aggregation']!r}")
-        if c['attention_style'] not in {'v2', 'dot-product', 'v3', 'scaled_dot-product'}:
+        if not mean_pool and c['attention_style'] not in {'v2', 'dot-product', 'v3', 'scaled_dot-product'}:
             bad.append(f"attention_style={c['attention_style']!r}")
         if c['discrete_networks_num_layers'] != 1:
             bad.append('discrete_networks_num_layers != 1')

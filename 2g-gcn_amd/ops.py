@@ -20,7 +20,7 @@ import torch
 from .kernels import get_kernels
 
 SUPPORTED_NOTE = ("the HIP path implements message_type 'v2' + message_granularity 'v1' + message_aggregation 'att' "
-                  "with attention_style 'v2'/'v3', discrete_networks_num_layers == 1, "
+                  "(attention_style 'v2'/'v3') or 'mp', discrete_networks_num_layers == 1, "
                   "object_segment_update_strategy 'ind', no time-position / segment-length features, "
                   "cat_level_states off, bias=True (every configuration shipped in the reference's conf/models/)")
 
@@ -73,6 +73,11 @@ class Plan:
         style = c['attention_style']
         self.scale_frame = 1.0 / math.sqrt(2 * h) if style in {'v3', 'scaled_dot-product'} else 1.0
         self.scale_seg = 1.0 / math.sqrt(h) if style in {'v3', 'scaled_dot-product'} else 1.0
+        if c['message_aggregation'] in {'mp', 'mean_pooling'}:
+            # mean pooling over the real senders (e.g. models.py:1034-1037: sum of the masked messages / clamp(count, 1))
+            # IS the attention path with every score equal: softmax over the valid senders = 1 / count, no valid sender
+            # -> zeros, and no gradient reaches the features. A zero score scale gives exactly that.
+            self.scale_frame = self.scale_seg = 0.0
         # segment-level message blocks appended to the GRUCell input (models.py:798,807 / :843,851)
         self.seg_mh = [r for r, on in (('hh', self.rel_hh), ('oh', self.rel_oh)) if on] if self.msg_segment else []
         self.seg_mo = [r for r, on in (('ho', self.rel_ho), ('oo', self.rel_oo)) if on] if self.msg_segment else []

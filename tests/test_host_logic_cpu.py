@@ -162,11 +162,11 @@ def test_randomised_layouts_vs_oracle(fake_backend):
     Covers e.g. a GIVEN segmentation combined with filter_discrete_updates (the filter applies to it too)."""
     import random
     from tools.parity_fuzz import one_case
-    rng = random.Random(5)
+    rng = random.Random(2)
     seen, axes = set(), set()
     for i in range(16):
         d = one_case(rng, i, dev='cpu')
         assert d['worst_output_rel'] < 1e-4, d     # (gradients: asserted per tensor inside one_case)
         seen.add((d['given_seg'], d['filt']))
-        axes.update([d['strat'], d['att']])
-    assert len(seen) == 4 and axes == {'gs', 'st', 'v2', 'v3'}
+        axes.update([d['strat'], d['att'], d['agg']])
+    assert len(seen) == 4 and axes == {'gs', 'st', 'v2', 'v3', 'att', 'mp'}
