@@ -254,15 +254,14 @@ class TGGCN(nn.Module):
                 human_human_distances=None, human_object_distances=None, object_object_distances=None,
                 steps_per_example=None, inspect_model=False):
         """Same contract as the reference forward (vhoi/models.py:584-933): returns the list of 6 tensors
-        [y_hs, y_hss, frame_rec, frame_pred, rec, pred] (12 with affordance heads)."""
+        [y_hs, y_hss, frame_rec, frame_pred, rec, pred] (12 with affordance heads); with ``inspect_model=True`` the pair
+        (that list, [a_frame, a_segment_forward, a_segment_backward]) of :928-933."""
         if self._unsupported:
             raise NotImplementedError('configuration not implemented by the gfx950 path: ' + ', '.join(self._unsupported)
                                       + '; ' + ops.SUPPORTED_NOTE)
         if human_human_distances is not None or human_object_distances is not None or \
                 object_object_distances is not None:
             raise NotImplementedError('distance-based attention is not implemented by the gfx950 path')
-        if inspect_model:
-            raise NotImplementedError('inspect_model=True is not implemented by the gfx950 path')
         bs, T, H, F_h = x_human.shape
         O = x_objects.shape[2]
         vw = F_h - 2048  # generalises the reference's hard-coded 76 / 120 / 104 split (vhoi/models.py:631-639)
@@ -301,8 +300,11 @@ class TGGCN(nn.Module):
         hs = human_segmentation.float() if human_segmentation is not None else None
         osg = objects_segmentation.float() if objects_segmentation is not None else None
         out = ops.TGGCNFunction.apply(plan, names, self.training, bn_bufs, x_human, x_objects, objects_mask, hs, osg,
-                                      noise, *params)
-        return list(out)
+                                      noise, bool(inspect_model), *params)
+        out = list(out)
+        if inspect_model:   # (outputs, [frame-level, segment forward, segment backward] objects->human attention weights)
+            return out[:-3], out[-3:]
+        return out
 
 
 def select_model(model_name: str):

@@ -684,13 +684,29 @@ def tggcn_backward(K, plan: Plan, P, S, x_human, x_objects, objects_mask, d_outp
     return G.g
 
 
+def attention_scores(plan, S):
+    """`inspect_model=True` (vhoi/models.py:928-931; predict.py --inspect_model): the objects->human attention weights of
+    the frame level and of the forward / backward segment-level chains, each (bs, H, T, O). They are views of the
+    weights the attention kernels saved for the backward pass -- nothing is recomputed."""
+    p = plan
+    if not p.rel_oh or not p.msg_segment or p.scale_frame == 0.0:
+        # the reference stacks empty lists / has no weights in these configurations and fails as well
+        raise RuntimeError('inspect_model needs message_objects_to_human, message_segment and attention aggregation')
+    bs, T, H, O = p.bs, p.T, p.H, p.O
+    lo, hi = H * H, H * H + H * O                                   # the (receiver human, sender object) block
+    a_f = S['att'].view(bs, T, -1)[:, :, lo:hi].reshape(bs, T, H, O).permute(0, 2, 1, 3).contiguous()
+    seg = S['seg_bufs']['att']                                      # [direction][time][clip][natt]
+    a_s = [seg[d][:, :, lo:hi].reshape(T, bs, H, O).permute(1, 2, 0, 3).contiguous() for d in range(2)]
+    return [a_f, a_s[0], a_s[1]]
+
+
 class TGGCNFunction(torch.autograd.Function):
     """One autograd node for the whole hot path. Inputs after the fixed ones are the parameters in the order of
     ``used_parameter_names(plan)``."""
 
     @staticmethod
     def forward(ctx, plan, names, training, bn_bufs, x_human, x_objects, objects_mask, human_seg, object_seg, noise,
-                *params):
+                inspect, *params):
         K = get_kernels()
         P = dict(zip(names, params))
         outputs, S = tggcn_forward(K, plan, P, x_human, x_objects, objects_mask, human_seg, object_seg, noise,
@@ -701,6 +717,12 @@ class TGGCNFunction(torch.autograd.Function):
         hard = outputs[:n_gate // 2]
         ctx.mark_non_differentiable(*[o for o, gk in zip(hard, ('h', 'o')) if not S['gates'][gk]['learned']])
         ctx.set_materialize_grads(False)
+        ctx.n_extra = 0
+        if inspect:
+            extra = attention_scores(plan, S)
+            ctx.mark_non_differentiable(*extra)
+            ctx.n_extra = len(extra)
+            outputs = list(outputs) + extra
         return tuple(outputs)
 
     @staticmethod
@@ -708,7 +730,7 @@ class TGGCNFunction(torch.autograd.Function):
         K = get_kernels()
         plan = ctx.plan
         x_human, x_objects, objects_mask = ctx.inputs
-        d_outputs = list(d_outputs)
+        d_outputs = list(d_outputs)[:len(d_outputs) - ctx.n_extra]
         gates = ctx.S['gates']
         # a gate tensor that was given as an input (not learned) carries no gradient
         n_gate = 2 if plan.n_aff is None else 4
@@ -723,11 +745,11 @@ class TGGCNFunction(torch.autograd.Function):
         for i, n in enumerate(ctx.names):
             prm = ctx.P[n]
             g = getattr(prm, 'grad', None)
-            if (ctx.needs_input_grad[10 + i] and g is not None and g.is_contiguous() and g.dtype == torch.float32
+            if (ctx.needs_input_grad[11 + i] and g is not None and g.is_contiguous() and g.dtype == torch.float32
                     and g.device == prm.device and not getattr(prm, '_backward_hooks', None)):
                 sinks[n] = g
         grads = tggcn_backward(K, plan, ctx.P, ctx.S, x_human, x_objects, objects_mask, d_outputs, sinks)
-        out = [None] * 10
+        out = [None] * 11
         for n in ctx.names:
             g = grads.get(n)
             if g is not None:

@@ -170,3 +170,33 @@ def test_randomised_layouts_vs_oracle(fake_backend):
         seen.add((d['given_seg'], d['filt']))
         axes.update([d['strat'], d['att'], d['agg']])
     assert len(seen) == 4 and axes == {'gs', 'st', 'v2', 'v3', 'att', 'mp'}
+
+
+def test_inspect_model_returns_the_reference_attention_scores(fake_backend):
+    """predict.py --inspect_model: (outputs, [a_frame, a_segment_forward, a_segment_backward]), each (bs, H, T, O)
+    (vhoi/models.py:928-933), against the oracle."""
+    from oracle import cpu_ref
+    z, meta = load_g4('c2_stage1')
+    m = build_model(meta).eval()
+    noise = torch.from_numpy(z['gumbel_noise'])
+    m._gumbel_noise_override = noise
+    kw = g4_inputs(z)
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    with torch.no_grad():
+        out, att = m(**kw, inspect_model=True)
+        ref_out, ref_att = cpu_ref.tggcn_forward(sd, dict(m.cfg), kw['x_human'], kw['x_objects'], kw['objects_mask'],
+                                                 human_segmentation=kw.get('human_segmentation'),
+                                                 objects_segmentation=kw.get('objects_segmentation'), training=False,
+                                                 gumbel_noise=noise, inspect_model=True)
+    assert len(out) == len(ref_out) == 6 and len(att) == len(ref_att) == 3
+    bs, T, H = z['x_human'].shape[:3]
+    O = z['x_objects'].shape[2]
+    for a, r in zip(att, ref_att):
+        assert tuple(a.shape) == tuple(r.shape) == (bs, H, T, O)
+        assert (a - r).abs().max().item() < 1e-5
+        assert not a.requires_grad
+    for o, r in zip(out, ref_out):
+        assert (o - r).abs().max().item() < 1e-4 * max(1.0, r.abs().max().item())
+    # the slice predict.py takes (human 0) sums to one over the real objects wherever a clip has any
+    s = att[0][:, 0].sum(-1)
+    assert torch.all(((s - 1).abs() < 1e-5) | (s.abs() < 1e-6))

@@ -251,3 +251,25 @@ def test_randomised_layouts_vs_oracle():
         d = one_case(rng, i, dev=DEV)
         worst_o, worst_g = max(worst_o, d['worst_output_rel']), max(worst_g, d['worst_grad_rel'])
     print(f'30 random cases: worst output {worst_o:.2e}, worst gradient {worst_g:.2e}')
+
+
+def test_inspect_model_attention_scores_vs_oracle():
+    """predict.py --inspect_model on the HIP path: the three (bs, H, T, O) objects->human attention tensors."""
+    z, meta = load_g4('c2_stage1')
+    m = _model_from_meta(meta).eval()
+    noise = torch.from_numpy(z['gumbel_noise'])
+    m._gumbel_noise_override = noise
+    kw = g4_inputs(z)
+    sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    with torch.no_grad():
+        out, att = m(**{k: v.to(DEV) for k, v in kw.items()}, inspect_model=True)
+        ref_out, ref_att = cpu_ref.tggcn_forward(sd, dict(m.cfg), kw['x_human'], kw['x_objects'], kw['objects_mask'],
+                                                 human_segmentation=kw.get('human_segmentation'),
+                                                 objects_segmentation=kw.get('objects_segmentation'), training=False,
+                                                 gumbel_noise=noise, inspect_model=True)
+    assert len(att) == 3 and len(out) == len(ref_out)
+    for a, r in zip(att, ref_att):
+        assert tuple(a.shape) == tuple(r.shape)
+        assert (a.cpu() - r).abs().max().item() < 1e-5
+    for o, r in zip(out, ref_out):
+        assert (o.cpu() - r).abs().max().item() < REL * max(1.0, r.abs().max().item())
