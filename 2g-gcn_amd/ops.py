@@ -22,7 +22,7 @@ from .kernels import get_kernels
 SUPPORTED_NOTE = ("the HIP path implements message_type 'v2' + message_granularity 'v1' + message_aggregation 'att' "
                   "(attention_style 'v2'/'v3') or 'mp', discrete_networks_num_layers == 1, "
                   "object_segment_update_strategy 'ind', no time-position / segment-length features, "
-                  "cat_level_states off, bias=True (every configuration shipped in the reference's conf/models/)")
+                  "cat_level_states off, bias=True (a superset of every configuration shipped in the reference's conf/models/)")
 
 
 def _v2(t, width=None):
@@ -68,6 +68,8 @@ class Plan:
         self.learn_h = not human_seg_given
         self.learn_o = not object_seg_given
         self.filter = bool(c['filter_discrete_updates'])
+        # share_level_mlps (models.py:565-570): the frame-level heads ARE the segment-level head modules
+        self.share_heads = bool(c.get('share_level_mlps')) and not bool(c.get('cat_level_states'))
         self.thr = float(c['update_segment_threshold'])
         self.gs = c['discrete_optimization_strategy'] in {'gumbel-sigmoid', 'gs'}
         style = c['attention_style']
@@ -97,6 +99,10 @@ _FRAME_MLP = {'hh': 'humans_to_human_message_mlp', 'ho': 'human_to_object_messag
               'so': 'geometry_to_object_message_mlp', 'sh': 'geometry_to_human_message_mlp'}
 _SEG_MLP = {'hh': 'humans_to_human_segment_message_mlp', 'ho': 'human_to_object_segment_message_mlp',
             'oh': 'objects_to_human_segment_message_mlp', 'oo': 'objects_to_object_segment_message_mlp'}
+
+
+def _head_name(plan, name):
+    return name.replace('_frame', '') if plan.share_heads else name
 
 
 def used_parameter_names(plan: Plan):
@@ -133,6 +139,7 @@ def used_parameter_names(plan: Plan):
         heads += ['object_frame_recognition_mlp', 'object_frame_prediction_mlp', 'object_recognition_mlp',
                   'object_prediction_mlp']
     for m in heads:
+        m = _head_name(plan, m)
         names += [m + '.0.weight', m + '.0.bias']
     # share_level_mlps aliases produce duplicate names; keep the first occurrence
     seen, out = set(), []
@@ -392,6 +399,7 @@ def tggcn_forward(K, plan: Plan, P, x_human, x_objects, objects_mask, human_seg,
     S.update(R_h=R_h, R_o=R_o)
 
     def head(name, Xin, E, C):
+        name = _head_name(p, name)
         logits = empty(nF * E, C)
         K.gemm([dict(A=_v2(Xin), B=P[name + '.0.weight'], C=logits, bias=P.get(name + '.0.bias'))])
         return K.logsoftmax_permute_fwd(logits, bs, T, E, C)
@@ -447,6 +455,7 @@ def tggcn_backward(K, plan: Plan, P, S, x_human, x_objects, objects_mask, d_outp
         for name, y, dy in zip(names, ys, dys):
             if dy is None:
                 continue
+            name = _head_name(p, name)
             dlog = K.logsoftmax_permute_bwd(y, dy.contiguous())
             _lin_w_grads(K, G, name + '.0.weight', name + '.0.bias' if (name + '.0.bias') in P else None, dlog, _v2(Xin))
             if dX is None:

@@ -168,8 +168,8 @@ def test_randomised_layouts_vs_oracle(fake_backend):
         d = one_case(rng, i, dev='cpu')
         assert d['worst_output_rel'] < 1e-4, d     # (gradients: asserted per tensor inside one_case)
         seen.add((d['given_seg'], d['filt']))
-        axes.update([d['strat'], d['att'], d['agg']])
-    assert len(seen) == 4 and axes == {'gs', 'st', 'v2', 'v3', 'att', 'mp'}
+        axes.update([d['strat'], d['att'], d['agg'], ('shared heads', d['share'], d['training'])])
+    assert len(seen) == 4 and {'gs', 'st', 'v2', 'v3', 'att', 'mp', ('shared heads', True, True)} <= axes
 
 
 def test_inspect_model_returns_the_reference_attention_scores(fake_backend):
