@@ -245,7 +245,7 @@ class TGGCN(nn.Module):
             bad.append(f"object_segment_update_strategy={c['object_segment_update_strategy']!r}")
         if not c['bias']:
             bad.append('bias=False')
-        for k in ('add_segment_length', 'add_time_position', 'cat_level_states'):
+        for k in ('add_segment_length', 'add_time_position'):
             if c[k]:
                 bad.append(k)
         self._unsupported = bad

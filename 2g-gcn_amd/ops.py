@@ -22,7 +22,7 @@ from .kernels import get_kernels
 SUPPORTED_NOTE = ("the HIP path implements message_type 'v2' + message_granularity 'v1' + message_aggregation 'att' "
                   "(attention_style 'v2'/'v3') or 'mp', discrete_networks_num_layers == 1, "
                   "object_segment_update_strategy 'ind', no time-position / segment-length features, "
-                  "cat_level_states off, bias=True (a superset of every configuration shipped in the reference's conf/models/)")
+                  "bias=True (a superset of every configuration shipped in the reference's conf/models/)")
 
 
 def _v2(t, width=None):
@@ -70,6 +70,8 @@ class Plan:
         self.filter = bool(c['filter_discrete_updates'])
         # share_level_mlps (models.py:565-570): the frame-level heads ARE the segment-level head modules
         self.share_heads = bool(c.get('share_level_mlps')) and not bool(c.get('cat_level_states'))
+        # cat_level_states (models.py:901-903): the segment-level heads read cat[reordered segment state, frame-level state]
+        self.cat_levels = bool(c.get('cat_level_states'))
         self.thr = float(c['update_segment_threshold'])
         self.gs = c['discrete_optimization_strategy'] in {'gumbel-sigmoid', 'gs'}
         style = c['attention_style']
@@ -202,11 +204,20 @@ class _Grads:
             self.g[name] = t
 
 
-def _lin_w_grads(K, G, wname, bname, dY, X):
-    """dW = dY^T X (tall reduction -> k-major x k-major GEMM with split-K), db = column sums of dY."""
+def _lin_w_grads(K, G, wname, bname, dY, X, cols=None, total=None):
+    """dW = dY^T X (tall reduction -> k-major x k-major GEMM with split-K), db = column sums of dY.
+    cols=(c0, c1), total: X pairs with the column block [c0, c1) of a weight that is `total` columns wide."""
     N, Kin = dY.shape[-1], X.shape[-1]
     dst = G.sink(wname)
-    if dst is not None:
+    if cols is not None:
+        c0, c1 = cols
+        if dst is None:
+            dst = G.g.get(wname)
+            if dst is None:   # first block of this weight: a zeroed full-width gradient the blocks accumulate into
+                dst = torch.zeros(N, total, dtype=torch.float32, device=dY.device)
+                G.g[wname] = dst
+        K.gemm([dict(A=dY, B=X, C=dst.view(N, total)[:, c0:c1], accumulate=True)], a_kmajor=True, b_kmajor=True)
+    elif dst is not None:
         K.gemm([dict(A=dY, B=X, C=dst.view(N, Kin), accumulate=True)], a_kmajor=True, b_kmajor=True)
     else:
         dW = torch.empty(N, Kin, dtype=torch.float32, device=dY.device)
@@ -398,19 +409,28 @@ def tggcn_forward(K, plan: Plan, P, x_human, x_objects, objects_mask, human_seg,
     R_o = K.reorder_fwd(HS_o, u_o) if O > 0 else HS_o
     S.update(R_h=R_h, R_o=R_o)
 
-    def head(name, Xin, E, C):
+    def head(name, Xin, E, C, Xcat=None):
         name = _head_name(p, name)
         logits = empty(nF * E, C)
-        K.gemm([dict(A=_v2(Xin), B=P[name + '.0.weight'], C=logits, bias=P.get(name + '.0.bias'))])
+        W = P[name + '.0.weight']
+        if Xcat is None:
+            K.gemm([dict(A=_v2(Xin), B=W, C=logits, bias=P.get(name + '.0.bias'))])
+        else:  # cat[Xin, Xcat] W^T without the concatenation: two column blocks of W, the second launch accumulates
+            w1 = Xin.shape[-1]
+            K.gemm([dict(A=_v2(Xin), B=W[:, :w1], C=logits, bias=P.get(name + '.0.bias'))])
+            K.gemm([dict(A=_v2(Xcat), B=W[:, w1:], C=logits, accumulate=True)])
         return K.logsoftmax_permute_fwd(logits, bs, T, E, C)
 
+    cat_h = HFR[0] if p.cat_levels else None
+    cat_o = HFR[1] if p.cat_levels else None
+
     y_h = [head('human_frame_recognition_mlp', HFR[0], H, p.n_sub), head('human_frame_prediction_mlp', HFR[0], H, p.n_sub),
-           head('human_recognition_mlp', R_h, H, p.n_sub), head('human_prediction_mlp', R_h, H, p.n_sub)]
+           head('human_recognition_mlp', R_h, H, p.n_sub, cat_h), head('human_prediction_mlp', R_h, H, p.n_sub, cat_h)]
     if p.n_aff is None:
         outputs = [gates['h']['hard'], gates['h']['soft']] + y_h
     else:
         y_o = [head('object_frame_recognition_mlp', HFR[1], O, p.n_aff), head('object_frame_prediction_mlp', HFR[1], O, p.n_aff),
-               head('object_recognition_mlp', R_o, O, p.n_aff), head('object_prediction_mlp', R_o, O, p.n_aff)]
+               head('object_recognition_mlp', R_o, O, p.n_aff, cat_o), head('object_prediction_mlp', R_o, O, p.n_aff, cat_o)]
         outputs = [gates['h']['hard'], gates['o']['hard'], gates['h']['soft'], gates['o']['soft'],
                    y_h[0], y_h[1], y_o[0], y_o[1], y_h[2], y_h[3], y_o[2], y_o[3]]
     S['outputs'] = outputs
@@ -449,27 +469,50 @@ def tggcn_backward(K, plan: Plan, P, S, x_human, x_objects, objects_mask, d_outp
     HFR = S['HFR']
 
     # ---- H. heads: d logits -> dW, db, dX
-    def head_bwd(names, ys, dys, Xin, E):
-        """two heads (recognition, prediction) on the same input; returns dX (same shape as Xin) or None."""
+    def head_bwd(names, ys, dys, Xin, E, Xcat=None, dXcat=None):
+        """two heads (recognition, prediction) on the same input; returns dX (same shape as Xin) or None. With
+        cat_level_states the heads read cat[Xin, Xcat]: the second column block of W pairs with Xcat and its input
+        gradient is accumulated into dXcat (the frame-level state gradient); returns (dX, dXcat)."""
         dX, first = None, True
         for name, y, dy in zip(names, ys, dys):
             if dy is None:
                 continue
             name = _head_name(p, name)
             dlog = K.logsoftmax_permute_bwd(y, dy.contiguous())
-            _lin_w_grads(K, G, name + '.0.weight', name + '.0.bias' if (name + '.0.bias') in P else None, dlog, _v2(Xin))
+            W = P[name + '.0.weight']
+            bname = name + '.0.bias' if (name + '.0.bias') in P else None
             if dX is None:
                 dX = empty(*Xin.shape)
-            K.gemm([dict(A=dlog, B=P[name + '.0.weight'], C=_v2(dX), accumulate=not first)], b_kmajor=True)
+            if Xcat is None:
+                _lin_w_grads(K, G, name + '.0.weight', bname, dlog, _v2(Xin))
+                K.gemm([dict(A=dlog, B=W, C=_v2(dX), accumulate=not first)], b_kmajor=True)
+            else:
+                w1 = Xin.shape[-1]
+                _lin_w_grads(K, G, name + '.0.weight', bname, dlog, _v2(Xin), cols=(0, w1), total=W.shape[1])
+                _lin_w_grads(K, G, name + '.0.weight', None, dlog, _v2(Xcat), cols=(w1, W.shape[1]), total=W.shape[1])
+                K.gemm([dict(A=dlog, B=W[:, :w1], C=_v2(dX), accumulate=not first)], b_kmajor=True)
+                if dXcat is None:
+                    dXcat = empty(*Xcat.shape)
+                    K.gemm([dict(A=dlog, B=W[:, w1:], C=_v2(dXcat))], b_kmajor=True)
+                else:
+                    K.gemm([dict(A=dlog, B=W[:, w1:], C=_v2(dXcat), accumulate=True)], b_kmajor=True)
             first = False
-        return dX
+        return dX if Xcat is None else (dX, dXcat)
 
     dHFR_h = head_bwd(['human_frame_recognition_mlp', 'human_frame_prediction_mlp'], y_h[:2], dy_h[:2], HFR[0], H)
-    dR_h = head_bwd(['human_recognition_mlp', 'human_prediction_mlp'], y_h[2:], dy_h[2:], S['R_h'], H)
+    if p.cat_levels:
+        dR_h, dHFR_h = head_bwd(['human_recognition_mlp', 'human_prediction_mlp'], y_h[2:], dy_h[2:], S['R_h'], H,
+                                Xcat=HFR[0], dXcat=dHFR_h)
+    else:
+        dR_h = head_bwd(['human_recognition_mlp', 'human_prediction_mlp'], y_h[2:], dy_h[2:], S['R_h'], H)
     dHFR_o = dR_o = None
     if p.n_aff is not None:
         dHFR_o = head_bwd(['object_frame_recognition_mlp', 'object_frame_prediction_mlp'], y_o[:2], dy_o[:2], HFR[1], O)
-        dR_o = head_bwd(['object_recognition_mlp', 'object_prediction_mlp'], y_o[2:], dy_o[2:], S['R_o'], O)
+        if p.cat_levels:
+            dR_o, dHFR_o = head_bwd(['object_recognition_mlp', 'object_prediction_mlp'], y_o[2:], dy_o[2:], S['R_o'], O,
+                                    Xcat=HFR[1], dXcat=dHFR_o)
+        else:
+            dR_o = head_bwd(['object_recognition_mlp', 'object_prediction_mlp'], y_o[2:], dy_o[2:], S['R_o'], O)
 
     # ---- G. reorder backward
     gates = S['gates']

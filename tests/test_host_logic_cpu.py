@@ -168,8 +168,10 @@ def test_randomised_layouts_vs_oracle(fake_backend):
         d = one_case(rng, i, dev='cpu')
         assert d['worst_output_rel'] < 1e-4, d     # (gradients: asserted per tensor inside one_case)
         seen.add((d['given_seg'], d['filt']))
-        axes.update([d['strat'], d['att'], d['agg'], ('shared heads', d['share'], d['training'])])
-    assert len(seen) == 4 and {'gs', 'st', 'v2', 'v3', 'att', 'mp', ('shared heads', True, True)} <= axes
+        axes.update([d['strat'], d['att'], d['agg'], ('shared heads', d['share'] and not d['cat'], d['training']),
+                     ('cat levels', d['cat'], d['training'])])
+    assert len(seen) == 4 and {'gs', 'st', 'v2', 'v3', 'att', 'mp', ('shared heads', True, True),
+                               ('cat levels', True, True)} <= axes
 
 
 def test_inspect_model_returns_the_reference_attention_scores(fake_backend):
@@ -200,3 +202,29 @@ def test_inspect_model_returns_the_reference_attention_scores(fake_backend):
     # the slice predict.py takes (human 0) sums to one over the real objects wherever a clip has any
     s = att[0][:, 0].sum(-1)
     assert torch.all(((s - 1).abs() < 1e-5) | (s.abs() < 1e-6))
+
+
+def test_cat_level_states_in_place_gradient_route(fake_backend):
+    """cat_level_states writes the head weight gradient as two column blocks: the in-place route (existing .grad buffers,
+    the DataParallel case) must add exactly what the autograd route returns."""
+    z, meta = load_g4('c2_stage1')
+    cfg = dict(meta['cfg'], cat_level_states=True)
+    N = meta['N']
+    torch.manual_seed(4)
+    m = TGGCN(input_size=(2048 + 4 * N, 2048), num_classes=tuple(meta['classes']), **cfg).train()
+    assert m.human_recognition_mlp[0].weight.shape[1] == 4 * cfg['hidden_size']
+    m._gumbel_noise_override = torch.from_numpy(z['gumbel_noise'])
+    kw = g4_inputs(z)
+
+    def run():
+        out = m(**kw)
+        sum((o * (i + 1)).sum() for i, o in enumerate(out) if o.requires_grad).backward()
+
+    run()                                                   # autograd route: .grad tensors are created
+    first = {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
+    run()                                                   # in-place route: kernels add into the existing buffers
+    for n, p in m.named_parameters():
+        if p.grad is None:
+            continue
+        scale = max(first[n].abs().max().item(), 1e-6)
+        assert (p.grad - 2 * first[n]).abs().max().item() < 1e-5 * scale, n

@@ -50,6 +50,7 @@ def one_case(rng, idx, dev=DEV, dry=False):
     cfg['attention_style'] = rng.choice(['v3', 'v3', 'v2'])
     cfg['message_aggregation'] = rng.choice(['att', 'att', 'att', 'mp'])
     cfg['share_level_mlps'] = rng.random() < 0.2
+    cfg['cat_level_states'] = rng.random() < 0.2
     cfg['discrete_optimization_strategy'] = rng.choice(['gs', 'gs', 'gs', 'st'])
     cfg['update_segment_threshold'] = rng.choice([0.5, 0.5, 0.3, 0.7])
     cfg['bias'] = rng.random() < 0.95    # bias=False is declared unsupported: must raise NotImplementedError
@@ -60,7 +61,7 @@ def one_case(rng, idx, dev=DEV, dry=False):
     desc = dict(idx=idx, bs=bs, T=T, H=H, O=O, N=N, h=h, classes=classes, training=training, given_seg=given_seg,
                 geo2h=cfg['message_geometry_to_human'], geo2o=cfg['message_geometry_to_objects'],
                 seg_msg=cfg['message_segment'], filt=cfg['filter_discrete_updates'], h2o=cfg['message_human_to_objects'],
-                o2h=cfg['message_objects_to_human'], att=cfg['attention_style'], agg=cfg['message_aggregation'], share=cfg['share_level_mlps'], strat=cfg['discrete_optimization_strategy'],
+                o2h=cfg['message_objects_to_human'], att=cfg['attention_style'], agg=cfg['message_aggregation'], share=cfg['share_level_mlps'], cat=cfg['cat_level_states'], strat=cfg['discrete_optimization_strategy'],
                 thr=cfg['update_segment_threshold'], bias=cfg['bias'])
     seed = rng.randint(0, 10 ** 6)
     if dry:   # only advance the case generator (tools/parity_fuzz.py N SEED FIRST: replay from case FIRST)
