@@ -110,6 +110,7 @@ LOSS_MAX_TERMS, LOSS_BLOCKS = 16, 64  # TWOG_LOSS_MAX_TERMS, TWOG_LOSS_BLOCKS
 _I, _L, _F, _P = C.c_int, C.c_int64, C.c_float, C.c_void_p
 SIGNATURES = {
     'twog_gemm_f32': [C.POINTER(Gemm), _I, _I, _I, _P, C.c_size_t, _P],
+    'twog_gemm_last_class': [],
     'twog_gcn_max_nodes': [],
     'twog_bn_stats': [_P, _L, _I, _I, _P, _I, _P],
     'twog_bn_finalize': [_P, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _P, _P],

@@ -664,7 +664,11 @@ int launch(Group& g, int akm, int bkm, hipStream_t st) {
     return 0;
 }
 
+thread_local int g_last_class = 0;  // twog_gemm_last_class(): variant of this thread's most recent launch
+
 }  // namespace
+
+extern "C" int twog_gemm_last_class(void) { return g_last_class; }
 
 // Builds the launch descriptor of one chunk (<= MAXP problems): tile class, class-sorted problem list (order[i] = index of
 // the caller's problem that became sorted problem i), XCD map, split-K. Shared by the plain and the gate-fused launch.
@@ -773,6 +777,8 @@ extern "C" int twog_gemm_f32(const twog_gemm_t* problems, int n_problems, int a_
         bool grouped = false;  // grouped k-major rows keep the 4-wave tiles: their pointer-carrying 8-wave kernels exceed
                                // 128 VGPRs (3 waves/SIMD) and measure 7 % slower
         for (int i = 0; i < n; ++i) grouped = grouped || (a_kmajor && pr[i].A.inner > 1) || (b_kmajor && pr[i].B.inner > 1);
+        g_last_class = (big ? TWOG_GEMM_CLASS_TILE128 : 0) | (big && w8 && !grouped ? TWOG_GEMM_CLASS_WAVES8 : 0) |
+                       (grouped ? TWOG_GEMM_CLASS_KG : 0) | (g.splitk > 1 ? TWOG_GEMM_CLASS_SPLITK : 0);
         if (big && w8 && !grouped) rc = d128 == 2 ? launch<128, 128, 512, 2>(g, a_kmajor, b_kmajor, st) : launch<128, 128, 512, 1>(g, a_kmajor, b_kmajor, st);
         else if (big) rc = d128 == 2 ? launch<128, 128, 256, 2>(g, a_kmajor, b_kmajor, st) : launch<128, 128, 256, 1>(g, a_kmajor, b_kmajor, st);
         else rc = d64 == 2 ? launch<64, 64, 256, 2>(g, a_kmajor, b_kmajor, st) : launch<64, 64, 256, 1>(g, a_kmajor, b_kmajor, st);
@@ -830,6 +836,7 @@ int twog_internal_gemm_gate_bwd(const twog_gemm_t* pr, int n, const twog_gru_ste
     static const int depth = getenv("TWOG_GEMM_DEPTH") ? atoi(getenv("TWOG_GEMM_DEPTH")) : 0;
     const int d64 = depth ? ((depth >> 2) & 3) : 2;
     dim3 grid(g.total_tiles, 1), block(256);
+    g_last_class = TWOG_GEMM_CLASS_GATE;
     if (d64 == 2) hipLaunchKernelGGL(gemm_gate_bwd_kernel<2>, grid, block, 0, (hipStream_t)stream, g, ga);
     else hipLaunchKernelGGL(gemm_gate_bwd_kernel<1>, grid, block, 0, (hipStream_t)stream, g, ga);
     TWOG_CHECK_LAUNCH();

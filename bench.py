@@ -1,11 +1,12 @@
 #!/usr/bin/env python3
 """Headline benchmark of the 2G-GCN hot path on MI355X.
 
-  python bench.py --gpus N --steps K --warmup W
-  (N > 1: launched by torch.distributed.run, one rank per GPU over RCCL)
+  python bench.py --gpus N --steps K --warmup W [--scaling weak|strong]
+  (N > 1: one rank per GPU over RCCL -- either launched by torch.distributed.run (WORLD_SIZE set), or, when started
+  bare, bench.py starts the N ranks itself as child processes before touching the GPU and exits with their code)
 
 Workload (BASELINE.json configs[2]): synthetic clips T=120, N=34 geometry nodes (H=2 humans, O=8 objects), C=h=512,
-64 clips per GPU per step (weak scaling: global batch = 64*N), fp32. One "step" = forward + the reference's stage-1
+64 clips per GPU per step (weak scaling: global batch = 64*N; --scaling strong: global batch 64, 64/N per GPU), fp32. One "step" = forward + the reference's stage-1
 loss list (NLL on the two segment-level heads, vhoi/losses.py:53-61) + backward + gradient all-reduce (N > 1) + fused
 Adam; inputs are resident in HBM before the timed region. Prints ONE JSON line on rank 0.
 
@@ -35,6 +36,7 @@ def _cpu_quota():
 
 # before torch creates its thread pools: oversubscribing the quota gets the whole cgroup throttled in 100 ms periods,
 # which stalls the thread that feeds the GPU (measured: sporadic +90 ms steps)
+_OMP_FROM_USER = 'OMP_NUM_THREADS' in os.environ
 os.environ.setdefault('OMP_NUM_THREADS', str(max(1, _cpu_quota() // int(os.environ.get('LOCAL_WORLD_SIZE', '1')) - 4)))
 
 import torch  # noqa: E402
@@ -106,9 +108,7 @@ class GemmProfiler:
             e0.record()
             self.orig(problems, a_kmajor, b_kmajor, split_k_workspace)
             e1.record()
-            # same rule as twog_gemm_f32 (gemm_f32.hip): 128x128 tiles when wide and the chip can be filled
-            reach = tiles128 * (kmax // 512 if kmax >= 1024 else 1)
-            big = wide and (tiles128 >= 256 or reach >= 256)
+            big = bool(self.K.gemm_last_class() & self.K.GEMM_TILE128)  # the tile class the library actually picked
             self.records.append(('128x128' if big else '64x64', flops, e0, e1, abytes))
             self.shapes.append((a_kmajor, b_kmajor, [(n_rows(p['C']), p['C'].shape[-1], (n_rows(p['A']) if a_kmajor else p['A'].shape[-1]), (p['batch'][0] if p.get('batch') else 1)) for p in problems]))
         self.K.gemm = gemm
@@ -142,10 +142,21 @@ class GemmProfiler:
         return agg
 
 
-def cpu_baseline(sample_frames=None, sample_clips=8):
-    """The oracle (port of the reference's PyTorch-CPU path) forward+backward on a bounded sample of the same workload:
-    `sample_clips` full-length clips (the reference's own batch size, conf/models/2G-GCN_stage1.yaml:31) -- about 15 s of
-    CPU work on the GPU box's 16 granted cores. (`sample_frames` < T shortens the clips; the cost is linear in frames.)"""
+def _cpu_model():
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
+
+
+def cpu_baseline(sample_frames=None, sample_clips=4, repeats=3):
+    """The oracle (port of the reference's PyTorch-CPU path) on a bounded sample of the same workload: `sample_clips`
+    full-length clips, 1 warm-up + `repeats` timed forward+backward passes (median reported; forward alone as well) --
+    about 30 s of CPU work on the GPU box's 16 granted cores. (`sample_frames` < T shortens the clips; the cost is
+    linear in frames.)"""
     sample_frames = T if sample_frames is None else sample_frames
     from oracle import cpu_ref
     import twog_gcn_amd  # noqa: F401
@@ -164,20 +175,31 @@ def cpu_baseline(sample_frames=None, sample_clips=8):
     x_objects = torch.rand(nb, Ts, O, 2048, generator=g)
     mask, seg = torch.ones(nb, O), torch.ones(nb, Ts, H)
     tgt = [torch.randint(0, N_CLASSES, (nb, Ts, H), generator=g) for _ in range(2)]
-    t0 = time.perf_counter()
-    out = cpu_ref.tggcn_forward(sd, CFG, x_human, x_objects, mask, human_segmentation=seg, training=True)
-    t_fwd = time.perf_counter() - t0
-    loss = torch.nn.functional.nll_loss(out[4], tgt[0]) + torch.nn.functional.nll_loss(out[5], tgt[1])
-    loss.backward()
-    dt = time.perf_counter() - t0
+    t_fwd, t_all = [], []
+    for rep in range(repeats + 1):
+        for v in sd.values():
+            if v.is_floating_point():
+                v.grad = None
+        t0 = time.perf_counter()
+        out = cpu_ref.tggcn_forward(sd, CFG, x_human, x_objects, mask, human_segmentation=seg, training=True)
+        t1 = time.perf_counter()
+        loss = torch.nn.functional.nll_loss(out[4], tgt[0]) + torch.nn.functional.nll_loss(out[5], tgt[1])
+        loss.backward()
+        t2 = time.perf_counter()
+        if rep > 0:  # rep 0 is the warm-up
+            t_fwd.append(t1 - t0)
+            t_all.append(t2 - t0)
+    med = lambda v: sorted(v)[len(v) // 2]
     clips = nb * Ts / T
-    return dict(value=clips / dt, unit='clips/s', cores=cores, kind='port',
-                sample=f'{nb} clips (the reference batch size) x {Ts} of {T} frames (H={H},O={O},N={N_NODES},h={CFG["hidden_size"]}), one '
-                       f'forward+backward in {dt:.1f} s' + ('' if Ts == T else ', scaled linearly in frames'),
-                forward_clips_per_s=clips / t_fwd)
+    return dict(value=clips / med(t_all), unit='clips/s', cores=cores, kind='port', cpu_model=_cpu_model(),
+                threads=cores, repeats=repeats, warmup=1,
+                sample=f'{nb} clips x {Ts} of {T} frames (H={H},O={O},N={N_NODES},h={CFG["hidden_size"]}); 1 warm-up + '
+                       f'{repeats} timed forward+backward passes, median {med(t_all):.1f} s (all: '
+                       f'{", ".join(f"{t:.1f}" for t in t_all)})' + ('' if Ts == T else ', scaled linearly in frames'),
+                forward_clips_per_s=clips / med(t_fwd), forward_seconds=[round(t, 2) for t in t_fwd])
 
 
-def cpu_baseline_in_child(workload='c3', timeout_s=240):
+def cpu_baseline_in_child(workload='c3', timeout_s=420):
     """Runs the CPU leg in a child process (bounded by a timeout) so it can never take the bench line down."""
     import subprocess
     try:
@@ -195,6 +217,24 @@ def log(msg):
     print(f'[bench {time.strftime("%H:%M:%S")}] {msg}', file=sys.stderr, flush=True)
 
 
+def launch_ranks(n):
+    """Starts `n` ranks of this script through torch.distributed.run (one process per GPU, rendezvous on 127.0.0.1 at a
+    free port) as a child process and returns its exit code. Must run before anything initialises the GPU."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}',
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')  # dmabuf IPC: RCCL needs it on this driver
+    if not _OMP_FROM_USER:
+        env.pop('OMP_NUM_THREADS', None)               # each rank sizes its own pools from LOCAL_WORLD_SIZE
+    log(f'launching {n} ranks: {" ".join(cmd)}')
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -205,7 +245,10 @@ def main():
                     help='c3 = the headline configuration; c2 / c5 = the other single-GPU shapes (informational)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-baseline-only', action='store_true', help=argparse.SUPPRESS)
-    ap.add_argument('--forward-only', action='store_true', help='additionally report forward-only clips/s')
+    ap.add_argument('--forward-only', action='store_true', help=argparse.SUPPRESS)  # always reported now
+    ap.add_argument('--scaling', choices=['weak', 'strong'], default='weak',
+                    help='weak: the workload\'s batch per GPU (global = batch * N); strong: the workload\'s batch is the '
+                         'GLOBAL batch, batch / N clips per GPU (SURVEY 8e: fixed global bs64 = 8 x 8 at N = 8)')
     args = ap.parse_args()
     wl = select_workload(args.workload)
     if args.batch is None:
@@ -213,10 +256,27 @@ def main():
     if args.cpu_baseline_only:
         print(json.dumps(cpu_baseline()), flush=True)
         return
+    if args.gpus < 1:
+        ap.error('--gpus must be >= 1')
 
+    # ---- rank launch. Under torch.distributed.run the environment carries the world; started bare with --gpus N > 1
+    # this process becomes the launcher: it starts N ranks as CHILD processes (nothing here has touched the GPU yet --
+    # no exec after HIP initialisation) and exits with their return code.
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus))
     world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world != args.gpus:
+        print(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with\n  python -m torch.distributed.run '
+              f'--nnodes=1 --nproc-per-node {args.gpus} --master-addr 127.0.0.1 --master-port 29500 bench.py '
+              f'--gpus {args.gpus} ...\nor start bench.py bare (no WORLD_SIZE) and it spawns the ranks itself',
+              file=sys.stderr)
+        sys.exit(2)
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if args.scaling == 'strong':
+        if args.batch % world:
+            ap.error(f'--scaling strong needs the global batch ({args.batch}) divisible by --gpus ({world})')
+        args.batch //= world
     import torch.distributed as dist
     # TWOG_BENCH_BACKEND=gloo lets several ranks share one GPU (plumbing check of the N > 1 flow on a 1-GPU box);
     # the measured configuration is always nccl (= RCCL), one rank per GPU
@@ -231,6 +291,11 @@ def main():
             dist.init_process_group(backend)
     device = torch.device('cuda', local_rank)
     torch.cuda.set_device(device)
+    devices = [f'rank{rank}:cuda:{local_rank}']
+    if world > 1:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, devices[0])
+        devices = gathered
 
     import twog_gcn_amd  # noqa: F401
     from twog_gcn_amd.models import TGGCN
@@ -315,7 +380,7 @@ def main():
     gcn_bytes = bs * T * (16 * N_NODES + 512 * N_NODES)
 
     fwd_only = None
-    if args.forward_only:
+    if True:  # forward-only clips/s is part of every line (north star: ">= 50x the reference CPU forward")
         with torch.no_grad():
             model(x_human, x_objects, mask, human_segmentation=seg)
             torch.cuda.synchronize()
@@ -323,6 +388,7 @@ def main():
             for _ in range(max(2, args.steps // 2)):
                 model(x_human, x_objects, mask, human_segmentation=seg)
             torch.cuda.synchronize()
+            barrier()
             fwd_only = bs * world * max(2, args.steps // 2) / (time.perf_counter() - t1)
 
     if rank == 0:
@@ -340,10 +406,11 @@ def main():
         result = {
             'metric': 'clips/sec fwd+bwd, T=120 N=34 C=512' if args.workload == 'c3' else f'clips/sec fwd+bwd, {wl["name"]} (informational)', 'value': bs * world * args.steps / dt, 'unit': 'clips/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'fp32', 'data': 'synthetic',
+            'higher_is_better': True, 'scaling': args.scaling, 'vs_baseline': None, 'dtype': 'fp32', 'data': 'synthetic',
             'config': {'workload': f'{wl["name"]}: bs{bs} per GPU, T={T}, H={H}, O={O}, N={N_NODES}, h={CFG["hidden_size"]}, '
                                    f'classes {N_CLASSES}, 2G-GCN_stage1 parameters',
                        'global_batch': bs * world, 'per_gpu_batch': bs, 'parallelism': f'dp{world}',
+                       'devices': devices, 'collective_backend': backend if world > 1 else None,
                        'step': 'forward + multi-task loss (fused HIP criterion) + backward + gradient all-reduce + fused Adam',
                        'loss_last': float(loss.detach())},
             'roofline': {'bound': 'mfma', 'kernel': f'gemm_kernel<{kind.replace("x", ",")},*> (fp32 v_mfma_f32_32x32x2_f32)',

@@ -57,6 +57,14 @@ typedef struct {
 } twog_gemm_t;
 int twog_gemm_f32(const twog_gemm_t* problems, int n_problems, int a_kmajor, int b_kmajor, void* workspace,
                   size_t workspace_bytes, void* stream);
+/* Which kernel variant the calling thread's most recent twog_gemm_f32 chunk (or fused gate launch) selected -- lets a
+ * test assert that it exercised the variant it was written for. Bit field: */
+#define TWOG_GEMM_CLASS_TILE128 1  /* 128x128 tiles (else 64x64)                        */
+#define TWOG_GEMM_CLASS_WAVES8  2  /* 8-wave workgroups (else 4)                        */
+#define TWOG_GEMM_CLASS_KG      4  /* k-major operand with (outer, inner) grouped rows  */
+#define TWOG_GEMM_CLASS_SPLITK  8  /* deterministic split-K + ordered reduce            */
+#define TWOG_GEMM_CLASS_GATE    16 /* gate backward fused into the epilogue             */
+int twog_gemm_last_class(void);
 
 /* ===============================================================================================================
  * Geometric-level GCN (pyrutils/torch/models_gcn.py:6-100; called at vhoi/models.py:640-645).

@@ -76,7 +76,8 @@ def test_gemm_unaligned_k(K):
 
 
 def test_gemm_big_tiles_and_views(K):
-    # 128x128 tile path + row-strided views (column slices of wider buffers, 3-D (outer, inner, cols) rows)
+    # row-strided views (column slices of wider buffers, 3-D (outer, inner, cols) rows) on the 64x64 class (25 tiles of
+    # 128 do not fill the chip); the 128x128 class has its own tests below (test_gemm_128_class*)
     bs, T, E, w = 4, 30, 5, 96
     base = rnd(bs, T, E, w)
     W = rnd(640, 32, seed=1)
@@ -136,6 +137,119 @@ def test_gemm_grouped_batched_splitk(K):
     assert torch.equal(w_gpu, w_gpu2), 'split-K reduction must be deterministic'
 
 
+# ------------------------------------------------------------------------------------------- GEMM, 128x128 tile class
+# The kernels that carry the bench's roofline entry: gemm_kernel<128,128,...> in every operand layout the step uses
+# (forward NN, dX NT, dW TT with split-K, GCN-style TN), the grouped-row k-major (KG, 4-wave) variants of the recurrent
+# weight gradients, bias / ReLU / accumulate epilogues and splitk_reduce<128,128>. Every case ASSERTS the variant that
+# ran (twog_gemm_last_class), so a change of the tile policy cannot silently move these shapes to the 64x64 class.
+# Checked against an fp64 matmul (torch on the device is the checker here, never the product).
+def _gemm128_run(K, akm, bkm, M, N, K_, *, bias, act, acc, ws=True, group=None, seed=0, expect=None, rtol=3e-5):
+    """group=(outer, inner, skip): k-major operands are 3-D views [outer, inner, cols] cut out of [outer, inner + skip,
+    wider] buffers (the 'all but the first time step of every clip' form of dW_hh, ops.py)."""
+    dev = DEV
+    g = torch.Generator().manual_seed(1000 + seed)
+
+    def mk(rows, cols, kmajor, scale):
+        if group is not None and kmajor:
+            outer, inner, skip = group
+            assert outer * inner == rows
+            base = (torch.randn(outer, inner + skip, cols + 8, generator=g) * scale).to(dev)
+            return base[:, skip:, 4:4 + cols]
+        return (torch.randn(rows, cols, generator=g) * scale).to(dev)
+
+    A = mk(K_, M, True, 1.0) if akm else mk(M, K_, False, 1.0)
+    B = mk(K_, N, True, 0.1) if bkm else mk(N, K_, False, 0.1)
+    b = (torch.randn(N, generator=g)).to(dev) if bias else None
+    C0 = torch.randn(M, N, generator=g).to(dev)
+    Cg = C0.clone()
+    K.gemm([dict(A=A, B=B, C=Cg, bias=b, act=act, accumulate=acc)], a_kmajor=akm, b_kmajor=bkm, split_k_workspace=ws)
+    cls = K.gemm_last_class()
+    if expect is not None:
+        want, mask = expect
+        assert cls & mask == want, f'kernel class {cls:#x}, expected {want:#x} under mask {mask:#x}'
+    Am = A.reshape(-1, A.shape[-1]).double()
+    Bm = B.reshape(-1, B.shape[-1]).double()
+    ref = (Am.t() if akm else Am) @ (Bm if bkm else Bm.t())
+    if bias:
+        ref = ref + b.double()
+    if acc:
+        ref = ref + C0.double()
+    if act:
+        ref = torch.relu(ref)
+    err = (Cg.double() - ref).abs().max().item()
+    tol = rtol * ref.abs().max().item()
+    assert err <= tol, f'gemm128 akm={akm} bkm={bkm} {M}x{N}x{K_}: err {err:.3e} > {tol:.3e}'
+    return cls
+
+
+def _gemm128_cases(K, w8=True):
+    T128, W8, KG, SK = K.GEMM_TILE128, K.GEMM_WAVES8, K.GEMM_KG, K.GEMM_SPLITK
+    full = T128 | W8 | KG | SK
+    w = W8 if w8 else 0
+    # forward projection (NN), bias + ReLU: 480 x 4 tiles (+ ragged edge rows / columns in the second case)
+    _gemm128_run(K, False, False, 61440, 512, 2048, bias=True, act=1, acc=False, expect=(T128 | w, full))
+    _gemm128_run(K, False, False, 15361, 1500, 512, bias=True, act=0, acc=True, seed=1, expect=(T128 | w, full))
+    # dX (NT), accumulate into the entity-row gradient
+    _gemm128_run(K, False, True, 61440, 2048, 512, bias=False, act=0, acc=True, seed=2, expect=(T128 | w, full))
+    _gemm128_run(K, False, True, 20000, 1000, 1536, bias=False, act=0, acc=False, seed=3, expect=(T128 | w, full))
+    # dW (TT) with deterministic split-K over 61 440 rows (+ accumulate: the in-place gradient sink route)
+    _gemm128_run(K, True, True, 512, 2048, 61440, bias=False, act=0, acc=False, seed=4, expect=(T128 | w | SK, full),
+                 rtol=6e-5)
+    _gemm128_run(K, True, True, 1536, 2560, 30720, bias=True, act=1, acc=True, seed=5, expect=(T128 | w | SK, full),
+                 rtol=6e-5)
+    # TT without a workspace: no split-K, 16 x 16 tiles
+    _gemm128_run(K, True, True, 2048, 2048, 1024, bias=False, act=0, acc=False, ws=False, seed=6,
+                 expect=(T128 | w, full))
+    # TN (k-major A, row-major B: the GCN projection form)
+    _gemm128_run(K, True, False, 2048, 2100, 512, bias=True, act=0, acc=False, seed=7, expect=(T128 | w, full))
+    # grouped-row k-major operands (KG; always 4 waves): dW_hh form  1536 x 512 x (bs (T-1) E)  with split-K,
+    # and a wide one without split-K
+    _gemm128_run(K, True, True, 1536, 512, 8 * 59 * 8, bias=False, act=0, acc=False, group=(8, 59 * 8, 8), seed=8,
+                 expect=(T128 | KG | SK, full), rtol=6e-5)
+    _gemm128_run(K, True, True, 2048, 2048, 6 * 100, bias=False, act=0, acc=True, ws=False, group=(6, 100, 3), seed=9,
+                 expect=(T128 | KG, full))
+    # NT with a grouped k-major B only (carry form)
+    _gemm128_run(K, False, True, 2048, 2048, 4 * 128, bias=False, act=0, acc=False, ws=False, group=(4, 128, 2),
+                 seed=10, expect=(T128 | KG, full))
+
+
+def test_gemm_128_class(K):
+    _gemm128_cases(K, w8=True)
+
+
+def test_gemm_128_class_determinism(K):
+    # split-K slabs are summed in fixed order: two runs are bit-identical
+    g = torch.Generator().manual_seed(5)
+    A, B = torch.randn(30720, 1536, generator=g).to(DEV), (torch.randn(30720, 512, generator=g) * 0.1).to(DEV)
+    outs = []
+    for _ in range(2):
+        C = torch.empty(1536, 512, device=DEV)
+        K.gemm([dict(A=A, B=B, C=C)], a_kmajor=True, b_kmajor=True)
+        assert K.gemm_last_class() & (K.GEMM_TILE128 | K.GEMM_SPLITK) == (K.GEMM_TILE128 | K.GEMM_SPLITK)
+        outs.append(C)
+    assert torch.equal(outs[0], outs[1])
+
+
+def test_gemm_128_class_four_wave_tiles():
+    """The 4-wave 128x128 kernels without grouped rows are only reachable with TWOG_GEMM_W8=0 (read once per process):
+    run the same cases in a child process with that switch."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ('import tests.test_kernels_gpu as t; from twog_gcn_amd import kernels as k; '
+            't._gemm128_cases(k.get_kernels(), w8=False); print("four-wave OK")')
+    r = subprocess.run([sys.executable, '-c', code], cwd=root, env=dict(os.environ, TWOG_GEMM_W8='0'),
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and 'four-wave OK' in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_gemm_64_class_is_reported(K):
+    A, B, C = rnd(300, 64).to(DEV), rnd(200, 64, seed=1).to(DEV), torch.empty(300, 200, device=DEV)
+    K.gemm([dict(A=A, B=B, C=C)])
+    assert K.gemm_last_class() & K.GEMM_TILE128 == 0
+
+
 # ----------------------------------------------------------------------------------------------------------------- GCN
 @pytest.mark.parametrize('N', [1, 16, 19, 34, 50, 64])   # 50 / 64: the backward kernel's reduced-LDS path (no M copy)
 def test_gcn_kernels(K, N):
@@ -186,13 +300,13 @@ def test_gcn_kernels(K, N):
 
 
 # --------------------------------------------------------------------------------------------------------------- BiGRU
-@pytest.mark.parametrize('h,bs', [(16, 3), (72, 3), (512, 40)])
-def test_bigru(K, h, bs):
-    T = 5 if h < 512 else 3
+@pytest.mark.parametrize('h,bs,T', [(16, 3, 5), (72, 3, 5), (512, 40, 3), (512, 8, 120)])   # last: BASELINE T and width
+def test_bigru(K, h, bs, T):
     types_c, types_g = [], []
+    ws = 0.2 if T < 100 else 0.2 * math.sqrt(64.0 / h)   # long chains: keep the hidden pre-activations O(1)
     for i, E in enumerate((2, 3, 1)):
-        d = dict(gi=rnd(bs, T, E, 6 * h, seed=i), w_hh_f=rnd(3 * h, h, seed=10 + i, scale=0.2), b_hh_f=rnd(3 * h, seed=20 + i),
-                 w_hh_r=rnd(3 * h, h, seed=30 + i, scale=0.2), b_hh_r=rnd(3 * h, seed=40 + i))
+        d = dict(gi=rnd(bs, T, E, 6 * h, seed=i), w_hh_f=rnd(3 * h, h, seed=10 + i, scale=ws), b_hh_f=rnd(3 * h, seed=20 + i),
+                 w_hh_r=rnd(3 * h, h, seed=30 + i, scale=ws), b_hh_r=rnd(3 * h, seed=40 + i))
         types_c.append(d)
         types_g.append({k: v.to(DEV) for k, v in d.items()})
     res_c = F.bigru_fwd(types_c, bs, T, h)
@@ -302,7 +416,9 @@ def _seg_params(dev, bs, T, H, O, h, rels, msg_segment=True, seed=0):
                                                  # full width: 8 column tiles, several row tiles -- every partial slot of
                                                  # the fused gate-backward epilogue (with and without segment messages)
                                                  (24, 3, 2, 8, 512, (True, True, True, True), True),
-                                                 (24, 3, 2, 8, 512, (True, True, True, True), False)])
+                                                 (24, 3, 2, 8, 512, (True, True, True, True), False),
+                                                 # BASELINE length and width: a 120-step chain, forward and BPTT
+                                                 (4, 120, 2, 8, 512, (True, True, True, True), True)])
 def test_segment_recurrence(K, bs, T, H, O, h, rels, msg):
     pc = _seg_params('cpu', bs, T, H, O, h, rels, msg)
     pg = _seg_params(DEV, bs, T, H, O, h, rels, msg)

@@ -1,7 +1,8 @@
 """GPU: the shipped path (TGGCN on cuda through lib2ggcn_hip.so) against
   (1) the golden vectors captured from the real reference (small layouts C1/C2/C5, stage-1 and stage-2 semantics),
   (2) the CPU oracle on the synthetic N=34 layout (C3) at a reduced width, forward and backward,
-  (3) the CPU oracle at the full BASELINE width (T=120, N=34, h=512), forward,
+  (3) the CPU oracle at the full BASELINE sizes (configs[2] T=120 N=34 h=512; configs[1] bs8; configs[4] shard), forward
+      and backward,
   (4) size-independent properties at the full bench size: run-to-run bit determinism, batch independence in eval mode.
 Tolerance: 1e-4 relative (north_star), stated per assertion."""
 import numpy as np
@@ -100,9 +101,9 @@ def _synthetic(bs, T, H, O, N, seed=0):
     return x_human, x_objects, mask
 
 
-def _oracle_vs_hip(bs, T, H, O, N, h, backward, seed=3):
+def _oracle_vs_hip(bs, T, H, O, N, h, backward, seed=3, n_sub=13):
     torch.manual_seed(seed)
-    m = TGGCN(input_size=(2048 + 4 * N, 2048), num_classes=(13, None), hidden_size=h, gcn_node=N, **STAGE1)
+    m = TGGCN(input_size=(2048 + 4 * N, 2048), num_classes=(n_sub, None), hidden_size=h, gcn_node=N, **STAGE1)
     sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
     x_human, x_objects, mask = _synthetic(bs, T, H, O, N, seed)
     seg = torch.ones(bs, T, H)
@@ -150,9 +151,21 @@ def test_oracle_parity_c2_layout_hs128():
     _oracle_vs_hip(bs=2, T=10, H=2, O=4, N=26, h=128, backward=True, seed=5)
 
 
-def test_oracle_parity_full_width_forward():
-    """BASELINE width: T=120, N=34, h=512 (one clip pair; the oracle needs ~1 min on host cores)."""
-    _oracle_vs_hip(bs=2, T=120, H=2, O=8, N=34, h=512, backward=False, seed=7)
+def test_oracle_parity_full_width_forward_backward():
+    """BASELINE shape of the metric (configs[2]): T=120, N=34, h=512, forward AND backward -- a 120-step BPTT through the
+    fused gate-epilogue chains and the split-K weight gradients, every parameter gradient against the oracle (one clip
+    pair; the oracle needs a few minutes on the host cores)."""
+    _oracle_vs_hip(bs=2, T=120, H=2, O=8, N=34, h=512, backward=True, seed=7)
+
+
+def test_oracle_parity_c2_full_size():
+    """BASELINE configs[1] at size: MPHOI layout (H=2, O=4, N=26), hs512, bs8, T=120, forward + backward."""
+    _oracle_vs_hip(bs=8, T=120, H=2, O=4, N=26, h=512, backward=True, seed=9)
+
+
+def test_oracle_parity_c5_full_size():
+    """BASELINE configs[4] per-GPU shard at size: Bimanual layout (H=2, O=9, N=30), h=64, 16 clips, T=120."""
+    _oracle_vs_hip(bs=16, T=120, H=2, O=9, N=30, h=64, backward=True, seed=13, n_sub=14)
 
 
 def test_full_size_determinism_and_batch_independence():
