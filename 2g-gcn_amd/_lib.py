@@ -130,6 +130,7 @@ SIGNATURES = {
     'twog_attn_bwd': [C.POINTER(AttnBwd), _I, _P],
     'twog_segrnn_fwd': [C.POINTER(SegRnn), _P],
     'twog_segrnn_bwd': [C.POINTER(SegRnn), C.POINTER(SegRnnBwd), _P],
+    'twog_graph_cache_stats': [c_int64_p, c_int64_p],
     'twog_gate_fwd': [C.POINTER(Gate), _P],
     'twog_gate_bwd': [C.POINTER(Gate), _P, _P, _P, _P, _P],
     'twog_rank1_update': [Rows, _P, _P, _I, _I, _P],

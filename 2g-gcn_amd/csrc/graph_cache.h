@@ -3,15 +3,19 @@
 //
 // The loops are enqueued by host code in this library; at small batch the kernels are shorter than the host's launch
 // cost and the step becomes host-bound. A loop is therefore captured once into a hipGraph (stream capture of exactly the
-// launches the loop issues) and replayed with one hipGraphLaunch while its descriptor -- every pointer, shape and stride,
-// hashed -- stays the same, which is the steady state of a training loop under a caching allocator. A changed descriptor
-// is a different key (re-capture); the cache is small (64 loops) and flushed when full. TWOG_NO_GRAPHS=1 turns it off.
+// launches the loop issues) and replayed with one hipGraphLaunch while its descriptor -- every pointer, shape and stride
+// -- stays the same, which is the steady state of a training loop under a caching allocator. The 64-bit hash of the
+// descriptor only picks the bucket: every entry keeps the descriptor BYTES and a hit is confirmed with a compare, so two
+// descriptors that collide can never replay each other's pointers (a mismatch probes on under a salted key and
+// captures its own graph). The cache is small (64 loops) and flushed when full. TWOG_NO_GRAPHS=1 turns it off;
+// TWOG_GRAPH_HASH_BITS=k (tests) truncates the hash to k bits to force collisions.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <string>
 #include <unordered_map>
 
 namespace twog_graph {
@@ -22,7 +26,14 @@ inline uint64_t fnv1a(const void* data, size_t n, uint64_t h = 14695981039346656
     return h;
 }
 
-struct Entry { hipGraphExec_t exec; int uses; };
+struct Entry { hipGraphExec_t exec; int uses; std::string desc; };
+
+// descriptor bytes of a loop: the caller appends every struct / array its launches read
+struct Desc {
+    std::string bytes;
+    Desc& add(const void* p, size_t n) { bytes.append(static_cast<const char*>(p), n); return *this; }
+    template <class T> Desc& pod(const T& v) { return add(&v, sizeof(T)); }
+};
 
 // One instance per process (inline function static: shared by every translation unit of the library). The mutex makes
 // the entry points callable from several host threads (calls are serialised: capture is thread-local and a replay is
@@ -32,7 +43,8 @@ constexpr int MAX_DEVICES = 16;
 struct State {
     std::mutex mu;
     std::unordered_map<uint64_t, Entry> cache;
-    std::unordered_map<uint64_t, int> seen;  // a key is captured the second time it shows up
+    std::unordered_map<uint64_t, std::string> seen;  // a descriptor is captured the second time it shows up
+    uint64_t collisions = 0;                         // bucket hits whose descriptor bytes differed
     hipStream_t side[MAX_DEVICES] = {};
     hipEvent_t ev_in[MAX_DEVICES] = {}, ev_out[MAX_DEVICES] = {};
 };
@@ -41,11 +53,13 @@ inline State& state() {
     return s;
 }
 
-// enqueue(stream): issues the loop's launches on `stream`, returns 0 on success. key: hash of everything it reads.
+inline uint64_t collisions() { return state().collisions; }
+
+// enqueue(stream): issues the loop's launches on `stream`, returns 0 on success. desc: everything the launches read.
 // Graphs are captured and replayed on a stream owned by the library (the caller's stream may be the legacy default
 // stream, which cannot be captured), fenced against the caller's stream with two events.
 template <class F>
-int run(uint64_t key, hipStream_t user, F enqueue) {
+int run(const Desc& d, hipStream_t user, F enqueue) {
     static const bool off = getenv("TWOG_NO_GRAPHS") != nullptr;
     if (off) return enqueue(user);
     int dev = 0;
@@ -55,6 +69,9 @@ int run(uint64_t key, hipStream_t user, F enqueue) {
     }
     State& S = state();
     std::lock_guard<std::mutex> lock(S.mu);
+    static const int hash_bits = getenv("TWOG_GRAPH_HASH_BITS") ? atoi(getenv("TWOG_GRAPH_HASH_BITS")) : 64;
+    uint64_t key = fnv1a(d.bytes.data(), d.bytes.size());
+    if (hash_bits < 64) key = hash_bits <= 0 ? 0 : (key & ((1ull << hash_bits) - 1));
     key ^= 0x9e3779b97f4a7c15ull * (uint64_t)(dev + 1);
     hipStream_t& side = S.side[dev];
     hipEvent_t &ev_in = S.ev_in[dev], &ev_out = S.ev_out[dev];
@@ -69,10 +86,18 @@ int run(uint64_t key, hipStream_t user, F enqueue) {
             return enqueue(user);
         }
     }
+    // the hash picks the bucket, the bytes decide: an entry with other bytes is a collision -> probe on (salted key)
     auto it = cache.find(key);
+    while (it != cache.end() && it->second.desc != d.bytes) {
+        ++S.collisions;
+        key = key * 6364136223846793005ull + 1442695040888963407ull;
+        it = cache.find(key);
+    }
     if (it == cache.end()) {
-        if (seen[key]++ == 0) {
+        auto sn = seen.find(key);
+        if (sn == seen.end() || sn->second != d.bytes) {
             if (seen.size() > 256) seen.clear();
+            seen[key] = d.bytes;
             return enqueue(user);  // first sighting (also covers lazy one-time setup inside the launch paths)
         }
         hipGraph_t graph = nullptr;
@@ -97,7 +122,7 @@ int run(uint64_t key, hipStream_t user, F enqueue) {
             for (auto& kv : cache) (void)hipGraphExecDestroy(kv.second.exec);
             cache.clear();
         }
-        it = cache.emplace(key, Entry{exec, 0}).first;
+        it = cache.emplace(key, Entry{exec, 0, d.bytes}).first;
     }
     ++it->second.uses;
     if (hipEventRecord(ev_in, user) != hipSuccess || hipStreamWaitEvent(side, ev_in, 0) != hipSuccess) return -101;

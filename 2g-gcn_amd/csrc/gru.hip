@@ -295,18 +295,18 @@ static int bigru_bwd_impl(const twog_bigru_bwd_t* types, int n_types, int bs, in
 
 extern "C" int twog_bigru_fwd(const twog_bigru_t* types, int n_types, int bs, int T, int hidden, void* stream) {
     if (n_types > 4 || n_types < 0) return -1;
-    uint64_t key = twog_graph::fnv1a(types, sizeof(twog_bigru_t) * n_types);
-    const int dims[4] = {n_types, bs, T, hidden};
-    key = twog_graph::fnv1a(dims, sizeof(dims), key ^ 0x11);
+    const int dims[5] = {0x11, n_types, bs, T, hidden};
+    twog_graph::Desc key;
+    key.pod(dims).add(types, sizeof(twog_bigru_t) * n_types);
     return twog_graph::run(key, (hipStream_t)stream,
                            [&](hipStream_t st) { return bigru_fwd_impl(types, n_types, bs, T, hidden, st); });
 }
 
 extern "C" int twog_bigru_bwd(const twog_bigru_bwd_t* types, int n_types, int bs, int T, int hidden, void* stream) {
     if (n_types > 4 || n_types < 0) return -1;
-    uint64_t key = twog_graph::fnv1a(types, sizeof(twog_bigru_bwd_t) * n_types);
-    const int dims[4] = {n_types, bs, T, hidden};
-    key = twog_graph::fnv1a(dims, sizeof(dims), key ^ 0x22);
+    const int dims[5] = {0x22, n_types, bs, T, hidden};
+    twog_graph::Desc key;
+    key.pod(dims).add(types, sizeof(twog_bigru_bwd_t) * n_types);
     return twog_graph::run(key, (hipStream_t)stream,
                            [&](hipStream_t st) { return bigru_bwd_impl(types, n_types, bs, T, hidden, st); });
 }

@@ -359,12 +359,24 @@ static int segrnn_bwd_impl(const twog_segrnn_t* desc, const twog_segrnn_bwd_t* b
 }
 
 extern "C" int twog_segrnn_fwd(const twog_segrnn_t* desc, void* stream) {
-    const uint64_t key = twog_graph::fnv1a(desc, sizeof(*desc)) ^ 0x33;
+    const int tag = 0x33;
+    twog_graph::Desc key;
+    key.pod(tag).pod(*desc);
     return twog_graph::run(key, (hipStream_t)stream, [&](hipStream_t st) { return segrnn_fwd_impl(desc, st); });
 }
 
 extern "C" int twog_segrnn_bwd(const twog_segrnn_t* desc, const twog_segrnn_bwd_t* bdesc, void* stream) {
-    const uint64_t key = twog_graph::fnv1a(bdesc, sizeof(*bdesc), twog_graph::fnv1a(desc, sizeof(*desc))) ^ 0x44;
+    const int tag = 0x44;
+    twog_graph::Desc key;
+    key.pod(tag).pod(*desc).pod(*bdesc);
     return twog_graph::run(key, (hipStream_t)stream,
                            [&](hipStream_t st) { return segrnn_bwd_impl(desc, bdesc, st); });
+}
+
+extern "C" int twog_graph_cache_stats(int64_t* entries, int64_t* collisions) {
+    twog_graph::State& S = twog_graph::state();
+    std::lock_guard<std::mutex> lock(S.mu);
+    if (entries) *entries = (int64_t)S.cache.size();
+    if (collisions) *collisions = (int64_t)S.collisions;
+    return 0;
 }

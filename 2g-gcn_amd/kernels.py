@@ -366,6 +366,12 @@ class HipKernels:
         self._check(self.lib.twog_segrnn_bwd(C.byref(s), C.byref(b), self._stream()), 'twog_segrnn_bwd')
         return out
 
+    def graph_cache_stats(self):
+        """(captured loops, hash-bucket hits resolved by the descriptor compare) of the library's hipGraph cache."""
+        n, c = C.c_int64(0), C.c_int64(0)
+        self._check(self.lib.twog_graph_cache_stats(C.byref(n), C.byref(c)), 'twog_graph_cache_stats')
+        return n.value, c.value
+
     # ---------------------------------------------------------------- gates
     def _fill_gate(self, g, d):
         g.x = rows_of(d['x'])

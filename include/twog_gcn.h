@@ -268,6 +268,9 @@ typedef struct {
     float* du_part_o;
 } twog_segrnn_bwd_t;
 int twog_segrnn_bwd(const twog_segrnn_t* desc, const twog_segrnn_bwd_t* bdesc, void* stream);
+/* hipGraph cache of the time loops (twog_bigru_*, twog_segrnn_*): number of captured loops and of hash-bucket hits whose
+ * descriptor bytes differed (each was resolved by the byte compare; see csrc/graph_cache.h). Diagnostics / tests. */
+int twog_graph_cache_stats(int64_t* entries, int64_t* collisions);
 
 /* ===============================================================================================================
  * Segment-boundary gates (vhoi/models.py:1477-1533, :1620-1627; pyrutils/torch/distributions.py:4-53) with
