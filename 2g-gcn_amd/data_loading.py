@@ -68,18 +68,17 @@ def _next_labels(y):
 
 
 def segmentation_from_output_class(y, segmentation_type='input'):
-    """Frame is a segment end iff the label changes at the next frame (last frame always); :885-896."""
-    x = np.array(y, dtype=np.float32)
-    missing = y == -1.0
-    x = np.where(missing, np.nan, x)
-    ends = (x[:, 1:] - x[:, :-1]) != 0.0
-    ends = np.concatenate([ends, np.full_like(ends, fill_value=True)[:, -1:]], axis=1)
-    x[ends] = 1.0
-    x[~ends & ~np.isnan(x)] = 0.0
-    x[np.isnan(x)] = 1.0
-    if segmentation_type == 'output':
-        x[missing] = -1.0
-    return x
+    """End-of-segment flags from per-frame labels (reference behaviour: vhoi/data_loading.py:885-896): a frame ends a
+    segment when the next frame carries another label -- a missing (-1) neighbour counts as another label -- and the last
+    frame of every row always does. Missing frames themselves read 1.0 ('input' style) or -1.0 ('output' style)."""
+    labels = np.asarray(y)
+    missing = labels == -1
+    ends = np.ones(labels.shape, dtype=bool)                       # last column: always an end
+    ends[:, :-1] = np.diff(labels.astype(np.float64), axis=1) != 0
+    ends[:, :-1] |= missing[:, 1:] | missing[:, :-1]
+    seg = ends.astype(np.float32)
+    seg[missing] = -1.0 if segmentation_type == 'output' else 1.0
+    return seg
 
 
 def ignore_last_step_end_flag(x):
@@ -98,14 +97,18 @@ def ignore_last_step_end_flag_general(x):
 
 
 def smooth_segmentation(x, sigma: float):
-    """:544-559."""
-    if sigma:
-        from scipy.ndimage import gaussian_filter1d
-        missing = x == -1.0
-        x[missing] = 0.0
-        x = np.clip(gaussian_filter1d(x, sigma=sigma, axis=1, mode='constant') * 2.5 * sigma, 0.0, 1.0)
-        x[missing] = -1.0
-    return x
+    """Budget targets (reference behaviour: vhoi/data_loading.py:544-559): the 0/1 end flags blurred along time with a
+    unit-mass Gaussian (zero beyond the clip ends), rescaled by 2.5 sigma and clipped to [0, 1]; missing (-1) frames
+    contribute nothing and stay -1. sigma == 0: unchanged."""
+    if not sigma:
+        return x
+    from scipy.ndimage import gaussian_filter1d
+    missing = x == -1.0
+    flags = np.where(missing, np.float32(0.0), x).astype(x.dtype, copy=False)
+    blurred = gaussian_filter1d(flags, sigma=sigma, axis=1, mode='constant')
+    out = np.minimum(np.maximum(blurred * (2.5 * sigma), 0.0), 1.0).astype(x.dtype, copy=False)
+    out[missing] = -1.0
+    return out
 
 
 def compute_centroid(bb):
@@ -316,10 +319,54 @@ def maybe_scale_input_tensors(x, model_name, scaling_strategy=None, scalers=None
     return [xh, xo] + x[2:], {'human_scaler': hs, 'object_scaler': os_}
 
 
+class LengthBucketedBatchSampler:
+    """Opt-in batch sampler: clips are ordered by their number of valid steps and cut into
+    consecutive batches, so a batch holds clips of similar length and can be trimmed to ITS longest clip instead of the
+    split's (`trim_to_batch_length`). With `shuffle` the ORDER of the batches is permuted per epoch (the membership of a
+    batch is fixed by the lengths). This is NOT the reference's batching (a plain shuffled DataLoader over tensors
+    padded to the split maximum, vhoi/data_loading.py:362-379) and it changes the numbers: the model has no length
+    masking, its backward-direction GRUs start on the padding and its forced last-step segment end sits on the padded
+    T -- hence off by default."""
+
+    def __init__(self, num_steps, batch_size: int, shuffle: bool = False, generator=None, drop_last: bool = False):
+        steps = torch.as_tensor(num_steps).flatten()
+        order = torch.argsort(steps, stable=True).tolist()
+        self.batches = [order[i:i + batch_size] for i in range(0, len(order), batch_size)]
+        if drop_last and self.batches and len(self.batches[-1]) < batch_size:
+            self.batches.pop()
+        self.shuffle, self.generator = shuffle, generator
+
+    def __len__(self):
+        return len(self.batches)
+
+    def __iter__(self):
+        if self.shuffle:
+            for i in torch.randperm(len(self.batches), generator=self.generator).tolist():
+                yield self.batches[i]
+        else:
+            yield from self.batches
+
+
+def trim_to_batch_length(tensors, steps_slot: int = 7):
+    """Cuts the time axis (dim 1) of every tensor that runs over the input frames down to the longest clip of the batch
+    (slot `steps_slot` = steps_per_example, Appendix B). Tensors with another time length (the full-rate targets of
+    test_data=True) are left alone; predict.py's match_shape copes with them as before."""
+    t_in = tensors[0].shape[1]
+    t_b = max(1, min(t_in, int(tensors[steps_slot].max().item())))
+    return [t[:, :t_b].contiguous() if (t.dim() >= 2 and t.shape[1] == t_in) else t for t in tensors]
+
+
+def _trim_collate(samples):
+    return trim_to_batch_length([torch.stack(col, 0) for col in zip(*samples)])
+
+
 def create_data_loader(data, model_name: str, model_input_type: str, dataset_name: str, batch_size: int, shuffle: bool,
                        scaling_strategy: Optional[str] = None, scalers: Optional[dict] = None, sigma: float = 0.0,
-                       downsampling: int = 1, test_data: bool = False, pin_memory: bool = False):
-    """vhoi/data_loading.py:362-379 (plus an opt-in pinned-memory dataset for asynchronous H2D copies)."""
+                       downsampling: int = 1, test_data: bool = False, pin_memory: bool = False,
+                       length_bucketing: bool = False):
+    """vhoi/data_loading.py:362-379 (plus an opt-in pinned-memory dataset for asynchronous H2D copies, and the opt-in
+    `length_bucketing`: batches of similar-length clips trimmed to their own longest clip -- see
+    LengthBucketedBatchSampler for why it is not the default)."""
     name = dataset_name.lower()
     if name == 'cad120':
         x, y = assemble_tensors(data, model_name, model_input_type, sigma, downsampling, test_data)
@@ -332,8 +379,13 @@ def create_data_loader(data, model_name: str, model_input_type: str, dataset_nam
     tensors = [torch.from_numpy(np.ascontiguousarray(a)) for a in x + y]
     if pin_memory and torch.cuda.is_available():
         tensors = [t.pin_memory() for t in tensors]
-    loader = DataLoader(TensorDataset(*tensors), batch_size=batch_size, shuffle=shuffle, num_workers=0,
-                        pin_memory=False, drop_last=False)
+    if length_bucketing:
+        sampler = LengthBucketedBatchSampler(tensors[7], batch_size, shuffle=shuffle)
+        loader = DataLoader(TensorDataset(*tensors), batch_sampler=sampler, num_workers=0, pin_memory=False,
+                            collate_fn=_trim_collate)
+    else:
+        loader = DataLoader(TensorDataset(*tensors), batch_size=batch_size, shuffle=shuffle, num_workers=0,
+                            pin_memory=False, drop_last=False)
     segmentations = assemble_cad120_segmentations_from_frame_level_features(data) if name == 'cad120' else None
     return loader, scalers, segmentations
 
@@ -519,7 +571,8 @@ class DevicePrefetcher:
         slot (one host copy; DataLoader's collate + pin would make two); otherwise the loader's own batches are
         copied into the slot."""
         ds = self.loader.dataset
-        if self.on_gpu and isinstance(ds, TensorDataset) and self.loader.batch_sampler is not None:
+        if self.on_gpu and isinstance(ds, TensorDataset) and self.loader.batch_sampler is not None and \
+                self.loader.collate_fn is not _trim_collate:
             for k, idx in enumerate(self._batch_indices()):
                 slot = k & 1
                 self._wait_slot_free(slot)
@@ -562,6 +615,13 @@ class DevicePrefetcher:
             ev = torch.cuda.Event()
             ev.record(self.copy_stream)
         self._slot_events[k & 1] = ev
+        # tensors the fetcher leaves on the host are still views of this batch's pinned staging slot, which is rewritten
+        # two batches later: hand out private copies (these are the small ones: segmentations, distances, targets), so a
+        # consumer may keep them across iterations -- "exactly what fetch yields" includes their lifetime
+        slots = {b.untyped_storage().data_ptr() for b in self._slots[k & 1].values()}
+        out = type(out)(type(group)(t.clone() if (isinstance(t, torch.Tensor) and not t.is_cuda and
+                                                   t.untyped_storage().data_ptr() in slots) else t for t in group)
+                        if isinstance(group, (list, tuple)) else group for group in out)
         return out, ev
 
     def _hand_over(self, staged):
@@ -579,7 +639,10 @@ class DevicePrefetcher:
         ds, bs = self._resident, self.loader.batch_size
         for idx in self._batch_indices():
             idx = torch.as_tensor(idx, dtype=torch.int64, device=self.device)
-            yield self.fetch([t.index_select(0, idx) for t in ds.tensors], device=self.device, **self.kw)
+            batch = [t.index_select(0, idx) for t in ds.tensors]
+            if self.loader.collate_fn is _trim_collate:   # length-bucketed loader: trim to the batch's longest clip
+                batch = trim_to_batch_length(batch)
+            yield self.fetch(batch, device=self.device, **self.kw)
 
     def __iter__(self):
         if self._resident is not None:

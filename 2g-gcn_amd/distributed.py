@@ -40,6 +40,8 @@ class FlatParameters:
                 p.grad = self.grad[off:off + p.numel()].view_as(p)
                 off += n
         self.params = params
+        from . import ops
+        ops.enable_grad_sinks(params)   # the backward kernels add straight into these flat gradient views
         self.numel = total
         self.stage_ranges = {}
         if stage_of is not None:
@@ -101,11 +103,20 @@ class DataParallel:
         self.flat = FlatParameters(model, stage_of=ops.grad_ready_stage if overlap else None)
         self.bucket = max(1, bucket_mb) * (1 << 20) // 4
         if overlap and self.world > 1:
-            ops.set_grad_stage_hook(self._stage_ready)
+            ops.set_grad_stage_hook(model, self._stage_ready)   # scoped to this model; close() removes it
         if self.world > 1 and broadcast:
             dist.broadcast(self.flat.flat, src=0, group=self.group)
             for b in model.buffers():
                 dist.broadcast(b, src=0, group=self.group)
+
+    def close(self):
+        """Detaches this wrapper from the model (stage hook, sync-BN / noise-shard settings)."""
+        from . import ops
+        if getattr(self.model, '_twog_grad_stage_hook', None) == self._stage_ready:
+            ops.set_grad_stage_hook(self.model, None)
+        for attr in ('_bn_stats_reduce', '_noise_shard'):
+            if hasattr(self.model, attr):
+                delattr(self.model, attr)
 
     @property
     def grad_scale(self):
@@ -122,7 +133,7 @@ class DataParallel:
                                                group=self.group, async_op=True))
 
     def _stage_ready(self, stage):
-        """Called from inside the backward pass (ops.set_grad_stage_hook): every gradient of `stage` is final, start its
+        """Called from inside this model's backward pass (ops.set_grad_stage_hook): every gradient of `stage` is final, start its
         all-reduce now (a few large chunks; ring collectives over xGMI are per-link bound)."""
         if stage in self._launched or stage not in self.flat.stage_ranges:
             return

@@ -274,6 +274,7 @@ class TGGCN(nn.Module):
         n_sub, n_aff = self.num_classes
         plan = ops.Plan(self.cfg, bs, T, H, O, self.gcn_node, x_objects.shape[-1], n_sub, n_aff,
                         human_segmentation is not None, objects_segmentation is not None)
+        plan.stage_hook = getattr(self, '_twog_grad_stage_hook', None)   # data-parallel overlap (ops.set_grad_stage_hook)
         noise = None
         n_gated = (H if plan.learn_h else 0) + (O if plan.learn_o else 0)
         if plan.gs and n_gated:

@@ -154,14 +154,11 @@ def used_parameter_names(plan: Plan):
 
 # ---- gradient readiness (data-parallel overlap): the backward pass finishes the parameter gradients in three stages;
 # distributed.DataParallel lays its flat buffer out in this order and starts each stage's all-reduce from the hook
-_GRAD_STAGE_HOOK = None
-
-
-def set_grad_stage_hook(fn):
-    """fn(stage) is called from inside the backward pass as soon as every gradient of `stage` (see grad_ready_stage) is
-    final; None removes the hook."""
-    global _GRAD_STAGE_HOOK
-    _GRAD_STAGE_HOOK = fn
+def set_grad_stage_hook(model, fn):
+    """fn(stage) is called from inside the backward pass of THIS model's forward calls as soon as every gradient of
+    `stage` (see grad_ready_stage) is final; None removes the hook. The hook is scoped to the module (it travels with
+    each forward's Plan), so a second model in the process -- an EMA copy, a discarded wrapper -- never triggers it."""
+    model._twog_grad_stage_hook = fn
 
 
 def grad_ready_stage(name: str) -> int:
@@ -175,9 +172,19 @@ def grad_ready_stage(name: str) -> int:
     return 2
 
 
-def _stage_done(stage):
-    if _GRAD_STAGE_HOOK is not None:
-        _GRAD_STAGE_HOOK(stage)
+def enable_grad_sinks(params, on: bool = True):
+    """Opts parameters in to (or out of) the in-place gradient route of TGGCNFunction.backward: a tagged parameter that
+    owns a contiguous fp32 ``.grad`` gets its gradient ADDED into that buffer by the kernels, and autograd sees None for
+    it. Caveat (why this is opt-in): ``torch.autograd.grad(loss, params)`` / ``backward(inputs=...)`` then return None
+    for these parameters and still add into ``.grad``; use it only where the step owns the buffers (DataParallel)."""
+    for p in params:
+        p._twog_grad_sink = bool(on)
+
+
+def _stage_done(plan, stage):
+    hook = getattr(plan, 'stage_hook', None)
+    if hook is not None:
+        hook(stage)
 
 
 class _Grads:
@@ -602,7 +609,7 @@ def tggcn_backward(K, plan: Plan, P, S, x_human, x_objects, objects_mask, d_outp
         if (mlp + '.0.bias') in P:
             G.add(mlp + '.0.bias', K.colsum(dlogit.view(-1, 1)))
 
-    _stage_done(0)
+    _stage_done(p, 0)
 
     # ---- D. frame-level attention + sender MLPs backward
     MSGH, MSGO, MSGS = S['MSGH'], S['MSGO'], S['MSGS']
@@ -670,7 +677,7 @@ def tggcn_backward(K, plan: Plan, P, S, x_human, x_objects, objects_mask, d_outp
             G.add(f'{name}_bd_rnn.bias_hh_l0{sfx}', K.colsum(dghv[:, d * 3 * h:(d + 1) * 3 * h]))
             K.gemm([dict(A=dgi_d, B=P[f'{name}_bd_rnn.weight_ih_l0{sfx}'], C=dEv[:, :h], accumulate=True)], b_kmajor=True)
 
-    _stage_done(1)
+    _stage_done(p, 1)
 
     # ---- B. embeddings backward
     xh_in = x_human.view(nF * H, x_human.shape[-1])[:, :2048]
@@ -790,15 +797,19 @@ class TGGCNFunction(torch.autograd.Function):
         for i in range(n_gate):
             if not gates[kinds[i]]['learned']:
                 d_outputs[i] = None
-        # parameters that already own a contiguous fp32 .grad buffer receive their gradient in place (grad += g inside
-        # the producing kernels); autograd gets None for them, so no AccumulateGrad add runs. Parameter hooks do not
-        # fire on this route -- twog_gcn_amd.distributed.DataParallel reduces the flat buffer itself.
+        # OPT-IN in-place gradient route (enable_grad_sinks; distributed.FlatParameters turns it on for its flat
+        # gradient views): such a parameter receives `grad += g` from the producing kernels themselves and autograd gets
+        # None for it, so no AccumulateGrad add runs. Never taken implicitly: torch.autograd.grad / backward(inputs=...)
+        # and hooks (tensor hooks, post-accumulate-grad hooks = optimizer-in-backward) need the autograd route, which
+        # every untagged parameter -- and every tagged one that carries a hook -- keeps.
         sinks = {}
         for i, n in enumerate(ctx.names):
             prm = ctx.P[n]
             g = getattr(prm, 'grad', None)
-            if (ctx.needs_input_grad[11 + i] and g is not None and g.is_contiguous() and g.dtype == torch.float32
-                    and g.device == prm.device and not getattr(prm, '_backward_hooks', None)):
+            if (getattr(prm, '_twog_grad_sink', False) and ctx.needs_input_grad[11 + i] and g is not None
+                    and g.is_contiguous() and g.dtype == torch.float32 and g.device == prm.device
+                    and not getattr(prm, '_backward_hooks', None)
+                    and not getattr(prm, '_post_accumulate_grad_hooks', None)):
                 sinks[n] = g
         grads = tggcn_backward(K, plan, ctx.P, ctx.S, x_human, x_objects, objects_mask, d_outputs, sinks)
         out = [None] * 11
@@ -807,5 +818,4 @@ class TGGCNFunction(torch.autograd.Function):
             if g is not None:
                 g = g.reshape(ctx.P[n].shape)
             out.append(g)
-        ctx.S = None
-        return tuple(out)
+        return tuple(out)   # ctx.S lives as long as the graph does (retain_graph=True may run this again)

@@ -7,6 +7,7 @@ import torch
 
 import twog_gcn_amd  # noqa: F401
 from twog_gcn_amd import kernels as twog_kernels
+from twog_gcn_amd import ops
 from twog_gcn_amd.models import TGGCN, select_model
 from tests.fake_kernels import FakeKernels
 from tests.helpers import G4_CASES, load_g4, det_state_dict, g4_inputs, sample_grad
@@ -110,6 +111,7 @@ def test_in_place_gradient_route_equals_autograd_accumulation(fake_backend):
         if prealloc:
             for p in m.parameters():
                 p.grad = torch.zeros_like(p)
+            ops.enable_grad_sinks(m.parameters())
         for _ in range(passes):
             out = m(**g4_inputs(z))
             sum((o * o).sum() for o in out if o.requires_grad).backward()
@@ -140,12 +142,12 @@ def test_gradient_stages_are_final_when_the_hook_fires(case, fake_backend):
     assert set(flat.stage_ranges) == {0, 1, 2}
     assert sum(e - b for b, e in flat.stage_ranges.values()) == flat.numel
     snaps = {}
-    ops.set_grad_stage_hook(lambda st: snaps.setdefault(st, flat.grad[slice(*flat.stage_ranges[st])].clone()))
+    ops.set_grad_stage_hook(m, lambda st: snaps.setdefault(st, flat.grad[slice(*flat.stage_ranges[st])].clone()))
     try:
         out = m(**g4_inputs(z))
         sum((o * o).sum() for o in out if o.requires_grad).backward()
     finally:
-        ops.set_grad_stage_hook(None)
+        ops.set_grad_stage_hook(m, None)
     assert set(snaps) == {0, 1}
     for st, snap in snaps.items():
         final = flat.grad[slice(*flat.stage_ranges[st])]
@@ -154,6 +156,15 @@ def test_gradient_stages_are_final_when_the_hook_fires(case, fake_backend):
     # and the stage-2 block (embeddings, GCN) is what remains
     b2, e2 = flat.stage_ranges[2]
     assert float(flat.grad[b2:e2].abs().max()) > 0
+    # the hook is scoped to its model: the backward of ANOTHER model in the process never calls it
+    calls = []
+    ops.set_grad_stage_hook(m, calls.append)
+    other = build_model(meta)
+    other.train()
+    other._gumbel_noise_override = m._gumbel_noise_override
+    sum((o * o).sum() for o in other(**g4_inputs(z)) if o.requires_grad).backward()
+    assert calls == []
+    ops.set_grad_stage_hook(m, None)
 
 
 def test_randomised_layouts_vs_oracle(fake_backend):
@@ -222,9 +233,40 @@ def test_cat_level_states_in_place_gradient_route(fake_backend):
 
     run()                                                   # autograd route: .grad tensors are created
     first = {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
+    ops.enable_grad_sinks(m.parameters())
     run()                                                   # in-place route: kernels add into the existing buffers
     for n, p in m.named_parameters():
         if p.grad is None:
             continue
         scale = max(first[n].abs().max().item(), 1e-6)
         assert (p.grad - 2 * first[n]).abs().max().item() < 1e-5 * scale, n
+
+
+def test_gradient_sink_route_is_opt_in(fake_backend):
+    """Without enable_grad_sinks an existing .grad buffer changes nothing about the autograd contract:
+    torch.autograd.grad returns every gradient (and leaves .grad alone), post-accumulate-grad hooks fire; a tagged
+    parameter that carries such a hook keeps the autograd route too."""
+    z, meta = load_g4('c2_stage1')
+    noise = torch.from_numpy(z['gumbel_noise'])
+    m = build_model(meta)
+    m.train()
+    m._gumbel_noise_override = noise if len(noise) else None
+    for p in m.parameters():
+        p.grad = torch.zeros_like(p)
+    out = m(**g4_inputs(z))
+    loss = sum((o * o).sum() for o in out if o.requires_grad)
+    used = [p for n, p in m.named_parameters() if 'att_mlp' not in n and 'geometry_to_object_segment' not in n]
+    gs = torch.autograd.grad(loss, used, allow_unused=True, retain_graph=True)
+    assert sum(g is not None for g in gs) > 50
+    assert all(float(p.grad.abs().max()) == 0.0 for p in m.parameters())     # .grad untouched by autograd.grad
+    fired = []
+    w = m.human_embedding_mlp[0].weight
+    w.register_post_accumulate_grad_hook(lambda p: fired.append(float(p.grad.abs().sum())))
+    ops.enable_grad_sinks(m.parameters())                                     # tagged, but w has a hook
+    loss.backward()
+    assert len(fired) == 1 and fired[0] > 0
+    ref = dict(zip([id(p) for p in used], gs))
+    for p in used:
+        g = ref[id(p)]
+        if g is not None:
+            assert float((p.grad - g).abs().max()) <= 1e-5 * (float(g.abs().max()) + 1e-12)
