@@ -11,6 +11,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLDEN = os.path.join(ROOT, 'tests', 'golden')
 
 G4_CASES = ['c2_stage1', 'c2_stage2', 'c1_stage1', 'c1_stage2', 'c5_stage1', 'c2_geo2human', 'c2_dot_st']
+# round 2: the rest of the constructor's configuration surface (reference outputs, tools/make_golden.py)
+G4_CASES_R2 = ['c1_sah', 'c1_coh', 'c2_gate3', 'c2_nobias', 'c2_time_s', 'c2_time_u_periodic', 'c2_seglen',
+               'c2_seglen_periodic', 'c2_concat', 'c2_general', 'c2_specific', 'c2_relational', 'c2_distance',
+               'c2_ctor_defaults', 'c1_relational_geo2h']
 
 
 def load_g4(name):
@@ -39,6 +43,9 @@ def g4_inputs(z):
         kw['human_segmentation'] = torch.from_numpy(z['human_segmentation'])
     if 'objects_segmentation' in z.files:
         kw['objects_segmentation'] = torch.from_numpy(z['objects_segmentation'])
+    for k in ('human_human_distances', 'human_object_distances', 'object_object_distances'):
+        if k in z.files:
+            kw[k] = torch.from_numpy(z[k])
     return kw
 
 

@@ -5,7 +5,7 @@ import pytest
 import torch
 
 from oracle import cpu_ref, detgen
-from tests.helpers import GOLDEN, G4_CASES, load_g4, det_state_dict, g4_inputs, sample_grad, rel_err
+from tests.helpers import GOLDEN, G4_CASES, G4_CASES_R2, load_g4, det_state_dict, g4_inputs, sample_grad, rel_err
 
 TOL = 2e-5  # oracle vs reference: same fp32 CPU ops, differences are summation order only
 
@@ -66,7 +66,7 @@ def test_g5_reorder_and_filter():
         assert np.array_equal(f, z[f'filtered_{thr}'])
 
 
-@pytest.mark.parametrize('name', G4_CASES)
+@pytest.mark.parametrize('name', G4_CASES + G4_CASES_R2)
 def test_g4_full_forward_backward(name):
     z, meta = load_g4(name)
     sd = det_state_dict(meta['state_dict_shapes'], seed=meta['seed'], gain=meta['gain'], requires_grad=True)

@@ -29,8 +29,8 @@ rs = None
 
 def oracle(dtype):
     global rs
-    sd = {k: (v.to(dtype).requires_grad_(True) if v.is_floating_point() and 'running' not in k
-              else (v.to(dtype) if v.is_floating_point() else v.clone())) for k, v in sd0.items()}
+    sd = {k: (v.detach().to(dtype).clone().requires_grad_(True) if v.is_floating_point() and 'running' not in k
+              else (v.detach().to(dtype).clone() if v.is_floating_point() else v.clone())) for k, v in sd0.items()}
     out = cpu_ref.tggcn_forward(sd, dict(m.cfg), x_human.to(dtype), x_objects.to(dtype), mask.to(dtype),
                                 human_segmentation=seg.to(dtype), training=True, gumbel_noise=noise.to(dtype))
     if rs is None:

@@ -157,6 +157,30 @@ CASES = {
     'c2_geo2human': ('mphoi', 2, 4, 26, 8, 2, 5, (13, None), dict(message_geometry_to_human=True), 'human_ones', 16),
     'c2_dot_st': ('mphoi', 2, 4, 26, 8, 2, 5, (13, None),
                   dict(attention_style='v2', discrete_optimization_strategy='st'), 'none', 17),
+    # ---- round 2: the rest of the constructor's configuration surface (none is enabled by a shipped config)
+    'c1_sah': ('cad120', 1, 5, 19, 8, 2, 6, (10, 12),
+               dict(message_humans_to_human=False, object_segment_update_strategy='sah'), 'none', 21),
+    'c1_coh': ('cad120', 1, 5, 19, 8, 2, 6, (10, 12),
+               dict(message_humans_to_human=False, object_segment_update_strategy='coh'), 'none', 36),
+    'c2_gate3': ('mphoi', 2, 4, 26, 8, 2, 5, (13, None), dict(discrete_networks_num_layers=3), 'none', 23),
+    'c2_nobias': ('mphoi', 2, 4, 26, 8, 2, 5, (13, None), dict(bias=False), 'human_ones', 24),
+    'c2_time_s': ('mphoi', 2, 4, 26, 8, 2, 5, (13, None),
+                  dict(add_time_position=1, time_position_strategy='s', positional_encoding_style='e'), 'human_ones', 25),
+    'c2_time_u_periodic': ('mphoi', 2, 4, 26, 8, 2, 5, (13, None),
+                           dict(add_time_position=1, time_position_strategy='u', positional_encoding_style='p'),
+                           'none', 26),
+    'c2_seglen': ('mphoi', 2, 4, 26, 8, 2, 6, (13, None), dict(add_segment_length=1), 'none', 27),
+    'c2_seglen_periodic': ('mphoi', 2, 4, 26, 8, 2, 6, (13, None),
+                           dict(add_segment_length=1, positional_encoding_style='p'), 'human_ones', 28),
+    'c2_concat': ('mphoi', 2, 4, 26, 8, 2, 5, (13, None), dict(attention_style='v1'), 'human_ones', 29),
+    'c2_general': ('mphoi', 2, 4, 26, 8, 2, 5, (13, None), dict(attention_style='v4'), 'human_ones', 30),
+    'c2_specific': ('mphoi', 2, 4, 26, 8, 2, 5, (13, None), dict(message_granularity='v2'), 'human_ones', 31),
+    'c2_relational': ('mphoi', 2, 4, 26, 8, 2, 5, (13, None), dict(message_type='v1'), 'human_ones', 32),
+    'c2_distance': ('mphoi', 2, 4, 26, 8, 2, 5, (13, None), dict(), 'human_ones+dist', 33),
+    'c2_ctor_defaults': ('mphoi', 2, 4, 26, 8, 2, 5, (13, None), 'defaults', 'human_ones', 34),
+    'c1_relational_geo2h': ('cad120', 1, 5, 19, 8, 2, 5, (10, 12),
+                            dict(message_humans_to_human=False, message_type='v1', message_geometry_to_human=True),
+                            'none', 41),
 }
 
 
@@ -178,10 +202,15 @@ def make_inputs(name, H, O, N, bs, T, seed):
     return x_human, x_objects, mask
 
 
-def g4_full():
+def g4_full(only=None):
     for name, (layout, H, O, N, hid, bs, T, classes, over, segmode, seed) in CASES.items():
-        cfg = dict(STAGE1)
-        cfg.update(over)
+        if only and name not in only:
+            continue
+        if over == 'defaults':   # the constructor's own defaults (vhoi/models.py:179-190)
+            cfg = {}
+        else:
+            cfg = dict(STAGE1)
+            cfg.update(over)
         cfg.update(hidden_size=hid, gcn_node=N)
         F_h = 2048 + 4 * N
         model = TGGCN(input_size=(F_h, 2048), num_classes=classes, **cfg)
@@ -191,6 +220,15 @@ def g4_full():
         kw = dict(x_human=torch.from_numpy(x_human), x_objects=torch.from_numpy(x_objects),
                   objects_mask=torch.from_numpy(mask), steps_per_example=torch.full((bs,), float(T)))
         seg_h = seg_o = None
+        dists = {}
+        if segmode.endswith('+dist'):   # centroid distances as the loader builds them; some exact zeros = "no sender"
+            segmode = segmode[:-5]
+            for key, shp in (('human_human_distances', (bs, T, H, H)), ('human_object_distances', (bs, T, H, O)),
+                             ('object_object_distances', (bs, T, O, O))):
+                d = detgen.uniform(name + '.' + key, shp, 0.05, 2.0, seed=seed).astype(np.float32)
+                d[detgen.uniform01(name + '.z' + key, shp, seed=seed) < 0.15] = 0.0
+                dists[key] = d
+                kw[key] = torch.from_numpy(d)
         if segmode == 'human_ones':
             seg_h = np.ones((bs, T, H), dtype=np.float32)
         elif segmode == 'both_given':
@@ -224,6 +262,7 @@ def g4_full():
             save['human_segmentation'] = seg_h
         if seg_o is not None:
             save['objects_segmentation'] = seg_o
+        save.update(dists)
         for i, o in enumerate(out):
             save[f'out{i}'] = o.detach().numpy()
         none_grads = []
@@ -237,6 +276,9 @@ def g4_full():
         bn = model.geometry_embedding_gcn.joint_embed.cnn[0].bn
         save['bn_running_mean'] = bn.running_mean.numpy().copy()
         save['bn_running_var'] = bn.running_var.numpy().copy()
+        if over == 'defaults':
+            cfg = {k: getattr(model, k) for k in STAGE1 if hasattr(model, k)}
+            cfg.update(hidden_size=hid, gcn_node=N, discrete_networks_num_layers=1, bias=True, share_level_mlps=False)
         meta = dict(layout=layout, H=H, O=O, N=N, hidden=hid, bs=bs, T=T, classes=list(classes), cfg=cfg,
                     segmode=segmode, seed=seed, gain=1.6,
                     state_dict_shapes={k: list(v.shape) for k, v in model.state_dict().items()})
@@ -423,6 +465,9 @@ def g8_postprocess():
 if __name__ == '__main__':
     torch.set_num_threads(8)
     os.makedirs(OUT, exist_ok=True)
+    if len(sys.argv) > 1 and sys.argv[1] == 'g4':   # python tools/make_golden.py g4 [case ...]
+        g4_full(only=set(sys.argv[2:]) or None)
+        sys.exit(0)
     g1_geo_gcn()
     g3_messages()
     g5_reorder_filter()
