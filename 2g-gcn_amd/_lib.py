@@ -131,6 +131,12 @@ SIGNATURES = {
     'twog_segrnn_fwd': [C.POINTER(SegRnn), _P],
     'twog_segrnn_bwd': [C.POINTER(SegRnn), C.POINTER(SegRnnBwd), _P],
     'twog_graph_cache_stats': [c_int64_p, c_int64_p],
+    'twog_pos_embed_fwd': [_P, _P, _I, _I, _I, _I, _P, _P, _I, _I, Rows, _P, _P],
+    'twog_periodic_embed_bwd': [Rows, _P, _I, _I, _P, _P],
+    'twog_seglen_fwd': [_P, _P, _I, _I, _I, _I, _P, _P],
+    'twog_seglen_bwd': [_P, _P, _I, _I, _I, _I, _P, _P, _P],
+    'twog_mul': [_P, _P, _P, _L, _I, _P],
+    'twog_scale_rows': [Rows, _P, _I, _I, _P],
     'twog_gate_fwd': [C.POINTER(Gate), _P],
     'twog_gate_bwd': [C.POINTER(Gate), _P, _P, _P, _P, _P],
     'twog_rank1_update': [Rows, _P, _P, _I, _I, _P],

@@ -232,8 +232,8 @@ class HipKernels:
             keep += [tmp, zeros]
             a = arr[i]
             a.gi, a.w_hh_f, a.b_hh_f, a.w_hh_r, a.b_hh_r = (gi.data_ptr(), y['w_hh_f'].data_ptr(),
-                                                             y['b_hh_f'].data_ptr(), y['w_hh_r'].data_ptr(),
-                                                             y['b_hh_r'].data_ptr())
+                                                             _ptr(y.get('b_hh_f')), y['w_hh_r'].data_ptr(),
+                                                             _ptr(y.get('b_hh_r')))
             a.out, a.save, a.tmp_gh, a.zeros, a.E = out.data_ptr(), save.data_ptr(), tmp.data_ptr(), zeros.data_ptr(), E
             outs.append((out, save))
         self._check(self.lib.twog_bigru_fwd(arr, n, bs, T, h, self._stream()), 'twog_bigru_fwd')
@@ -468,6 +468,49 @@ class HipKernels:
     def add_rows(self, src, dst):
         self._check(self.lib.twog_add_rows(rows_of(src), rows_of(dst), n_rows(src), src.shape[-1], self._stream()),
                     'twog_add_rows')
+
+    # ---------------------------------------------------------------- position features / rare gate strategies
+    def pos_embed_fwd(self, out, bs, T, E, hidden, w=None, b=None, periodic=False, s=None, steps=None, divide=False):
+        """out: (bs*T*E, hidden) row-strided view (a column block of the entity rows). Returns the scalars [bs*T*E]."""
+        s_out = torch.empty(bs * T * E, dtype=torch.float32, device=out.device)
+        self._check(self.lib.twog_pos_embed_fwd(_ptr(s), _ptr(steps), bs, T, E, int(divide), _ptr(w), _ptr(b),
+                                                int(periodic), hidden, rows_of(out), s_out.data_ptr(), self._stream()),
+                    'twog_pos_embed_fwd')
+        return s_out
+
+    def periodic_embed_bwd(self, dout, s):
+        ds = torch.empty(n_rows(dout), dtype=torch.float32, device=dout.device)
+        self._check(self.lib.twog_periodic_embed_bwd(rows_of(dout), s.data_ptr(), n_rows(dout), dout.shape[-1],
+                                                     ds.data_ptr(), self._stream()), 'twog_periodic_embed_bwd')
+        return ds
+
+    def seglen_fwd(self, u, steps, divide):
+        bs, T, E = u.shape
+        assert u.is_contiguous()
+        s = torch.empty(bs, T, E, dtype=torch.float32, device=u.device)
+        self._check(self.lib.twog_seglen_fwd(u.data_ptr(), _ptr(steps), bs, T, E, int(divide), s.data_ptr(),
+                                             self._stream()), 'twog_seglen_fwd')
+        return s
+
+    def seglen_bwd(self, u, steps, divide, ds, du):
+        """du (bs, T, E) += d(segment lengths)/d(hard gates) applied to ds."""
+        bs, T, E = u.shape
+        assert ds.is_contiguous() and du.is_contiguous()
+        self._check(self.lib.twog_seglen_bwd(u.data_ptr(), _ptr(steps), bs, T, E, int(divide), ds.data_ptr(),
+                                             du.data_ptr(), self._stream()), 'twog_seglen_bwd')
+
+    def mul(self, a, b, out=None, accumulate=False):
+        assert a.is_contiguous() and b.is_contiguous() and a.numel() == b.numel()
+        if out is None:
+            out, accumulate = torch.empty_like(a), False
+        assert out.is_contiguous()
+        self._check(self.lib.twog_mul(a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel(), int(accumulate),
+                                      self._stream()), 'twog_mul')
+        return out
+
+    def scale_rows(self, x, s):
+        self._check(self.lib.twog_scale_rows(rows_of(x), s.data_ptr(), n_rows(x), x.shape[-1], self._stream()),
+                    'twog_scale_rows')
 
     def adam_step(self, param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
         self._check(self.lib.twog_adam_step(param.data_ptr(), grad.data_ptr(), exp_avg.data_ptr(),

@@ -236,18 +236,14 @@ class TGGCN(nn.Module):
             bad.append(f"message_aggregation={c['message_aggregation']!r}")
         if not mean_pool and c['attention_style'] not in {'v2', 'dot-product', 'v3', 'scaled_dot-product'}:
             bad.append(f"attention_style={c['attention_style']!r}")
-        if c['discrete_networks_num_layers'] != 1:
-            bad.append('discrete_networks_num_layers != 1')
+        if c['discrete_networks_num_layers'] < 1:
+            bad.append('discrete_networks_num_layers < 1')
         if c['discrete_optimization_strategy'] not in {'gumbel-sigmoid', 'gs', 'straight-through', 'st'}:
             raise ValueError('strategy must be either straight-through or gumbel-sigmoid, not '
                              f"{c['discrete_optimization_strategy']}.")
-        if c['object_segment_update_strategy'] not in {'independent', 'ind'}:
-            bad.append(f"object_segment_update_strategy={c['object_segment_update_strategy']!r}")
-        if not c['bias']:
-            bad.append('bias=False')
-        for k in ('add_segment_length', 'add_time_position'):
-            if c[k]:
-                bad.append(k)
+        if (c['add_time_position'] or c['add_segment_length']) and c['hidden_size'] % 2 and \
+                c['positional_encoding_style'] not in {'e', 'embedding'}:
+            bad.append('periodic position embedding with an odd hidden_size')   # the reference asserts (models.py:1787)
         self._unsupported = bad
 
     def forward(self, x_human, x_objects, objects_mask, human_segmentation=None, objects_segmentation=None,
@@ -275,8 +271,11 @@ class TGGCN(nn.Module):
         plan = ops.Plan(self.cfg, bs, T, H, O, self.gcn_node, x_objects.shape[-1], n_sub, n_aff,
                         human_segmentation is not None, objects_segmentation is not None)
         plan.stage_hook = getattr(self, '_twog_grad_stage_hook', None)   # data-parallel overlap (ops.set_grad_stage_hook)
+        plan.steps = None
+        if steps_per_example is not None and (plan.time_s or plan.time_u or plan.seglen):
+            plan.steps = steps_per_example.to(device=x_human.device, dtype=torch.float32).contiguous()
         noise = None
-        n_gated = (H if plan.learn_h else 0) + (O if plan.learn_o else 0)
+        n_gated = (H if plan.learn_h else 0) + (O if plan.own_o else 0)
         if plan.gs and n_gated:
             if self._gumbel_noise_override is not None:
                 noise = self._gumbel_noise_override

@@ -20,9 +20,8 @@ import torch
 from .kernels import get_kernels
 
 SUPPORTED_NOTE = ("the HIP path implements message_type 'v2' + message_granularity 'v1' + message_aggregation 'att' "
-                  "(attention_style 'v2'/'v3') or 'mp', discrete_networks_num_layers == 1, "
-                  "object_segment_update_strategy 'ind', no time-position / segment-length features, "
-                  "bias=True (a superset of every configuration shipped in the reference's conf/models/)")
+                  "(attention_style 'v2'/'v3') or 'mp' (a superset of every configuration shipped in the reference's "
+                  "conf/models/)")
 
 
 def _v2(t, width=None):
@@ -52,21 +51,55 @@ class Plan:
             if on:
                 self.col_h[name] = col
                 col += h
-        self.Wh = col
+        # optional position features (models.py:754-779): the time / segment-length embeddings are appended to the
+        # GRUCell input ('s' strategy, add_segment_length) -> column blocks right behind the messages, inside the
+        # frame-level input window [h, h + fw); the gate MLPs' time feature ('u' strategy, :655-662) sits behind it
+        tp = bool(c.get('add_time_position'))
+        self.time_s = tp and c.get('time_position_strategy') == 's'
+        self.time_u = tp and c.get('time_position_strategy') == 'u'
+        self.seglen = bool(c.get('add_segment_length'))
+        self.periodic = c.get('positional_encoding_style') in {'p', 'periodic'}
+
+        def tail(col, cols):
+            if self.time_s:
+                cols['time_s'] = col
+                col += h
+            if self.seglen:
+                cols['seglen'] = col
+                col += h
+            fw_end = col
+            if self.time_u:
+                cols['time_u'] = col
+                col += h
+            return fw_end, col
+
+        self.fw_end_h, self.Wh = tail(col, self.col_h)
         col = 2 * h
         self.col_o = {}
         for name, on in (('ho', self.rel_ho), ('so', self.rel_so), ('oo', self.rel_oo)):
             if on:
                 self.col_o[name] = col
                 col += h
-        self.Wo = col
+        self.fw_end_o, self.Wo = tail(col, self.col_o)
         self.Ws = 2 * h
+        self.has_bias = bool(c.get('bias', True))
+        self.n_gate_hidden = int(c.get('discrete_networks_num_layers', 1)) - 1
+        ostrat = c['object_segment_update_strategy']
+        self.ostrat = ('sah' if ostrat in {'same_as_human', 'sah'} else
+                       'coh' if ostrat in {'conditional_on_human', 'coh'} else 'ind')
         # sender-message buffers (frame level): humans send (hh | ho), objects (oh | oo), geometry (so | sh)
         self.snd_h = [r for r, on in (('hh', self.rel_hh), ('ho', self.rel_ho)) if on]
         self.snd_o = [r for r, on in (('oh', self.rel_oh), ('oo', self.rel_oo)) if on]
         self.snd_s = [r for r, on in (('so', self.rel_so), ('sh', self.rel_sh)) if on]
         self.learn_h = not human_seg_given
         self.learn_o = not object_seg_given
+        # 'same_as_human' (models.py:1523-1525): with exactly one human the objects take the human's decisions (no gate
+        # MLP, no noise of their own); with more humans the reference falls into the branch whose MLP it never built
+        self.alias_o = self.learn_o and self.ostrat == 'sah' and H == 1
+        if self.learn_o and self.ostrat == 'sah' and H != 1 and O > 0:
+            raise AttributeError("'TGGCN' object has no attribute 'update_object_segment_mlp' (object_segment_update_"
+                                 "strategy 'same_as_human' needs exactly one human, vhoi/models.py:199, :1523-1528)")
+        self.own_o = self.learn_o and not self.alias_o   # objects run their own gate MLP (and draw their own noise)
         self.filter = bool(c['filter_discrete_updates'])
         # share_level_mlps (models.py:565-570): the frame-level heads ARE the segment-level head modules
         self.share_heads = bool(c.get('share_level_mlps')) and not bool(c.get('cat_level_states'))
@@ -85,15 +118,15 @@ class Plan:
         # segment-level message blocks appended to the GRUCell input (models.py:798,807 / :843,851)
         self.seg_mh = [r for r, on in (('hh', self.rel_hh), ('oh', self.rel_oh)) if on] if self.msg_segment else []
         self.seg_mo = [r for r, on in (('ho', self.rel_ho), ('oo', self.rel_oo)) if on] if self.msg_segment else []
-        self.fw_h = self.Wh - h  # width of the frame-level part xx_hs of the human GRUCell input
-        self.fw_o = self.Wo - h
+        self.fw_h = self.fw_end_h - h  # width of the frame-level part xx_hs of the human GRUCell input
+        self.fw_o = self.fw_end_o - h
 
     # gate input column blocks, in the reference's weight order
-    def gate_cols_h(self):  # [x, h, m_hh, m_oh, m_sh]  (models.py:1494)
-        return [0, self.h] + [self.col_h[r] for r in ('hh', 'oh', 'sh') if r in self.col_h]
+    def gate_cols_h(self):  # [x, h, m_hh, m_oh, m_sh, x_time]  (models.py:1494)
+        return [0, self.h] + [self.col_h[r] for r in ('hh', 'oh', 'sh', 'time_u') if r in self.col_h]
 
-    def gate_cols_o(self):  # [x, h, m_ho, m_oo, m_so]  (models.py:1527) -- differs from the xx_os order
-        return [0, self.h] + [self.col_o[r] for r in ('ho', 'oo', 'so') if r in self.col_o]
+    def gate_cols_o(self):  # [x, h, m_ho, m_oo, m_so, x_time]  (models.py:1527) -- differs from the xx_os order
+        return [0, self.h] + [self.col_o[r] for r in ('ho', 'oo', 'so', 'time_u') if r in self.col_o]
 
 
 _FRAME_MLP = {'hh': 'humans_to_human_message_mlp', 'ho': 'human_to_object_message_mlp',
@@ -131,10 +164,15 @@ def used_parameter_names(plan: Plan):
     for cell in ('human_segment_rnn_fcell', 'human_segment_rnn_bcell', 'object_segment_rnn_fcell',
                  'object_segment_rnn_bcell'):
         names += [cell + '.weight_ih', cell + '.weight_hh', cell + '.bias_ih', cell + '.bias_hh']
-    if plan.learn_h:
-        names += ['update_human_segment_mlp.0.weight', 'update_human_segment_mlp.0.bias']
-    if plan.learn_o:
-        names += ['update_object_segment_mlp.0.weight', 'update_object_segment_mlp.0.bias']
+    for on, mlp in ((plan.learn_h, 'update_human_segment_mlp'), (plan.own_o, 'update_object_segment_mlp')):
+        if on:
+            for layer in range(plan.n_gate_hidden + 1):
+                names += [f'{mlp}.{2 * layer}.weight', f'{mlp}.{2 * layer}.bias']
+    if not plan.periodic:
+        if plan.time_s or plan.time_u:
+            names += ['time_position_mlp.0.weight', 'time_position_mlp.0.bias']
+        if plan.seglen:
+            names += ['segment_length_mlp.0.weight', 'segment_length_mlp.0.bias']
     heads = ['human_frame_recognition_mlp', 'human_frame_prediction_mlp', 'human_recognition_mlp',
              'human_prediction_mlp']
     if plan.n_aff is not None:
@@ -143,6 +181,11 @@ def used_parameter_names(plan: Plan):
     for m in heads:
         m = _head_name(plan, m)
         names += [m + '.0.weight', m + '.0.bias']
+    if not plan.has_bias:
+        # bias=False reaches every Linear / GRU / GRUCell of the model, but not the geometric-level GCN: Geo_gcn builds
+        # its convolutions with bias=True regardless (pyrutils/torch/models_gcn.py:20-21), and BatchNorm keeps its shift
+        names = [n for n in names if n.startswith('geometry_embedding_gcn.') or
+                 not (n.endswith('.bias') or '.bias_' in n)]
     # share_level_mlps aliases produce duplicate names; keep the first occurrence
     seen, out = set(), []
     for n in names:
@@ -187,6 +230,15 @@ def _stage_done(plan, stage):
         hook(stage)
 
 
+class _Params(dict):
+    """name -> parameter. A bias the model was built without (bias=False) reads as None: every kernel takes a NULL bias."""
+
+    def __missing__(self, k):
+        if k.endswith('.bias') or '.bias_' in k:
+            return None
+        raise KeyError(k)
+
+
 class _Grads:
     """Accumulates parameter gradients by name (several stages can contribute to one parameter).
 
@@ -195,13 +247,19 @@ class _Grads:
     column-sum epilogue with accumulate) -- the same ``grad += g`` autograd's AccumulateGrad would do, without the
     temporary and the extra elementwise launch per parameter -- and is then reported to autograd as None."""
 
-    def __init__(self, K, sinks=None):
-        self.K, self.g, self.sinks = K, {}, sinks or {}
+    def __init__(self, K, sinks=None, known=None):
+        self.K, self.g, self.sinks, self.known = K, {}, sinks or {}, known
 
     def sink(self, name):
         return self.sinks.get(name)
 
+    def has(self, name):
+        """False for a parameter the model does not have (a bias under bias=False)."""
+        return self.known is None or dict.__contains__(self.known, name)
+
     def add(self, name, t):
+        if not self.has(name):
+            return
         dst = self.sinks.get(name)
         if dst is None:
             dst = self.g.get(name)
@@ -230,7 +288,7 @@ def _lin_w_grads(K, G, wname, bname, dY, X, cols=None, total=None):
         dW = torch.empty(N, Kin, dtype=torch.float32, device=dY.device)
         K.gemm([dict(A=dY, B=X, C=dW)], a_kmajor=True, b_kmajor=True)
         G.add(wname, dW)
-    if bname is not None:
+    if bname is not None and G.has(bname):
         dstb = G.sink(bname)
         if dstb is not None:
             K.colsum(dY, out=dstb.view(-1), accumulate=True)
@@ -274,9 +332,11 @@ def geo_gcn_forward(K, P, x_human, bs, T, N, training, bn_bufs, S):
 def tggcn_forward(K, plan: Plan, P, x_human, x_objects, objects_mask, human_seg, object_seg, noise, training, bn_bufs):
     """Returns (outputs list, saved dict). P: dict name -> parameter tensor."""
     p = plan
+    P = _Params(P)
     bs, T, H, O, N, h = p.bs, p.T, p.H, p.O, p.N, p.h
     dev = x_human.device
-    S = {}  # saved for backward
+    steps = getattr(p, 'steps', None)   # steps_per_example (bs,): only the optional position features read it
+    S = {'steps': steps}  # saved for backward
     nF = bs * T
 
     def empty(*shape):
@@ -350,8 +410,37 @@ def tggcn_forward(K, plan: Plan, P, x_human, x_objects, objects_mask, human_seg,
     K.attn_fwd([fdesc])
     S.update(HUM=HUM, OBJ=OBJ, GEO=GEO, MSGH=MSGH, MSGO=MSGO, MSGS=MSGS, att=att)
 
+    # ------------------------------------------------------------------ time feature (models.py:655-662, :754-761)
+    pos = {}   # saved scalars of the position features: name -> (kind -> [bs*T*E])
+
+    def pos_fill(name, mlp, s_by_kind=None):
+        """Fills the column block `name` of the human and object rows with the embedding of the time feature
+        (s_by_kind None) or of the given scalars; returns the scalars per kind."""
+        out = {}
+        for kind, Ev, E, cols in (('h', HUMv, H, p.col_h), ('o', OBJv, O, p.col_o)):
+            if E == 0:
+                continue
+            c = cols[name]
+            w = None if p.periodic else P[mlp + '.0.weight'].view(-1)
+            b = None if p.periodic else P[mlp + '.0.bias']
+            if s_by_kind is None:
+                if steps is None:
+                    raise ValueError('add_time_position / add_segment_length need steps_per_example')
+                out[kind] = K.pos_embed_fwd(Ev[:, c:c + h], bs, T, E, h, w=w, b=b, periodic=p.periodic, steps=steps,
+                                            divide=not p.periodic)
+            else:
+                out[kind] = K.pos_embed_fwd(Ev[:, c:c + h], bs, T, E, h, w=w, b=b, periodic=p.periodic,
+                                            s=s_by_kind[kind].view(-1))
+        return out
+
+    if p.time_u:
+        pos['time_u'] = pos_fill('time_u', 'time_position_mlp')
+    if p.time_s:
+        pos['time_s'] = pos_fill('time_s', 'time_position_mlp')
+
     # ------------------------------------------------------------------ gates (models.py:697-702, :738-745, :751-753)
-    n_gated = (H if p.learn_h else 0) + (O if p.learn_o else 0)
+    n_gated = (H if p.learn_h else 0) + (O if p.own_o else 0)
+    n_hid = p.n_gate_hidden
     gates = {}
     for kind, learn, seg, Ev, E, cols, mlp, off in (
             ('h', p.learn_h, human_seg, HUMv, H, p.gate_cols_h(), 'update_human_segment_mlp', 0),
@@ -365,14 +454,60 @@ def tggcn_forward(K, plan: Plan, P, x_human, x_objects, objects_mask, human_seg,
                 hard, _ = K.filter_fwd(seg, p.thr)
             gates[kind] = dict(hard=hard, soft=seg, learned=False)
             continue
-        d = dict(x=Ev, seg_col=cols, hidden=h, w=P[mlp + '.0.weight'], b=P.get(mlp + '.0.bias'),
+        if kind == 'o' and p.alias_o:
+            # 'same_as_human' with one human (models.py:1523-1525): every object takes the human's decisions; the
+            # forced end at the last (padded) step is applied to the objects' copies as well (:744-745)
+            gh = gates['h']
+            hard = gh['hard'].expand(bs, T, O).contiguous()
+            soft = gh['soft'].expand(bs, T, O).contiguous()
+            if T > 0 and O > 0:
+                hard[:, T - 1].fill_(1.0)
+            gmask = None
+            if p.filter:
+                hard, gmask = K.filter_fwd(soft, p.thr)
+            gates[kind] = dict(hard=hard, soft=soft, learned=gh['learned'], alias=True, gmask=gmask)
+            continue
+        # discrete_networks_num_layers > 1 (models.py:532-548): hidden Linear + ReLU layers in front of the 1-unit
+        # sigmoid layer. The first layer reads the gate-input blocks in place (one accumulating GEMM per block).
+        x_in, seg_cols, acts = Ev, cols, []
+        if n_hid:
+            a = empty(nF * E, h)
+            w0 = P[mlp + '.0.weight']
+            for bi, c in enumerate(cols):
+                K.gemm([dict(A=Ev[:, c:c + h], B=w0[:, bi * h:(bi + 1) * h], C=a,
+                             bias=P[mlp + '.0.bias'] if bi == 0 else None, accumulate=bi > 0,
+                             act=1 if bi == len(cols) - 1 else 0)])
+            acts.append(a)
+            for layer in range(1, n_hid):
+                a2 = empty(nF * E, h)
+                K.gemm([dict(A=a, B=P[f'{mlp}.{2 * layer}.weight'], C=a2, bias=P[f'{mlp}.{2 * layer}.bias'], act=1)])
+                acts.append(a2)
+                a = a2
+            x_in, seg_cols = a, [0]
+        last = f'{mlp}.{2 * n_hid}'
+        d = dict(x=x_in, seg_col=seg_cols, hidden=h, w=P[last + '.weight'], b=P[last + '.bias'],
                  noise=noise if p.gs else None, bs=bs, T=T, E=E, noise_entities=n_gated, noise_offset=off,
                  force_last=1, threshold=p.thr)
         hard, soft = K.gate_fwd(d)
+        hard_ind, coh = hard, None
+        if kind == 'o' and p.ostrat == 'coh' and H == 1 and not p.filter:
+            # 'conditional_on_human' (models.py:1531-1532): object ends only where the (single) human ends; the last
+            # step is forced afterwards (:744-745)
+            coh = gates['h']['hard'].expand(bs, T, O).contiguous()
+            hard = K.mul(hard_ind, coh)
+            if T > 0 and O > 0:
+                hard[:, T - 1].fill_(1.0)
         gmask = None
         if p.filter:
             hard, gmask = K.filter_fwd(soft, p.thr)
-        gates[kind] = dict(hard=hard, soft=soft, learned=True, desc=d, gmask=gmask)
+        gates[kind] = dict(hard=hard, soft=soft, learned=True, desc=d, gmask=gmask, acts=acts, hard_ind=hard_ind, coh=coh)
+    if p.seglen:
+        # segment-length feature (models.py:762-779): scan of the hard decisions, then the same embedding as the time
+        if steps is None:
+            raise ValueError('add_segment_length needs steps_per_example')
+        sl = {k: K.seglen_fwd(gates[k]['hard'], steps, not p.periodic) for k, E in (('h', H), ('o', O)) if E > 0}
+        pos['seglen'] = pos_fill('seglen', 'segment_length_mlp', sl)
+    S['pos'] = pos
     S['gates'] = gates
     u_h, u_o = gates['h']['hard'], gates['o']['hard']
 
@@ -403,9 +538,10 @@ def tggcn_forward(K, plan: Plan, P, x_human, x_objects, objects_mask, human_seg,
         sh_rel = [r for r in ('hh', 'ho') if getattr(p, 'rel_' + r)]
         so_rel = [r for r in ('oh', 'oo') if getattr(p, 'rel_' + r)]
         seg_p['w_smsg_h'] = torch.cat([P[_SEG_MLP[r] + '.0.weight'] for r in sh_rel], 0) if sh_rel else None
-        seg_p['b_smsg_h'] = torch.cat([P[_SEG_MLP[r] + '.0.bias'] for r in sh_rel], 0) if sh_rel else None
         seg_p['w_smsg_o'] = torch.cat([P[_SEG_MLP[r] + '.0.weight'] for r in so_rel], 0) if so_rel else None
-        seg_p['b_smsg_o'] = torch.cat([P[_SEG_MLP[r] + '.0.bias'] for r in so_rel], 0) if so_rel else None
+        bias_on = p.has_bias
+        seg_p['b_smsg_h'] = torch.cat([P[_SEG_MLP[r] + '.0.bias'] for r in sh_rel], 0) if (sh_rel and bias_on) else None
+        seg_p['b_smsg_o'] = torch.cat([P[_SEG_MLP[r] + '.0.bias'] for r in so_rel], 0) if (so_rel and bias_on) else None
         S['seg_rels'] = (sh_rel, so_rel)
     seg_bufs = K.segrnn_fwd(seg_p)
     S.update(seg_p=seg_p, seg_bufs=seg_bufs)
@@ -449,10 +585,11 @@ def tggcn_backward(K, plan: Plan, P, S, x_human, x_objects, objects_mask, d_outp
     Returns dict name -> gradient for every parameter used by the forward that has no entry in `sinks`
     (see _Grads: gradients with a sink have been added into it)."""
     p = plan
+    P = _Params(P)
     bs, T, H, O, N, h = p.bs, p.T, p.H, p.O, p.N, p.h
     dev = x_human.device
     nF = bs * T
-    G = _Grads(K, sinks)
+    G = _Grads(K, sinks, known=P)
 
     def empty(*shape):
         return torch.empty(*shape, dtype=torch.float32, device=dev)
@@ -487,7 +624,7 @@ def tggcn_backward(K, plan: Plan, P, S, x_human, x_objects, objects_mask, d_outp
             name = _head_name(p, name)
             dlog = K.logsoftmax_permute_bwd(y, dy.contiguous())
             W = P[name + '.0.weight']
-            bname = name + '.0.bias' if (name + '.0.bias') in P else None
+            bname = name + '.0.bias'
             if dX is None:
                 dX = empty(*Xin.shape)
             if Xcat is None:
@@ -586,28 +723,119 @@ def tggcn_backward(K, plan: Plan, P, S, x_human, x_objects, objects_mask, d_outp
                 G.add(_SEG_MLP[r] + '.0.weight', dWp[i * h:(i + 1) * h])
                 G.add(_SEG_MLP[r] + '.0.bias', dbp[i * h:(i + 1) * h])
 
-    # ---- gates backward (straight-through: d hard / d soft = 1, cut at the forced last step; models.py:701-702)
-    for kind, Ev, dEv, E, cols, mlp, du in (('h', HUMv, dHUMv, H, p.gate_cols_h(), 'update_human_segment_mlp', so['d_u_h']),
-                                             ('o', OBJv, dOBJv, O, p.gate_cols_o(), 'update_object_segment_mlp', so['d_u_o'])):
+    # ---- position features appended to the GRUCell inputs: parameter gradients, and -- segment lengths -- the gradient
+    # that reaches the hard decisions through the length scan (straight-through values carry it on to the soft ones)
+    pos = S.get('pos', {})
+    steps = S.get('steps')
+    du_of = {'h': so['d_u_h'], 'o': so['d_u_o']}
+
+    def pos_backward(name, mlp, to_scalars=False):
+        for kind, Ev, dEv, E, cols in (('h', HUMv, dHUMv, H, p.col_h), ('o', OBJv, dOBJv, O, p.col_o)):
+            if E == 0:
+                continue
+            c = cols[name]
+            sc = pos[name][kind]
+            dblk = dEv[:, c:c + h]
+            ds = None
+            if p.periodic:
+                if to_scalars:
+                    ds = K.periodic_embed_bwd(dblk, sc)
+            else:
+                dpre = K.relu_bwd(dblk, Ev[:, c:c + h])
+                G.add(mlp + '.0.weight', K.colsum(dpre, rowscale=sc).view(h, 1))
+                G.add(mlp + '.0.bias', K.colsum(dpre))
+                if to_scalars:
+                    ds = empty(nF * E, 1)
+                    K.gemm([dict(A=dpre, B=P[mlp + '.0.weight'].view(1, h), C=ds)])
+            if to_scalars and gates[kind]['learned']:
+                K.seglen_bwd(gates[kind]['hard'], steps, not p.periodic, ds.view(bs, T, E), du_of[kind])
+
+    if p.seglen:
+        pos_backward('seglen', 'segment_length_mlp', to_scalars=True)
+    if p.time_s:
+        pos_backward('time_s', 'time_position_mlp')
+
+    def row_sums(x):   # (bs, T, E) -> (bs, T, 1): sum over the entities, as a (rows x E) . ones GEMM
+        out = empty(bs * T, 1)
+        K.gemm([dict(A=x.view(bs * T, x.shape[-1]), B=torch.ones(1, x.shape[-1], dtype=torch.float32, device=dev), C=out)])
+        return out.view(bs, T, 1)
+
+    # ---- gates backward (straight-through: d hard / d soft = 1, cut at the forced last step; models.py:701-702).
+    # Objects first: with one human, 'same_as_human' / 'conditional_on_human' send gradient on to the human's decisions.
+    extra_soft_h = None
+    for kind, Ev, dEv, E, cols, mlp in (('o', OBJv, dOBJv, O, p.gate_cols_o(), 'update_object_segment_mlp'),
+                                        ('h', HUMv, dHUMv, H, p.gate_cols_h(), 'update_human_segment_mlp')):
         gt = gates[kind]
+        du = du_of[kind]
         if not gt['learned'] or E == 0:
             continue
         dh_ext = d_hard[kind]
         if dh_ext is not None:
             K.add_rows(_v2(dh_ext.contiguous().view(1, -1)), _v2(du.view(1, -1)))
+        dsoft = d_soft[kind].contiguous() if d_soft[kind] is not None else None
+        if kind == 'o' and gt.get('alias'):
+            # the objects' decisions ARE the human's: everything that reached them goes to the human's gate
+            if p.filter:
+                tot = K.mul(du, gt['gmask'])
+                if dsoft is not None:
+                    K.add_rows(_v2(dsoft.view(1, -1)), _v2(tot.view(1, -1)))
+                extra_soft_h = row_sums(tot)
+            else:
+                if T > 0:
+                    du[:, T - 1].zero_()                    # forced last step: no gradient (models.py:744-745)
+                K.add_rows(_v2(row_sums(du).view(1, -1)), _v2(du_of['h'].view(1, -1)))
+                if dsoft is not None:
+                    extra_soft_h = row_sums(dsoft)
+            continue
+        if kind == 'o' and gt.get('coh') is not None:
+            # hard = hard_ind * hard_h (then the last step forced): product rule on the straight-through values
+            if gates['h']['learned']:
+                t_ = K.mul(du, gt['hard_ind'])
+                if T > 0:
+                    t_[:, T - 1].zero_()
+                K.add_rows(_v2(row_sums(t_).view(1, -1)), _v2(du_of['h'].view(1, -1)))
+            du = K.mul(du, gt['coh'])
+        if kind == 'h' and extra_soft_h is not None:
+            if dsoft is None:
+                dsoft = extra_soft_h.contiguous()
+            else:
+                dsoft = dsoft.clone()
+                K.add_rows(_v2(extra_soft_h.view(1, -1)), _v2(dsoft.view(1, -1)))
         d = gt['desc']
         if p.filter:
             d = dict(d)
             d['force_last'] = 0  # the filter rebuilds the hard gates from the soft ones (Appendix A13)
-        dlogit = K.gate_bwd(d, du, d_soft[kind].contiguous() if d_soft[kind] is not None else None, gt['gmask'])
-        w = P[mlp + '.0.weight'].view(-1)
-        dw = empty(w.numel())
-        for i, c in enumerate(cols):
-            K.rank1_update(dEv[:, c:c + h], dlogit, w[i * h:(i + 1) * h])
-            K.colsum(Ev[:, c:c + h], rowscale=dlogit, out=dw[i * h:(i + 1) * h])
-        G.add(mlp + '.0.weight', dw.view(1, -1))
-        if (mlp + '.0.bias') in P:
-            G.add(mlp + '.0.bias', K.colsum(dlogit.view(-1, 1)))
+        dlogit = K.gate_bwd(d, du, dsoft, gt['gmask'])
+        n_hid = p.n_gate_hidden
+        last = f'{mlp}.{2 * n_hid}'
+        w = P[last + '.weight'].view(-1)
+        if not n_hid:
+            dw = empty(w.numel())
+            for i, c in enumerate(cols):
+                K.rank1_update(dEv[:, c:c + h], dlogit, w[i * h:(i + 1) * h])
+                K.colsum(Ev[:, c:c + h], rowscale=dlogit, out=dw[i * h:(i + 1) * h])
+            G.add(last + '.weight', dw.view(1, -1))
+            G.add(last + '.bias', K.colsum(dlogit.view(-1, 1)))
+            continue
+        acts = gt['acts']
+        G.add(last + '.weight', K.colsum(acts[-1], rowscale=dlogit).view(1, -1))
+        G.add(last + '.bias', K.colsum(dlogit.view(-1, 1)))
+        dA = zeros(nF * E, h)
+        K.rank1_update(dA, dlogit, w)
+        dpre = K.relu_bwd(dA, acts[-1], dA)
+        for layer in range(n_hid - 1, 0, -1):
+            name = f'{mlp}.{2 * layer}'
+            _lin_w_grads(K, G, name + '.weight', name + '.bias', dpre, acts[layer - 1])
+            dprev = empty(nF * E, h)
+            K.gemm([dict(A=dpre, B=P[name + '.weight'], C=dprev)], b_kmajor=True)
+            dpre = K.relu_bwd(dprev, acts[layer - 1], dprev)
+        w0 = P[mlp + '.0.weight']
+        for bi, c in enumerate(cols):
+            _lin_w_grads(K, G, mlp + '.0.weight', (mlp + '.0.bias') if bi == 0 else None, dpre, Ev[:, c:c + h],
+                         cols=(bi * h, (bi + 1) * h), total=w0.shape[1])
+            K.gemm([dict(A=dpre, B=w0[:, bi * h:(bi + 1) * h], C=dEv[:, c:c + h], accumulate=True)], b_kmajor=True)
+    if p.time_u:
+        pos_backward('time_u', 'time_position_mlp')
 
     _stage_done(p, 0)
 

@@ -273,6 +273,28 @@ int twog_segrnn_bwd(const twog_segrnn_t* desc, const twog_segrnn_bwd_t* bdesc, v
 int twog_graph_cache_stats(int64_t* entries, int64_t* collisions);
 
 /* ===============================================================================================================
+ * Optional position features and the less common gate strategies (disabled in every shipped configuration).
+ * twog_pos_embed_fwd: out[(b,t,e)][hidden] = relu(w * s + b) (positional_encoding_style 'e': time_position_mlp /
+ *   segment_length_mlp = build_mlp([1, h], ['relu']), vhoi/models.py:259-264) or the periodic embedding
+ *   [sin(s / w_k) | cos(s / w_k)], w_k = 1e4^(k / (h/2 - 1)) (make_periodic_embedding, :1778-1794). The scalar s of row
+ *   (b,t,e) is s[row] when `s` is given, else the time feature (t + 1) (/ steps[b] when `divide`;
+ *   _assemble_time_tensor, :935-952). s_out (optional) receives the scalars [bs*T*E] for the backward pass.
+ * twog_periodic_embed_bwd: ds[row] of the periodic embedding (the 'e' style uses a GEMM and twog_colsum).
+ * twog_seglen_fwd / _bwd: _assemble_segment_length_tensor (:954-981): per (clip, entity) scan over time of the hard
+ *   gates u [bs][T][E]; the backward ADDS into du.
+ * twog_mul: out[i] = a[i] * b[i] (+ out[i] if accumulate): 'conditional_on_human' object gates (:1531-1532).
+ * twog_scale_rows: x[r][:] *= s[r] (receiver mask of a relational message, :720/:729).
+ * =============================================================================================================== */
+int twog_pos_embed_fwd(const float* s, const float* steps, int bs, int T, int E, int divide, const float* w,
+                       const float* b, int periodic, int hidden, twog_rows_t out, float* s_out, void* stream);
+int twog_periodic_embed_bwd(twog_rows_t dout, const float* s, int rows, int hidden, float* ds, void* stream);
+int twog_seglen_fwd(const float* u, const float* steps, int bs, int T, int E, int divide, float* s_out, void* stream);
+int twog_seglen_bwd(const float* u, const float* steps, int bs, int T, int E, int divide, const float* ds, float* du,
+                    void* stream);
+int twog_mul(const float* a, const float* b, float* out, int64_t n, int accumulate, void* stream);
+int twog_scale_rows(twog_rows_t x, const float* s, int rows, int cols, void* stream);
+
+/* ===============================================================================================================
  * Segment-boundary gates (vhoi/models.py:1477-1533, :1620-1627; pyrutils/torch/distributions.py:4-53) with
  * discrete_networks_num_layers == 1: p = sigmoid(w . [column blocks of the entity row] + b); 'gs': Gumbel-sigmoid
  * with PRE-DRAWN noise, 'st' (noise == NULL): straight-through; hard = soft > thr; last step forced to 1 (:701-702).

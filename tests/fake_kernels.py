@@ -177,11 +177,11 @@ class FakeKernels:
             E = gi.shape[2]
             out = torch.zeros(bs, T, E, 2 * h, device=gi.device)
             save = torch.zeros(2, bs, T, E, 4 * h, device=gi.device)
-            for d, (w, b) in enumerate(((y['w_hh_f'], y['b_hh_f']), (y['w_hh_r'], y['b_hh_r']))):
+            for d, (w, b) in enumerate(((y['w_hh_f'], y.get('b_hh_f')), (y['w_hh_r'], y.get('b_hh_r')))):
                 hp = torch.zeros(bs, E, h, device=gi.device)
                 order = range(T) if d == 0 else range(T - 1, -1, -1)
                 for t in order:
-                    gh = hp @ w.t() + b
+                    gh = hp @ w.t() + (b if b is not None else 0.0)
                     r, z, n, hn, g = self._gates(gi[:, t, :, d * 3 * h:(d + 1) * 3 * h], gh, hp, h)
                     out[:, t, :, d * h:(d + 1) * h] = g
                     save[d, :, t] = torch.cat([r, z, n, hn], -1)
@@ -362,9 +362,9 @@ class FakeKernels:
             for t in order:
                 if msg:
                     if nsh:
-                        bufs['msrc_h'][d, :, t] = torch.relu(prev_h @ p['w_smsg_h'].t() + p['b_smsg_h'])
+                        bufs['msrc_h'][d, :, t] = torch.relu(prev_h @ p['w_smsg_h'].t() + (p['b_smsg_h'] if p.get('b_smsg_h') is not None else 0.0))
                     if nso:
-                        bufs['msrc_o'][d, :, t] = torch.relu(prev_o @ p['w_smsg_o'].t() + p['b_smsg_o'])
+                        bufs['msrc_o'][d, :, t] = torch.relu(prev_o @ p['w_smsg_o'].t() + (p['b_smsg_o'] if p.get('b_smsg_o') is not None else 0.0))
                     self.attn_fwd([self._seg_attn_desc(p, bufs, d, t, prev_h, prev_o)])
                 new = []
                 for kind, E, prev in (('h', H, prev_h), ('o', O, prev_o)):
@@ -372,7 +372,8 @@ class FakeKernels:
                     nm = nmh if kind == 'h' else nmo
                     if msg and nm:
                         gi = gi + bufs['mg_' + kind][d, :, t] @ p['w_ihm_' + kind][d].t()
-                    gh = prev @ p['w_hh_' + kind][d].t() + p['b_hh_' + kind][d]
+                    bhh = p['b_hh_' + kind][d]
+                    gh = prev @ p['w_hh_' + kind][d].t() + (bhh if bhh is not None else 0.0)
                     r, zz, n, hn, g = self._gates(gi, gh, prev, h)
                     u = p['u_' + kind][:, t].unsqueeze(-1)
                     hnew = u * g + (1 - u) * prev
@@ -534,6 +535,68 @@ class FakeKernels:
 
     def add_rows(self, src, dst):
         dst.add_(src.reshape(dst.shape))
+
+    # ------------------------------------------------------------------ position features / rare gate strategies
+    def pos_embed_fwd(self, out, bs, T, E, hidden, w=None, b=None, periodic=False, s=None, steps=None, divide=False):
+        if s is None:
+            t = torch.arange(1, T + 1, dtype=torch.float32).view(1, T, 1).expand(bs, T, E)
+            if divide:
+                t = t / steps.view(bs, 1, 1)
+            s = t.reshape(-1)
+        s = s.reshape(-1).clone()
+        x = s.view(-1, 1)
+        if periodic:
+            wk = torch.tensor([1e4]) ** torch.linspace(0, 1, hidden // 2)
+            v = torch.cat([torch.sin(x / wk), torch.cos(x / wk)], dim=-1)
+        else:
+            v = torch.relu(x * w.view(1, -1) + (b.view(1, -1) if b is not None else 0.0))
+        out.copy_(v.reshape(out.shape))
+        return s
+
+    def periodic_embed_bwd(self, dout, s):
+        hidden = dout.shape[-1]
+        half = hidden // 2
+        wk = torch.tensor([1e4]) ** torch.linspace(0, 1, half)
+        x = s.view(-1, 1)
+        d = _mat(dout)
+        return ((d[:, :half] * torch.cos(x / wk) - d[:, half:] * torch.sin(x / wk)) / wk).sum(-1)
+
+    def seglen_fwd(self, u, steps, divide):
+        bs, T, E = u.shape
+        out = torch.zeros_like(u)
+        acc = torch.zeros(bs, E)
+        for t in range(T):
+            xt = torch.full((bs, 1), float(t + 1))
+            if divide:
+                xt = xt / steps.view(bs, 1)
+            rel = u[:, t] * xt
+            rel = torch.where(rel != 0, rel - acc, rel)
+            acc = acc + rel
+            out[:, t] = rel
+        return out
+
+    def seglen_bwd(self, u, steps, divide, ds, du):
+        bs, T, E = u.shape
+        da = torch.zeros(bs, E)
+        for t in range(T - 1, -1, -1):
+            xt = torch.full((bs, 1), float(t + 1))
+            if divide:
+                xt = xt / steps.view(bs, 1)
+            dr = ds[:, t] + da
+            du[:, t] += dr * xt
+            da = torch.where(u[:, t] * xt != 0, da - dr, da)
+
+    def mul(self, a, b, out=None, accumulate=False):
+        if out is None:
+            return a * b
+        if accumulate:
+            out += a * b
+        else:
+            out.copy_(a * b)
+        return out
+
+    def scale_rows(self, x, s):
+        x.mul_(s.view(*([-1] + [1] * (x.dim() - 1))) if x.dim() == 2 else s.view(x.shape[0], x.shape[1], 1))
 
     def adam_step(self, param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
         grad = grad * grad_scale

@@ -15,6 +15,9 @@ G4_CASES = ['c2_stage1', 'c2_stage2', 'c1_stage1', 'c1_stage2', 'c5_stage1', 'c2
 G4_CASES_R2 = ['c1_sah', 'c1_coh', 'c2_gate3', 'c2_nobias', 'c2_time_s', 'c2_time_u_periodic', 'c2_seglen',
                'c2_seglen_periodic', 'c2_concat', 'c2_general', 'c2_specific', 'c2_relational', 'c2_distance',
                'c2_ctor_defaults', 'c1_relational_geo2h']
+# ... of which the product path (HIP kernels / their test double) runs these so far
+G4_CASES_R2_BUILT = ['c1_sah', 'c1_coh', 'c2_gate3', 'c2_nobias', 'c2_time_s', 'c2_time_u_periodic', 'c2_seglen',
+                     'c2_seglen_periodic']
 
 
 def load_g4(name):

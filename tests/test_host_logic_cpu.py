@@ -10,7 +10,7 @@ from twog_gcn_amd import kernels as twog_kernels
 from twog_gcn_amd import ops
 from twog_gcn_amd.models import TGGCN, select_model
 from tests.fake_kernels import FakeKernels
-from tests.helpers import G4_CASES, load_g4, det_state_dict, g4_inputs, sample_grad
+from tests.helpers import G4_CASES, G4_CASES_R2_BUILT, load_g4, det_state_dict, g4_inputs, sample_grad
 from oracle import detgen
 
 
@@ -29,7 +29,7 @@ def build_model(meta):
     return m
 
 
-@pytest.mark.parametrize('name', G4_CASES)
+@pytest.mark.parametrize('name', G4_CASES + G4_CASES_R2_BUILT)
 def test_full_forward_backward_vs_reference(name, fake_backend):
     z, meta = load_g4(name)
     m = build_model(meta)

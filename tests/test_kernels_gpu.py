@@ -611,3 +611,62 @@ def test_graph_cache_survives_hash_collisions():
     r = subprocess.run([sys.executable, '-c', code], cwd=root, env=dict(os.environ, TWOG_GRAPH_HASH_BITS='0'),
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and 'collisions resolved' in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+# ------------------------------------------------------------------------ position features / rare gate strategies
+@pytest.mark.parametrize('periodic', [False, True])
+def test_position_feature_kernels(K, periodic):
+    bs, T, E, h, W = 3, 7, 4, 32, 96
+    steps = torch.tensor([7.0, 5.0, 6.0])
+    w, b = rnd(h, seed=1), rnd(h, seed=2)
+    # time feature into a column block of wider rows
+    rows_c, rows_g = torch.zeros(bs * T * E, W), torch.zeros(bs * T * E, W, device=DEV)
+    s_c = F.pos_embed_fwd(rows_c[:, 32:64], bs, T, E, h, w=w, b=b, periodic=periodic, steps=steps, divide=not periodic)
+    s_g = K.pos_embed_fwd(rows_g[:, 32:64], bs, T, E, h, w=w.to(DEV), b=b.to(DEV), periodic=periodic,
+                          steps=steps.to(DEV), divide=not periodic)
+    close(s_g, s_c, what='time scalars')
+    close(rows_g, rows_c, rtol=2e-5, atol=2e-5, what='time embedding (other columns untouched)')
+    # segment lengths from hard decisions, their embedding, and the backward pass through the scan
+    u = (rnd(bs, T, E, seed=3) > 0).float()
+    u[:, -1] = 1.0
+    sl_c, sl_g = F.seglen_fwd(u, steps, not periodic), K.seglen_fwd(u.to(DEV), steps.to(DEV), not periodic)
+    close(sl_g, sl_c, what='segment lengths')
+    F.pos_embed_fwd(rows_c[:, 64:96], bs, T, E, h, w=w, b=b, periodic=periodic, s=sl_c.view(-1))
+    K.pos_embed_fwd(rows_g[:, 64:96], bs, T, E, h, w=w.to(DEV), b=b.to(DEV), periodic=periodic, s=sl_g.view(-1))
+    close(rows_g, rows_c, rtol=2e-5, atol=2e-5, what='segment-length embedding')
+    ds = rnd(bs, T, E, seed=4)
+    du_c, du_g = rnd(bs, T, E, seed=5), rnd(bs, T, E, seed=5).to(DEV)
+    F.seglen_bwd(u, steps, not periodic, ds, du_c)
+    K.seglen_bwd(u.to(DEV), steps.to(DEV), not periodic, ds.to(DEV), du_g)
+    close(du_g, du_c, rtol=2e-5, atol=2e-5, what='d hard gates through the length scan')
+    if periodic:
+        dout = rnd(bs * T * E, W, seed=6)
+        close(K.periodic_embed_bwd(dout.to(DEV)[:, 64:96], sl_g.view(-1)), F.periodic_embed_bwd(dout[:, 64:96], sl_c.view(-1)),
+              rtol=2e-5, atol=2e-5, what='d scalar of the periodic embedding')
+    # autograd check of the scan's backward rule on the CPU specification itself
+    uu = u.clone().requires_grad_(True)
+    acc, rels = torch.zeros(bs, E), []
+    for t in range(T):
+        xt = torch.full((bs, 1), float(t + 1)) / (steps.view(bs, 1) if not periodic else 1.0)
+        rel = uu[:, t] * xt
+        rel = torch.where(rel.bool(), rel - acc, rel)
+        acc = acc + rel
+        rels.append(rel)
+    (torch.stack(rels, 1) * ds).sum().backward()
+    close(du_c - rnd(bs, T, E, seed=5), uu.grad, rtol=1e-5, atol=1e-5, what='scan backward rule vs autograd')
+
+
+def test_mul_and_scale_rows(K):
+    a, b = rnd(5, 9, 3), rnd(5, 9, 3, seed=1)
+    close(K.mul(a.to(DEV), b.to(DEV)), a * b, what='mul')
+    o = rnd(5, 9, 3, seed=2)
+    og = o.clone().to(DEV)
+    K.mul(a.to(DEV), b.to(DEV), out=og, accumulate=True)
+    close(og, o + a * b, what='mul accumulate')
+    x = rnd(6, 40)
+    s = rnd(6, seed=3)
+    xg = x.clone().to(DEV)
+    K.scale_rows(xg[:, 8:24], s.to(DEV))
+    xc = x.clone()
+    xc[:, 8:24] *= s.view(-1, 1)
+    close(xg, xc, what='scale_rows on a column block')

@@ -13,7 +13,7 @@ import twog_gcn_amd  # noqa: F401
 from twog_gcn_amd import kernels as twog_kernels
 from twog_gcn_amd.models import TGGCN
 from oracle import cpu_ref, detgen
-from tests.helpers import G4_CASES, load_g4, det_state_dict, g4_inputs, sample_grad
+from tests.helpers import G4_CASES, G4_CASES_R2_BUILT, load_g4, det_state_dict, g4_inputs, sample_grad
 
 pytestmark = pytest.mark.gpu
 DEV = 'cuda:0'
@@ -40,7 +40,7 @@ def _model_from_meta(meta):
     return m.to(DEV)
 
 
-@pytest.mark.parametrize('name', G4_CASES)
+@pytest.mark.parametrize('name', G4_CASES + G4_CASES_R2_BUILT)
 def test_golden_reference_vectors(name):
     z, meta = load_g4(name)
     m = _model_from_meta(meta)
