@@ -104,6 +104,25 @@ class Loss(C.Structure):  # twog_loss_t
                 ('ignore_value', C.c_float)]
 
 
+class Relation(C.Structure):  # twog_relation_t
+    _fields_ = [('q', Rows), ('k', Rows), ('msg', Rows), ('p_r', Rows), ('p_s', Rows), ('out', Rows),
+                ('a_r', C.c_void_p), ('c_s', C.c_void_p), ('dist', C.c_void_p), ('dist_ld_inst', C.c_int64),
+                ('dist_ld_r', C.c_int64), ('dist_ld_s', C.c_int64), ('send_mask', C.c_void_p),
+                ('recv_mask', C.c_void_p), ('att', C.c_void_p), ('scale', C.c_float), ('score_bias', C.c_float),
+                ('score_mode', C.c_int32), ('msg_mode', C.c_int32), ('relu_scores', C.c_int32),
+                ('exclude_self', C.c_int32), ('n_inst', C.c_int32), ('inst_per_clip', C.c_int32), ('R', C.c_int32),
+                ('S', C.c_int32), ('D', C.c_int32), ('hidden', C.c_int32)]
+
+
+class RelationBwd(C.Structure):  # twog_relation_bwd_t
+    _fields_ = [('f', Relation), ('dout', Rows), ('dmsg', Rows), ('dp_r', Rows), ('dp_s', Rows), ('dq', Rows),
+                ('dk', Rows), ('da_r', C.c_void_p), ('dc_s', C.c_void_p), ('dq_accumulate', C.c_int32),
+                ('dk_accumulate', C.c_int32), ('relu_mask_dmsg', C.c_int32), ('pad_', C.c_int32)]
+
+
+REL_SUM, REL_DOT, REL_ADDITIVE, REL_DISTANCE, REL_MEAN = 0, 1, 2, 3, 4   # TWOG_REL_*
+REL_MSG_SENDER, REL_MSG_PAIR = 0, 1
+
 LOSS_MAX_TERMS, LOSS_BLOCKS = 16, 64  # TWOG_LOSS_MAX_TERMS, TWOG_LOSS_BLOCKS
 
 # name -> (argtypes) ; every function returns int except twog_version
@@ -137,6 +156,9 @@ SIGNATURES = {
     'twog_seglen_bwd': [_P, _P, _I, _I, _I, _I, _P, _P, _P],
     'twog_mul': [_P, _P, _P, _L, _I, _P],
     'twog_scale_rows': [Rows, _P, _I, _I, _P],
+    'twog_relation_limits': [],
+    'twog_relation_fwd': [C.POINTER(Relation), _P],
+    'twog_relation_bwd': [C.POINTER(RelationBwd), _P],
     'twog_gate_fwd': [C.POINTER(Gate), _P],
     'twog_gate_bwd': [C.POINTER(Gate), _P, _P, _P, _P, _P],
     'twog_rank1_update': [Rows, _P, _P, _I, _I, _P],

@@ -17,6 +17,7 @@
 #include <mutex>
 #include <string>
 #include <unordered_map>
+#include <unordered_set>
 
 namespace twog_graph {
 
@@ -43,7 +44,7 @@ constexpr int MAX_DEVICES = 16;
 struct State {
     std::mutex mu;
     std::unordered_map<uint64_t, Entry> cache;
-    std::unordered_map<uint64_t, std::string> seen;  // a descriptor is captured the second time it shows up
+    std::unordered_set<std::string> seen;            // a descriptor is captured the second time it shows up
     uint64_t collisions = 0;                         // bucket hits whose descriptor bytes differed
     hipStream_t side[MAX_DEVICES] = {};
     hipEvent_t ev_in[MAX_DEVICES] = {}, ev_out[MAX_DEVICES] = {};
@@ -94,10 +95,9 @@ int run(const Desc& d, hipStream_t user, F enqueue) {
         it = cache.find(key);
     }
     if (it == cache.end()) {
-        auto sn = seen.find(key);
-        if (sn == seen.end() || sn->second != d.bytes) {
+        if (seen.find(d.bytes) == seen.end()) {   // keyed by the bytes themselves: immune to bucket collisions
             if (seen.size() > 256) seen.clear();
-            seen[key] = d.bytes;
+            seen.insert(d.bytes);
             return enqueue(user);  // first sighting (also covers lazy one-time setup inside the launch paths)
         }
         hipGraph_t graph = nullptr;

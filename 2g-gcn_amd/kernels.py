@@ -469,6 +469,44 @@ class HipKernels:
         self._check(self.lib.twog_add_rows(rows_of(src), rows_of(dst), n_rows(src), src.shape[-1], self._stream()),
                     'twog_add_rows')
 
+    # ---------------------------------------------------------------- general single-relation message passing
+    REL_SUM, REL_DOT, REL_ADDITIVE, REL_DISTANCE, REL_MEAN = (L.REL_SUM, L.REL_DOT, L.REL_ADDITIVE, L.REL_DISTANCE,
+                                                              L.REL_MEAN)
+    REL_MSG_SENDER, REL_MSG_PAIR = L.REL_MSG_SENDER, L.REL_MSG_PAIR
+
+    def _fill_relation(self, a, d):
+        for k in ('q', 'k', 'msg', 'p_r', 'p_s', 'out'):
+            setattr(a, k, rows_of(d.get(k)))
+        a.a_r, a.c_s = _ptr(d.get('a_r')), _ptr(d.get('c_s'))
+        dist = d.get('dist')   # (n_inst, R, S) view, any strides
+        if dist is not None:
+            assert dist.dim() == 3 and dist.dtype == torch.float32
+            a.dist, (a.dist_ld_inst, a.dist_ld_r, a.dist_ld_s) = dist.data_ptr(), dist.stride()
+        else:
+            a.dist, a.dist_ld_inst, a.dist_ld_r, a.dist_ld_s = 0, 0, 0, 0
+        a.send_mask, a.recv_mask, a.att = _ptr(d.get('send_mask')), _ptr(d.get('recv_mask')), _ptr(d.get('att'))
+        a.scale, a.score_bias = float(d.get('scale', 1.0)), float(d.get('score_bias', 0.0))
+        a.score_mode, a.msg_mode = int(d['score_mode']), int(d['msg_mode'])
+        a.relu_scores, a.exclude_self = int(d.get('relu_scores', 0)), int(d.get('exclude_self', 0))
+        a.n_inst, a.inst_per_clip, a.R, a.S = d['n_inst'], d['inst_per_clip'], d['R'], d['S']
+        a.D, a.hidden = int(d.get('D', 0)), d['hidden']
+
+    def relation_fwd(self, d):
+        a = L.Relation()
+        self._fill_relation(a, d)
+        self._check(self.lib.twog_relation_fwd(C.byref(a), self._stream()), 'twog_relation_fwd')
+
+    def relation_bwd(self, d):
+        """d: dict(f=<forward descriptor>, dout, dmsg | dp_r, dp_s, dq, dk, da_r, dc_s, dq_accumulate, ...)."""
+        b = L.RelationBwd()
+        self._fill_relation(b.f, d['f'])
+        for k in ('dout', 'dmsg', 'dp_r', 'dp_s', 'dq', 'dk'):
+            setattr(b, k, rows_of(d.get(k)))
+        b.da_r, b.dc_s = _ptr(d.get('da_r')), _ptr(d.get('dc_s'))
+        b.dq_accumulate, b.dk_accumulate = int(d.get('dq_accumulate', 0)), int(d.get('dk_accumulate', 0))
+        b.relu_mask_dmsg = int(d.get('relu_mask_dmsg', 0))
+        self._check(self.lib.twog_relation_bwd(C.byref(b), self._stream()), 'twog_relation_bwd')
+
     # ---------------------------------------------------------------- position features / rare gate strategies
     def pos_embed_fwd(self, out, bs, T, E, hidden, w=None, b=None, periodic=False, s=None, steps=None, divide=False):
         """out: (bs*T*E, hidden) row-strided view (a column block of the entity rows). Returns the scalars [bs*T*E]."""

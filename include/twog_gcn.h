@@ -295,6 +295,63 @@ int twog_mul(const float* a, const float* b, float* out, int64_t n, int accumula
 int twog_scale_rows(twog_rows_t x, const float* s, int rows, int cols, void* stream);
 
 /* ===============================================================================================================
+ * General message passing of ONE relation (receiver set R, sender set S per instance): the message / aggregation forms
+ * of the reference beyond the shipped one (twog_attn_* covers sender-only messages + dot-product attention for the
+ * four entity relations at once): relational messages (compute_relational_message, vhoi/models.py:1667-1690),
+ * 'specific' granularity (:1712-1713), attention styles 'concat' / 'general' (:1739-1746), distance-based attention
+ * (:1757-1775) and mean pooling (:1034-1037). Linear layers on cat[receiver, sender] are split by the caller into a
+ * receiver and a sender projection (GEMMs); this kernel combines them per pair:
+ *      out[r] = recv_mask[r] * sum_s w[r][s] * M(r, s)
+ *      M(r, s) = msg[s]                              (TWOG_REL_MSG_SENDER)
+ *              = relu(p_r[r] + p_s[s])               (TWOG_REL_MSG_PAIR)
+ *      w[r][.] = send_mask[s]                        (TWOG_REL_SUM: masked sum, relational)
+ *              = softmax_s(scale <q[r], k[s]> + score_bias [relu])   (TWOG_REL_DOT; 'general': k = A k precomputed)
+ *              = softmax_s(relu(a_r[r] + c_s[s]))    (TWOG_REL_ADDITIVE: 'concat')
+ *              = softmax_s(1 / (dist[r][s] + 1e-7)), dist == 0 excluded     (TWOG_REL_DISTANCE)
+ *              = 1 / max(#valid senders, 1)          (TWOG_REL_MEAN)
+ * over the valid senders (send_mask != 0, and s != r when exclude_self); no valid sender -> all-zero weights (the
+ * reference's NaN -> 0). Rows of one instance must be equally strided (inner <= 1 or inner == R resp. S).
+ * =============================================================================================================== */
+#define TWOG_REL_SUM 0
+#define TWOG_REL_DOT 1
+#define TWOG_REL_ADDITIVE 2
+#define TWOG_REL_DISTANCE 3
+#define TWOG_REL_MEAN 4
+#define TWOG_REL_MSG_SENDER 0
+#define TWOG_REL_MSG_PAIR 1
+typedef struct {
+    twog_rows_t q, k;        /* [inst*R][D], [inst*S][D]      (TWOG_REL_DOT) */
+    twog_rows_t msg;         /* [inst*S][hidden]              (TWOG_REL_MSG_SENDER) */
+    twog_rows_t p_r, p_s;    /* [inst*R][hidden], [inst*S][hidden] (TWOG_REL_MSG_PAIR) */
+    twog_rows_t out;         /* [inst*R][hidden] */
+    const float* a_r;        /* [inst*R] (TWOG_REL_ADDITIVE; the layer's bias folded in) */
+    const float* c_s;        /* [inst*S] */
+    const float* dist;       /* element (inst, r, s) at inst*dist_ld_inst + r*dist_ld_r + s*dist_ld_s (TWOG_REL_DISTANCE) */
+    int64_t dist_ld_inst, dist_ld_r, dist_ld_s;
+    const float* send_mask;  /* [clip][S] or NULL */
+    const float* recv_mask;  /* [clip][R] or NULL */
+    float* att;              /* out (fwd): weights [inst][R][S], or NULL */
+    float scale, score_bias;
+    int32_t score_mode, msg_mode, relu_scores, exclude_self;
+    int32_t n_inst, inst_per_clip, R, S, D, hidden;
+} twog_relation_t;
+int twog_relation_limits(void); /* max R, S */
+int twog_relation_fwd(const twog_relation_t* rel, void* stream);
+typedef struct {
+    twog_relation_t f;
+    twog_rows_t dout;        /* [inst*R][hidden] gradient wrt out */
+    twog_rows_t dmsg;        /* out [inst*S][hidden] (MSG_SENDER; NULL = not needed) */
+    twog_rows_t dp_r, dp_s;  /* out (MSG_PAIR) */
+    twog_rows_t dq, dk;      /* out [..][D] (DOT; NULL = not needed) */
+    float* da_r;             /* out [inst*R] (ADDITIVE) */
+    float* dc_s;             /* out [inst*S] */
+    int32_t dq_accumulate, dk_accumulate; /* add into dq / dk instead of overwriting */
+    int32_t relu_mask_dmsg;  /* dmsg *= (msg > 0): the sender MLP's ReLU folded in */
+    int32_t pad_;
+} twog_relation_bwd_t;
+int twog_relation_bwd(const twog_relation_bwd_t* rel, void* stream);
+
+/* ===============================================================================================================
  * Segment-boundary gates (vhoi/models.py:1477-1533, :1620-1627; pyrutils/torch/distributions.py:4-53) with
  * discrete_networks_num_layers == 1: p = sigmoid(w . [column blocks of the entity row] + b); 'gs': Gumbel-sigmoid
  * with PRE-DRAWN noise, 'st' (noise == NULL): straight-through; hard = soft > thr; last step forced to 1 (:701-702).

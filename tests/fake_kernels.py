@@ -536,6 +536,90 @@ class FakeKernels:
     def add_rows(self, src, dst):
         dst.add_(src.reshape(dst.shape))
 
+    # ------------------------------------------------------------------ general single-relation message passing
+    REL_SUM, REL_DOT, REL_ADDITIVE, REL_DISTANCE, REL_MEAN = 0, 1, 2, 3, 4
+    REL_MSG_SENDER, REL_MSG_PAIR = 0, 1
+
+    @staticmethod
+    def _rel_rows(t, n_inst, n):
+        """(n_inst*n, w) 2-D view or (n_inst, n, w) 3-D view -> (n_inst, n, w)"""
+        return None if t is None else (t if t.dim() == 3 else t.reshape(n_inst, n, t.shape[-1]))
+
+    def _rel_forward(self, d, leaf=None):
+        """Specification of twog_relation_fwd as differentiable torch code (leaf: dict of tensors to differentiate)."""
+        nI, ipc, R, S = d['n_inst'], d['inst_per_clip'], d['R'], d['S']
+        g = lambda k: (leaf or {}).get(k, d.get(k))
+        valid = torch.ones(nI, R, S)
+        mval = torch.ones(nI, 1, S)
+        if d.get('send_mask') is not None:
+            mval = d['send_mask'].repeat_interleave(ipc, 0).view(nI, 1, S)
+            valid = valid * (mval != 0).float()
+        if d.get('exclude_self'):
+            valid = valid * (1 - torch.eye(R, S)).view(1, R, S)
+        mode = d['score_mode']
+        if mode == self.REL_DOT:
+            q, k = self._rel_rows(g('q'), nI, R), self._rel_rows(g('k'), nI, S)
+            sc = torch.einsum('nrd,nsd->nrs', q, k) * d.get('scale', 1.0) + d.get('score_bias', 0.0)
+            if d.get('relu_scores'):
+                sc = torch.relu(sc)
+        elif mode == self.REL_ADDITIVE:
+            sc = torch.relu(g('a_r').view(nI, R, 1) + g('c_s').view(nI, 1, S))
+        elif mode == self.REL_DISTANCE:
+            dist = d['dist']
+            valid = valid * (dist != 0).float()
+            sc = 1.0 / (dist + 1e-7)
+        else:
+            sc = None
+        if mode == self.REL_SUM:
+            w = valid * mval
+        elif mode == self.REL_MEAN:
+            w = valid / valid.sum(-1, keepdim=True).clamp(min=1.0)
+        else:
+            sc = torch.where(valid.bool(), sc, torch.full_like(sc, float('-inf')))
+            w = torch.softmax(sc, dim=-1)
+            w = torch.where(torch.isnan(w), torch.zeros_like(w), w)
+        if d['msg_mode'] == self.REL_MSG_SENDER:
+            out = torch.einsum('nrs,nsh->nrh', w, self._rel_rows(g('msg'), nI, S))
+        else:
+            pr, ps = self._rel_rows(g('p_r'), nI, R), self._rel_rows(g('p_s'), nI, S)
+            out = (w.unsqueeze(-1) * torch.relu(pr.unsqueeze(2) + ps.unsqueeze(1))).sum(2)
+        if d.get('recv_mask') is not None:
+            out = out * d['recv_mask'].repeat_interleave(ipc, 0).view(nI, R, 1)
+        return out, w
+
+    def relation_fwd(self, d):
+        out, w = self._rel_forward(d)
+        d['out'].copy_(out.reshape(d['out'].shape))
+        if d.get('att') is not None:
+            d['att'].copy_(w.reshape(d['att'].shape))
+
+    def relation_bwd(self, b):
+        d = b['f']
+        keys = [k for k in ('q', 'k', 'msg', 'p_r', 'p_s', 'a_r', 'c_s') if d.get(k) is not None]
+        leaf = {k: d[k].detach().clone().requires_grad_(True) for k in keys}
+        if d.get('q') is not None and d.get('k') is not None and d['q'].data_ptr() == d['k'].data_ptr() and \
+                d['q'].shape == d['k'].shape:
+            pass   # self relation: q and k stay separate leaves; their gradients go to dq / dk separately
+        out, _ = self._rel_forward(d, leaf)
+        nI, R = d['n_inst'], d['R']
+        out.backward(self._rel_rows(b['dout'], nI, R).reshape(out.shape))
+        grad = lambda k: (leaf[k].grad if leaf[k].grad is not None else torch.zeros_like(leaf[k])) if k in leaf else None
+        if b.get('dmsg') is not None:
+            gm = grad('msg')
+            if b.get('relu_mask_dmsg'):
+                gm = gm * (d['msg'] > 0).float()
+            b['dmsg'].copy_(gm.reshape(b['dmsg'].shape))
+        for src, dst in (('p_r', 'dp_r'), ('p_s', 'dp_s'), ('a_r', 'da_r'), ('c_s', 'dc_s')):
+            if b.get(dst) is not None and src in leaf:
+                b[dst].copy_(grad(src).reshape(b[dst].shape))
+        for src, dst, acc in (('q', 'dq', 'dq_accumulate'), ('k', 'dk', 'dk_accumulate')):
+            if b.get(dst) is not None:
+                gq = grad(src) if src in leaf else torch.zeros(b[dst].shape)
+                if b.get(acc):
+                    b[dst].add_(gq.reshape(b[dst].shape))
+                else:
+                    b[dst].copy_(gq.reshape(b[dst].shape))
+
     # ------------------------------------------------------------------ position features / rare gate strategies
     def pos_embed_fwd(self, out, bs, T, E, hidden, w=None, b=None, periodic=False, s=None, steps=None, divide=False):
         if s is None:
