@@ -108,15 +108,16 @@ class Relation(C.Structure):  # twog_relation_t
     _fields_ = [('q', Rows), ('k', Rows), ('msg', Rows), ('p_r', Rows), ('p_s', Rows), ('out', Rows),
                 ('a_r', C.c_void_p), ('c_s', C.c_void_p), ('dist', C.c_void_p), ('dist_ld_inst', C.c_int64),
                 ('dist_ld_r', C.c_int64), ('dist_ld_s', C.c_int64), ('send_mask', C.c_void_p),
-                ('recv_mask', C.c_void_p), ('att', C.c_void_p), ('scale', C.c_float), ('score_bias', C.c_float),
+                ('recv_mask', C.c_void_p), ('att', C.c_void_p), ('score_bias', C.c_void_p), ('scale', C.c_float),
                 ('score_mode', C.c_int32), ('msg_mode', C.c_int32), ('relu_scores', C.c_int32),
                 ('exclude_self', C.c_int32), ('n_inst', C.c_int32), ('inst_per_clip', C.c_int32), ('R', C.c_int32),
-                ('S', C.c_int32), ('D', C.c_int32), ('hidden', C.c_int32)]
+                ('S', C.c_int32), ('D', C.c_int32), ('hidden', C.c_int32), ('pad_', C.c_int32)]
 
 
 class RelationBwd(C.Structure):  # twog_relation_bwd_t
     _fields_ = [('f', Relation), ('dout', Rows), ('dmsg', Rows), ('dp_r', Rows), ('dp_s', Rows), ('dq', Rows),
-                ('dk', Rows), ('da_r', C.c_void_p), ('dc_s', C.c_void_p), ('dq_accumulate', C.c_int32),
+                ('dk', Rows), ('da_r', C.c_void_p), ('dc_s', C.c_void_p), ('dscore_sum', C.c_void_p),
+                ('dq_accumulate', C.c_int32),
                 ('dk_accumulate', C.c_int32), ('relu_mask_dmsg', C.c_int32), ('pad_', C.c_int32)]
 
 

@@ -53,7 +53,7 @@ __device__ __forceinline__ void pair_scores(const twog_relation_t& A, int inst, 
         if (A.exclude_self && r == s) valid = 0.f;
         float sc = 0.f, raw = 0.f;
         if (A.score_mode == TWOG_REL_DOT) {
-            raw = wdot(q.row(r), k.row(s), A.D, lane) * A.scale + A.score_bias;
+            raw = wdot(q.row(r), k.row(s), A.D, lane) * A.scale + (A.score_bias ? A.score_bias[0] : 0.f);
             sc = A.relu_scores ? fmaxf(raw, 0.f) : raw;
         } else if (A.score_mode == TWOG_REL_ADDITIVE) {
             raw = A.a_r[(int64_t)inst * R + r] + A.c_s[(int64_t)inst * S + s];
@@ -220,6 +220,11 @@ __global__ __launch_bounds__(256) void relation_bwd_kernel(const twog_relation_b
             B.dc_s[(int64_t)inst * S + s] = t;
         }
         return;
+    }
+    if (B.dscore_sum && threadIdx.x == 0) {
+        float t = 0.f;
+        for (int p = 0; p < R * S; ++p) t += sD[p];
+        B.dscore_sum[inst] = t;
     }
     // dot scores: dq[r] (+)= scale sum_s dscore k[s] ; dk[s] (+)= scale sum_r dscore q[r].
     // q and k may be views of the same rows (self relations: humans -> human): the two passes are separated by a barrier

@@ -485,7 +485,7 @@ class HipKernels:
         else:
             a.dist, a.dist_ld_inst, a.dist_ld_r, a.dist_ld_s = 0, 0, 0, 0
         a.send_mask, a.recv_mask, a.att = _ptr(d.get('send_mask')), _ptr(d.get('recv_mask')), _ptr(d.get('att'))
-        a.scale, a.score_bias = float(d.get('scale', 1.0)), float(d.get('score_bias', 0.0))
+        a.scale, a.score_bias = float(d.get('scale', 1.0)), _ptr(d.get('score_bias'))
         a.score_mode, a.msg_mode = int(d['score_mode']), int(d['msg_mode'])
         a.relu_scores, a.exclude_self = int(d.get('relu_scores', 0)), int(d.get('exclude_self', 0))
         a.n_inst, a.inst_per_clip, a.R, a.S = d['n_inst'], d['inst_per_clip'], d['R'], d['S']
@@ -502,7 +502,7 @@ class HipKernels:
         self._fill_relation(b.f, d['f'])
         for k in ('dout', 'dmsg', 'dp_r', 'dp_s', 'dq', 'dk'):
             setattr(b, k, rows_of(d.get(k)))
-        b.da_r, b.dc_s = _ptr(d.get('da_r')), _ptr(d.get('dc_s'))
+        b.da_r, b.dc_s, b.dscore_sum = _ptr(d.get('da_r')), _ptr(d.get('dc_s')), _ptr(d.get('dscore_sum'))
         b.dq_accumulate, b.dk_accumulate = int(d.get('dq_accumulate', 0)), int(d.get('dk_accumulate', 0))
         b.relu_mask_dmsg = int(d.get('relu_mask_dmsg', 0))
         self._check(self.lib.twog_relation_bwd(C.byref(b), self._stream()), 'twog_relation_bwd')

@@ -227,15 +227,14 @@ class TGGCN(nn.Module):
     def _check_supported(self):
         c = self.cfg
         bad = []
-        if c['message_type'] not in {'v2', 'non-relational'}:
-            bad.append(f"message_type={c['message_type']!r}")
-        if c['message_granularity'] not in {'v1', 'generic'}:
-            bad.append(f"message_granularity={c['message_granularity']!r}")
-        mean_pool = c['message_aggregation'] in {'mp', 'mean_pooling'}
-        if not mean_pool and c['message_aggregation'] not in {'att', 'attention'}:
-            bad.append(f"message_aggregation={c['message_aggregation']!r}")
-        if not mean_pool and c['attention_style'] not in {'v2', 'dot-product', 'v3', 'scaled_dot-product'}:
-            bad.append(f"attention_style={c['attention_style']!r}")
+        relational = c['message_type'] in {'v1', 'relational'}
+        general = (relational or c['message_granularity'] in {'v2', 'specific'} or
+                   (c['message_aggregation'] not in {'mp', 'mean_pooling'} and
+                    c['attention_style'] not in {'v2', 'dot-product', 'v3', 'scaled_dot-product'}))
+        if general and c['message_segment']:
+            # the frame level runs every message / attention form (relation.hip); the segment-level loop (segrnn.hip)
+            # so far the shipped one: sender-only messages with dot-product attention or mean pooling
+            bad.append('message_segment with relational / receiver-specific messages or concat / general attention')
         if c['discrete_networks_num_layers'] < 1:
             bad.append('discrete_networks_num_layers < 1')
         if c['discrete_optimization_strategy'] not in {'gumbel-sigmoid', 'gs', 'straight-through', 'st'}:
@@ -255,9 +254,12 @@ class TGGCN(nn.Module):
         if self._unsupported:
             raise NotImplementedError('configuration not implemented by the gfx950 path: ' + ', '.join(self._unsupported)
                                       + '; ' + ops.SUPPORTED_NOTE)
-        if human_human_distances is not None or human_object_distances is not None or \
-                object_object_distances is not None:
-            raise NotImplementedError('distance-based attention is not implemented by the gfx950 path')
+        dists = dict(hh=human_human_distances, ho=human_object_distances, oo=object_object_distances)
+        dists = {k: v.to(device=x_human.device, dtype=torch.float32).contiguous() for k, v in dists.items()
+                 if v is not None}
+        if dists and self.cfg['message_segment']:
+            raise NotImplementedError('distance-based attention with message_segment is not implemented by the gfx950 '
+                                      'path (the segment-level loop runs dot-product attention / mean pooling)')
         bs, T, H, F_h = x_human.shape
         O = x_objects.shape[2]
         vw = F_h - 2048  # generalises the reference's hard-coded 76 / 120 / 104 split (vhoi/models.py:631-639)
@@ -271,6 +273,7 @@ class TGGCN(nn.Module):
         plan = ops.Plan(self.cfg, bs, T, H, O, self.gcn_node, x_objects.shape[-1], n_sub, n_aff,
                         human_segmentation is not None, objects_segmentation is not None)
         plan.stage_hook = getattr(self, '_twog_grad_stage_hook', None)   # data-parallel overlap (ops.set_grad_stage_hook)
+        plan.dists = dists or None
         plan.steps = None
         if steps_per_example is not None and (plan.time_s or plan.time_u or plan.seglen):
             plan.steps = steps_per_example.to(device=x_human.device, dtype=torch.float32).contiguous()

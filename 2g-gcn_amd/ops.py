@@ -82,6 +82,13 @@ class Plan:
                 col += h
         self.fw_end_o, self.Wo = tail(col, self.col_o)
         self.Ws = 2 * h
+        # message / aggregation forms (models.py:1025-1049 and the nine sibling methods)
+        style = c['attention_style']
+        self.relational = c['message_type'] in {'v1', 'relational'}
+        self.specific = (not self.relational) and c['message_granularity'] in {'v2', 'specific'}
+        self.mean_pool = (not self.relational) and c['message_aggregation'] in {'mp', 'mean_pooling'}
+        self.att_style = ('concat' if style in {'v1', 'concat'} else 'general' if style in {'v4', 'general'} else 'dot')
+        self.dists = None   # distance tensors of this call (distance-based attention), set by the model's forward
         self.has_bias = bool(c.get('bias', True))
         self.n_gate_hidden = int(c.get('discrete_networks_num_layers', 1)) - 1
         ostrat = c['object_segment_update_strategy']
@@ -121,6 +128,12 @@ class Plan:
         self.fw_h = self.fw_end_h - h  # width of the frame-level part xx_hs of the human GRUCell input
         self.fw_o = self.fw_end_o - h
 
+    def general_frame(self):
+        """True when the frame-level messages need the general single-relation kernels (relation.hip) instead of the
+        tuned four-relations kernel (attn.hip: sender-only messages + dot-product attention / mean pooling)."""
+        return (self.relational or self.specific or
+                (not self.mean_pool and (self.att_style != 'dot' or self.dists is not None)))
+
     # gate input column blocks, in the reference's weight order
     def gate_cols_h(self):  # [x, h, m_hh, m_oh, m_sh, x_time]  (models.py:1494)
         return [0, self.h] + [self.col_h[r] for r in ('hh', 'oh', 'sh', 'time_u') if r in self.col_h]
@@ -134,6 +147,16 @@ _FRAME_MLP = {'hh': 'humans_to_human_message_mlp', 'ho': 'human_to_object_messag
               'so': 'geometry_to_object_message_mlp', 'sh': 'geometry_to_human_message_mlp'}
 _SEG_MLP = {'hh': 'humans_to_human_segment_message_mlp', 'ho': 'human_to_object_segment_message_mlp',
             'oh': 'objects_to_human_segment_message_mlp', 'oo': 'objects_to_object_segment_message_mlp'}
+
+
+# relational messages (models.py:323-520): '<receiver>_<sender>_{pairwise,full}_relation_mlp'
+_REL_PREFIX = {'hh': 'human_human', 'ho': 'object_human', 'oh': 'human_object', 'oo': 'object_object',
+               'sh': 'human_geometry', 'so': 'object_geometry'}
+_ATT_MLP = {'hh': 'humans_to_human_message_att_mlp', 'ho': 'humans_to_object_message_att_mlp',
+            'oh': 'objects_to_human_message_att_mlp', 'oo': 'objects_to_object_message_att_mlp',
+            'sh': 'geometry_to_human_message_att_mlp', 'so': 'geometry_to_object_message_att_mlp'}
+# relation -> (receiver kind, sender kind)
+_REL_ENDS = {'hh': ('h', 'h'), 'oh': ('h', 'o'), 'sh': ('h', 's'), 'ho': ('o', 'h'), 'so': ('o', 's'), 'oo': ('o', 'o')}
 
 
 def _head_name(plan, name):
@@ -156,7 +179,16 @@ def used_parameter_names(plan: Plan):
         for sfx in ('', '_reverse'):
             names += [f'{r}.weight_ih_l0{sfx}', f'{r}.weight_hh_l0{sfx}', f'{r}.bias_ih_l0{sfx}', f'{r}.bias_hh_l0{sfx}']
     for rel in plan.snd_h + plan.snd_o + plan.snd_s:
-        names += [_FRAME_MLP[rel] + '.0.weight', _FRAME_MLP[rel] + '.0.bias']
+        if plan.relational:
+            names += [f'{_REL_PREFIX[rel]}_{kind}_relation_mlp.0.{wb}' for kind in ('pairwise', 'full')
+                      for wb in ('weight', 'bias')]
+        else:
+            names += [_FRAME_MLP[rel] + '.0.weight', _FRAME_MLP[rel] + '.0.bias']
+            if not plan.mean_pool and plan.att_style != 'dot':
+                # (a single (geometry) sender always gets weight 1 -- the softmax over one sender is constant -- so its
+                # attention parameters receive an exactly-zero gradient, in the reference too)
+                names += [_ATT_MLP[rel] + ('.weight' if plan.att_style == 'general' else '.0.weight'),
+                          _ATT_MLP[rel] + ('.bias' if plan.att_style == 'general' else '.0.bias')]
     if plan.msg_segment:
         for rel in ('hh', 'ho', 'oh', 'oo'):
             if getattr(plan, 'rel_' + rel):
@@ -329,6 +361,191 @@ def geo_gcn_forward(K, P, x_human, bs, T, N, training, bn_bufs, S):
     return Gout
 
 
+def _rel_sets(p, rel, HUMv, OBJv, GEOv):
+    """(receiver rows, R, sender rows, S, column of the received block) of a relation."""
+    rows = {'h': (HUMv, p.H), 'o': (OBJv, p.O), 's': (GEOv, 1)}
+    rk, sk = _REL_ENDS[rel]
+    (Rv, R), (Sv, Sn) = rows[rk], rows[sk]
+    col = (p.col_h if rk == 'h' else p.col_o)[rel]
+    return Rv, R, Sv, Sn, col
+
+
+def _rel_distances(p, rel, nF):
+    """(n_inst, R, S) view of the distance tensor this relation attends by, or None (models.py:667-735: hh / oh / ho /
+    oo take the centroid distances when they are passed in; the geometry node has none)."""
+    d = p.dists or {}
+    H, O = p.H, p.O
+    if rel == 'hh' and d.get('hh') is not None:
+        return d['hh'].view(nF, H, H)
+    if rel == 'oh' and d.get('ho') is not None:
+        return d['ho'].view(nF, H, O)
+    if rel == 'ho' and d.get('ho') is not None:
+        return d['ho'].view(nF, H, O).transpose(1, 2)   # receiver = object k, senders = humans (:711)
+    if rel == 'oo' and d.get('oo') is not None:
+        return d['oo'].view(nF, O, O)
+    return None
+
+
+def frame_messages_general_fwd(K, p, P, HUMv, OBJv, GEOv, objects_mask):
+    """Frame-level messages in every form the tuned kernel does not cover (relational, receiver-specific, concat /
+    bilinear / distance-based attention): per relation a couple of GEMMs -- a Linear on cat[receiver, sender] is split
+    into a receiver and a sender projection -- and one launch of the general relation kernel (relation.hip). Writes the
+    received-message column blocks of the entity rows; returns what the backward pass needs."""
+    bs, T, h = p.bs, p.T, p.h
+    nF, D = bs * T, 2 * h
+    dev = HUMv.device
+    saved = {}
+
+    def empty(*shape):
+        return torch.empty(*shape, dtype=torch.float32, device=dev)
+
+    for rel in ('hh', 'oh', 'sh', 'ho', 'so', 'oo'):
+        if not getattr(p, 'rel_' + rel):
+            continue
+        Rv, R, Sv, Sn, col = _rel_sets(p, rel, HUMv, OBJv, GEOv)
+        if R == 0:
+            continue
+        FR, FS = Rv[:, :D], Sv[:, :D]
+        out_block = Rv[:, col:col + h]
+        sk = _REL_ENDS[rel][1]
+        f = dict(n_inst=nF, inst_per_clip=T, R=R, S=Sn, D=D, hidden=h, exclude_self=int(rel in ('hh', 'oo')),
+                 send_mask=objects_mask if sk == 'o' else None)
+        rec = dict(rel=rel, f=f)
+        if p.relational:
+            # m = f( sum_s mask_s * g(cat[receiver, sender_s]) )   (models.py:1667-1690)
+            g_, f_ = _REL_PREFIX[rel] + '_pairwise_relation_mlp.0', _REL_PREFIX[rel] + '_full_relation_mlp.0'
+            gw = P[g_ + '.weight']
+            p_r, p_s, agg = empty(nF * R, h), empty(nF * Sn, h), empty(nF * R, h)
+            K.gemm([dict(A=FR, B=gw[:, :D], C=p_r), dict(A=FS, B=gw[:, D:], C=p_s, bias=P[g_ + '.bias'])])
+            f.update(score_mode=K.REL_SUM, msg_mode=K.REL_MSG_PAIR, p_r=p_r, p_s=p_s, out=agg)
+            K.relation_fwd(f)
+            K.gemm([dict(A=agg, B=P[f_ + '.weight'], C=out_block, bias=P[f_ + '.bias'], act=1)])
+            if rel in ('ho', 'so'):   # the receiver's mask multiplies the finished message (:720, :729)
+                rows_mask = objects_mask.view(bs, 1, p.O).expand(bs, T, p.O).contiguous().view(-1)
+                K.scale_rows(out_block, rows_mask)
+            rec.update(agg=agg)
+            saved[rel] = rec
+            continue
+        m_ = _FRAME_MLP[rel] + '.0'
+        w = P[m_ + '.weight']
+        if p.specific:     # message_fn(cat[receiver, sender]) (:1712-1713): receiver part + sender part, ReLU per pair
+            p_r, p_s = empty(nF * R, h), empty(nF * Sn, h)
+            K.gemm([dict(A=FR, B=w[:, :D], C=p_r), dict(A=FS, B=w[:, D:], C=p_s, bias=P[m_ + '.bias'])])
+            f.update(msg_mode=K.REL_MSG_PAIR, p_r=p_r, p_s=p_s)
+        else:
+            msg = empty(nF * Sn, h)
+            K.gemm([dict(A=FS, B=w, C=msg, bias=P[m_ + '.bias'], act=1)])
+            f.update(msg_mode=K.REL_MSG_SENDER, msg=msg)
+        f.update(out=out_block, recv_mask=objects_mask if rel in ('ho', 'so') else None)
+        dist = _rel_distances(p, rel, nF)
+        if sk == 's':
+            f.update(score_mode=K.REL_SUM)        # one sender: its softmax weight is 1 whatever the score (Appendix A4)
+        elif p.mean_pool:
+            f.update(score_mode=K.REL_MEAN)
+        elif dist is not None:
+            f.update(score_mode=K.REL_DISTANCE, dist=dist)
+        elif p.att_style == 'dot':
+            f.update(score_mode=K.REL_DOT, q=FR, k=FS, scale=p.scale_frame)
+        elif p.att_style == 'concat':   # relu(Linear(cat[query, key]) -> 1) (:1739-1741)
+            a_ = _ATT_MLP[rel] + '.0'
+            aw = P[a_ + '.weight']
+            a_r, c_s = empty(nF * R, 1), empty(nF * Sn, 1)
+            K.gemm([dict(A=FR, B=aw[:, :D], C=a_r, bias=P[a_ + '.bias']), dict(A=FS, B=aw[:, D:], C=c_s)])
+            f.update(score_mode=K.REL_ADDITIVE, a_r=a_r, c_s=c_s)
+        else:                           # relu(Bilinear(query, key)) (:1746): keys transformed once per sender
+            a_ = _ATT_MLP[rel]
+            kp = empty(nF * Sn, D)
+            K.gemm([dict(A=FS, B=P[a_ + '.weight'].view(D, D), C=kp)])
+            f.update(score_mode=K.REL_DOT, q=FR, k=kp, scale=1.0, relu_scores=1, score_bias=P[a_ + '.bias'])
+        if rel == 'oh':
+            f['att'] = empty(nF, R, Sn)   # inspect_model: objects -> human weights (:1203-1237)
+        K.relation_fwd(f)
+        saved[rel] = rec
+    return saved
+
+
+def frame_messages_general_bwd(K, p, P, G, saved, HUMv, OBJv, GEOv, dHUMv, dOBJv, dGEOv):
+    """Backward of frame_messages_general_fwd: gradients of the message / relation / attention parameters, and the
+    feature gradients added into the entity-row gradient columns [0, 2h)."""
+    bs, T, h = p.bs, p.T, p.h
+    nF, D = bs * T, 2 * h
+    dev = HUMv.device
+
+    def empty(*shape):
+        return torch.empty(*shape, dtype=torch.float32, device=dev)
+
+    def split_linear_bwd(wname, bname, dp_r, dp_s, FR, FS, dFR, dFS):
+        """Linear on cat[receiver, sender] whose two halves were applied separately (the bias went with the sender)."""
+        w = P[wname]
+        _lin_w_grads(K, G, wname, None, dp_r, FR, cols=(0, D), total=w.shape[1])
+        _lin_w_grads(K, G, wname, bname, dp_s, FS, cols=(D, 2 * D), total=w.shape[1])
+        K.gemm([dict(A=dp_r, B=w[:, :D], C=dFR, accumulate=True)], b_kmajor=True)
+        K.gemm([dict(A=dp_s, B=w[:, D:], C=dFS, accumulate=True)], b_kmajor=True)
+
+    dsets = {'h': dHUMv, 'o': dOBJv, 's': dGEOv}
+    for rel, rec in saved.items():
+        Rv, R, Sv, Sn, col = _rel_sets(p, rel, HUMv, OBJv, GEOv)
+        rk, sk = _REL_ENDS[rel]
+        FR, FS = Rv[:, :D], Sv[:, :D]
+        dFR, dFS = dsets[rk][:, :D], dsets[sk][:, :D]
+        dout_block = dsets[rk][:, col:col + h]
+        f = rec['f']
+        if p.relational:
+            g_, f_ = _REL_PREFIX[rel] + '_pairwise_relation_mlp.0', _REL_PREFIX[rel] + '_full_relation_mlp.0'
+            dpre = K.relu_bwd(dout_block, Rv[:, col:col + h])      # a masked receiver's block is 0: its gradient too
+            _lin_w_grads(K, G, f_ + '.weight', f_ + '.bias', dpre, rec['agg'])
+            dagg = empty(nF * R, h)
+            K.gemm([dict(A=dpre, B=P[f_ + '.weight'], C=dagg)], b_kmajor=True)
+            dp_r, dp_s = empty(nF * R, h), empty(nF * Sn, h)
+            K.relation_bwd(dict(f=f, dout=dagg, dp_r=dp_r, dp_s=dp_s))
+            split_linear_bwd(g_ + '.weight', g_ + '.bias', dp_r, dp_s, FR, FS, dFR, dFS)
+            continue
+        m_ = _FRAME_MLP[rel] + '.0'
+        if sk == 's' and not p.mean_pool and p.att_style != 'dot':
+            for n_ in ((_ATT_MLP[rel] + '.weight', _ATT_MLP[rel] + '.bias') if p.att_style == 'general' else
+                       (_ATT_MLP[rel] + '.0.weight', _ATT_MLP[rel] + '.0.bias')):
+                if G.has(n_):
+                    G.add(n_, torch.zeros_like(P[n_]))
+        b = dict(f=f, dout=dout_block, relu_mask_dmsg=1)
+        if p.specific:
+            b.update(dp_r=empty(nF * R, h), dp_s=empty(nF * Sn, h))
+        else:
+            b.update(dmsg=empty(nF * Sn, h))
+        mode = f['score_mode']
+        dkp = None
+        if mode == K.REL_DOT and 'score_bias' not in f:
+            b.update(dq=dFR, dk=dFS, dq_accumulate=1, dk_accumulate=1)
+        elif mode == K.REL_DOT:       # bilinear: keys are the transformed ones
+            dkp = empty(nF * Sn, D)
+            b.update(dq=dFR, dq_accumulate=1, dk=dkp, dscore_sum=empty(nF))
+        elif mode == K.REL_ADDITIVE:
+            b.update(da_r=empty(nF * R), dc_s=empty(nF * Sn))
+        K.relation_bwd(b)
+        if p.specific:
+            split_linear_bwd(m_ + '.weight', m_ + '.bias', b['dp_r'], b['dp_s'], FR, FS, dFR, dFS)
+        else:
+            _lin_w_grads(K, G, m_ + '.weight', m_ + '.bias', b['dmsg'], FS)
+            K.gemm([dict(A=b['dmsg'], B=P[m_ + '.weight'], C=dFS, accumulate=True)], b_kmajor=True)
+        if mode == K.REL_ADDITIVE:
+            a_ = _ATT_MLP[rel] + '.0'
+            aw = P[a_ + '.weight'].view(-1)
+            dw = empty(2 * D)
+            K.colsum(FR, rowscale=b['da_r'], out=dw[:D])
+            K.colsum(FS, rowscale=b['dc_s'], out=dw[D:])
+            G.add(a_ + '.weight', dw.view(1, -1))
+            G.add(a_ + '.bias', K.colsum(b['da_r'].view(-1, 1)))
+            K.rank1_update(dFR, b['da_r'], aw[:D])
+            K.rank1_update(dFS, b['dc_s'], aw[D:])
+        elif dkp is not None:
+            a_ = _ATT_MLP[rel]
+            A_ = P[a_ + '.weight'].view(D, D)
+            dA = empty(D, D)
+            K.gemm([dict(A=dkp, B=FS, C=dA)], a_kmajor=True, b_kmajor=True)
+            G.add(a_ + '.weight', dA.view(1, D, D))
+            G.add(a_ + '.bias', K.colsum(b['dscore_sum'].view(-1, 1)))
+            K.gemm([dict(A=dkp, B=A_, C=dFS, accumulate=True)], b_kmajor=True)
+
+
 def tggcn_forward(K, plan: Plan, P, x_human, x_objects, objects_mask, human_seg, object_seg, noise, training, bn_bufs):
     """Returns (outputs list, saved dict). P: dict name -> parameter tensor."""
     p = plan
@@ -379,36 +596,40 @@ def tggcn_forward(K, plan: Plan, P, x_human, x_objects, objects_mask, human_seg,
     S['HFR'] = HFR
 
     # ------------------------------------------------------------------ D. frame-level messages + attention
-    MSGH = empty(nF * H, max(len(p.snd_h), 1) * h)
-    MSGO = empty(nF * O, max(len(p.snd_o), 1) * h)
-    MSGS = empty(nF, max(len(p.snd_s), 1) * h)
-    probs = []
-    for buf, Ev, rels in ((MSGH, HUMv, p.snd_h), (MSGO, OBJv, p.snd_o), (MSGS, GEOv, p.snd_s)):
-        for i, rel in enumerate(rels):
-            probs.append(dict(A=Ev[:, :2 * h], B=P[_FRAME_MLP[rel] + '.0.weight'], C=buf[:, i * h:(i + 1) * h],
-                              bias=P[_FRAME_MLP[rel] + '.0.bias'], act=1))
-    K.gemm(probs)
-    natt = H * H + 2 * H * O + O * O
-    att = empty(nF, natt)
+    if p.general_frame():
+        S['frame_general'] = frame_messages_general_fwd(K, p, P, HUMv, OBJv, GEOv, objects_mask)
+        S.update(HUM=HUM, OBJ=OBJ, GEO=GEO)
+    else:
+        MSGH = empty(nF * H, max(len(p.snd_h), 1) * h)
+        MSGO = empty(nF * O, max(len(p.snd_o), 1) * h)
+        MSGS = empty(nF, max(len(p.snd_s), 1) * h)
+        probs = []
+        for buf, Ev, rels in ((MSGH, HUMv, p.snd_h), (MSGO, OBJv, p.snd_o), (MSGS, GEOv, p.snd_s)):
+            for i, rel in enumerate(rels):
+                probs.append(dict(A=Ev[:, :2 * h], B=P[_FRAME_MLP[rel] + '.0.weight'], C=buf[:, i * h:(i + 1) * h],
+                                  bias=P[_FRAME_MLP[rel] + '.0.bias'], act=1))
+        K.gemm(probs)
+        natt = H * H + 2 * H * O + O * O
+        att = empty(nF, natt)
 
-    def msgv(buf, rels, rel):
-        if rel not in rels:
-            return None
-        i = rels.index(rel)
-        return buf[:, i * h:(i + 1) * h]
+        def msgv(buf, rels, rel):
+            if rel not in rels:
+                return None
+            i = rels.index(rel)
+            return buf[:, i * h:(i + 1) * h]
 
-    fdesc = dict(feat_h=HUMv[:, :2 * h], feat_o=OBJv[:, :2 * h],
-                 msg_hh=msgv(MSGH, p.snd_h, 'hh'), msg_ho=msgv(MSGH, p.snd_h, 'ho'),
-                 msg_oh=msgv(MSGO, p.snd_o, 'oh'), msg_oo=msgv(MSGO, p.snd_o, 'oo'),
-                 msg_so=msgv(MSGS, p.snd_s, 'so'), msg_sh=msgv(MSGS, p.snd_s, 'sh'),
-                 obj_mask=objects_mask, att=att, n_inst=nF, inst_per_clip=T, H=H, O=O, D=2 * h, hidden=h,
-                 scale=p.scale_frame, recv_mask_ho=1)
-    for rel, c in p.col_h.items():
-        fdesc['out_' + rel] = HUMv[:, c:c + h]
-    for rel, c in p.col_o.items():
-        fdesc['out_' + rel] = OBJv[:, c:c + h]
-    K.attn_fwd([fdesc])
-    S.update(HUM=HUM, OBJ=OBJ, GEO=GEO, MSGH=MSGH, MSGO=MSGO, MSGS=MSGS, att=att)
+        fdesc = dict(feat_h=HUMv[:, :2 * h], feat_o=OBJv[:, :2 * h],
+                     msg_hh=msgv(MSGH, p.snd_h, 'hh'), msg_ho=msgv(MSGH, p.snd_h, 'ho'),
+                     msg_oh=msgv(MSGO, p.snd_o, 'oh'), msg_oo=msgv(MSGO, p.snd_o, 'oo'),
+                     msg_so=msgv(MSGS, p.snd_s, 'so'), msg_sh=msgv(MSGS, p.snd_s, 'sh'),
+                     obj_mask=objects_mask, att=att, n_inst=nF, inst_per_clip=T, H=H, O=O, D=2 * h, hidden=h,
+                     scale=p.scale_frame, recv_mask_ho=1)
+        for rel, c in p.col_h.items():
+            fdesc['out_' + rel] = HUMv[:, c:c + h]
+        for rel, c in p.col_o.items():
+            fdesc['out_' + rel] = OBJv[:, c:c + h]
+        K.attn_fwd([fdesc])
+        S.update(HUM=HUM, OBJ=OBJ, GEO=GEO, MSGH=MSGH, MSGO=MSGO, MSGS=MSGS, att=att)
 
     # ------------------------------------------------------------------ time feature (models.py:655-662, :754-761)
     pos = {}   # saved scalars of the position features: name -> (kind -> [bs*T*E])
@@ -840,36 +1061,39 @@ def tggcn_backward(K, plan: Plan, P, S, x_human, x_objects, objects_mask, d_outp
     _stage_done(p, 0)
 
     # ---- D. frame-level attention + sender MLPs backward
-    MSGH, MSGO, MSGS = S['MSGH'], S['MSGO'], S['MSGS']
-    dMSGH, dMSGO, dMSGS = empty(*MSGH.shape), empty(*MSGO.shape), empty(*MSGS.shape)
+    if p.general_frame():
+        frame_messages_general_bwd(K, p, P, G, S['frame_general'], HUMv, OBJv, GEOv, dHUMv, dOBJv, dGEOv)
+    else:
+        MSGH, MSGO, MSGS = S['MSGH'], S['MSGO'], S['MSGS']
+        dMSGH, dMSGO, dMSGS = empty(*MSGH.shape), empty(*MSGO.shape), empty(*MSGS.shape)
 
-    def msgv(buf, rels, rel):
-        if rel not in rels:
-            return None
-        i = rels.index(rel)
-        return buf[:, i * h:(i + 1) * h]
+        def msgv(buf, rels, rel):
+            if rel not in rels:
+                return None
+            i = rels.index(rel)
+            return buf[:, i * h:(i + 1) * h]
 
-    f = dict(feat_h=HUMv[:, :2 * h], feat_o=OBJv[:, :2 * h],
-             msg_hh=msgv(MSGH, p.snd_h, 'hh'), msg_ho=msgv(MSGH, p.snd_h, 'ho'),
-             msg_oh=msgv(MSGO, p.snd_o, 'oh'), msg_oo=msgv(MSGO, p.snd_o, 'oo'),
-             msg_so=msgv(MSGS, p.snd_s, 'so'), msg_sh=msgv(MSGS, p.snd_s, 'sh'),
-             obj_mask=objects_mask, att=S['att'], n_inst=nF, inst_per_clip=T, H=H, O=O, D=2 * h, hidden=h,
-             scale=p.scale_frame, recv_mask_ho=1)
-    bdesc = dict(f=f, dfeat_h=dHUMv[:, :2 * h], dfeat_o=dOBJv[:, :2 * h], dfeat_accumulate=1, relu_mask_dmsg=1,
-                 dmsg_hh=msgv(dMSGH, p.snd_h, 'hh'), dmsg_ho=msgv(dMSGH, p.snd_h, 'ho'),
-                 dmsg_oh=msgv(dMSGO, p.snd_o, 'oh'), dmsg_oo=msgv(dMSGO, p.snd_o, 'oo'),
-                 dmsg_so=msgv(dMSGS, p.snd_s, 'so'), dmsg_sh=msgv(dMSGS, p.snd_s, 'sh'))
-    for rel, c in p.col_h.items():
-        bdesc['dout_' + rel] = dHUMv[:, c:c + h]
-    for rel, c in p.col_o.items():
-        bdesc['dout_' + rel] = dOBJv[:, c:c + h]
-    K.attn_bwd([bdesc])
-    for dbuf, Ev, dEv, rels in ((dMSGH, HUMv, dHUMv, p.snd_h), (dMSGO, OBJv, dOBJv, p.snd_o), (dMSGS, GEOv, dGEOv, p.snd_s)):
-        for i, rel in enumerate(rels):
-            dpre = dbuf[:, i * h:(i + 1) * h]
-            name = _FRAME_MLP[rel]
-            _lin_w_grads(K, G, name + '.0.weight', name + '.0.bias', dpre, Ev[:, :2 * h])
-            K.gemm([dict(A=dpre, B=P[name + '.0.weight'], C=dEv[:, :2 * h], accumulate=True)], b_kmajor=True)
+        f = dict(feat_h=HUMv[:, :2 * h], feat_o=OBJv[:, :2 * h],
+                 msg_hh=msgv(MSGH, p.snd_h, 'hh'), msg_ho=msgv(MSGH, p.snd_h, 'ho'),
+                 msg_oh=msgv(MSGO, p.snd_o, 'oh'), msg_oo=msgv(MSGO, p.snd_o, 'oo'),
+                 msg_so=msgv(MSGS, p.snd_s, 'so'), msg_sh=msgv(MSGS, p.snd_s, 'sh'),
+                 obj_mask=objects_mask, att=S['att'], n_inst=nF, inst_per_clip=T, H=H, O=O, D=2 * h, hidden=h,
+                 scale=p.scale_frame, recv_mask_ho=1)
+        bdesc = dict(f=f, dfeat_h=dHUMv[:, :2 * h], dfeat_o=dOBJv[:, :2 * h], dfeat_accumulate=1, relu_mask_dmsg=1,
+                     dmsg_hh=msgv(dMSGH, p.snd_h, 'hh'), dmsg_ho=msgv(dMSGH, p.snd_h, 'ho'),
+                     dmsg_oh=msgv(dMSGO, p.snd_o, 'oh'), dmsg_oo=msgv(dMSGO, p.snd_o, 'oo'),
+                     dmsg_so=msgv(dMSGS, p.snd_s, 'so'), dmsg_sh=msgv(dMSGS, p.snd_s, 'sh'))
+        for rel, c in p.col_h.items():
+            bdesc['dout_' + rel] = dHUMv[:, c:c + h]
+        for rel, c in p.col_o.items():
+            bdesc['dout_' + rel] = dOBJv[:, c:c + h]
+        K.attn_bwd([bdesc])
+        for dbuf, Ev, dEv, rels in ((dMSGH, HUMv, dHUMv, p.snd_h), (dMSGO, OBJv, dOBJv, p.snd_o), (dMSGS, GEOv, dGEOv, p.snd_s)):
+            for i, rel in enumerate(rels):
+                dpre = dbuf[:, i * h:(i + 1) * h]
+                name = _FRAME_MLP[rel]
+                _lin_w_grads(K, G, name + '.0.weight', name + '.0.bias', dpre, Ev[:, :2 * h])
+                K.gemm([dict(A=dpre, B=P[name + '.0.weight'], C=dEv[:, :2 * h], accumulate=True)], b_kmajor=True)
 
     # ---- C. BiGRU embedding + BiGRU backward
     ents = (('human', HUMv, dHUMv, H, dHFR_h), ('object', OBJv, dOBJv, O, dHFR_o), ('geometry', GEOv, dGEOv, 1, None))

@@ -331,9 +331,11 @@ typedef struct {
     const float* send_mask;  /* [clip][S] or NULL */
     const float* recv_mask;  /* [clip][R] or NULL */
     float* att;              /* out (fwd): weights [inst][R][S], or NULL */
-    float scale, score_bias;
+    const float* score_bias; /* device scalar added to the dot score (the Bilinear bias of 'general'), or NULL */
+    float scale;
     int32_t score_mode, msg_mode, relu_scores, exclude_self;
     int32_t n_inst, inst_per_clip, R, S, D, hidden;
+    int32_t pad_;
 } twog_relation_t;
 int twog_relation_limits(void); /* max R, S */
 int twog_relation_fwd(const twog_relation_t* rel, void* stream);
@@ -345,6 +347,7 @@ typedef struct {
     twog_rows_t dq, dk;      /* out [..][D] (DOT; NULL = not needed) */
     float* da_r;             /* out [inst*R] (ADDITIVE) */
     float* dc_s;             /* out [inst*S] */
+    float* dscore_sum;       /* out [inst]: sum over the pairs of d(raw score) = d score_bias per instance (DOT), or NULL */
     int32_t dq_accumulate, dk_accumulate; /* add into dq / dk instead of overwriting */
     int32_t relu_mask_dmsg;  /* dmsg *= (msg > 0): the sender MLP's ReLU folded in */
     int32_t pad_;

@@ -559,7 +559,8 @@ class FakeKernels:
         mode = d['score_mode']
         if mode == self.REL_DOT:
             q, k = self._rel_rows(g('q'), nI, R), self._rel_rows(g('k'), nI, S)
-            sc = torch.einsum('nrd,nsd->nrs', q, k) * d.get('scale', 1.0) + d.get('score_bias', 0.0)
+            sb = g('score_bias')
+            sc = torch.einsum('nrd,nsd->nrs', q, k) * d.get('scale', 1.0) + (sb if sb is not None else 0.0)
             if d.get('relu_scores'):
                 sc = torch.relu(sc)
         elif mode == self.REL_ADDITIVE:
@@ -595,14 +596,15 @@ class FakeKernels:
 
     def relation_bwd(self, b):
         d = b['f']
-        keys = [k for k in ('q', 'k', 'msg', 'p_r', 'p_s', 'a_r', 'c_s') if d.get(k) is not None]
+        keys = [k for k in ('q', 'k', 'msg', 'p_r', 'p_s', 'a_r', 'c_s', 'score_bias') if d.get(k) is not None]
         leaf = {k: d[k].detach().clone().requires_grad_(True) for k in keys}
         if d.get('q') is not None and d.get('k') is not None and d['q'].data_ptr() == d['k'].data_ptr() and \
                 d['q'].shape == d['k'].shape:
             pass   # self relation: q and k stay separate leaves; their gradients go to dq / dk separately
-        out, _ = self._rel_forward(d, leaf)
         nI, R = d['n_inst'], d['R']
-        out.backward(self._rel_rows(b['dout'], nI, R).reshape(out.shape))
+        with torch.enable_grad():   # called from inside an autograd backward pass, where grad mode is off
+            out, _ = self._rel_forward(d, leaf)
+            out.backward(self._rel_rows(b['dout'], nI, R).reshape(out.shape).detach())
         grad = lambda k: (leaf[k].grad if leaf[k].grad is not None else torch.zeros_like(leaf[k])) if k in leaf else None
         if b.get('dmsg') is not None:
             gm = grad('msg')
@@ -612,6 +614,11 @@ class FakeKernels:
         for src, dst in (('p_r', 'dp_r'), ('p_s', 'dp_s'), ('a_r', 'da_r'), ('c_s', 'dc_s')):
             if b.get(dst) is not None and src in leaf:
                 b[dst].copy_(grad(src).reshape(b[dst].shape))
+        if b.get('dscore_sum') is not None:
+            # per-instance sums are an implementation detail of the kernel; the double puts the total into element 0
+            b['dscore_sum'].zero_()
+            if 'score_bias' in leaf and leaf['score_bias'].grad is not None:
+                b['dscore_sum'][0] = leaf['score_bias'].grad.reshape(-1)[0]
         for src, dst, acc in (('q', 'dq', 'dq_accumulate'), ('k', 'dk', 'dk_accumulate')):
             if b.get(dst) is not None:
                 gq = grad(src) if src in leaf else torch.zeros(b[dst].shape)

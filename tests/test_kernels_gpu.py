@@ -728,3 +728,103 @@ def test_entity_attention_product_layout_full_size(K, n_inst, ipc):
     K.attn_bwd([bg])
     for name, g, c in zip(('dHUM', 'dOBJ', 'dMSGH', 'dMSGO', 'dMSGS'), outs_g, outs_c):
         close(g, c, rtol=2e-4, atol=2e-5, what=name)
+
+
+# ------------------------------------------------------------------------------ general single-relation message passing
+def _relation_case(dev, score, msg_mode, R, S, D, h, n_inst, ipc, exclude_self, send_mask, recv_mask, relu_scores, seed=0):
+    t = lambda *s, sd=0, sc=1.0: rnd(*s, seed=seed + sd, scale=sc).to(dev)
+    W = 2 * h + 8
+    d = dict(score_mode=score, msg_mode=msg_mode, n_inst=n_inst, inst_per_clip=ipc, R=R, S=S, D=D, hidden=h,
+             exclude_self=exclude_self, relu_scores=relu_scores, scale=1.0 / math.sqrt(D),
+             out=torch.zeros(n_inst * R, W, device=dev)[:, 4:4 + h])
+    n_clip = n_inst // ipc
+    if send_mask:
+        m = (rnd(n_clip, S, seed=seed + 1) > -0.4).float()
+        m[0] = 0.0            # a clip whose senders are all virtual: weights must be 0, not NaN
+        d['send_mask'] = m.to(dev)
+    if recv_mask:
+        d['recv_mask'] = (rnd(n_clip, R, seed=seed + 2) > -0.4).float().to(dev)
+    if score == F.REL_DOT:
+        d.update(q=t(n_inst * R, D + 4, sd=3)[:, :D], k=t(n_inst, S, D, sd=4))     # 2-D strided and 3-D row sets
+        if relu_scores:
+            d['score_bias'] = t(1, sd=5)
+    elif score == F.REL_ADDITIVE:
+        d.update(a_r=t(n_inst * R, sd=6), c_s=t(n_inst * S, sd=7))
+    elif score == F.REL_DISTANCE:
+        dist = rnd(n_inst, S, R, seed=seed + 8).abs() + 0.05
+        dist[rnd(n_inst, S, R, seed=seed + 9) > 1.0] = 0.0                         # distance 0 = "no such sender"
+        d['dist'] = dist.to(dev).transpose(1, 2)                                    # strided (n_inst, R, S) view
+    if msg_mode == F.REL_MSG_SENDER:
+        d['msg'] = t(n_inst * S, 2 * h, sd=10)[:, h:]
+    else:
+        d.update(p_r=t(n_inst * R, h, sd=11), p_s=t(n_inst * S, h, sd=12))
+    return d
+
+
+@pytest.mark.parametrize('score,msg_mode,R,S,excl,smask,rmask,relu', [
+    (F.REL_SUM, F.REL_MSG_PAIR, 2, 4, 0, 1, 0, 0),        # relational objects -> human
+    (F.REL_SUM, F.REL_MSG_PAIR, 5, 5, 1, 1, 0, 0),        # relational objects -> object (self excluded)
+    (F.REL_SUM, F.REL_MSG_SENDER, 4, 1, 0, 0, 1, 0),      # geometry -> objects, receiver mask
+    (F.REL_DOT, F.REL_MSG_PAIR, 2, 2, 1, 0, 0, 0),        # specific + dot, humans -> human
+    (F.REL_DOT, F.REL_MSG_SENDER, 4, 2, 0, 0, 1, 1),      # general (bilinear: relu + bias), humans -> objects
+    (F.REL_ADDITIVE, F.REL_MSG_SENDER, 2, 9, 0, 1, 0, 0),  # concat, objects -> human
+    (F.REL_ADDITIVE, F.REL_MSG_PAIR, 9, 9, 1, 1, 0, 0),    # concat + specific, objects -> object
+    (F.REL_DISTANCE, F.REL_MSG_SENDER, 3, 6, 0, 1, 0, 0),
+    (F.REL_MEAN, F.REL_MSG_PAIR, 6, 6, 1, 1, 0, 0)])
+def test_relation_kernels(K, score, msg_mode, R, S, excl, smask, rmask, relu):
+    D, h, n_inst, ipc = 24, 40, 6, 3
+    dc = _relation_case('cpu', score, msg_mode, R, S, D, h, n_inst, ipc, excl, smask, rmask, relu)
+    dg = _relation_case(DEV, score, msg_mode, R, S, D, h, n_inst, ipc, excl, smask, rmask, relu)
+    dc['att'], dg['att'] = torch.zeros(n_inst, R, S), torch.zeros(n_inst, R, S, device=DEV)
+    F.relation_fwd(dc)
+    K.relation_fwd(dg)
+    close(dg['att'], dc['att'], rtol=1e-4, atol=1e-6, what='weights')
+    assert not torch.isnan(dg['att']).any()
+    close(dg['out'], dc['out'], rtol=1e-4, atol=1e-5, what='out')
+
+    def bwd(dev, d):
+        t = lambda *s, sd=0: rnd(*s, seed=200 + sd).to(dev)
+        b = dict(f=d, dout=t(n_inst * R, h, sd=1), relu_mask_dmsg=1)
+        if msg_mode == F.REL_MSG_SENDER:
+            b['dmsg'] = torch.zeros(n_inst * S, h, device=dev)
+        else:
+            b.update(dp_r=torch.zeros(n_inst * R, h, device=dev), dp_s=torch.zeros(n_inst * S, h, device=dev))
+        if score == F.REL_DOT:
+            b.update(dq=t(n_inst * R, D, sd=2), dq_accumulate=1, dk=torch.zeros(n_inst * S, D, device=dev),
+                     dscore_sum=torch.zeros(n_inst, device=dev) if relu else None)
+        elif score == F.REL_ADDITIVE:
+            b.update(da_r=torch.zeros(n_inst * R, device=dev), dc_s=torch.zeros(n_inst * S, device=dev))
+        return b
+
+    bc, bg = bwd('cpu', dc), bwd(DEV, dg)
+    F.relation_bwd(bc)
+    K.relation_bwd(bg)
+    for k in ('dmsg', 'dp_r', 'dp_s', 'dq', 'dk', 'da_r', 'dc_s'):
+        if bc.get(k) is not None:
+            close(bg[k], bc[k], rtol=2e-4, atol=2e-5, what=k)
+    if bc.get('dscore_sum') is not None:   # per-instance partials on the device, their total in the specification
+        close(bg['dscore_sum'].sum(), bc['dscore_sum'].sum(), rtol=2e-4, atol=2e-5, what='d score bias')
+
+
+def test_relation_self_relation_accumulates_both_feature_gradients(K):
+    """humans -> human with dot scores: queries and keys are the SAME rows and both gradients are added into one
+    buffer (ops.py passes dq = dk = the entity-row gradient columns)."""
+    R = S = 3
+    D, h, n_inst = 16, 8, 4
+    feat = rnd(n_inst * R, D, seed=1)
+    msg = rnd(n_inst * S, h, seed=2)
+    dout = rnd(n_inst * R, h, seed=3)
+
+    def run(Kx, dev):
+        f_ = feat.to(dev)
+        d = dict(score_mode=F.REL_DOT, msg_mode=F.REL_MSG_SENDER, n_inst=n_inst, inst_per_clip=1, R=R, S=S, D=D, hidden=h,
+                 exclude_self=1, scale=0.25, q=f_, k=f_, msg=msg.to(dev), out=torch.zeros(n_inst * R, h, device=dev))
+        Kx.relation_fwd(d)
+        dfeat = torch.ones(n_inst * R, D, device=dev)
+        Kx.relation_bwd(dict(f=d, dout=dout.to(dev), dmsg=torch.zeros(n_inst * S, h, device=dev), dq=dfeat, dk=dfeat,
+                             dq_accumulate=1, dk_accumulate=1))
+        return d['out'], dfeat
+
+    (oc, gc), (og, gg) = run(F, 'cpu'), run(K, DEV)
+    close(og, oc, what='out')
+    close(gg, gc, rtol=2e-4, atol=2e-5, what='dq + dk into one buffer')

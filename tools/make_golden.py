@@ -178,6 +178,25 @@ CASES = {
     'c2_relational': ('mphoi', 2, 4, 26, 8, 2, 5, (13, None), dict(message_type='v1'), 'human_ones', 32),
     'c2_distance': ('mphoi', 2, 4, 26, 8, 2, 5, (13, None), dict(), 'human_ones+dist', 33),
     'c2_ctor_defaults': ('mphoi', 2, 4, 26, 8, 2, 5, (13, None), 'defaults', 'human_ones', 34),
+    # the same message / attention forms at the frame level only (message_segment off)
+    'c2_concat_f': ('mphoi', 2, 4, 26, 8, 2, 5, (13, None), dict(attention_style='v1', message_segment=False),
+                    'human_ones', 42),
+    'c2_general_f': ('mphoi', 2, 4, 26, 8, 2, 5, (13, None), dict(attention_style='v4', message_segment=False),
+                     'human_ones', 43),
+    'c2_specific_f': ('mphoi', 2, 4, 26, 8, 2, 5, (13, None), dict(message_granularity='v2', message_segment=False),
+                      'human_ones', 44),
+    'c2_specific_concat_mp_f': ('mphoi', 2, 4, 26, 8, 2, 5, (13, None),
+                                dict(message_granularity='v2', message_aggregation='mp', attention_style='v1',
+                                     message_segment=False), 'none', 45),
+    'c2_specific_general_f': ('mphoi', 2, 4, 26, 8, 2, 5, (13, None),
+                              dict(message_granularity='v2', attention_style='v4', message_segment=False,
+                                   message_geometry_to_human=True), 'human_ones', 46),
+    'c2_relational_f': ('mphoi', 2, 4, 26, 8, 2, 5, (13, None), dict(message_type='v1', message_segment=False),
+                        'human_ones', 47),
+    'c2_distance_f': ('mphoi', 2, 4, 26, 8, 2, 5, (13, None), dict(message_segment=False), 'human_ones+dist', 48),
+    'c1_relational_geo2h_f': ('cad120', 1, 5, 19, 8, 2, 5, (10, 12),
+                              dict(message_humans_to_human=False, message_type='v1', message_geometry_to_human=True,
+                                   message_segment=False), 'none', 49),
     'c1_relational_geo2h': ('cad120', 1, 5, 19, 8, 2, 5, (10, 12),
                             dict(message_humans_to_human=False, message_type='v1', message_geometry_to_human=True),
                             'none', 41),
