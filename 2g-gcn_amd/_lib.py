@@ -63,7 +63,7 @@ class AttnBwd(C.Structure):  # twog_attn_bwd_t
     _fields_ = [('f', Attn), ('dout_hh', Rows), ('dout_oh', Rows), ('dout_sh', Rows), ('dout_ho', Rows),
                 ('dout_so', Rows), ('dout_oo', Rows), ('dmsg_hh', Rows), ('dmsg_ho', Rows), ('dmsg_oh', Rows),
                 ('dmsg_oo', Rows), ('dmsg_so', Rows), ('dmsg_sh', Rows), ('dfeat_h', Rows), ('dfeat_o', Rows),
-                ('dfeat_accumulate', C.c_int32), ('relu_mask_dmsg', C.c_int32)]
+                ('dw_extra', C.c_void_p), ('dfeat_accumulate', C.c_int32), ('relu_mask_dmsg', C.c_int32)]
 
 
 class SegRnn(C.Structure):  # twog_segrnn_t
@@ -160,6 +160,8 @@ SIGNATURES = {
     'twog_relation_limits': [],
     'twog_relation_fwd': [C.POINTER(Relation), _P],
     'twog_relation_bwd': [C.POINTER(RelationBwd), _P],
+    'twog_ssp_fwd': [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    'twog_ssp_bwd': [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     'twog_gate_fwd': [C.POINTER(Gate), _P],
     'twog_gate_bwd': [C.POINTER(Gate), _P, _P, _P, _P, _P],
     'twog_rank1_update': [Rows, _P, _P, _I, _I, _P],

@@ -320,7 +320,7 @@ __global__ __launch_bounds__(1024) void attn_bwd_kernel(const BwdGroup g) {
             const int q = p - H * H - 2 * H * O, r = q / O, s = q - r * O;
             if (m_oo.on() && r != s) v = wave_dot(d_oo.row(r), m_oo.row(s), hid, lane);
         }
-        if (lane == 0) sdW[p] = v;
+        if (lane == 0) sdW[p] = B.dw_extra ? v + B.dw_extra[(int64_t)inst * natt + p] : v;
     }
     __syncthreads();
     // softmax backward per receiver: dscore = w * (dw - sum_s w dw) * scale

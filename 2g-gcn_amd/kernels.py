@@ -288,6 +288,7 @@ class HipKernels:
             for k in ['dout_hh', 'dout_oh', 'dout_sh', 'dout_ho', 'dout_so', 'dout_oo', 'dmsg_hh', 'dmsg_ho',
                       'dmsg_oh', 'dmsg_oo', 'dmsg_so', 'dmsg_sh', 'dfeat_h', 'dfeat_o']:
                 setattr(arr[i], k, rows_of(d.get(k)))
+            arr[i].dw_extra = _ptr(d.get('dw_extra'))
             arr[i].dfeat_accumulate = int(d.get('dfeat_accumulate', 0))
             arr[i].relu_mask_dmsg = int(d.get('relu_mask_dmsg', 0))
         self._check(self.lib.twog_attn_bwd(arr, n, self._stream()), 'twog_attn_bwd')
@@ -468,6 +469,27 @@ class HipKernels:
     def add_rows(self, src, dst):
         self._check(self.lib.twog_add_rows(rows_of(src), rows_of(dst), n_rows(src), src.shape[-1], self._stream()),
                     'twog_add_rows')
+
+    # ---------------------------------------------------------------- sender-side projection glue
+    def ssp_fwd(self, gi, ph, ps, att, mask, n_inst, inst_per_clip, H, O, att_off):
+        """gi (n_inst*O, cols) += mask * (sum_h att[k,h] ph[(inst,h)] + ps[inst]); ph (n_inst*H, cols), ps (n_inst, cols)."""
+        cols = gi.shape[-1]
+        assert gi.is_contiguous() and (ph is None or ph.is_contiguous()) and (ps is None or ps.is_contiguous())
+        natt = att.shape[-1] if att is not None else 0
+        self._check(self.lib.twog_ssp_fwd(gi.data_ptr(), _ptr(ph), _ptr(ps), _ptr(att), _ptr(mask), n_inst, inst_per_clip,
+                                          H, O, cols, natt, att_off, self._stream()), 'twog_ssp_fwd')
+
+    def ssp_bwd(self, dgi, ph, att, mask, n_inst, inst_per_clip, H, O, att_off, want_qs, dw=None):
+        """Returns (qh (n_inst*H, cols) or None, qs (n_inst, cols) or None); fills dw[:, att_off : att_off + O*H] if given."""
+        cols = dgi.shape[-1]
+        assert dgi.is_contiguous() and (ph is None or ph.is_contiguous())
+        qh = torch.empty(n_inst * H, cols, dtype=torch.float32, device=dgi.device) if ph is not None else None
+        qs = torch.empty(n_inst, cols, dtype=torch.float32, device=dgi.device) if want_qs else None
+        natt = att.shape[-1] if att is not None else 0
+        self._check(self.lib.twog_ssp_bwd(dgi.data_ptr(), _ptr(ph), _ptr(att), _ptr(mask), _ptr(qh), _ptr(qs), _ptr(dw),
+                                          n_inst, inst_per_clip, H, O, cols, natt, att_off, self._stream()),
+                    'twog_ssp_bwd')
+        return qh, qs
 
     # ---------------------------------------------------------------- general single-relation message passing
     REL_SUM, REL_DOT, REL_ADDITIVE, REL_DISTANCE, REL_MEAN = (L.REL_SUM, L.REL_DOT, L.REL_ADDITIVE, L.REL_DISTANCE,

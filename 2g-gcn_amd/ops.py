@@ -134,6 +134,24 @@ class Plan:
         return (self.relational or self.specific or
                 (not self.mean_pool and (self.att_style != 'dot' or self.dists is not None)))
 
+    def ssp_blocks(self):
+        """Sender-side projection (ssp.hip): the human->object and geometry->object message blocks of the objects'
+        GRUCell input are linear in the H + 1 senders of a frame, so W_ih is applied to the SENDERS' messages and the
+        result is scattered over the O receivers with the attention weights. Returns the (first, end) columns of those
+        blocks in the object rows -- they sit side by side right behind h_f -- or None when the form does not apply
+        (general message forms keep their own layout; no gain unless there are fewer senders than receivers)."""
+        import os
+        if self.general_frame() or self.O == 0 or os.environ.get('TWOG_NO_SSP'):
+            return None
+        n = int(self.rel_ho and self.H < self.O) + int(self.rel_so)
+        if n == 0 or (self.rel_ho and self.rel_so and not self.H < self.O):
+            return None
+        # ho only counts when it pays; with both relations on both blocks move together (they are adjacent)
+        first = self.col_o['ho'] if (self.rel_ho and self.H < self.O) else self.col_o['so']
+        if self.rel_ho and not (self.H < self.O):
+            return None if not self.rel_so else (self.col_o['so'], self.col_o['so'] + self.h)
+        return first, first + n * self.h
+
     # gate input column blocks, in the reference's weight order
     def gate_cols_h(self):  # [x, h, m_hh, m_oh, m_sh, x_time]  (models.py:1494)
         return [0, self.h] + [self.col_h[r] for r in ('hh', 'oh', 'sh', 'time_u') if r in self.col_h]
@@ -736,13 +754,39 @@ def tggcn_forward(K, plan: Plan, P, x_human, x_objects, objects_mask, human_seg,
     cells = {('h', 0): 'human_segment_rnn_fcell', ('h', 1): 'human_segment_rnn_bcell',
              ('o', 0): 'object_segment_rnn_fcell', ('o', 1): 'object_segment_rnn_bcell'}
     gi_h, gi_o = empty(bs, T, H, 6 * h), empty(bs, T, O, 6 * h)
-    probs = []
+    ssp = p.ssp_blocks()
+    probs, probs2, probs_s = [], [], []
     for kind, gi, Ev, fw in (('h', gi_h, HUMv, p.fw_h), ('o', gi_o, OBJv, p.fw_o)):
         for d in range(2):
             c = cells[(kind, d)]
-            probs.append(dict(A=Ev[:, h:h + fw], B=P[c + '.weight_ih'][:, :fw], C=_v2(gi)[:, d * 3 * h:(d + 1) * 3 * h],
-                              bias=P[c + '.bias_ih']))
+            w_ih, Cd = P[c + '.weight_ih'], _v2(gi)[:, d * 3 * h:(d + 1) * 3 * h]
+            if kind == 'h' or ssp is None:
+                probs.append(dict(A=Ev[:, h:h + fw], B=w_ih[:, :fw], C=Cd, bias=P[c + '.bias_ih']))
+                continue
+            # objects with sender-side projection: the window [h, h + fw) minus the blocks [c0, c1)
+            c0, c1 = ssp
+            probs.append(dict(A=Ev[:, h:c0], B=w_ih[:, :c0 - h], C=Cd, bias=P[c + '.bias_ih']))
+            if c1 < h + fw:
+                probs2.append(dict(A=Ev[:, c1:h + fw], B=w_ih[:, c1 - h:fw], C=Cd, accumulate=True))
     K.gemm(probs)
+    K.gemm(probs2)
+    if ssp is not None:
+        c0, c1 = ssp
+        ho_on = p.rel_ho and p.col_o['ho'] >= c0 and p.col_o['ho'] < c1
+        so_on = p.rel_so and p.col_o['so'] >= c0 and p.col_o['so'] < c1
+        ph = empty(nF * H, 6 * h) if ho_on else None
+        ps = empty(nF, 6 * h) if so_on else None
+        for d in range(2):
+            w_ih = P[cells[('o', d)] + '.weight_ih']
+            if ho_on:
+                cc = p.col_o['ho'] - h
+                probs_s.append(dict(A=msgv(MSGH, p.snd_h, 'ho'), B=w_ih[:, cc:cc + h], C=ph[:, d * 3 * h:(d + 1) * 3 * h]))
+            if so_on:
+                cc = p.col_o['so'] - h
+                probs_s.append(dict(A=msgv(MSGS, p.snd_s, 'so'), B=w_ih[:, cc:cc + h], C=ps[:, d * 3 * h:(d + 1) * 3 * h]))
+        K.gemm(probs_s)
+        K.ssp_fwd(_v2(gi_o), ph, ps, att, objects_mask, nF, T, H, O, H * H + H * O)
+        S['ssp'] = dict(ph=ph, ho_on=ho_on, so_on=so_on)
     seg_p = dict(bs=bs, T=T, H=H, O=O, hidden=h, msg_segment=p.msg_segment, rel_hh=p.rel_hh and p.msg_segment,
                  rel_ho=p.rel_ho and p.msg_segment, rel_oh=p.rel_oh and p.msg_segment,
                  rel_oo=p.rel_oo and p.msg_segment, att_scale=p.scale_seg, gi_h=gi_h, gi_o=gi_o, u_h=u_h, u_o=u_o,
@@ -903,7 +947,33 @@ def tggcn_backward(K, plan: Plan, P, S, x_human, x_objects, objects_mask, d_outp
             dgi_d = dgiv[:, d * 3 * h:(d + 1) * 3 * h]
             w_ih = P[c + '.weight_ih']
             dW_ih = empty(*w_ih.shape)
-            K.gemm([dict(A=dgi_d, B=Ev[:, h:h + fw], C=dW_ih[:, :fw])], a_kmajor=True, b_kmajor=True)
+            ssp = p.ssp_blocks() if kind == 'o' else None
+            if ssp is None:
+                K.gemm([dict(A=dgi_d, B=Ev[:, h:h + fw], C=dW_ih[:, :fw])], a_kmajor=True, b_kmajor=True)
+            else:
+                # sender-side projection (see forward): the receivers' rows only for the blocks outside [c0, c1); the
+                # sender blocks reduce over the H + 1 sender rows of every frame, weighted sums qh / qs of d_gi
+                c0, c1 = ssp
+                sx = S['ssp']
+                if d == 0:
+                    dw_extra = zeros(nF, S['att'].shape[-1])
+                    qh, qs = K.ssp_bwd(dgiv, sx['ph'], S['att'], objects_mask, nF, T, H, O, H * H + H * O, sx['so_on'],
+                                       dw=dw_extra)
+                    sx.update(qh=qh, qs=qs, dw_extra=dw_extra,
+                              dmsg_ho=zeros(nF * H, h) if sx['ho_on'] else None, dmsg_so=zeros(nF, h) if sx['so_on'] else None)
+                K.gemm([dict(A=dgi_d, B=Ev[:, h:c0], C=dW_ih[:, :c0 - h])], a_kmajor=True, b_kmajor=True)
+                if c1 < h + fw:
+                    K.gemm([dict(A=dgi_d, B=Ev[:, c1:h + fw], C=dW_ih[:, c1 - h:fw])], a_kmajor=True, b_kmajor=True)
+                for on, q, msgs, rel, dm in ((sx['ho_on'], sx['qh'], S['MSGH'], 'ho', sx['dmsg_ho']),
+                                             (sx['so_on'], sx['qs'], S['MSGS'], 'so', sx['dmsg_so'])):
+                    if not on:
+                        continue
+                    rels = p.snd_h if rel == 'ho' else p.snd_s
+                    i_ = rels.index(rel)
+                    cc = p.col_o[rel] - h
+                    q_d = q[:, d * 3 * h:(d + 1) * 3 * h]
+                    K.gemm([dict(A=q_d, B=msgs[:, i_ * h:(i_ + 1) * h], C=dW_ih[:, cc:cc + h])], a_kmajor=True, b_kmajor=True)
+                    K.gemm([dict(A=q_d, B=w_ih[:, cc:cc + h], C=dm, accumulate=True)], b_kmajor=True)
             if w_ih.shape[1] > fw:
                 K.gemm([dict(A=dgi_d, B=_v2(mg[d]), C=dW_ih[:, fw:])], a_kmajor=True, b_kmajor=True)
             G.add(c + '.weight_ih', dW_ih)
@@ -924,7 +994,12 @@ def tggcn_backward(K, plan: Plan, P, S, x_human, x_objects, objects_mask, d_outp
             G.add(c + '.weight_hh', dW_hh)
             G.add(c + '.bias_hh', K.colsum(dghv[:, d * 3 * h:(d + 1) * 3 * h]))
             # d xx (frame-level part of the GRUCell input) -> entity-row gradient columns [h, h+fw)
-            K.gemm([dict(A=dgi_d, B=w_ih[:, :fw], C=dEv[:, h:h + fw], accumulate=True)], b_kmajor=True)
+            if ssp is None:
+                K.gemm([dict(A=dgi_d, B=w_ih[:, :fw], C=dEv[:, h:h + fw], accumulate=True)], b_kmajor=True)
+            else:
+                K.gemm([dict(A=dgi_d, B=w_ih[:, :c0 - h], C=dEv[:, h:c0], accumulate=True)], b_kmajor=True)
+                if c1 < h + fw:
+                    K.gemm([dict(A=dgi_d, B=w_ih[:, c1 - h:fw], C=dEv[:, c1:h + fw], accumulate=True)], b_kmajor=True)
     if p.msg_segment:
         sh_rel, so_rel = S['seg_rels']
         for rels, E, dpre, HS, key in ((sh_rel, H, so['d_pre_h'], sb['hs_h'], 'h'), (so_rel, O, so['d_pre_o'], sb['hs_o'], 'o')):
@@ -1087,7 +1162,17 @@ def tggcn_backward(K, plan: Plan, P, S, x_human, x_objects, objects_mask, d_outp
             bdesc['dout_' + rel] = dHUMv[:, c:c + h]
         for rel, c in p.col_o.items():
             bdesc['dout_' + rel] = dOBJv[:, c:c + h]
+        sx = S.get('ssp')
+        if sx is not None:
+            bdesc['dw_extra'] = sx['dw_extra']   # d(loss)/d(att) through the sender-side projection (section F)
         K.attn_bwd([bdesc])
+        if sx is not None:
+            # ... and its share of the sender messages' gradient, through the message MLP's ReLU like the kernel's own
+            for on, rel, dm, msgs, dbuf, rels in ((sx['ho_on'], 'ho', sx['dmsg_ho'], MSGH, dMSGH, p.snd_h),
+                                                  (sx['so_on'], 'so', sx['dmsg_so'], MSGS, dMSGS, p.snd_s)):
+                if on:
+                    K.relu_bwd(dm, msgv(msgs, rels, rel), dm)
+                    K.add_rows(dm, msgv(dbuf, rels, rel))
         for dbuf, Ev, dEv, rels in ((dMSGH, HUMv, dHUMv, p.snd_h), (dMSGO, OBJv, dOBJv, p.snd_o), (dMSGS, GEOv, dGEOv, p.snd_s)):
             for i, rel in enumerate(rels):
                 dpre = dbuf[:, i * h:(i + 1) * h]

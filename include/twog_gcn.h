@@ -199,6 +199,8 @@ typedef struct {
     twog_rows_t dout_hh, dout_oh, dout_sh, dout_ho, dout_so, dout_oo; /* incoming gradients wrt out_*         */
     twog_rows_t dmsg_hh, dmsg_ho, dmsg_oh, dmsg_oo, dmsg_so, dmsg_sh; /* out: gradient wrt sender messages    */
     twog_rows_t dfeat_h, dfeat_o; /* out: gradient wrt features [..][D]                                       */
+    const float* dw_extra;        /* optional [n_inst][natt]: added to dL/d(weights) before the softmax backward (the
+                                     part of the gradient that reaches the weights outside this kernel: twog_ssp_bwd) */
     int32_t dfeat_accumulate;     /* 1: dfeat += */
     int32_t relu_mask_dmsg;       /* 1: dmsg *= (msg > 0), i.e. gradient wrt the pre-ReLU activation of the message MLP */
 } twog_attn_bwd_t;
@@ -293,6 +295,21 @@ int twog_seglen_bwd(const float* u, const float* steps, int bs, int T, int E, in
                     void* stream);
 int twog_mul(const float* a, const float* b, float* out, int64_t n, int accumulate, void* stream);
 int twog_scale_rows(twog_rows_t x, const float* s, int rows, int cols, void* stream);
+
+/* ===============================================================================================================
+ * Sender-side projection of aggregated messages. The objects' segment-level GRUCells read
+ * cat[h_f, m_ho, m_so, m_oo] (vhoi/models.py:748) through W_ih; m_ho[k] = mask_k sum_h att[k][h] msg_h (:1099-1143, :720)
+ * and m_so[k] = mask_k msg_s (:1384-1429, :729) are linear in the senders' messages, so the caller projects the H + 1
+ * sender rows of a frame (GEMM) and these kernels scatter / gather them over the O receivers:
+ *   fwd: gi[(inst,k)][:] += mask[clip][k] * ( sum_h att[inst][att_off + k*H + h] * ph[(inst,h)][:] + ps[inst][:] )
+ *   bwd: qh[(inst,h)][:] = sum_k mask_k att[k][h] dgi[(inst,k)][:]   qs[inst][:] = sum_k mask_k dgi[(inst,k)][:]
+ *        dw[inst][att_off + k*H + h] = mask_k <dgi[(inst,k)], ph[(inst,h)]>   (feeds twog_attn_bwd's dw_extra)
+ * ph / ps / qh / qs may be NULL (relation off). cols % 4 == 0, H <= 4, O <= 16.
+ * =============================================================================================================== */
+int twog_ssp_fwd(float* gi, const float* ph, const float* ps, const float* att, const float* mask, int n_inst,
+                 int inst_per_clip, int H, int O, int cols, int natt, int att_off, void* stream);
+int twog_ssp_bwd(const float* dgi, const float* ph, const float* att, const float* mask, float* qh, float* qs, float* dw,
+                 int n_inst, int inst_per_clip, int H, int O, int cols, int natt, int att_off, void* stream);
 
 /* ===============================================================================================================
  * General message passing of ONE relation (receiver set R, sender set S per instance): the message / aggregation forms

@@ -280,6 +280,11 @@ class FakeKernels:
             sc = d['scale']
             dfh = torch.zeros_like(fh)
             dfo = torch.zeros_like(fo)
+            dwx, ox = {}, 0
+            for r, (R, S_) in (('hh', (H, H)), ('oh', (H, O)), ('ho', (O, H)), ('oo', (O, O))):
+                if b.get('dw_extra') is not None:
+                    dwx[r] = b['dw_extra'].reshape(n, -1)[:, ox:ox + R * S_].reshape(n, R, S_)
+                ox += R * S_
 
             def one(rel, R, S_, recv_scale, fq, fk, dfq, dfk):
                 msg = d.get('msg_' + rel)
@@ -294,6 +299,8 @@ class FakeKernels:
                     dmsg = dmsg * (msgs > 0)
                 b['dmsg_' + rel].copy_(dmsg.reshape(b['dmsg_' + rel].shape))
                 dw = g @ msgs.transpose(1, 2)
+                if rel in dwx:
+                    dw = dw + dwx[rel]
                 ds = w[rel] * (dw - (w[rel] * dw).sum(-1, keepdim=True)) * sc
                 dfq += ds @ fk
                 dfk += ds.transpose(1, 2) @ fq
@@ -535,6 +542,32 @@ class FakeKernels:
 
     def add_rows(self, src, dst):
         dst.add_(src.reshape(dst.shape))
+
+    # ------------------------------------------------------------------ sender-side projection glue
+    def ssp_fwd(self, gi, ph, ps, att, mask, n_inst, inst_per_clip, H, O, att_off):
+        cols = gi.shape[-1]
+        m = (mask.repeat_interleave(inst_per_clip, 0) if mask is not None else torch.ones(n_inst, O)).view(n_inst, O, 1)
+        add = torch.zeros(n_inst, O, cols)
+        if ph is not None:
+            w = att[:, att_off:att_off + O * H].view(n_inst, O, H)
+            add = add + torch.einsum('nkh,nhc->nkc', w, ph.view(n_inst, H, cols))
+        if ps is not None:
+            add = add + ps.view(n_inst, 1, cols)
+        gi.add_((m * add).view(gi.shape))
+
+    def ssp_bwd(self, dgi, ph, att, mask, n_inst, inst_per_clip, H, O, att_off, want_qs, dw=None):
+        cols = dgi.shape[-1]
+        m = (mask.repeat_interleave(inst_per_clip, 0) if mask is not None else torch.ones(n_inst, O)).view(n_inst, O, 1)
+        g = dgi.view(n_inst, O, cols) * (m != 0).float()
+        qh = qs = None
+        if ph is not None:
+            w = att[:, att_off:att_off + O * H].view(n_inst, O, H)
+            qh = torch.einsum('nkh,nkc->nhc', w, g).reshape(n_inst * H, cols)
+            if dw is not None:
+                dw[:, att_off:att_off + O * H] = torch.einsum('nkc,nhc->nkh', g, ph.view(n_inst, H, cols)).reshape(n_inst, O * H)
+        if want_qs:
+            qs = g.sum(1)
+        return qh, qs
 
     # ------------------------------------------------------------------ general single-relation message passing
     REL_SUM, REL_DOT, REL_ADDITIVE, REL_DISTANCE, REL_MEAN = 0, 1, 2, 3, 4

@@ -73,16 +73,26 @@ def test_full_forward_backward_vs_reference(name, fake_backend):
         assert np.abs(g - g_ref).max() < 3e-4 * scale + 2e-6, (pname, float(np.abs(g - g_ref).max()), float(scale))
 
 
-def test_select_model_and_errors():
+def test_select_model_and_errors(fake_backend):
     assert select_model('2G-GCN') is TGGCN
     with pytest.raises(KeyError):
         select_model('nope')
     with pytest.raises(ValueError):
         TGGCN(input_size=(2152, 2048), num_classes=(13, None), hidden_size=8, discrete_optimization_strategy='bogus',
               message_type='v2', message_granularity='v1', attention_style='v3')
-    m = TGGCN(input_size=(2152, 2048), num_classes=(13, None), hidden_size=8)  # reference defaults: relational/concat
+    # a bare TGGCN(input_size, num_classes) -- the reference's constructor defaults (relational messages, frame level
+    # only) -- runs; the golden case c2_ctor_defaults pins its numbers
+    m = TGGCN(input_size=(2152, 2048), num_classes=(13, None), hidden_size=8)
+    out = m(torch.rand(1, 2, 2, 2152), torch.rand(1, 2, 4, 2048), torch.ones(1, 4))
+    assert len(out) == 6 and all(torch.isfinite(o).all() for o in out)
+    # what is still outside the HIP path says so loudly (no silent fallback): segment-level messages in the general forms
+    m = TGGCN(input_size=(2152, 2048), num_classes=(13, None), hidden_size=8, message_segment=True)
     with pytest.raises(NotImplementedError):
         m(torch.zeros(1, 2, 2, 2152), torch.zeros(1, 2, 4, 2048), torch.ones(1, 4))
+    with pytest.raises(AttributeError):   # 'same_as_human' with two humans: the reference never built that MLP either
+        TGGCN(input_size=(2152, 2048), num_classes=(13, None), hidden_size=8, message_type='v2', message_granularity='v1',
+              attention_style='v3', object_segment_update_strategy='sah')(
+            torch.zeros(1, 2, 2, 2152), torch.zeros(1, 2, 4, 2048), torch.ones(1, 4))
 
 
 def test_eval_mode_uses_running_stats(fake_backend):

@@ -828,3 +828,68 @@ def test_relation_self_relation_accumulates_both_feature_gradients(K):
     (oc, gc), (og, gg) = run(F, 'cpu'), run(K, DEV)
     close(og, oc, what='out')
     close(gg, gc, rtol=2e-4, atol=2e-5, what='dq + dk into one buffer')
+
+
+# ------------------------------------------------------------------------------------ sender-side projection glue
+@pytest.mark.parametrize('H,O,ph_on,ps_on', [(2, 8, True, True), (1, 5, True, False), (2, 4, False, True), (3, 9, True, True)])
+def test_sender_side_projection_kernels(K, H, O, ph_on, ps_on):
+    n_inst, ipc, cols = 12, 4, 96
+    natt = H * H + 2 * H * O + O * O
+    off = H * H + H * O
+    att = torch.softmax(rnd(n_inst, natt, seed=1), -1)
+    mask = (rnd(n_inst // ipc, O, seed=2) > -0.5).float()
+    mask[0] = 0
+    gi = rnd(n_inst * O, cols, seed=3)
+    ph = rnd(n_inst * H, cols, seed=4) if ph_on else None
+    ps = rnd(n_inst, cols, seed=5) if ps_on else None
+    dv = lambda t: None if t is None else t.to(DEV)
+    gc, gg = gi.clone(), gi.clone().to(DEV)
+    F.ssp_fwd(gc, ph, ps, att, mask, n_inst, ipc, H, O, off)
+    K.ssp_fwd(gg, dv(ph), dv(ps), att.to(DEV), mask.to(DEV), n_inst, ipc, H, O, off)
+    close(gg, gc, what='ssp fwd')
+    # the scatter equals projecting the aggregated messages: gi += mask * (att @ ph + ps)
+    dgi = rnd(n_inst * O, cols, seed=6)
+    dwc, dwg = torch.zeros(n_inst, natt), torch.zeros(n_inst, natt, device=DEV)
+    qhc, qsc = F.ssp_bwd(dgi, ph, att, mask, n_inst, ipc, H, O, off, ps_on, dw=dwc)
+    qhg, qsg = K.ssp_bwd(dgi.to(DEV), dv(ph), att.to(DEV), mask.to(DEV), n_inst, ipc, H, O, off, ps_on, dw=dwg)
+    if ph_on:
+        close(qhg, qhc, what='qh')
+        close(dwg, dwc, rtol=1e-4, atol=1e-5, what='dw')
+    if ps_on:
+        close(qsg, qsc, what='qs')
+    # adjointness: <ssp_fwd(0; ph, ps), dgi> == <ph, qh> + <ps, qs>
+    z = torch.zeros(n_inst * O, cols)
+    F.ssp_fwd(z, ph, ps, att, mask, n_inst, ipc, H, O, off)
+    lhs = (z * dgi).sum()
+    rhs = ((ph * qhc).sum() if ph_on else 0.0) + ((ps * qsc).sum() if ps_on else 0.0)
+    assert abs(float(lhs - rhs)) < 1e-3 * max(1.0, abs(float(lhs)))
+
+
+def test_attention_backward_takes_extra_weight_gradient(K):
+    H, O, D, h, n_inst, ipc = 2, 4, 64, 32, 6, 3
+    dc = _attn_case('cpu', H, O, D, h, n_inst, ipc, True, 1)
+    dg = _attn_case(DEV, H, O, D, h, n_inst, ipc, True, 1)
+    F.attn_fwd([dc])
+    K.attn_fwd([dg])
+    natt = H * H + 2 * H * O + O * O
+    extra = rnd(n_inst, natt, seed=77)
+
+    def bwd(dev, d):
+        t = lambda *s, sd=0: rnd(*s, seed=100 + sd).to(dev)
+        b = dict(f=d, dfeat_accumulate=0, relu_mask_dmsg=1, dfeat_h=torch.zeros(n_inst * H, D, device=dev),
+                 dfeat_o=torch.zeros(n_inst * O, D, device=dev), dw_extra=extra.to(dev))
+        for i, (rel, R) in enumerate((('hh', H), ('oh', H), ('ho', O), ('oo', O), ('so', O), ('sh', H))):
+            b['dout_' + rel] = t(n_inst * R, h, sd=10 + i)
+            S_ = {'hh': H, 'ho': H, 'oh': O, 'oo': O, 'so': 0, 'sh': 0}[rel]
+            b['dmsg_' + rel] = torch.zeros(n_inst * S_ if S_ else n_inst, h, device=dev)
+        return b
+
+    bc, bg = bwd('cpu', dc), bwd(DEV, dg)
+    F.attn_bwd([bc])
+    K.attn_bwd([bg])
+    for k in ('dfeat_h', 'dfeat_o', 'dmsg_ho', 'dmsg_oo'):
+        close(bg[k], bc[k], rtol=2e-4, atol=2e-5, what=k)
+    b0 = bwd('cpu', dc)
+    b0['dw_extra'] = None
+    F.attn_bwd([b0])
+    assert float((b0['dfeat_h'] - bc['dfeat_h']).abs().max()) > 1e-4   # the extra term does reach the features
