@@ -314,6 +314,7 @@ static int segrnn_bwd_impl(const twog_segrnn_t* desc, const twog_segrnn_bwd_t* b
             // at the chain start the features are the constant zero state: its gradient is dropped
             X.dfeat_h = rows_plain((first ? B.trash : B.carry_h + (int64_t)dir * d.bs * d.H * h), h);
             X.dfeat_o = rows_plain((first ? B.trash : B.carry_o + (int64_t)dir * d.bs * d.O * h), h);
+            X.dw_extra = nullptr;
             X.dfeat_accumulate = first ? 0 : 1;
             X.relu_mask_dmsg = 1;
         }
