@@ -89,8 +89,23 @@ class GemmProfiler:
 
     def __init__(self, K):
         self.K, self.orig, self.records, self.shapes = K, K.gemm, [], []
+        self.orig_attn = (K.attn_fwd, K.attn_bwd)
+        self.attn = {'fwd': [], 'bwd': []}   # HIP events around the frame-level attention launches
 
     def __enter__(self):
+        def timed(kind, fn):
+            def call(descs):
+                d = descs[0] if kind == 'fwd' else descs[0]['f']
+                if d['inst_per_clip'] <= 1:          # (segment-level calls happen inside the library's time loop)
+                    return fn(descs)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                fn(descs)
+                e1.record()
+                self.attn[kind].append((e0, e1))
+            return call
+        self.K.attn_fwd, self.K.attn_bwd = timed('fwd', self.orig_attn[0]), timed('bwd', self.orig_attn[1])
+
         def gemm(problems, a_kmajor=False, b_kmajor=False, split_k_workspace=True):
             from twog_gcn_amd.kernels import n_rows
             flops, abytes, tiles128, kmax, wide = 0.0, 0.0, 0, 0, True
@@ -116,6 +131,12 @@ class GemmProfiler:
 
     def __exit__(self, *a):
         self.K.gemm = self.orig
+        self.K.attn_fwd, self.K.attn_bwd = self.orig_attn
+
+    def attn_ms(self, kind):
+        torch.cuda.synchronize()
+        ev = self.attn[kind]
+        return sum(a.elapsed_time(b) for a, b in ev) / max(len(ev), 1) if ev else None
 
     def detail(self, steps):
         """Per distinct launch signature: calls per step, average time, TFLOP/s (TWOG_BENCH_GEMM_DETAIL=1)."""
@@ -378,6 +399,18 @@ def main():
         torch.cuda.synchronize()
         gcn_ms = e0.elapsed_time(e1) / 10
     gcn_bytes = bs * T * (16 * N_NODES + 512 * N_NODES)
+    # frame-level message attention (the other HBM-bound kernel pair of SURVEY 8d): algorithmic bytes per clip, fp32, each
+    # tensor once. Forward, SURVEY's figure: read the entity features [x, h] (4 T E 2h), write every receiver's message
+    # block (4 T (2H + 3O) h); the sender messages the kernel also has to read (4 T (2H + 2O + 1) h) are reported beside
+    # it. Backward: read d(received blocks) + features + sender messages, write d(sender messages), read-modify-write
+    # d(features).
+    hh_ = CFG['hidden_size']
+    E_ = H + O + 1
+    att_feat, att_out, att_msg = 4 * T * (H + O) * 2 * hh_, 4 * T * (2 * H + 3 * O) * hh_, 4 * T * (2 * H + 2 * O + 1) * hh_
+    att_fwd_bytes = bs * (4 * T * E_ * 2 * hh_ + att_out)
+    att_fwd_bytes_all = bs * (att_feat + att_out + att_msg)
+    att_bwd_bytes = bs * (att_out + att_feat + att_msg + att_msg + 2 * att_feat)
+    att_fwd_ms, att_bwd_ms = prof.attn_ms('fwd'), prof.attn_ms('bwd')
 
     fwd_only = None
     if True:  # forward-only clips/s is part of every line (north star: ">= 50x the reference CPU forward")
@@ -428,6 +461,18 @@ def main():
                              'algorithmic_bytes_per_batch': gcn_bytes,
                              'note': 'fp32 MFMA floor of this block (2.41 MFLOP/frame at 157.3 TFLOP/s) = 0.118 ms per bs64 '
                                      'batch, above its HBM floor (0.017 ms)'},
+            'roofline_attn_fwd': None if not att_fwd_ms else {
+                'bound': 'hbm', 'kernel': 'attn_fwd_kernel (frame level: 4 relations + geometry, one launch)',
+                'achieved': att_fwd_bytes / (att_fwd_ms * 1e-3) / 1e9, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
+                'frac': att_fwd_bytes / (att_fwd_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 'ms_per_launch': att_fwd_ms,
+                'algorithmic_bytes_per_launch': att_fwd_bytes,
+                'bytes_incl_sender_messages': att_fwd_bytes_all,
+                'achieved_incl_sender_messages': att_fwd_bytes_all / (att_fwd_ms * 1e-3) / 1e9},
+            'roofline_attn_bwd': None if not att_bwd_ms else {
+                'bound': 'hbm', 'kernel': 'attn_bwd_kernel (frame level)',
+                'achieved': att_bwd_bytes / (att_bwd_ms * 1e-3) / 1e9, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
+                'frac': att_bwd_bytes / (att_bwd_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 'ms_per_launch': att_bwd_ms,
+                'algorithmic_bytes_per_launch': att_bwd_bytes},
             'gemm_classes': {k: {'tflops': (v[0] / v[1] / 1e12 if v[1] else 0.0), 'ms_per_step': v[1] / args.steps * 1e3,
                                  'launches_per_step': v[2] / args.steps} for k, v in agg.items()},
             'host_gemm_share_of_step': total_gemm_s / dt,
