@@ -53,43 +53,6 @@ __device__ __forceinline__ void stage_rowset(RowSet& rs, int n, int width, float
     cursor += n * width;
 }
 
-// Batched staging for the latency regime: several row sets are copied into LDS with ALL their global loads in flight
-// at once. Copying set after set (stage_rowset) makes every set pay its own memory latency -- each LDS store waits for
-// its load before the next set's loads are even issued -- which dominated the segment-level launches (5 to 12 sets of
-// a few KB each per workgroup). Here a small table of (source row, destination) pairs is built in LDS first; then every
-// thread fetches up to STAGE_ITERS 16-byte pieces into registers back to back and stores them afterwards.
-constexpr int STAGE_ROWS_MAX = 96;   // >= 2 MAX_H + 2 MAX_O + 2 message rows + 3 MAX_H + 3 MAX_O gradient rows
-constexpr int STAGE_ITERS = 8;     // 1024 threads x 8 x 16 B = 128 KB per pass
-struct StageTable {
-    const float* src[STAGE_ROWS_MAX];
-    int dst[STAGE_ROWS_MAX];   // offset (floats) from the staging base
-    int n, width;
-};
-// tbl lives in LDS; n_rows is uniform (passed separately so that non-zero threads need not read it before the barrier)
-__device__ __forceinline__ void stage_run(const StageTable& tbl, int n_rows, float* base) {
-    __syncthreads();   // table complete
-    const int w4 = tbl.width >> 2, total = n_rows * w4;
-    for (int start = 0; start < total; start += STAGE_ITERS * blockDim.x) {
-        float4 v[STAGE_ITERS];
-#pragma unroll
-        for (int it = 0; it < STAGE_ITERS; ++it) {
-            const int i = start + it * blockDim.x + threadIdx.x;
-            if (i < total) {
-                const int r = i / w4, c = (i - r * w4) * 4;
-                v[it] = *reinterpret_cast<const float4*>(tbl.src[r] + c);
-            }
-        }
-#pragma unroll
-        for (int it = 0; it < STAGE_ITERS; ++it) {
-            const int i = start + it * blockDim.x + threadIdx.x;
-            if (i < total) {
-                const int r = i / w4, c = (i - r * w4) * 4;
-                *reinterpret_cast<float4*>(base + tbl.dst[r] + c) = v[it];
-            }
-        }
-    }
-}
-
 // layout of the saved attention weights of one instance
 __device__ __forceinline__ int att_off_hh(int, int) { return 0; }
 __device__ __forceinline__ int att_off_oh(int H, int) { return H * H; }
@@ -178,57 +141,29 @@ __global__ __launch_bounds__(1024) void attn_fwd_kernel(const FwdGroup g) {
     const RowSet o_hh = rowset(A.out_hh, inst, H), o_oh = rowset(A.out_oh, inst, H), o_sh = rowset(A.out_sh, inst, H);
     const RowSet o_ho = rowset(A.out_ho, inst, O), o_so = rowset(A.out_so, inst, O), o_oo = rowset(A.out_oo, inst, O);
     if (threadIdx.x < O) sMask[threadIdx.x] = A.obj_mask ? A.obj_mask[(int64_t)clip * O + threadIdx.x] : 1.f;
-    // latency regime: the instance is shared by gridDim.z = 2 workgroups -- both compute the (cheap) weights, half 0
-    // produces the messages to humans and the human / geometry messages to objects, half 1 the object -> object ones
-    const int half = blockIdx.z, nhalf = gridDim.z;
-    const bool do01 = nhalf == 1 || half == 0, do23 = nhalf == 1 || half == 1;
-    if (g.staged) {
-        // the message rows: one batched copy, every load in flight together with the feature loads below
-        __shared__ StageTable tbl;
-        float* cur = sMask + MAX_O + 4;
-        cur = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(cur) + 15) & ~uintptr_t(15));
-        if (threadIdx.x == 0) { tbl.n = 0; tbl.width = hid; }
-        int off = 0, nrows = 0;
-        StageTable& T_ = tbl;
-        auto add = [&](RowSet& rs, int n) {
-            if (!rs.on()) return;
-            if (threadIdx.x == 0)
-                for (int r = 0; r < n; ++r) { T_.src[nrows + r] = rs.row(r); T_.dst[nrows + r] = off + r * hid; }
-            rs.base = cur + off;
-            rs.step = hid;
-            off += n * hid;
-            nrows += n;
-        };
-        if (do01) { add(m_hh, H); add(m_ho, H); add(m_oh, O); add(m_so, 1); add(m_sh, 1); }
-        if (do23) add(m_oo, O);
-        // features first (their loads do not depend on the table), then the table-driven copy: one latency for both
-        const int d4 = D >> 2;
-        float4 fv[4];
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int i = it * blockDim.x + threadIdx.x;
-            if (i < E * d4) {
-                const int e = i / d4, c = (i - e * d4) * 4;
-                fv[it] = *reinterpret_cast<const float4*>((e < H ? fh.row(e) : fo.row(e - H)) + c);
-            }
-        }
-        stage_run(tbl, nrows, cur);
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int i = it * blockDim.x + threadIdx.x;
-            if (i < E * d4) *reinterpret_cast<float4*>(sF + i * 4) = fv[it];
-        }
-        for (int i = 4 * blockDim.x + threadIdx.x; i < E * d4; i += blockDim.x) {   // (E * D > 16 K floats: rare)
-            const int e = i / d4, c = (i - e * d4) * 4;
-            *reinterpret_cast<float4*>(sF + e * D + c) = *reinterpret_cast<const float4*>((e < H ? fh.row(e) : fo.row(e - H)) + c);
-        }
-    } else {   // throughput regime: features -> LDS, messages streamed from global memory later
+    {   // features -> LDS
         const int d4 = D >> 2;
         for (int i = threadIdx.x; i < E * d4; i += blockDim.x) {
             const int e = i / d4, c = (i - e * d4) * 4;
             const float* src = e < H ? fh.row(e) : fo.row(e - H);
             *reinterpret_cast<float4*>(sF + e * D + c) = *reinterpret_cast<const float4*>(src + c);
         }
+    }
+    // latency regime: the instance is shared by gridDim.z = 2 workgroups -- both compute the (cheap) weights, half 0
+    // produces the messages to humans and the human / geometry messages to objects, half 1 the object -> object ones
+    const int half = blockIdx.z, nhalf = gridDim.z;
+    const bool do01 = nhalf == 1 || half == 0, do23 = nhalf == 1 || half == 1;
+    if (g.staged) {
+        float* cur = sMask + MAX_O + 4;
+        cur = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(cur) + 15) & ~uintptr_t(15));
+        if (do01) {
+            stage_rowset(m_hh, H, hid, cur);
+            stage_rowset(m_ho, H, hid, cur);
+            stage_rowset(m_oh, O, hid, cur);
+            stage_rowset(m_so, 1, hid, cur);
+            stage_rowset(m_sh, 1, hid, cur);
+        }
+        if (do23) stage_rowset(m_oo, O, hid, cur);
     }
     __syncthreads();
     compute_weights(A, sF, sG, sW, sMask);
@@ -349,30 +284,20 @@ __global__ __launch_bounds__(1024) void attn_bwd_kernel(const BwdGroup g) {
     for (int i = threadIdx.x; i < natt; i += blockDim.x) sW[i] = A.att[(int64_t)inst * natt + i];
     if (threadIdx.x < O) sMask[threadIdx.x] = A.obj_mask ? A.obj_mask[(int64_t)clip * O + threadIdx.x] : 1.f;
     if (g.staged) {
-        __shared__ StageTable tbl;
         float* cur = sMask + MAX_O + 4;
         cur = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(cur) + 15) & ~uintptr_t(15));
-        if (threadIdx.x == 0) { tbl.n = 0; tbl.width = hid; }
-        int off = 0, nrows = 0;
-        StageTable& T_ = tbl;
-        auto add = [&](RowSet& rs, int n) {
-            if (!rs.on()) return;
-            if (threadIdx.x == 0)
-                for (int r = 0; r < n; ++r) { T_.src[nrows + r] = rs.row(r); T_.dst[nrows + r] = off + r * hid; }
-            rs.base = cur + off;
-            rs.step = hid;
-            off += n * hid;
-            nrows += n;
-        };
-        const bool on_hh = m_hh.on(), on_oh = m_oh.on(), on_sh = m_sh.on(), on_ho = m_ho.on(), on_so = m_so.on(), on_oo = m_oo.on();
-        add(m_hh, H); add(m_ho, H); add(m_oh, O); add(m_oo, O); add(m_so, 1); add(m_sh, 1);
-        if (on_hh) add(d_hh, H);
-        if (on_oh) add(d_oh, H);
-        if (on_sh) add(d_sh, H);
-        if (on_ho) add(d_ho, O);
-        if (on_so) add(d_so, O);
-        if (on_oo) add(d_oo, O);
-        stage_run(tbl, nrows, cur);
+        stage_rowset(m_hh, H, hid, cur);
+        stage_rowset(m_ho, H, hid, cur);
+        stage_rowset(m_oh, O, hid, cur);
+        stage_rowset(m_oo, O, hid, cur);
+        stage_rowset(m_so, 1, hid, cur);
+        stage_rowset(m_sh, 1, hid, cur);
+        if (m_hh.on()) stage_rowset(d_hh, H, hid, cur);
+        if (m_oh.on()) stage_rowset(d_oh, H, hid, cur);
+        if (m_sh.on()) stage_rowset(d_sh, H, hid, cur);
+        if (m_ho.on()) stage_rowset(d_ho, O, hid, cur);
+        if (m_so.on()) stage_rowset(d_so, O, hid, cur);
+        if (m_oo.on()) stage_rowset(d_oo, O, hid, cur);
     }
     __syncthreads();
     // latency regime (gridDim.z = 2): half 0 produces the sender-message gradients, half 1 the feature gradients
@@ -538,7 +463,7 @@ inline size_t lds_bwd(const twog_attn_t& a, bool staged) {
     if (staged) f += (n_msg_rows(a) + n_dout_rows(a)) * a.hidden;
     return sizeof(float) * f;
 }
-constexpr size_t LDS_LIMIT = 158 * 1024;   // dynamic part; the kernels' static tables take the rest
+constexpr size_t LDS_LIMIT = 160 * 1024;
 
 // the rows of one instance must be equally strided: plain rows (inner <= 1) or exactly one outer group per instance
 inline bool rows_ok(const twog_rows_t& m, int n) { return !m.ptr || m.inner <= 1 || m.inner == n; }

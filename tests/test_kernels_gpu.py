@@ -895,3 +895,34 @@ def test_attention_backward_takes_extra_weight_gradient(K):
     b0['dw_extra'] = None
     F.attn_bwd([b0])
     assert float((b0['dfeat_h'] - bc['dfeat_h']).abs().max()) > 1e-4   # the extra term does reach the features
+
+
+def test_bigru_forward_graph_with_forked_type_branch(K):
+    """BASELINE-size BiGRU step (528 tiles for 512 workgroup slots): once the loop is captured, the geometry sequence
+    advances on a forked capture branch. Sighting, capture and replay must all give the specification's result."""
+    from twog_gcn_amd import _lib as L
+    bs, T, h = 64, 3, 512
+    ws = 0.2 * math.sqrt(64.0 / h)
+    arr = (L.BiGru * 3)()
+    keep, wants = [], []
+    for i, E in enumerate((2, 8, 1)):
+        d = dict(gi=rnd(bs, T, E, 6 * h, seed=i), w_hh_f=rnd(3 * h, h, seed=10 + i, scale=ws), b_hh_f=rnd(3 * h, seed=20 + i),
+                 w_hh_r=rnd(3 * h, h, seed=30 + i, scale=ws), b_hh_r=rnd(3 * h, seed=40 + i))
+        wants.append(F.bigru_fwd([d], bs, T, h)[0][0])
+        g = {k: v.to(DEV) for k, v in d.items()}
+        bufs = dict(out=torch.empty(bs, T, E, 2 * h, device=DEV), save=torch.empty(2, bs, T, E, 4 * h, device=DEV),
+                    tmp=torch.empty(2, bs * E, 3 * h, device=DEV), zeros=torch.zeros(bs * E, h, device=DEV))
+        a = arr[i]
+        a.gi, a.w_hh_f, a.b_hh_f, a.w_hh_r, a.b_hh_r = (g[k].data_ptr() for k in ('gi', 'w_hh_f', 'b_hh_f', 'w_hh_r', 'b_hh_r'))
+        a.out, a.save, a.tmp_gh, a.zeros, a.E = (bufs['out'].data_ptr(), bufs['save'].data_ptr(), bufs['tmp'].data_ptr(),
+                                                 bufs['zeros'].data_ptr(), E)
+        keep.append((g, bufs))
+    st = torch.cuda.current_stream().cuda_stream
+    n0 = K.graph_cache_stats()[0]
+    for rep in range(4):
+        for _, bufs in keep:
+            bufs['out'].fill_(float('nan'))
+        assert K.lib.twog_bigru_fwd(arr, 3, bs, T, h, st) == 0
+        for (_, bufs), want in zip(keep, wants):
+            close(bufs['out'], want, rtol=1e-4, atol=1e-5, what=f'bigru rep {rep}')
+    assert K.graph_cache_stats()[0] == n0 + 1   # the loop was captured (and replayed twice)
