@@ -11,7 +11,6 @@
 // r, z, n and W_hn h are saved for the backward pass, which walks the chain in reverse with the transposed GEMM.
 #include "twog_common.h"
 #include "graph_cache.h"
-#include <mutex>
 
 namespace {
 
@@ -177,112 +176,48 @@ extern "C" int twog_gru_step_bwd(const twog_gru_step_bwd_t* steps, int n_steps, 
 // ---------------------------------------------------------------------------------------------------------------
 // Frame-level BiGRU recurrence for up to 4 entity types at once (humans, objects, geometry).
 // ---------------------------------------------------------------------------------------------------------------
-// one chain step s for the types [k0, k1): grouped hidden projection + gate kernel
-static int bigru_fwd_step(const twog_bigru_t* types, int k0, int k1, int bs, int T, int h, int s, void* stream) {
-    twog_gemm_t gm[8];
-    twog_gru_step_t st[8];
-    int n = 0;
-    for (int k = k0; k < k1; ++k) {
-        const twog_bigru_t& Y = types[k];
-        const int E = Y.E, rows = bs * E;
-        for (int dir = 0; dir < 2; ++dir) {
-            const int t = dir == 0 ? s : T - 1 - s;
-            const int tp = dir == 0 ? t - 1 : t + 1;
-            float* tmp = Y.tmp_gh + (int64_t)dir * rows * 3 * h;
-            twog_rows_t hprev = s == 0 ? rows_plain(Y.zeros, h)
-                                       : rows_be(Y.out + (int64_t)tp * E * 2 * h + dir * h, E, 2 * h, T);
-            twog_gemm_t& G = gm[n];
-            G.A = hprev;
-            G.B = rows_plain((dir == 0 ? Y.w_hh_f : Y.w_hh_r), h);
-            G.C = rows_plain(tmp, 3 * h);
-            G.bias = dir == 0 ? Y.b_hh_f : Y.b_hh_r;
-            G.M = rows; G.N = 3 * h; G.K = h; G.act = 0; G.accumulate = 0; G.batch = 1;
-            G.a_batch_stride = G.b_batch_stride = G.c_batch_stride = 0;
-            twog_gru_step_t& S = st[n];
-            S.gi = rows_be(Y.gi + (int64_t)t * E * 6 * h + dir * 3 * h, E, 6 * h, T);
-            S.gi2.ptr = nullptr; S.gi2.inner = 1; S.gi2.ld_inner = S.gi2.ld_outer = 0;
-            S.gh = rows_plain(tmp, 3 * h);
-            S.h_prev = hprev;
-            if (s == 0) S.h_prev.ptr = nullptr;
-            S.h_out = rows_be(Y.out + (int64_t)t * E * 2 * h + dir * h, E, 2 * h, T);
-            S.save = rows_be(Y.save + ((int64_t)dir * bs * T * E + (int64_t)t * E) * 4 * h, E, 4 * h, T);
-            S.u = nullptr; S.u_ld_outer = S.u_ld_inner = 0; S.u_inner = 1;
-            S.rows = rows; S.hidden = h;
-            ++n;
-        }
-    }
-    if (n == 0) return 0;
-    int rc = twog_gemm_f32(gm, n, 0, 0, nullptr, 0, stream);
-    if (rc) return rc;
-    return twog_gru_step_fwd(st, n, stream);
-}
-
-// second capture branch (per device): the chains of different entity types never exchange data inside the loop, so
-// while the loop is being captured into a graph the LAST type(s) can advance on a forked stream. That is worth it when
-// the grouped launch of all types needs one more round of resident workgroups than the launch without them (BASELINE
-// shape: 528 tiles of 64 x 64 for 512 slots -- the 48 tiles of the geometry sequence cost a whole extra round).
-static hipStream_t bigru_branch_stream(int dev) {
-    static hipStream_t side[twog_graph::MAX_DEVICES] = {};
-    static std::mutex mu;
-    std::lock_guard<std::mutex> lock(mu);
-    if (dev < 0 || dev >= twog_graph::MAX_DEVICES) return nullptr;
-    if (!side[dev] && hipStreamCreateWithFlags(&side[dev], hipStreamNonBlocking) != hipSuccess) {
-        (void)hipGetLastError();
-        side[dev] = nullptr;
-    }
-    return side[dev];
-}
-
 static int bigru_fwd_impl(const twog_bigru_t* types, int n_types, int bs, int T, int hidden, void* stream) {
     if (n_types > 4) return -1;
     const int h = hidden;
-    // how many types (counted from the end) leave the main launch within one round of 2 workgroups per CU
-    int split = n_types;
-    {
-        auto tiles = [&](int k) { return (int64_t)((bs * types[k].E + 63) / 64) * ((3 * h + 63) / 64) * 2; };
-        int64_t total = 0;
-        for (int k = 0; k < n_types; ++k) total += tiles(k);
-        int ncu = 256;
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
-        else (void)hipGetLastError();
-        const int64_t slots = 2 * (int64_t)ncu;
-        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-        const bool capturing = hipStreamIsCapturing((hipStream_t)stream, &cs) == hipSuccess && cs == hipStreamCaptureStatusActive;
-        static const bool off = getenv("TWOG_NO_BIGRU_BRANCH") != nullptr;
-        if (capturing && !off && n_types >= 2 && total > slots && total % slots != 0) {
-            int64_t main_tiles = total;
-            int k = n_types;
-            while (k > 1 && (main_tiles + slots - 1) / slots >= (total + slots - 1) / slots) main_tiles -= tiles(--k);
-            if ((main_tiles + slots - 1) / slots < (total + slots - 1) / slots) split = k;
+    for (int s = 0; s < T; ++s) {
+        twog_gemm_t gm[8];
+        twog_gru_step_t st[8];
+        int n = 0;
+        for (int k = 0; k < n_types; ++k) {
+            const twog_bigru_t& Y = types[k];
+            const int E = Y.E, rows = bs * E;
+            for (int dir = 0; dir < 2; ++dir) {
+                const int t = dir == 0 ? s : T - 1 - s;
+                const int tp = dir == 0 ? t - 1 : t + 1;
+                float* tmp = Y.tmp_gh + (int64_t)dir * rows * 3 * h;
+                twog_rows_t hprev = s == 0 ? rows_plain(Y.zeros, h)
+                                           : rows_be(Y.out + (int64_t)tp * E * 2 * h + dir * h, E, 2 * h, T);
+                twog_gemm_t& G = gm[n];
+                G.A = hprev;
+                G.B = rows_plain((dir == 0 ? Y.w_hh_f : Y.w_hh_r), h);
+                G.C = rows_plain(tmp, 3 * h);
+                G.bias = dir == 0 ? Y.b_hh_f : Y.b_hh_r;
+                G.M = rows; G.N = 3 * h; G.K = h; G.act = 0; G.accumulate = 0; G.batch = 1;
+                G.a_batch_stride = G.b_batch_stride = G.c_batch_stride = 0;
+                twog_gru_step_t& S = st[n];
+                S.gi = rows_be(Y.gi + (int64_t)t * E * 6 * h + dir * 3 * h, E, 6 * h, T);
+                S.gi2.ptr = nullptr; S.gi2.inner = 1; S.gi2.ld_inner = S.gi2.ld_outer = 0;
+                S.gh = rows_plain(tmp, 3 * h);
+                S.h_prev = hprev;
+                if (s == 0) S.h_prev.ptr = nullptr;
+                S.h_out = rows_be(Y.out + (int64_t)t * E * 2 * h + dir * h, E, 2 * h, T);
+                S.save = rows_be(Y.save + ((int64_t)dir * bs * T * E + (int64_t)t * E) * 4 * h, E, 4 * h, T);
+                S.u = nullptr; S.u_ld_outer = S.u_ld_inner = 0; S.u_inner = 1;
+                S.rows = rows; S.hidden = h;
+                ++n;
+            }
         }
+        int rc = twog_gemm_f32(gm, n, 0, 0, nullptr, 0, stream);
+        if (rc) return rc;
+        rc = twog_gru_step_fwd(st, n, stream);
+        if (rc) return rc;
     }
-    hipStream_t main_st = (hipStream_t)stream, br = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    if (split < n_types) {
-        int dev = 0;
-        (void)hipGetDevice(&dev);
-        br = bigru_branch_stream(dev);
-        if (!br || hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&ev_join, hipEventDisableTiming) != hipSuccess ||
-            hipEventRecord(ev_fork, main_st) != hipSuccess || hipStreamWaitEvent(br, ev_fork, 0) != hipSuccess) {
-            (void)hipGetLastError();
-            br = nullptr;
-            split = n_types;
-        }
-    }
-    int rc = 0;
-    for (int s = 0; s < T && !rc; ++s) {
-        rc = bigru_fwd_step(types, 0, split, bs, T, h, s, main_st);
-        if (!rc && br) rc = bigru_fwd_step(types, split, n_types, bs, T, h, s, br);
-    }
-    if (br) {   // join: the caller's stream continues only after the branch
-        if (hipEventRecord(ev_join, br) != hipSuccess || hipStreamWaitEvent(main_st, ev_join, 0) != hipSuccess) rc = rc ? rc : -103;
-    }
-    if (ev_fork) (void)hipEventDestroy(ev_fork);
-    if (ev_join) (void)hipEventDestroy(ev_join);
-    return rc;
+    return 0;
 }
 
 // Backward through time. d_out: gradient wrt `out` [bs][T][E][2h]; writes d_gi [bs][T][E][6h] and

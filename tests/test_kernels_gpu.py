@@ -897,9 +897,9 @@ def test_attention_backward_takes_extra_weight_gradient(K):
     assert float((b0['dfeat_h'] - bc['dfeat_h']).abs().max()) > 1e-4   # the extra term does reach the features
 
 
-def test_bigru_forward_graph_with_forked_type_branch(K):
-    """BASELINE-size BiGRU step (528 tiles for 512 workgroup slots): once the loop is captured, the geometry sequence
-    advances on a forked capture branch. Sighting, capture and replay must all give the specification's result."""
+def test_bigru_forward_graph_capture_and_replay_at_baseline_width(K):
+    """BASELINE-size BiGRU step (three entity types, 528 tiles): first sighting (direct launches), capture into a
+    hipGraph and two replays must all give the specification's result."""
     from twog_gcn_amd import _lib as L
     bs, T, h = 64, 3, 512
     ws = 0.2 * math.sqrt(64.0 / h)
