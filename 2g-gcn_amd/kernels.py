@@ -261,6 +261,36 @@ class HipKernels:
         self._check(self.lib.twog_bigru_bwd(arr, n, bs, T, h, self._stream()), 'twog_bigru_bwd')
         return outs
 
+    # ---------------------------------------------------------------- single GRU gate steps (general segment loop)
+    @staticmethod
+    def _u_fields(g, u):
+        """u: None or a (bs, E) view of a (bs, T, E) gate tensor at one time step."""
+        if u is None:
+            g.u, g.u_ld_outer, g.u_ld_inner, g.u_inner = 0, 0, 0, 1
+        else:
+            g.u, g.u_ld_outer, g.u_ld_inner, g.u_inner = u.data_ptr(), u.stride(0), u.stride(1), u.shape[1]
+
+    def gru_step_fwd(self, steps):
+        """steps: dicts with gi, gi2 (or None), gh, h_prev (or None), h_out, save (row-strided views), u, rows, hidden."""
+        arr = (L.GruStep * len(steps))()
+        for g, d in zip(arr, steps):
+            for k in ('gi', 'gi2', 'gh', 'h_prev', 'h_out', 'save'):
+                setattr(g, k, rows_of(d.get(k)))
+            self._u_fields(g, d.get('u'))
+            g.rows, g.hidden = d['rows'], d['hidden']
+        self._check(self.lib.twog_gru_step_fwd(arr, len(steps), self._stream()), 'twog_gru_step_fwd')
+
+    def gru_step_bwd(self, steps):
+        """steps: dicts with dh, dh2 (or None), save, h_prev (or None), dgi, dgh, dh_prev, u, du (same view form as u)."""
+        arr = (L.GruStepBwd * len(steps))()
+        for g, d in zip(arr, steps):
+            for k in ('dh', 'dh2', 'save', 'h_prev', 'dgi', 'dgh', 'dh_prev'):
+                setattr(g, k, rows_of(d.get(k)))
+            self._u_fields(g, d.get('u'))
+            g.du = _ptr(d.get('du'))
+            g.rows, g.hidden, g.dh_prev_accumulate = d['rows'], d['hidden'], int(d.get('dh_prev_accumulate', 0))
+        self._check(self.lib.twog_gru_step_bwd(arr, len(steps), self._stream()), 'twog_gru_step_bwd')
+
     # ---------------------------------------------------------------- entity attention
     _ATTN_ROWS = ['feat_h', 'feat_o', 'msg_hh', 'msg_ho', 'msg_oh', 'msg_oo', 'msg_so', 'msg_sh', 'out_hh', 'out_oh',
                   'out_sh', 'out_ho', 'out_so', 'out_oo']

@@ -227,14 +227,6 @@ class TGGCN(nn.Module):
     def _check_supported(self):
         c = self.cfg
         bad = []
-        relational = c['message_type'] in {'v1', 'relational'}
-        general = (relational or c['message_granularity'] in {'v2', 'specific'} or
-                   (c['message_aggregation'] not in {'mp', 'mean_pooling'} and
-                    c['attention_style'] not in {'v2', 'dot-product', 'v3', 'scaled_dot-product'}))
-        if general and c['message_segment']:
-            # the frame level runs every message / attention form (relation.hip); the segment-level loop (segrnn.hip)
-            # so far the shipped one: sender-only messages with dot-product attention or mean pooling
-            bad.append('message_segment with relational / receiver-specific messages or concat / general attention')
         if c['discrete_networks_num_layers'] < 1:
             bad.append('discrete_networks_num_layers < 1')
         if c['discrete_optimization_strategy'] not in {'gumbel-sigmoid', 'gs', 'straight-through', 'st'}:
@@ -257,9 +249,6 @@ class TGGCN(nn.Module):
         dists = dict(hh=human_human_distances, ho=human_object_distances, oo=object_object_distances)
         dists = {k: v.to(device=x_human.device, dtype=torch.float32).contiguous() for k, v in dists.items()
                  if v is not None}
-        if dists and self.cfg['message_segment']:
-            raise NotImplementedError('distance-based attention with message_segment is not implemented by the gfx950 '
-                                      'path (the segment-level loop runs dot-product attention / mean pooling)')
         bs, T, H, F_h = x_human.shape
         O = x_objects.shape[2]
         vw = F_h - 2048  # generalises the reference's hard-coded 76 / 120 / 104 split (vhoi/models.py:631-639)

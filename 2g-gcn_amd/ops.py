@@ -134,6 +134,12 @@ class Plan:
         return (self.relational or self.specific or
                 (not self.mean_pool and (self.att_style != 'dot' or self.dists is not None)))
 
+    def general_segment(self):
+        """True when the segment-level messages need the general relation kernels, i.e. the step-by-step loop composed
+        on the host (segment_recurrence_general_*) instead of the library's captured loop (segrnn.hip: sender-only
+        messages with dot-product attention or mean pooling)."""
+        return self.msg_segment and (self.general_frame() or self.dists is not None)
+
     def ssp_blocks(self):
         """Sender-side projection (ssp.hip): the human->object and geometry->object message blocks of the objects'
         GRUCell input are linear in the H + 1 senders of a frame, so W_ih is applied to the SENDERS' messages and the
@@ -209,8 +215,17 @@ def used_parameter_names(plan: Plan):
                           _ATT_MLP[rel] + ('.bias' if plan.att_style == 'general' else '.0.bias')]
     if plan.msg_segment:
         for rel in ('hh', 'ho', 'oh', 'oo'):
-            if getattr(plan, 'rel_' + rel):
-                names += [_SEG_MLP[rel] + '.0.weight', _SEG_MLP[rel] + '.0.bias']
+            if not getattr(plan, 'rel_' + rel):
+                continue
+            if plan.relational:
+                names += [f'{_REL_PREFIX[rel]}_segment_{kind}_relation_mlp.0.{wb}' for kind in ('pairwise', 'full')
+                          for wb in ('weight', 'bias')]
+                continue
+            names += [_SEG_MLP[rel] + '.0.weight', _SEG_MLP[rel] + '.0.bias']
+            if not plan.mean_pool and plan.att_style != 'dot':
+                a_ = _ATT_MLP[rel].replace('_message_att_mlp', '_segment_message_att_mlp')
+                names += [a_ + ('.weight' if plan.att_style == 'general' else '.0.weight'),
+                          a_ + ('.bias' if plan.att_style == 'general' else '.0.bias')]
     for cell in ('human_segment_rnn_fcell', 'human_segment_rnn_bcell', 'object_segment_rnn_fcell',
                  'object_segment_rnn_bcell'):
         names += [cell + '.weight_ih', cell + '.weight_hh', cell + '.bias_ih', cell + '.bias_hh']
@@ -379,83 +394,93 @@ def geo_gcn_forward(K, P, x_human, bs, T, N, training, bn_bufs, S):
     return Gout
 
 
-def _rel_sets(p, rel, HUMv, OBJv, GEOv):
-    """(receiver rows, R, sender rows, S, column of the received block) of a relation."""
-    rows = {'h': (HUMv, p.H), 'o': (OBJv, p.O), 's': (GEOv, 1)}
-    rk, sk = _REL_ENDS[rel]
-    (Rv, R), (Sv, Sn) = rows[rk], rows[sk]
-    col = (p.col_h if rk == 'h' else p.col_o)[rel]
-    return Rv, R, Sv, Sn, col
-
-
-def _rel_distances(p, rel, nF):
-    """(n_inst, R, S) view of the distance tensor this relation attends by, or None (models.py:667-735: hh / oh / ho /
-    oo take the centroid distances when they are passed in; the geometry node has none)."""
-    d = p.dists or {}
+def _rel_distance_view(p, dists, rel, n_inst):
+    """(n_inst, R, S) view of the distance tensor a relation attends by, or None (models.py:667-735 / :792-858: hh / oh /
+    ho / oo take the centroid distances when they are passed in; the geometry node has none). dists: tensors whose
+    leading dimensions flatten to n_inst."""
+    d = dists or {}
     H, O = p.H, p.O
     if rel == 'hh' and d.get('hh') is not None:
-        return d['hh'].view(nF, H, H)
+        return d['hh'].reshape(n_inst, H, H)
     if rel == 'oh' and d.get('ho') is not None:
-        return d['ho'].view(nF, H, O)
+        return d['ho'].reshape(n_inst, H, O)
     if rel == 'ho' and d.get('ho') is not None:
-        return d['ho'].view(nF, H, O).transpose(1, 2)   # receiver = object k, senders = humans (:711)
+        return d['ho'].reshape(n_inst, H, O).transpose(1, 2)   # receiver = object k, senders = humans (:711)
     if rel == 'oo' and d.get('oo') is not None:
-        return d['oo'].view(nF, O, O)
+        return d['oo'].reshape(n_inst, O, O)
     return None
 
 
-def frame_messages_general_fwd(K, p, P, HUMv, OBJv, GEOv, objects_mask):
-    """Frame-level messages in every form the tuned kernel does not cover (relational, receiver-specific, concat /
-    bilinear / distance-based attention): per relation a couple of GEMMs -- a Linear on cat[receiver, sender] is split
-    into a receiver and a sender projection -- and one launch of the general relation kernel (relation.hip). Writes the
-    received-message column blocks of the entity rows; returns what the backward pass needs."""
-    bs, T, h = p.bs, p.T, p.h
-    nF, D = bs * T, 2 * h
-    dev = HUMv.device
+class _RelLevel:
+    """Where the general relation code reads and writes at one level: the frame level (all frames at once; features =
+    cat[x, h_f] columns of the entity rows, D = 2h) or one step of the segment level (features = the previous segment
+    states, D = h). Parameter names per relation follow the reference's constructor (models.py:323-520)."""
+
+    def __init__(self, p, segment, n_inst, ipc, feats, outs, dists, scale, dfeats=None, douts=None):
+        self.p, self.segment, self.n_inst, self.ipc = p, segment, n_inst, ipc
+        self.feats, self.outs, self.dists, self.scale = feats, outs, dists, scale
+        self.dfeats, self.douts = dfeats, douts
+        self.D = p.h if segment else 2 * p.h
+        self.sizes = {'h': p.H, 'o': p.O, 's': 1}
+
+    def names(self, rel):
+        seg = '_segment' if self.segment else ''
+        msg = (_SEG_MLP if self.segment else _FRAME_MLP)[rel] + '.0'
+        att = _ATT_MLP[rel].replace('_message_att_mlp', seg + '_message_att_mlp')
+        return dict(msg=msg, att=att, g=f'{_REL_PREFIX[rel]}{seg}_pairwise_relation_mlp.0',
+                    f=f'{_REL_PREFIX[rel]}{seg}_full_relation_mlp.0')
+
+    def recv_masked(self, rel):   # the receiver's object mask multiplies frame-level ho / so messages only (:720, :729)
+        return (not self.segment) and rel in ('ho', 'so')
+
+
+def relations_general_fwd(K, p, P, L, objects_mask, rels):
+    """Messages of the relations `rels` at level L in every form the tuned kernel does not cover (relational,
+    receiver-specific, concat / bilinear / distance-based attention): per relation a couple of GEMMs -- a Linear on
+    cat[receiver, sender] is split into a receiver and a sender projection -- and one launch of the general relation
+    kernel (relation.hip). Writes L.outs[rel]; returns what the backward pass needs."""
+    h, D, nI = p.h, L.D, L.n_inst
+    dev = objects_mask.device
     saved = {}
 
     def empty(*shape):
         return torch.empty(*shape, dtype=torch.float32, device=dev)
 
-    for rel in ('hh', 'oh', 'sh', 'ho', 'so', 'oo'):
-        if not getattr(p, 'rel_' + rel):
-            continue
-        Rv, R, Sv, Sn, col = _rel_sets(p, rel, HUMv, OBJv, GEOv)
+    for rel in rels:
+        rk, sk = _REL_ENDS[rel]
+        R, Sn = L.sizes[rk], L.sizes[sk]
         if R == 0:
             continue
-        FR, FS = Rv[:, :D], Sv[:, :D]
-        out_block = Rv[:, col:col + h]
-        sk = _REL_ENDS[rel][1]
-        f = dict(n_inst=nF, inst_per_clip=T, R=R, S=Sn, D=D, hidden=h, exclude_self=int(rel in ('hh', 'oo')),
+        FR, FS, out_block = L.feats[rk], L.feats[sk], L.outs[rel]
+        nm = L.names(rel)
+        f = dict(n_inst=nI, inst_per_clip=L.ipc, R=R, S=Sn, D=D, hidden=h, exclude_self=int(rel in ('hh', 'oo')),
                  send_mask=objects_mask if sk == 'o' else None)
         rec = dict(rel=rel, f=f)
         if p.relational:
             # m = f( sum_s mask_s * g(cat[receiver, sender_s]) )   (models.py:1667-1690)
-            g_, f_ = _REL_PREFIX[rel] + '_pairwise_relation_mlp.0', _REL_PREFIX[rel] + '_full_relation_mlp.0'
-            gw = P[g_ + '.weight']
-            p_r, p_s, agg = empty(nF * R, h), empty(nF * Sn, h), empty(nF * R, h)
-            K.gemm([dict(A=FR, B=gw[:, :D], C=p_r), dict(A=FS, B=gw[:, D:], C=p_s, bias=P[g_ + '.bias'])])
+            gw = P[nm['g'] + '.weight']
+            p_r, p_s, agg = empty(nI * R, h), empty(nI * Sn, h), empty(nI * R, h)
+            K.gemm([dict(A=FR, B=gw[:, :D], C=p_r), dict(A=FS, B=gw[:, D:], C=p_s, bias=P[nm['g'] + '.bias'])])
             f.update(score_mode=K.REL_SUM, msg_mode=K.REL_MSG_PAIR, p_r=p_r, p_s=p_s, out=agg)
             K.relation_fwd(f)
-            K.gemm([dict(A=agg, B=P[f_ + '.weight'], C=out_block, bias=P[f_ + '.bias'], act=1)])
-            if rel in ('ho', 'so'):   # the receiver's mask multiplies the finished message (:720, :729)
-                rows_mask = objects_mask.view(bs, 1, p.O).expand(bs, T, p.O).contiguous().view(-1)
+            K.gemm([dict(A=agg, B=P[nm['f'] + '.weight'], C=out_block, bias=P[nm['f'] + '.bias'], act=1)])
+            if L.recv_masked(rel):   # the receiver's mask multiplies the finished message (:720, :729)
+                rows_mask = objects_mask.view(p.bs, 1, p.O).expand(p.bs, L.ipc, p.O).contiguous().view(-1)
                 K.scale_rows(out_block, rows_mask)
             rec.update(agg=agg)
             saved[rel] = rec
             continue
-        m_ = _FRAME_MLP[rel] + '.0'
-        w = P[m_ + '.weight']
+        w = P[nm['msg'] + '.weight']
         if p.specific:     # message_fn(cat[receiver, sender]) (:1712-1713): receiver part + sender part, ReLU per pair
-            p_r, p_s = empty(nF * R, h), empty(nF * Sn, h)
-            K.gemm([dict(A=FR, B=w[:, :D], C=p_r), dict(A=FS, B=w[:, D:], C=p_s, bias=P[m_ + '.bias'])])
+            p_r, p_s = empty(nI * R, h), empty(nI * Sn, h)
+            K.gemm([dict(A=FR, B=w[:, :D], C=p_r), dict(A=FS, B=w[:, D:], C=p_s, bias=P[nm['msg'] + '.bias'])])
             f.update(msg_mode=K.REL_MSG_PAIR, p_r=p_r, p_s=p_s)
         else:
-            msg = empty(nF * Sn, h)
-            K.gemm([dict(A=FS, B=w, C=msg, bias=P[m_ + '.bias'], act=1)])
+            msg = empty(nI * Sn, h)
+            K.gemm([dict(A=FS, B=w, C=msg, bias=P[nm['msg'] + '.bias'], act=1)])
             f.update(msg_mode=K.REL_MSG_SENDER, msg=msg)
-        f.update(out=out_block, recv_mask=objects_mask if rel in ('ho', 'so') else None)
-        dist = _rel_distances(p, rel, nF)
+        f.update(out=out_block, recv_mask=objects_mask if L.recv_masked(rel) else None)
+        dist = _rel_distance_view(p, L.dists, rel, nI)
         if sk == 's':
             f.update(score_mode=K.REL_SUM)        # one sender: its softmax weight is 1 whatever the score (Appendix A4)
         elif p.mean_pool:
@@ -463,31 +488,28 @@ def frame_messages_general_fwd(K, p, P, HUMv, OBJv, GEOv, objects_mask):
         elif dist is not None:
             f.update(score_mode=K.REL_DISTANCE, dist=dist)
         elif p.att_style == 'dot':
-            f.update(score_mode=K.REL_DOT, q=FR, k=FS, scale=p.scale_frame)
+            f.update(score_mode=K.REL_DOT, q=FR, k=FS, scale=L.scale)
         elif p.att_style == 'concat':   # relu(Linear(cat[query, key]) -> 1) (:1739-1741)
-            a_ = _ATT_MLP[rel] + '.0'
-            aw = P[a_ + '.weight']
-            a_r, c_s = empty(nF * R, 1), empty(nF * Sn, 1)
-            K.gemm([dict(A=FR, B=aw[:, :D], C=a_r, bias=P[a_ + '.bias']), dict(A=FS, B=aw[:, D:], C=c_s)])
+            aw = P[nm['att'] + '.0.weight']
+            a_r, c_s = empty(nI * R, 1), empty(nI * Sn, 1)
+            K.gemm([dict(A=FR, B=aw[:, :D], C=a_r, bias=P[nm['att'] + '.0.bias']), dict(A=FS, B=aw[:, D:], C=c_s)])
             f.update(score_mode=K.REL_ADDITIVE, a_r=a_r, c_s=c_s)
         else:                           # relu(Bilinear(query, key)) (:1746): keys transformed once per sender
-            a_ = _ATT_MLP[rel]
-            kp = empty(nF * Sn, D)
-            K.gemm([dict(A=FS, B=P[a_ + '.weight'].view(D, D), C=kp)])
-            f.update(score_mode=K.REL_DOT, q=FR, k=kp, scale=1.0, relu_scores=1, score_bias=P[a_ + '.bias'])
+            kp = empty(nI * Sn, D)
+            K.gemm([dict(A=FS, B=P[nm['att'] + '.weight'].view(D, D), C=kp)])
+            f.update(score_mode=K.REL_DOT, q=FR, k=kp, scale=1.0, relu_scores=1, score_bias=P[nm['att'] + '.bias'])
         if rel == 'oh':
-            f['att'] = empty(nF, R, Sn)   # inspect_model: objects -> human weights (:1203-1237)
+            f['att'] = empty(nI, R, Sn)   # inspect_model: objects -> human weights (:1203-1237)
         K.relation_fwd(f)
         saved[rel] = rec
     return saved
 
 
-def frame_messages_general_bwd(K, p, P, G, saved, HUMv, OBJv, GEOv, dHUMv, dOBJv, dGEOv):
-    """Backward of frame_messages_general_fwd: gradients of the message / relation / attention parameters, and the
-    feature gradients added into the entity-row gradient columns [0, 2h)."""
-    bs, T, h = p.bs, p.T, p.h
-    nF, D = bs * T, 2 * h
-    dev = HUMv.device
+def relations_general_bwd(K, p, P, G, L, saved):
+    """Backward of relations_general_fwd: gradients of the message / relation / attention parameters (added to G), and
+    the feature gradients ADDED into L.dfeats; L.douts[rel] is the gradient wrt the written message block."""
+    h, D, nI = p.h, L.D, L.n_inst
+    dev = next(iter(L.feats.values())).device
 
     def empty(*shape):
         return torch.empty(*shape, dtype=torch.float32, device=dev)
@@ -500,44 +522,43 @@ def frame_messages_general_bwd(K, p, P, G, saved, HUMv, OBJv, GEOv, dHUMv, dOBJv
         K.gemm([dict(A=dp_r, B=w[:, :D], C=dFR, accumulate=True)], b_kmajor=True)
         K.gemm([dict(A=dp_s, B=w[:, D:], C=dFS, accumulate=True)], b_kmajor=True)
 
-    dsets = {'h': dHUMv, 'o': dOBJv, 's': dGEOv}
     for rel, rec in saved.items():
-        Rv, R, Sv, Sn, col = _rel_sets(p, rel, HUMv, OBJv, GEOv)
         rk, sk = _REL_ENDS[rel]
-        FR, FS = Rv[:, :D], Sv[:, :D]
-        dFR, dFS = dsets[rk][:, :D], dsets[sk][:, :D]
-        dout_block = dsets[rk][:, col:col + h]
+        R, Sn = L.sizes[rk], L.sizes[sk]
+        FR, FS = L.feats[rk], L.feats[sk]
+        dFR, dFS = L.dfeats[rk], L.dfeats[sk]
+        dout_block = L.douts[rel]
+        nm = L.names(rel)
         f = rec['f']
         if p.relational:
-            g_, f_ = _REL_PREFIX[rel] + '_pairwise_relation_mlp.0', _REL_PREFIX[rel] + '_full_relation_mlp.0'
-            dpre = K.relu_bwd(dout_block, Rv[:, col:col + h])      # a masked receiver's block is 0: its gradient too
-            _lin_w_grads(K, G, f_ + '.weight', f_ + '.bias', dpre, rec['agg'])
-            dagg = empty(nF * R, h)
-            K.gemm([dict(A=dpre, B=P[f_ + '.weight'], C=dagg)], b_kmajor=True)
-            dp_r, dp_s = empty(nF * R, h), empty(nF * Sn, h)
+            dpre = K.relu_bwd(dout_block, L.outs[rel])      # a masked receiver's block is 0: its gradient too
+            _lin_w_grads(K, G, nm['f'] + '.weight', nm['f'] + '.bias', dpre, rec['agg'])
+            dagg = empty(nI * R, h)
+            K.gemm([dict(A=dpre, B=P[nm['f'] + '.weight'], C=dagg)], b_kmajor=True)
+            dp_r, dp_s = empty(nI * R, h), empty(nI * Sn, h)
             K.relation_bwd(dict(f=f, dout=dagg, dp_r=dp_r, dp_s=dp_s))
-            split_linear_bwd(g_ + '.weight', g_ + '.bias', dp_r, dp_s, FR, FS, dFR, dFS)
+            split_linear_bwd(nm['g'] + '.weight', nm['g'] + '.bias', dp_r, dp_s, FR, FS, dFR, dFS)
             continue
-        m_ = _FRAME_MLP[rel] + '.0'
+        m_ = nm['msg']
         if sk == 's' and not p.mean_pool and p.att_style != 'dot':
-            for n_ in ((_ATT_MLP[rel] + '.weight', _ATT_MLP[rel] + '.bias') if p.att_style == 'general' else
-                       (_ATT_MLP[rel] + '.0.weight', _ATT_MLP[rel] + '.0.bias')):
+            for n_ in ((nm['att'] + '.weight', nm['att'] + '.bias') if p.att_style == 'general' else
+                       (nm['att'] + '.0.weight', nm['att'] + '.0.bias')):
                 if G.has(n_):
                     G.add(n_, torch.zeros_like(P[n_]))
         b = dict(f=f, dout=dout_block, relu_mask_dmsg=1)
         if p.specific:
-            b.update(dp_r=empty(nF * R, h), dp_s=empty(nF * Sn, h))
+            b.update(dp_r=empty(nI * R, h), dp_s=empty(nI * Sn, h))
         else:
-            b.update(dmsg=empty(nF * Sn, h))
+            b.update(dmsg=empty(nI * Sn, h))
         mode = f['score_mode']
         dkp = None
         if mode == K.REL_DOT and 'score_bias' not in f:
             b.update(dq=dFR, dk=dFS, dq_accumulate=1, dk_accumulate=1)
         elif mode == K.REL_DOT:       # bilinear: keys are the transformed ones
-            dkp = empty(nF * Sn, D)
-            b.update(dq=dFR, dq_accumulate=1, dk=dkp, dscore_sum=empty(nF))
+            dkp = empty(nI * Sn, D)
+            b.update(dq=dFR, dq_accumulate=1, dk=dkp, dscore_sum=empty(nI))
         elif mode == K.REL_ADDITIVE:
-            b.update(da_r=empty(nF * R), dc_s=empty(nF * Sn))
+            b.update(da_r=empty(nI * R), dc_s=empty(nI * Sn))
         K.relation_bwd(b)
         if p.specific:
             split_linear_bwd(m_ + '.weight', m_ + '.bias', b['dp_r'], b['dp_s'], FR, FS, dFR, dFS)
@@ -545,7 +566,7 @@ def frame_messages_general_bwd(K, p, P, G, saved, HUMv, OBJv, GEOv, dHUMv, dOBJv
             _lin_w_grads(K, G, m_ + '.weight', m_ + '.bias', b['dmsg'], FS)
             K.gemm([dict(A=b['dmsg'], B=P[m_ + '.weight'], C=dFS, accumulate=True)], b_kmajor=True)
         if mode == K.REL_ADDITIVE:
-            a_ = _ATT_MLP[rel] + '.0'
+            a_ = nm['att'] + '.0'
             aw = P[a_ + '.weight'].view(-1)
             dw = empty(2 * D)
             K.colsum(FR, rowscale=b['da_r'], out=dw[:D])
@@ -555,13 +576,166 @@ def frame_messages_general_bwd(K, p, P, G, saved, HUMv, OBJv, GEOv, dHUMv, dOBJv
             K.rank1_update(dFR, b['da_r'], aw[:D])
             K.rank1_update(dFS, b['dc_s'], aw[D:])
         elif dkp is not None:
-            a_ = _ATT_MLP[rel]
+            a_ = nm['att']
             A_ = P[a_ + '.weight'].view(D, D)
             dA = empty(D, D)
             K.gemm([dict(A=dkp, B=FS, C=dA)], a_kmajor=True, b_kmajor=True)
             G.add(a_ + '.weight', dA.view(1, D, D))
             G.add(a_ + '.bias', K.colsum(b['dscore_sum'].view(-1, 1)))
             K.gemm([dict(A=dkp, B=A_, C=dFS, accumulate=True)], b_kmajor=True)
+
+
+_FRAME_RELS = ('hh', 'oh', 'sh', 'ho', 'so', 'oo')
+
+
+def _frame_level(p, HUMv, OBJv, GEOv, dHUMv=None, dOBJv=None, dGEOv=None):
+    h, D = p.h, 2 * p.h
+    nF = p.bs * p.T
+    rows = {'h': HUMv, 'o': OBJv, 's': GEOv}
+    cols = {r: (p.col_h if _REL_ENDS[r][0] == 'h' else p.col_o).get(r) for r in _FRAME_RELS}
+    feats = {k: v[:, :D] for k, v in rows.items()}
+    outs = {r: rows[_REL_ENDS[r][0]][:, c:c + h] for r, c in cols.items() if c is not None}
+    dfeats = douts = None
+    if dHUMv is not None:
+        drows = {'h': dHUMv, 'o': dOBJv, 's': dGEOv}
+        dfeats = {k: v[:, :D] for k, v in drows.items()}
+        douts = {r: drows[_REL_ENDS[r][0]][:, c:c + h] for r, c in cols.items() if c is not None}
+    dists = None
+    if p.dists:
+        dists = {k: v.reshape(nF, *v.shape[2:]) for k, v in p.dists.items()}
+    return _RelLevel(p, False, nF, p.T, feats, outs, dists, p.scale_frame, dfeats, douts)
+
+
+def frame_messages_general_fwd(K, p, P, HUMv, OBJv, GEOv, objects_mask):
+    L = _frame_level(p, HUMv, OBJv, GEOv)
+    return relations_general_fwd(K, p, P, L, objects_mask, [r for r in _FRAME_RELS if getattr(p, 'rel_' + r)])
+
+
+def frame_messages_general_bwd(K, p, P, G, saved, HUMv, OBJv, GEOv, dHUMv, dOBJv, dGEOv):
+    relations_general_bwd(K, p, P, G, _frame_level(p, HUMv, OBJv, GEOv, dHUMv, dOBJv, dGEOv), saved)
+
+
+_SEG_RELS = ('hh', 'oh', 'ho', 'oo')
+_SEG_CELLS = {('h', 0): 'human_segment_rnn_fcell', ('h', 1): 'human_segment_rnn_bcell',
+              ('o', 0): 'object_segment_rnn_fcell', ('o', 1): 'object_segment_rnn_bcell'}
+
+
+def _seg_step_level(p, bufs, d, t, tp, first, zeros, carry=None, d_mg=None):
+    """The relation level of one chain step: features = the previous segment states (zeros at the chain start),
+    outputs = this step's blocks of the aggregated-message buffers mg_h / mg_o."""
+    h = p.h
+    prev = {}
+    for kind, E in (('h', p.H), ('o', p.O)):
+        prev[kind] = zeros[kind] if first else bufs['hs_' + kind][:, tp, :, d * h:(d + 1) * h]
+    outs, douts = {}, {}
+    for kind, rels in (('h', p.seg_mh), ('o', p.seg_mo)):
+        for i, rel in enumerate(rels):
+            outs[rel] = bufs['mg_' + kind][d, :, t, :, i * h:(i + 1) * h]
+            if d_mg is not None:
+                douts[rel] = d_mg[kind][:, i * h:(i + 1) * h]
+    dists = {k: v[:, t] for k, v in p.dists.items()} if p.dists else None
+    return _RelLevel(p, True, p.bs, 1, prev, outs, dists, p.scale_seg, carry, douts or None)
+
+
+def segment_recurrence_general_fwd(K, p, P, gi, u, objects_mask):
+    """Segment-level loop (models.py:785-880) for the message forms the library's captured loop does not run: one chain
+    step after the other composed from the host -- general relation kernels for the messages, GEMMs for the
+    projections, the fused gate kernel for h_t = u GRUCell(x, h) + (1 - u) h. Same buffers as twog_segrnn_fwd. Slow
+    (hundreds of small launches per direction) but complete; none of these forms is in a shipped configuration."""
+    bs, T, h = p.bs, p.T, p.h
+    dev = objects_mask.device
+    E_of = {'h': p.H, 'o': p.O}
+    nm = {'h': len(p.seg_mh), 'o': len(p.seg_mo)}
+
+    def e(*shape):
+        return torch.empty(*[max(int(x), 0) for x in shape], dtype=torch.float32, device=dev)
+
+    bufs = {}
+    for kind, E in E_of.items():
+        bufs['hs_' + kind], bufs['save_' + kind] = e(bs, T, E, 2 * h), e(2, bs, T, E, 4 * h)
+        bufs['mg_' + kind] = e(2, bs, T, E, nm[kind] * h)
+    zeros = {k: torch.zeros(bs, E, h, dtype=torch.float32, device=dev) for k, E in E_of.items()}
+    rels = [r for r in _SEG_RELS if getattr(p, 'rel_' + r)]
+    saved = {}
+    for s_ in range(T):
+        first = s_ == 0
+        for d in range(2):
+            t = s_ if d == 0 else T - 1 - s_
+            tp = t - 1 if d == 0 else t + 1
+            L = _seg_step_level(p, bufs, d, t, tp, first, zeros)
+            saved[(s_, d)] = relations_general_fwd(K, p, P, L, objects_mask, rels)
+            steps = []
+            for kind, E in E_of.items():
+                if E == 0:
+                    continue
+                c = _SEG_CELLS[(kind, d)]
+                fw = p.fw_h if kind == 'h' else p.fw_o
+                gh = e(bs * E, 3 * h)
+                K.gemm([dict(A=L.feats[kind], B=P[c + '.weight_hh'], C=gh, bias=P[c + '.bias_hh'])])
+                gim = None
+                if nm[kind]:
+                    gim = e(bs * E, 3 * h)
+                    K.gemm([dict(A=bufs['mg_' + kind][d, :, t], B=P[c + '.weight_ih'][:, fw:], C=gim)])
+                steps.append(dict(gi=gi[kind][:, t, :, d * 3 * h:(d + 1) * 3 * h], gi2=gim, gh=gh,
+                                  h_prev=None if first else L.feats[kind],
+                                  h_out=bufs['hs_' + kind][:, t, :, d * h:(d + 1) * h], save=bufs['save_' + kind][d, :, t],
+                                  u=u[kind][:, t], rows=bs * E, hidden=h))
+            K.gru_step_fwd(steps)
+    bufs['general'] = saved
+    return bufs
+
+
+def segment_recurrence_general_bwd(K, p, P, G, bufs, gi_unused, u, objects_mask, d_hs):
+    """Backward through segment_recurrence_general_fwd. Returns d_gi / d_gh / d_u like twog_segrnn_bwd (the caller turns
+    them into the GRUCell weight gradients with large GEMMs); the message parameters' gradients are added to G here,
+    step by step."""
+    bs, T, h = p.bs, p.T, p.h
+    dev = objects_mask.device
+    E_of = {'h': p.H, 'o': p.O}
+    nm = {'h': len(p.seg_mh), 'o': len(p.seg_mo)}
+
+    def e(*shape):
+        return torch.empty(*[max(int(x), 0) for x in shape], dtype=torch.float32, device=dev)
+
+    out = {}
+    for kind, E in E_of.items():
+        out['d_gi_' + kind], out['d_gh_' + kind] = e(bs, T, E, 6 * h), e(bs, T, E, 6 * h)
+        out['d_u_' + kind] = torch.zeros(bs, T, E, dtype=torch.float32, device=dev)
+    carry = [{k: e(bs, E, h) for k, E in E_of.items()} for _ in range(2)]
+    trash = {k: e(bs, E, h) for k, E in E_of.items()}
+    zeros = {k: torch.zeros(bs, E, h, dtype=torch.float32, device=dev) for k, E in E_of.items()}
+    for s_ in range(T - 1, -1, -1):
+        first, last = s_ == 0, s_ == T - 1
+        for d in range(2):
+            t = s_ if d == 0 else T - 1 - s_
+            tp = t - 1 if d == 0 else t + 1
+            steps, d_mg = [], {}
+            prev = {k: (None if first else bufs['hs_' + k][:, tp, :, d * h:(d + 1) * h]) for k in E_of}
+            for kind, E in E_of.items():
+                if E == 0:
+                    continue
+                steps.append(dict(dh=d_hs[kind][:, t, :, d * h:(d + 1) * h], dh2=None if last else carry[d][kind],
+                                  save=bufs['save_' + kind][d, :, t], h_prev=prev[kind],
+                                  dgi=out['d_gi_' + kind][:, t, :, d * 3 * h:(d + 1) * 3 * h],
+                                  dgh=out['d_gh_' + kind][:, t, :, d * 3 * h:(d + 1) * 3 * h], dh_prev=carry[d][kind],
+                                  u=u[kind][:, t], du=out['d_u_' + kind][:, t], rows=bs * E, hidden=h))
+            K.gru_step_bwd(steps)
+            for kind, E in E_of.items():
+                if E == 0:
+                    continue
+                c = _SEG_CELLS[(kind, d)]
+                fw = p.fw_h if kind == 'h' else p.fw_o
+                if not first:   # carried state gradient through W_hh
+                    K.gemm([dict(A=out['d_gh_' + kind][:, t, :, d * 3 * h:(d + 1) * 3 * h], B=P[c + '.weight_hh'],
+                                 C=carry[d][kind], accumulate=True)], b_kmajor=True)
+                if nm[kind]:
+                    d_mg[kind] = e(bs * E, nm[kind] * h)
+                    K.gemm([dict(A=out['d_gi_' + kind][:, t, :, d * 3 * h:(d + 1) * 3 * h], B=P[c + '.weight_ih'][:, fw:],
+                                 C=d_mg[kind])], b_kmajor=True)
+            if d_mg:
+                L = _seg_step_level(p, bufs, d, t, tp, first, zeros, carry=trash if first else carry[d], d_mg=d_mg)
+                relations_general_bwd(K, p, P, G, L, bufs['general'][(s_, d)])
+    return out
 
 
 def tggcn_forward(K, plan: Plan, P, x_human, x_objects, objects_mask, human_seg, object_seg, noise, training, bn_bufs):
@@ -798,7 +972,7 @@ def tggcn_forward(K, plan: Plan, P, x_human, x_objects, objects_mask, human_seg,
                  w_ihm_h=[P[cells[('h', d)] + '.weight_ih'][:, p.fw_h:] for d in range(2)],
                  w_ihm_o=[P[cells[('o', d)] + '.weight_ih'][:, p.fw_o:] for d in range(2)],
                  ld_ih_h=P[cells[('h', 0)] + '.weight_ih'].shape[1], ld_ih_o=P[cells[('o', 0)] + '.weight_ih'].shape[1])
-    if p.msg_segment:
+    if p.msg_segment and not p.general_segment():
         # packed sender MLPs (a copy of four h x h matrices; keeps one GEMM per sender type inside the time loop)
         sh_rel = [r for r in ('hh', 'ho') if getattr(p, 'rel_' + r)]
         so_rel = [r for r in ('oh', 'oo') if getattr(p, 'rel_' + r)]
@@ -808,7 +982,10 @@ def tggcn_forward(K, plan: Plan, P, x_human, x_objects, objects_mask, human_seg,
         seg_p['b_smsg_h'] = torch.cat([P[_SEG_MLP[r] + '.0.bias'] for r in sh_rel], 0) if (sh_rel and bias_on) else None
         seg_p['b_smsg_o'] = torch.cat([P[_SEG_MLP[r] + '.0.bias'] for r in so_rel], 0) if (so_rel and bias_on) else None
         S['seg_rels'] = (sh_rel, so_rel)
-    seg_bufs = K.segrnn_fwd(seg_p)
+    if p.general_segment():
+        seg_bufs = segment_recurrence_general_fwd(K, p, P, {'h': gi_h, 'o': gi_o}, {'h': u_h, 'o': u_o}, objects_mask)
+    else:
+        seg_bufs = K.segrnn_fwd(seg_p)
     S.update(seg_p=seg_p, seg_bufs=seg_bufs)
     HS_h, HS_o = seg_bufs['hs_h'], seg_bufs['hs_o']
 
@@ -930,7 +1107,11 @@ def tggcn_backward(K, plan: Plan, P, S, x_human, x_objects, objects_mask, d_outp
 
     # ---- F. segment-level recurrence backward
     seg_p, sb = S['seg_p'], S['seg_bufs']
-    so = K.segrnn_bwd(seg_p, sb, dHS_h, dHS_o)
+    if p.general_segment():
+        so = segment_recurrence_general_bwd(K, p, P, G, sb, None, {'h': seg_p['u_h'], 'o': seg_p['u_o']}, objects_mask,
+                                            {'h': dHS_h, 'o': dHS_o})
+    else:
+        so = K.segrnn_bwd(seg_p, sb, dHS_h, dHS_o)
     HUM, OBJ, GEO = S['HUM'], S['OBJ'], S['GEO']
     HUMv, OBJv, GEOv = _v2(HUM), _v2(OBJ), _v2(GEO)
     dHUM, dOBJ, dGEO = zeros(bs, T, H, p.Wh), zeros(bs, T, O, p.Wo), zeros(bs, T, 1, p.Ws)
@@ -1000,7 +1181,7 @@ def tggcn_backward(K, plan: Plan, P, S, x_human, x_objects, objects_mask, d_outp
                 K.gemm([dict(A=dgi_d, B=w_ih[:, :c0 - h], C=dEv[:, h:c0], accumulate=True)], b_kmajor=True)
                 if c1 < h + fw:
                     K.gemm([dict(A=dgi_d, B=w_ih[:, c1 - h:fw], C=dEv[:, c1:h + fw], accumulate=True)], b_kmajor=True)
-    if p.msg_segment:
+    if p.msg_segment and not p.general_segment():
         sh_rel, so_rel = S['seg_rels']
         for rels, E, dpre, HS, key in ((sh_rel, H, so['d_pre_h'], sb['hs_h'], 'h'), (so_rel, O, so['d_pre_o'], sb['hs_o'], 'o')):
             if not rels or E == 0:

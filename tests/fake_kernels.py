@@ -170,6 +170,34 @@ class FakeKernels:
         dgh = torch.cat([dr_pre, dz_pre, dn_pre * r], -1)
         return dgi, dgh, dprev, du
 
+    def gru_step_fwd(self, steps):
+        for d in steps:
+            h = d['hidden']
+            gi = d['gi'] if d.get('gi2') is None else d['gi'] + d['gi2'].reshape(d['gi'].shape)
+            hp = d['h_prev'] if d.get('h_prev') is not None else torch.zeros(*d['h_out'].shape)
+            r, z, n, hn, g = self._gates(gi, d['gh'].reshape(gi.shape), hp.reshape(d['h_out'].shape), h)
+            u = d.get('u')
+            new = g if u is None else u.unsqueeze(-1) * g + (1 - u.unsqueeze(-1)) * hp.reshape(g.shape)
+            d['h_out'].copy_(new.reshape(d['h_out'].shape))
+            if d.get('save') is not None:
+                d['save'].copy_(torch.cat([r, z, n, hn], -1).reshape(d['save'].shape))
+
+    def gru_step_bwd(self, steps):
+        for d in steps:
+            h = d['hidden']
+            dh = d['dh'] if d.get('dh2') is None else d['dh'] + d['dh2'].reshape(d['dh'].shape)
+            hp = d['h_prev'] if d.get('h_prev') is not None else torch.zeros(*d['dh'].shape)
+            save = d['save'].reshape(*dh.shape[:-1], 4 * h)
+            dgi, dgh, dprev, du = self._gates_bwd(dh, save, hp.reshape(dh.shape), h, d.get('u'))
+            d['dgi'].copy_(dgi.reshape(d['dgi'].shape))
+            d['dgh'].copy_(dgh.reshape(d['dgh'].shape))
+            if d.get('dh_prev_accumulate'):
+                d['dh_prev'].add_(dprev.reshape(d['dh_prev'].shape))
+            else:
+                d['dh_prev'].copy_(dprev.reshape(d['dh_prev'].shape))
+            if d.get('du') is not None:
+                d['du'].add_(du.reshape(d['du'].shape))
+
     def bigru_fwd(self, types, bs, T, h):
         outs = []
         for y in types:

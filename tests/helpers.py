@@ -17,11 +17,8 @@ G4_CASES_R2 = ['c1_sah', 'c1_coh', 'c2_gate3', 'c2_nobias', 'c2_time_s', 'c2_tim
                'c2_ctor_defaults', 'c1_relational_geo2h', 'c2_concat_f', 'c2_general_f', 'c2_specific_f',
                'c2_specific_concat_mp_f', 'c2_specific_general_f', 'c2_relational_f', 'c2_distance_f',
                'c1_relational_geo2h_f']
-# ... of which the product path (HIP kernels / their test double) runs these so far
-G4_CASES_R2_BUILT = ['c1_sah', 'c1_coh', 'c2_gate3', 'c2_nobias', 'c2_time_s', 'c2_time_u_periodic', 'c2_seglen',
-                     'c2_seglen_periodic', 'c2_ctor_defaults', 'c2_concat_f', 'c2_general_f', 'c2_specific_f',
-                     'c2_specific_concat_mp_f', 'c2_specific_general_f', 'c2_relational_f', 'c2_distance_f',
-                     'c1_relational_geo2h_f']
+# every one of them runs on the product path (HIP kernels / their test double)
+G4_CASES_R2_BUILT = list(G4_CASES_R2)
 
 
 def load_g4(name):

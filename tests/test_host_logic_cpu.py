@@ -85,10 +85,13 @@ def test_select_model_and_errors(fake_backend):
     m = TGGCN(input_size=(2152, 2048), num_classes=(13, None), hidden_size=8)
     out = m(torch.rand(1, 2, 2, 2152), torch.rand(1, 2, 4, 2048), torch.ones(1, 4))
     assert len(out) == 6 and all(torch.isfinite(o).all() for o in out)
-    # what is still outside the HIP path says so loudly (no silent fallback): segment-level messages in the general forms
     m = TGGCN(input_size=(2152, 2048), num_classes=(13, None), hidden_size=8, message_segment=True)
+    out = m(torch.rand(1, 2, 2, 2152), torch.rand(1, 2, 4, 2048), torch.ones(1, 4))   # ... with segment-level messages
+    assert len(out) == 6 and all(torch.isfinite(o).all() for o in out)
+    # what the path cannot run says so loudly (no silent fallback)
     with pytest.raises(NotImplementedError):
-        m(torch.zeros(1, 2, 2, 2152), torch.zeros(1, 2, 4, 2048), torch.ones(1, 4))
+        TGGCN(input_size=(2152, 2048), num_classes=(13, None), hidden_size=7, add_time_position=True,
+              positional_encoding_style='p')(torch.zeros(1, 2, 2, 2152), torch.zeros(1, 2, 4, 2048), torch.ones(1, 4))
     with pytest.raises(AttributeError):   # 'same_as_human' with two humans: the reference never built that MLP either
         TGGCN(input_size=(2152, 2048), num_classes=(13, None), hidden_size=8, message_type='v2', message_granularity='v1',
               attention_style='v3', object_segment_update_strategy='sah')(

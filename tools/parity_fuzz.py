@@ -109,12 +109,11 @@ def one_case(rng, idx, dev=DEV, dry=False):
     if h % 2:
         cfg['positional_encoding_style'] = 'e'
     general = rng.random() < 0.3
-    if general:   # relational / receiver-specific messages, concat / bilinear attention: frame level only so far
-        cfg['message_segment'] = False
+    if general:   # relational / receiver-specific messages, concat / bilinear attention (both levels)
         cfg['message_type'] = rng.choice(['v1', 'v2', 'v2'])
         cfg['message_granularity'] = rng.choice(['v1', 'v2'])
         cfg['attention_style'] = rng.choice(['v1', 'v4', 'v3'])
-    use_dist = (not cfg['message_segment']) and rng.random() < 0.25
+    use_dist = rng.random() < 0.2
     cad = H == 1 and rng.random() < 0.5
     classes = (10, 12) if cad else (13, None)
     training = rng.random() < 0.8
