@@ -22,7 +22,7 @@ namespace {
 constexpr int MAX_H = 4, MAX_O = 12, MAX_E = MAX_H + MAX_O;
 constexpr int NATT_MAX = MAX_H * MAX_H + 2 * MAX_H * MAX_O + MAX_O * MAX_O;
 constexpr int MAXG = 4;
-struct FwdGroup { twog_attn_t a[MAXG]; int staged; int vec; };  // vec: every message / output row is 16-byte aligned
+struct FwdGroup { twog_attn_t a[MAXG]; int staged; };
 struct BwdGroup { twog_attn_bwd_t a[MAXG]; int staged; };
 
 // the n rows (inst*n .. inst*n+n-1) of a twog_rows_t resolved to base + e*step  (host guarantees inner <= 1 or == n)
@@ -141,33 +141,6 @@ __global__ __launch_bounds__(1024) void attn_fwd_kernel(const FwdGroup g) {
     const RowSet o_hh = rowset(A.out_hh, inst, H), o_oh = rowset(A.out_oh, inst, H), o_sh = rowset(A.out_sh, inst, H);
     const RowSet o_ho = rowset(A.out_ho, inst, O), o_so = rowset(A.out_so, inst, O), o_oo = rowset(A.out_oo, inst, O);
     if (threadIdx.x < O) sMask[threadIdx.x] = A.obj_mask ? A.obj_mask[(int64_t)clip * O + threadIdx.x] : 1.f;
-    // throughput regime: every thread owns ONE (group, 4 consecutive columns) item; its sender-message values are requested
-    // here, as 16-byte loads, before the features are staged and the weights computed -- the message traffic (the larger
-    // half of the kernel's bytes) then overlaps the Gram / softmax phase instead of following it.
-    const int h4 = hid >> 2;
-    const bool vec_items = !g.staged && g.vec && gridDim.z == 1 && 4 * h4 <= (int)blockDim.x;
-    const int v_grp = vec_items ? (int)threadIdx.x / h4 : 4, v_j = vec_items ? ((int)threadIdx.x - v_grp * h4) * 4 : 0;
-    float4 vm[MAX_O + MAX_H + 1];   // group 0: hh | oh | sh ; group 1: ho | so ; groups 2, 3: oo
-    if (vec_items && v_grp < 4) {
-        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-        for (int i = 0; i < MAX_O + MAX_H + 1; ++i) vm[i] = z4;
-        auto ld = [&](const RowSet& rs, int r) { return *reinterpret_cast<const float4*>(rs.row(r) + v_j); };
-        if (v_grp == 0) {
-#pragma unroll
-            for (int s_ = 0; s_ < MAX_H; ++s_) if (m_hh.on() && s_ < H) vm[s_] = ld(m_hh, s_);
-#pragma unroll
-            for (int s_ = 0; s_ < MAX_O; ++s_) if (m_oh.on() && s_ < O) vm[MAX_H + s_] = ld(m_oh, s_);
-            if (m_sh.on()) vm[MAX_H + MAX_O] = ld(m_sh, 0);
-        } else if (v_grp == 1) {
-#pragma unroll
-            for (int s_ = 0; s_ < MAX_H; ++s_) if (m_ho.on() && s_ < H) vm[s_] = ld(m_ho, s_);
-            if (m_so.on()) vm[MAX_H] = ld(m_so, 0);
-        } else {
-#pragma unroll
-            for (int s_ = 0; s_ < MAX_O; ++s_) if (m_oo.on() && s_ < O) vm[s_] = ld(m_oo, s_);
-        }
-    }
     {   // features -> LDS
         const int d4 = D >> 2;
         for (int i = threadIdx.x; i < E * d4; i += blockDim.x) {
@@ -202,61 +175,6 @@ __global__ __launch_bounds__(1024) void attn_fwd_kernel(const FwdGroup g) {
     // 2, 3: object->object messages for the first / second half of the receivers.
     const int o_half = (O + 1) / 2;
     const bool rmask = A.recv_mask_ho != 0;
-    if (vec_items) {
-        if (v_grp >= 4) return;
-        auto st = [&](const RowSet& rs, int r, float4 v) { *reinterpret_cast<float4*>(rs.row(r) + v_j) = v; };
-        auto fma4 = [](float w, float4 m, float4 a) {
-            a.x = fmaf(w, m.x, a.x); a.y = fmaf(w, m.y, a.y); a.z = fmaf(w, m.z, a.z); a.w = fmaf(w, m.w, a.w);
-            return a;
-        };
-        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (v_grp == 0) {
-            if (m_hh.on())
-                for (int r = 0; r < H; ++r) {
-                    const float* w = sW + att_off_hh(H, O) + r * H;
-                    float4 a = z4;
-#pragma unroll
-                    for (int s_ = 0; s_ < MAX_H; ++s_) if (s_ < H) a = fma4(w[s_], vm[s_], a);
-                    st(o_hh, r, a);
-                }
-            if (m_oh.on())
-                for (int r = 0; r < H; ++r) {
-                    const float* w = sW + att_off_oh(H, O) + r * O;
-                    float4 a = z4;
-#pragma unroll
-                    for (int s_ = 0; s_ < MAX_O; ++s_) if (s_ < O) a = fma4(w[s_], vm[MAX_H + s_], a);
-                    st(o_oh, r, a);
-                }
-            if (m_sh.on())
-                for (int r = 0; r < H; ++r) st(o_sh, r, vm[MAX_H + MAX_O]);
-        } else if (v_grp == 1) {
-            if (m_ho.on())
-                for (int k = 0; k < O; ++k) {
-                    const float* w = sW + att_off_ho(H, O) + k * H;
-                    float4 a = z4;
-#pragma unroll
-                    for (int s_ = 0; s_ < MAX_H; ++s_) if (s_ < H) a = fma4(w[s_], vm[s_], a);
-                    if (rmask) { const float mk = sMask[k]; a.x *= mk; a.y *= mk; a.z *= mk; a.w *= mk; }
-                    st(o_ho, k, a);
-                }
-            if (m_so.on())
-                for (int k = 0; k < O; ++k) {
-                    float4 a = vm[MAX_H];
-                    if (rmask) { const float mk = sMask[k]; a.x *= mk; a.y *= mk; a.z *= mk; a.w *= mk; }
-                    st(o_so, k, a);
-                }
-        } else if (m_oo.on()) {
-            const int k0 = v_grp == 2 ? 0 : o_half, k1 = v_grp == 2 ? o_half : O;
-            for (int k = k0; k < k1; ++k) {
-                const float* w = sW + att_off_oo(H, O) + k * O;
-                float4 a = z4;
-#pragma unroll
-                for (int s_ = 0; s_ < MAX_O; ++s_) if (s_ < O) a = fma4(w[s_], vm[s_], a);
-                st(o_oo, k, a);
-            }
-        }
-        return;
-    }
     const int idx_lo = do01 ? 0 : 2 * hid, idx_hi = do23 ? 4 * hid : 2 * hid;
     for (int idx = idx_lo + threadIdx.x; idx < idx_hi; idx += blockDim.x) {
         const int grp = idx / hid, j = idx - grp * hid;
@@ -592,17 +510,6 @@ extern "C" int twog_attn_fwd(const twog_attn_t* a, int n, void* stream) {
     }
     if (lds > LDS_LIMIT) return -3;
     g.staged = staged ? 1 : 0;
-    auto aligned = [](const twog_rows_t& m) {
-        return !m.ptr || ((reinterpret_cast<uintptr_t>(m.ptr) & 15) == 0 && (m.ld_outer & 3) == 0 && (m.inner <= 1 || (m.ld_inner & 3) == 0));
-    };
-    g.vec = 1;
-    for (int i = 0; i < n; ++i) {
-        const twog_attn_t& x = a[i];
-        if (!(aligned(x.msg_hh) && aligned(x.msg_ho) && aligned(x.msg_oh) && aligned(x.msg_oo) && aligned(x.msg_so) &&
-              aligned(x.msg_sh) && aligned(x.out_hh) && aligned(x.out_oh) && aligned(x.out_sh) && aligned(x.out_ho) &&
-              aligned(x.out_so) && aligned(x.out_oo)))
-            g.vec = 0;
-    }
     static std::atomic<uint32_t> lds_attr_done{0};
     twog_allow_dynamic_lds(attn_fwd_kernel, (int)LDS_LIMIT, lds_attr_done);
     // throughput regime: 512 threads (the LDS feature tile limits a CU to 3 workgroups: 24 waves instead of 12)
