@@ -432,10 +432,13 @@ def main():
         # HBM-side bytes per launch of the dominant kernel come from the committed rocprofv3 PMC passes of this same
         # command (tools/bench_pmc.sh -> profiles/): counters cannot be read from inside the process.
         traffic, traffic_src = None, None
-        tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_gemm128_hbm_traffic.json')
-        if kind == '128x128' and os.path.exists(tpath):
-            tj = json.load(open(tpath))
-            traffic, traffic_src = tj['hbm_bytes_per_launch'], 'profiles/r01_gemm128_hbm_traffic.json: ' + tj['source']
+        import glob
+        tfiles = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles',
+                                               'r*_gemm128_hbm_traffic.json')))
+        if kind == '128x128' and tfiles:   # the latest round's committed counter passes
+            tj = json.load(open(tfiles[-1]))
+            traffic = tj['hbm_bytes_per_launch']
+            traffic_src = 'profiles/' + os.path.basename(tfiles[-1]) + ': ' + tj['source']
         result = {
             'metric': 'clips/sec fwd+bwd, T=120 N=34 C=512' if args.workload == 'c3' else f'clips/sec fwd+bwd, {wl["name"]} (informational)', 'value': bs * world * args.steps / dt, 'unit': 'clips/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
