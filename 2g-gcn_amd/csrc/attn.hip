@@ -59,66 +59,100 @@ __device__ __forceinline__ int att_off_oh(int H, int) { return H * H; }
 __device__ __forceinline__ int att_off_ho(int H, int O) { return H * H + H * O; }
 __device__ __forceinline__ int att_off_oo(int H, int O) { return H * H + 2 * H * O; }
 
-// masked softmax of one receiver's scores straight from / to LDS: w[0..S) <- softmax over the valid senders, 0 elsewhere
-// (no valid sender -> all zeros: the reference's NaN -> 0 replacement)
-template <typename Ok>
-__device__ __forceinline__ void softmax_row(const float* score, float* w, int S, bool relation_on, Ok ok) {
+// masked softmax of one receiver's scores: every thread of the (relation, receiver) rows runs the SAME code -- the row is
+// described by (base, S, excluded sender, use the object mask) -- with its <= MAX_O scores pulled into registers first, so
+// the wave that holds these rows neither diverges four ways nor pays a dependent LDS round trip per sender and pass.
+// w[0..S) <- softmax over the valid senders, 0 elsewhere (no valid sender -> all zeros: the reference's NaN -> 0).
+__device__ __forceinline__ void softmax_row(const float* score, float* w, int S, bool relation_on, int excluded,
+                                            bool use_mask, const float* sMask) {
+    float sc[MAX_O];
+    bool ok[MAX_O];
     float m = -INFINITY;
-    for (int s = 0; s < S; ++s)
-        if (ok(s)) m = fmaxf(m, score[s]);
-    float sum = 0.f;
-    for (int s = 0; s < S; ++s) {
-        const float e = ok(s) ? expf(score[s] - m) : 0.f;
-        w[s] = e;
-        sum += e;
+#pragma unroll
+    for (int s = 0; s < MAX_O; ++s) {
+        ok[s] = s < S && s != excluded && (!use_mask || sMask[s < S ? s : 0] != 0.f);
+        sc[s] = ok[s] ? score[s < S ? s : 0] : -INFINITY;
+        m = fmaxf(m, sc[s]);
     }
-    for (int s = 0; s < S; ++s) w[s] = (relation_on && ok(s)) ? w[s] / sum : 0.f;
+    float sum = 0.f;
+#pragma unroll
+    for (int s = 0; s < MAX_O; ++s) {
+        sc[s] = ok[s] ? expf(sc[s] - m) : 0.f;
+        sum += sc[s];
+    }
+#pragma unroll
+    for (int s = 0; s < MAX_O; ++s)
+        if (s < S) w[s] = (relation_on && ok[s]) ? sc[s] / sum : 0.f;
 }
 
-// pairwise scores + the four masked softmaxes. sF: [E][D] features in LDS; sG: [E][E] scratch; sW: weights out.
-__device__ __forceinline__ void compute_weights(const twog_attn_t& A, const float* sF, float* sG, float* sW,
-                                                const float* sMask) {
+constexpr int GRAM_PART = 1024;   // floats of LDS scratch for the partial dot products
+
+// pairwise scores + the four masked softmaxes. sF: [E][ldf] features in LDS (ldf = D + 4: consecutive rows start 4 banks
+// apart, so lanes that read different rows at the same column never collide); sG: [E][E] scratch; sP: GRAM_PART floats of
+// scratch; sW: weights out.
+// Gram matrix: the P = E(E+1)/2 pairs x Q column chunks are spread over the threads (thread -> pair p, chunk q); every
+// thread accumulates its strided share of one dot product from LDS, the Q partials of a pair are added by one thread.
+// (One wave per pair with a 6-step cross-lane reduction each -- the first version -- made this phase a chain of dependent
+// LDS / permute latencies: 10 of the 19 us of a segment-level launch, measured with cycle stamps.)
+__device__ __forceinline__ void compute_weights(const twog_attn_t& A, const float* sF, int ldf, float* sG, float* sP,
+                                                float* sW, const float* sMask) {
     const int H = A.H, O = A.O, E = H + O, D = A.D;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    const float scale = A.scale;
-    // Gram matrix of the entity features: one wave per (a <= b) pair
-    for (int p = wv; p < E * E; p += nw) {
-        const int a = p / E, b = p - a * E;
-        if (b < a) continue;
-        const float4* fa = reinterpret_cast<const float4*>(sF + a * D);
-        const float4* fb = reinterpret_cast<const float4*>(sF + b * D);
+    const int P = E * (E + 1) / 2;
+    int Q = (int)blockDim.x / (P > 0 ? P : 1);
+    if (Q > GRAM_PART / (P > 0 ? P : 1)) Q = GRAM_PART / (P > 0 ? P : 1);
+    if (Q < 1) Q = 1;
+    const int t = threadIdx.x;
+    if (t < P * Q) {
+        int p = t % P;
+        const int q = t / P;
+        int a = 0;
+        while (p >= E - a) { p -= E - a; ++a; }
+        const int b = a + p;
+        const float4* fa = reinterpret_cast<const float4*>(sF + a * ldf);
+        const float4* fb = reinterpret_cast<const float4*>(sF + b * ldf);
         float acc = 0.f;
-        for (int d = lane; d < (D >> 2); d += 64) {
+        for (int d = q; d < (D >> 2); d += Q) {
             const float4 x = fa[d], y = fb[d];
             acc = fmaf(x.x, y.x, acc);
             acc = fmaf(x.y, y.y, acc);
             acc = fmaf(x.z, y.z, acc);
             acc = fmaf(x.w, y.w, acc);
         }
-        acc = wave_sum(acc) * scale;
-        if (lane == 0) {
-            sG[a * E + b] = acc;
-            sG[b * E + a] = acc;
-        }
+        sP[q * P + (t % P)] = acc;
+    }
+    __syncthreads();
+    if (t < P) {
+        int p = t, a = 0;
+        while (p >= E - a) { p -= E - a; ++a; }
+        const int b = a + p;
+        float acc = 0.f;
+        for (int q = 0; q < Q; ++q) acc += sP[q * P + t];   // fixed order: deterministic
+        acc *= A.scale;
+        sG[a * E + b] = acc;
+        sG[b * E + a] = acc;
     }
     __syncthreads();
     // one thread per (relation, receiver): scores are row pieces of sG, weights go to sW
     const int i = threadIdx.x;
-    if (i < H) {  // hh: receiver human i, senders humans != i
-        softmax_row(sG + i * E, sW + att_off_hh(H, O) + i * H, H, A.msg_hh.ptr != nullptr,
-                    [&](int s) { return s != i; });
-    } else if (i < 2 * H) {  // oh: receiver human, senders objects (masked)
-        const int h = i - H;
-        softmax_row(sG + h * E + H, sW + att_off_oh(H, O) + h * O, O, A.msg_oh.ptr != nullptr,
-                    [&](int s) { return sMask[s] != 0.f; });
-    } else if (i < 2 * H + O) {  // ho: receiver object, senders humans
-        const int k = i - 2 * H;
-        softmax_row(sG + (H + k) * E, sW + att_off_ho(H, O) + k * H, H, A.msg_ho.ptr != nullptr,
-                    [&](int) { return true; });
-    } else if (i < 2 * H + 2 * O) {  // oo: receiver object k, senders objects != k (masked)
-        const int k = i - 2 * H - O;
-        softmax_row(sG + (H + k) * E + H, sW + att_off_oo(H, O) + k * O, O, A.msg_oo.ptr != nullptr,
-                    [&](int s) { return s != k && sMask[s] != 0.f; });
+    if (i < 2 * H + 2 * O) {
+        const float* sc;
+        float* w;
+        int S, excl = -1;
+        bool on, use_mask = false;
+        if (i < H) {                      // hh: receiver human i, senders humans != i
+            sc = sG + i * E; w = sW + att_off_hh(H, O) + i * H; S = H; on = A.msg_hh.ptr != nullptr; excl = i;
+        } else if (i < 2 * H) {           // oh: receiver human, senders objects (masked)
+            const int h = i - H;
+            sc = sG + h * E + H; w = sW + att_off_oh(H, O) + h * O; S = O; on = A.msg_oh.ptr != nullptr; use_mask = true;
+        } else if (i < 2 * H + O) {       // ho: receiver object, senders humans
+            const int k = i - 2 * H;
+            sc = sG + (H + k) * E; w = sW + att_off_ho(H, O) + k * H; S = H; on = A.msg_ho.ptr != nullptr;
+        } else {                          // oo: receiver object k, senders objects != k (masked)
+            const int k = i - 2 * H - O;
+            sc = sG + (H + k) * E + H; w = sW + att_off_oo(H, O) + k * O; S = O; on = A.msg_oo.ptr != nullptr;
+            excl = k; use_mask = true;
+        }
+        softmax_row(sc, w, S, on, excl, use_mask, sMask);
     }
     __syncthreads();
 }
@@ -129,10 +163,12 @@ __global__ __launch_bounds__(1024) void attn_fwd_kernel(const FwdGroup g) {
     const int inst = blockIdx.x;
     if (inst >= A.n_inst) return;
     const int H = A.H, O = A.O, E = H + O, D = A.D, hid = A.hidden;
-    float* sF = sm;            // [E][D]
-    float* sG = sF + E * D;    // [E][E]
+    const int ldf = D + 4;     // padded feature rows (see compute_weights)
+    float* sF = sm;            // [E][ldf]
+    float* sG = sF + E * ldf;  // [E][E]
     float* sW = sG + MAX_E * MAX_E;
     float* sMask = sW + NATT_MAX;
+    float* sP = sMask + MAX_O + 4;   // [GRAM_PART]
     const int clip = inst / A.inst_per_clip;
     const RowSet fh = rowset(A.feat_h, inst, H), fo = rowset(A.feat_o, inst, O);
     RowSet m_hh = rowset(A.msg_hh, inst, H), m_ho = rowset(A.msg_ho, inst, H);
@@ -146,7 +182,7 @@ __global__ __launch_bounds__(1024) void attn_fwd_kernel(const FwdGroup g) {
         for (int i = threadIdx.x; i < E * d4; i += blockDim.x) {
             const int e = i / d4, c = (i - e * d4) * 4;
             const float* src = e < H ? fh.row(e) : fo.row(e - H);
-            *reinterpret_cast<float4*>(sF + e * D + c) = *reinterpret_cast<const float4*>(src + c);
+            *reinterpret_cast<float4*>(sF + e * ldf + c) = *reinterpret_cast<const float4*>(src + c);
         }
     }
     // latency regime: the instance is shared by gridDim.z = 2 workgroups -- both compute the (cheap) weights, half 0
@@ -154,7 +190,7 @@ __global__ __launch_bounds__(1024) void attn_fwd_kernel(const FwdGroup g) {
     const int half = blockIdx.z, nhalf = gridDim.z;
     const bool do01 = nhalf == 1 || half == 0, do23 = nhalf == 1 || half == 1;
     if (g.staged) {
-        float* cur = sMask + MAX_O + 4;
+        float* cur = sP + GRAM_PART;
         cur = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(cur) + 15) & ~uintptr_t(15));
         if (do01) {
             stage_rowset(m_hh, H, hid, cur);
@@ -166,7 +202,7 @@ __global__ __launch_bounds__(1024) void attn_fwd_kernel(const FwdGroup g) {
         if (do23) stage_rowset(m_oo, O, hid, cur);
     }
     __syncthreads();
-    compute_weights(A, sF, sG, sW, sMask);
+    compute_weights(A, sF, ldf, sG, sP, sW, sMask);
     const int natt = H * H + 2 * H * O + O * O;
     if (A.att && half == 0)
         for (int i = threadIdx.x; i < natt; i += blockDim.x) A.att[(int64_t)inst * natt + i] = sW[i];
@@ -454,7 +490,7 @@ inline size_t n_dout_rows(const twog_attn_t& a) {
            (a.msg_ho.ptr ? a.O : 0) + (a.msg_so.ptr ? a.O : 0) + (a.msg_oo.ptr ? a.O : 0);
 }
 inline size_t lds_fwd(const twog_attn_t& a, bool staged) {
-    size_t f = (size_t)(a.H + a.O) * a.D + MAX_E * MAX_E + NATT_MAX + MAX_O + 8;
+    size_t f = (size_t)(a.H + a.O) * (a.D + 4) + MAX_E * MAX_E + NATT_MAX + MAX_O + 8 + GRAM_PART;
     if (staged) f += n_msg_rows(a) * a.hidden;
     return sizeof(float) * f;
 }

@@ -58,23 +58,13 @@ def main():
         wri = csv.DictWriter(fo, fieldnames=list(rows[0].keys()))
         wri.writeheader()
         wri.writerows(rows)
-    if len(sys.argv) > 3:   # traffic of the dominant kernel class (what bench.py quotes as roofline.traffic)
-        import json
-        big = [r for r in rows if r['kernel'].startswith('gemm_kernel<128, 128')]
-        n = sum(r['dispatches'] for r in big)
-        tot = sum(r['hbm_read_bytes'] + r['hbm_write_bytes'] for r in big)
-        json.dump(dict(kernel='gemm_kernel<128,128,*>', dispatches=n, hbm_bytes_total=float(tot),
-                       hbm_bytes_per_launch=tot / max(n, 1),
-                       source='rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `python3 bench.py --steps 1 --warmup 1 '
-                              '--no-cpu-baseline` (tools/bench_pmc.sh); read bytes = 2 * FETCH_SIZE KiB (gfx950 correction)'),
-                  open(sys.argv[3], 'w'))
     big = [r for r in rows if r['kernel'].startswith('gemm_kernel<128, 128')]
     if big and len(sys.argv) > 3:
         import json
         nd = sum(r['dispatches'] for r in big)
         by = sum(r['hbm_read_bytes'] + r['hbm_write_bytes'] for r in big)
         json.dump(dict(kernel='gemm_kernel<128,128,*>', dispatches=nd, hbm_bytes_total=by, hbm_bytes_per_launch=by / nd,
-                       source='rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `python3 bench.py --steps 1 --warmup 1`'
+                       source='rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline`'
                               ' (tools/bench_pmc.sh); read bytes = 2 * FETCH_SIZE KiB (gfx950 correction)'),
                   open(sys.argv[3], 'w'), indent=1)
     tot = sum(r['hbm_read_bytes'] + r['hbm_write_bytes'] for r in rows)
