@@ -41,16 +41,18 @@ __device__ __forceinline__ RowSet rowset(const twog_rows_t& m, int inst, int n) 
 }
 
 // copies the n x width floats of a row set into LDS (16-byte accesses) and re-points the set at the copy
+// (rows are laid out width + 4 floats apart: consecutive rows start 4 LDS banks apart, so lanes that read different rows
+// at the same column -- the thread-level partial dot products of the backward kernel -- do not collide)
 __device__ __forceinline__ void stage_rowset(RowSet& rs, int n, int width, float*& cursor) {
     if (!rs.on()) return;
-    const int w4 = width >> 2;
+    const int w4 = width >> 2, ld = width + 4;
     for (int i = threadIdx.x; i < n * w4; i += blockDim.x) {
         const int r = i / w4, c = (i - r * w4) * 4;
-        *reinterpret_cast<float4*>(cursor + r * width + c) = *reinterpret_cast<const float4*>(rs.row(r) + c);
+        *reinterpret_cast<float4*>(cursor + r * ld + c) = *reinterpret_cast<const float4*>(rs.row(r) + c);
     }
     rs.base = cursor;
-    rs.step = width;
-    cursor += n * width;
+    rs.step = ld;
+    cursor += n * ld;
 }
 
 // layout of the saved attention weights of one instance
@@ -319,8 +321,9 @@ __global__ __launch_bounds__(1024) void attn_bwd_kernel(const BwdGroup g) {
     const bool rmask = A.recv_mask_ho != 0, relu_mask = B.relu_mask_dmsg != 0;
     for (int i = threadIdx.x; i < natt; i += blockDim.x) sW[i] = A.att[(int64_t)inst * natt + i];
     if (threadIdx.x < O) sMask[threadIdx.x] = A.obj_mask ? A.obj_mask[(int64_t)clip * O + threadIdx.x] : 1.f;
+    float* sP = sMask + MAX_O + 4;   // [GRAM_PART] partial dot products (latency regime)
     if (g.staged) {
-        float* cur = sMask + MAX_O + 4;
+        float* cur = sP + GRAM_PART;
         cur = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(cur) + 15) & ~uintptr_t(15));
         stage_rowset(m_hh, H, hid, cur);
         stage_rowset(m_ho, H, hid, cur);
@@ -339,8 +342,57 @@ __global__ __launch_bounds__(1024) void attn_bwd_kernel(const BwdGroup g) {
     // latency regime (gridDim.z = 2): half 0 produces the sender-message gradients, half 1 the feature gradients
     const int half = blockIdx.z, nhalf = gridDim.z;
     const bool do_feat = nhalf == 1 || half == 1, do_msg = nhalf == 1 || half == 0;
-    // dL/dw[r][s] = recv_mask_r * <dout[r], msg[s]>   (one wave per pair)
-    if (do_feat)
+    // dL/dw[r][s] = recv_mask_r * <dout[r], msg[s]>
+    // latency regime (rows staged in LDS): thread -> (pair p, column chunk q) partial dot products, then one ordered add
+    // per pair -- no chain of per-pair cross-lane reductions (see compute_weights)
+    auto pair_rows = [&](int p, const float*& dr, const float*& mr, float& rs) {
+        dr = mr = nullptr;
+        rs = 1.f;
+        if (p < H * H) {
+            const int r = p / H, s_ = p - r * H;
+            if (m_hh.on() && r != s_) { dr = d_hh.row(r); mr = m_hh.row(s_); }
+        } else if (p < H * H + H * O) {
+            const int q = p - H * H, r = q / O, s_ = q - r * O;
+            if (m_oh.on()) { dr = d_oh.row(r); mr = m_oh.row(s_); }
+        } else if (p < H * H + 2 * H * O) {
+            const int q = p - H * H - H * O, r = q / H, s_ = q - r * H;
+            if (m_ho.on()) { dr = d_ho.row(r); mr = m_ho.row(s_); rs = rmask ? sMask[r] : 1.f; }
+        } else {
+            const int q = p - H * H - 2 * H * O, r = q / O, s_ = q - r * O;
+            if (m_oo.on() && r != s_) { dr = d_oo.row(r); mr = m_oo.row(s_); }
+        }
+    };
+    if (do_feat && g.staged) {
+        int Q = (int)blockDim.x / natt;
+        if (Q > GRAM_PART / natt) Q = GRAM_PART / natt;
+        if (Q < 1) Q = 1;
+        const int t = threadIdx.x;
+        if (t < natt * Q) {
+            const int p = t % natt, q = t / natt;
+            const float *dr, *mr;
+            float rs;
+            pair_rows(p, dr, mr, rs);
+            float acc = 0.f;
+            if (dr) {
+                const float4* a4 = reinterpret_cast<const float4*>(dr);
+                const float4* b4 = reinterpret_cast<const float4*>(mr);
+                for (int j = q; j < (hid >> 2); j += Q) {
+                    const float4 x = a4[j], y = b4[j];
+                    acc = fmaf(x.x, y.x, acc);
+                    acc = fmaf(x.y, y.y, acc);
+                    acc = fmaf(x.z, y.z, acc);
+                    acc = fmaf(x.w, y.w, acc);
+                }
+            }
+            sP[q * natt + p] = acc * rs;
+        }
+        __syncthreads();
+        if (t < natt) {
+            float v = 0.f;
+            for (int q = 0; q < Q; ++q) v += sP[q * natt + t];
+            sdW[t] = B.dw_extra ? v + B.dw_extra[(int64_t)inst * natt + t] : v;
+        }
+    } else if (do_feat)
     for (int p = wv; p < natt; p += nw) {
         float v = 0.f;
         if (p < H * H) {
@@ -491,12 +543,12 @@ inline size_t n_dout_rows(const twog_attn_t& a) {
 }
 inline size_t lds_fwd(const twog_attn_t& a, bool staged) {
     size_t f = (size_t)(a.H + a.O) * (a.D + 4) + MAX_E * MAX_E + NATT_MAX + MAX_O + 8 + GRAM_PART;
-    if (staged) f += n_msg_rows(a) * a.hidden;
+    if (staged) f += n_msg_rows(a) * (a.hidden + 4);
     return sizeof(float) * f;
 }
 inline size_t lds_bwd(const twog_attn_t& a, bool staged) {
-    size_t f = 2 * (size_t)NATT_MAX + MAX_E * MAX_E + MAX_O + 8;
-    if (staged) f += (n_msg_rows(a) + n_dout_rows(a)) * a.hidden;
+    size_t f = 2 * (size_t)NATT_MAX + MAX_E * MAX_E + MAX_O + 8 + GRAM_PART;
+    if (staged) f += (n_msg_rows(a) + n_dout_rows(a)) * (a.hidden + 4);
     return sizeof(float) * f;
 }
 constexpr size_t LDS_LIMIT = 160 * 1024;
