@@ -113,17 +113,24 @@ __device__ __forceinline__ void store_tile(const TileRegs<ROWS, COLS, NT>& t, fl
     }
 }
 
-template <int BM, int BN, int NT, bool AKM, bool BKM, bool FAST, int TM, int TN, int D, bool KG>
+// KS = 2 (k-split inside the workgroup): the NT threads form two groups of NT/2; both stage the operand tiles together,
+// group g multiplies the k-chunks [g * BK/16, (g+1) * BK/16) of every k-tile; the two partial tiles are added through
+// LDS by the caller (gemm_tile). For launches with fewer tiles than CUs (the recurrent chains) this puts two waves on
+// every SIMD and halves the dependent MFMA chain of a tile: +1 % on the bs64 step, +7 % at 8 clips per GPU. (The
+// k-loop of such a launch is NOT bound by its MFMAs or by load latency -- a prefetch distance of 4 changed nothing --
+// but by the ~27 GB/s a lone 64x64 tile pulls through its CU's L2 port at 16 FLOP/B; measured)
+template <int BM, int BN, int NT, bool AKM, bool BKM, bool FAST, int TM, int TN, int D, bool KG, int KS = 1>
 __device__ __forceinline__ void gemm_mainloop(const twog_rows_t A, const twog_rows_t B, int M, int N, int a_vec,
                                               int b_vec, int m0, int n0, int k_begin, int k_end, float* smem,
                                               f32x16 (&acc)[TM][TN]) {
-    constexpr int WM = BM / (NT / 128), WN = BN / 2;  // waves in a (NT/128) x 2 grid
+    constexpr int NTG = NT / KS;                        // threads of one k-group
+    constexpr int WM = BM / (NTG / 128), WN = BN / 2;  // waves of a group in a (NTG/128) x 2 grid
     constexpr int LDA = AKM ? (BM + 4) : (BK + 4);
     constexpr int LDB = BKM ? (BN + 4) : (BK + 4);
     constexpr int A_ELEMS = AKM ? BK * LDA : BM * LDA;
     constexpr int B_ELEMS = BKM ? BK * LDB : BN * LDB;
     constexpr int STAGE = A_ELEMS + B_ELEMS;  // buffer b: A at smem + b*STAGE, B right behind it
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) % (NTG / 64), kgrp = (threadIdx.x >> 6) / (NTG / 64);
     const int li = lane & 31, kh = lane >> 5;
     const int wm = (wave >> 1) * WM, wn = (wave & 1) * WN;
     const int tid = threadIdx.x;
@@ -266,10 +273,12 @@ __device__ __forceinline__ void gemm_mainloop(const twog_rows_t A, const twog_ro
         const float* a_s = smem + buf * STAGE;
         const float* b_s = a_s + A_ELEMS;
         float af[2][TM][4], bf[2][TN][4];
-        frag_load(a_s, b_s, 0, af[0], bf[0]);
+        constexpr int KCH = (BK / 8) / KS;   // 8-deep k-chunks per k-tile handled by this group
+        const int kbase = kgrp * KCH;
+        frag_load(a_s, b_s, kbase, af[0], bf[0]);
 #pragma unroll
-        for (int kk = 0; kk < BK / 8; ++kk) {
-            if (kk + 1 < BK / 8) frag_load(a_s, b_s, kk + 1, af[(kk + 1) & 1], bf[(kk + 1) & 1]);
+        for (int kk = 0; kk < KCH; ++kk) {
+            if (kk + 1 < KCH) frag_load(a_s, b_s, kbase + kk + 1, af[(kk + 1) & 1], bf[(kk + 1) & 1]);
 #pragma unroll
             for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -338,9 +347,10 @@ __device__ __forceinline__ void gemm_mainloop(const twog_rows_t A, const twog_ro
     }
 }
 
-template <int BM, int BN, int NT, bool AKM, bool BKM, int D, bool KG, bool GATE>
+template <int BM, int BN, int NT, bool AKM, bool BKM, int D, bool KG, bool GATE, int KS = 1>
 __device__ __forceinline__ void gemm_tile(const Group& g, const GateArgs* ga) {
-    constexpr int WM = BM / (NT / 128), WN = BN / 2;  // per-wave tile; waves in a (NT/128) x 2 grid
+    constexpr int NTG = NT / KS;
+    constexpr int WM = BM / (NTG / 128), WN = BN / 2;  // per-wave tile; the waves of a k-group in a (NTG/128) x 2 grid
     constexpr int TM = WM / 32, TN = WN / 32;  // 32x32 MFMA tiles per wave
     constexpr int LDA = AKM ? (BM + 4) : (BK + 4);
     constexpr int LDB = BKM ? (BN + 4) : (BK + 4);
@@ -392,9 +402,10 @@ __device__ __forceinline__ void gemm_tile(const Group& g, const GateArgs* ga) {
     const int k_begin = split * g.k_per_split;
     const int k_end = min(K, k_begin + g.k_per_split);
 
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) % (NTG / 64), kgrp = (threadIdx.x >> 6) / (NTG / 64);
     const int li = lane & 31, kh = lane >> 5;
     const int wm = (wave >> 1) * WM, wn = (wave & 1) * WN;
+    static_assert(KS == 1 || (KS == 2 && TM * TN == 1), "the in-workgroup k-split is written for the 64x64 class");
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -411,10 +422,10 @@ __device__ __forceinline__ void gemm_tile(const Group& g, const GateArgs* ga) {
     float bv[TN];
 #pragma unroll
     for (int b = 0; b < TN; ++b)
-        bv[b] = (PREFETCH_C && bias && g.splitk == 1) ? bias[min(n0 + wn + b * 32 + li, N - 1)] : 0.f;
+        bv[b] = (PREFETCH_C && bias && g.splitk == 1 && kgrp == 0) ? bias[min(n0 + wn + b * 32 + li, N - 1)] : 0.f;
     float cprev[PREFETCH_C ? 16 : 1];
     if constexpr (PREFETCH_C) {
-        if (accumulate && g.splitk == 1) {
+        if (accumulate && g.splitk == 1 && kgrp == 0) {
             const int col = min(n0 + wn + li, N - 1);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -438,7 +449,7 @@ __device__ __forceinline__ void gemm_tile(const Group& g, const GateArgs* ga) {
     int gidx = -1;
     if constexpr (GATE) {
         gidx = ga->gate_of[pi];
-        if (gidx >= 0) {
+        if (gidx >= 0 && kgrp == 0) {
             const twog_gru_step_bwd_t& S = ga->s[gidx];
             const int H = S.hidden;
             const int colc = min(n0 + wn + li, N - 1);
@@ -468,9 +479,22 @@ __device__ __forceinline__ void gemm_tile(const Group& g, const GateArgs* ga) {
     // uniform per workgroup: aligned operands and a reduction range made of whole k-tiles -> branch-free staging
     const bool fast = a_vec && b_vec && ((k_end - k_begin) % BK == 0);
     if (fast)
-        gemm_mainloop<BM, BN, NT, AKM, BKM, true, TM, TN, D, KG>(A, B, M, N, a_vec, b_vec, m0, n0, k_begin, k_end, smem, acc);
+        gemm_mainloop<BM, BN, NT, AKM, BKM, true, TM, TN, D, KG, KS>(A, B, M, N, a_vec, b_vec, m0, n0, k_begin, k_end, smem, acc);
     else
-        gemm_mainloop<BM, BN, NT, AKM, BKM, false, TM, TN, 1, false>(A, B, M, N, a_vec, b_vec, m0, n0, k_begin, k_end, smem, acc);
+        gemm_mainloop<BM, BN, NT, AKM, BKM, false, TM, TN, 1, false, KS>(A, B, M, N, a_vec, b_vec, m0, n0, k_begin, k_end, smem, acc);
+    if constexpr (KS == 2) {
+        // add the two k-groups' partial tiles (fixed order: group 0 + group 1) through LDS; group 0 runs the epilogue
+        __syncthreads();   // every wave is done with the operand tiles
+        float* red = smem + ((wave * 16) << 6) + lane;
+        if (kgrp == 1) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) red[r << 6] = acc[0][0][r];
+        }
+        __syncthreads();
+        if (kgrp == 1) return;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[0][0][r] += red[r << 6];
+    }
 
     // epilogue. C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
     if (g.splitk > 1) {
@@ -580,6 +604,16 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(const Group g) {
 template <int D>
 __global__ __launch_bounds__(256, 2) void gemm_gate_bwd_kernel(const Group g, const GateArgs ga) {
     gemm_tile<64, 64, 256, false, true, D, false, true>(g, &ga);
+}
+
+// 64x64 tiles, 8 waves, k-split inside the workgroup (see gemm_mainloop): launches with fewer tiles than workgroup slots
+template <bool BKM, int D>
+__global__ __launch_bounds__(512, 2) void gemm_ks_kernel(const Group g) {
+    gemm_tile<64, 64, 512, false, BKM, D, false, false, 2>(g, nullptr);
+}
+template <int D>
+__global__ __launch_bounds__(512, 2) void gemm_gate_bwd_ks_kernel(const Group g, const GateArgs ga) {
+    gemm_tile<64, 64, 512, false, true, D, false, true, 2>(g, &ga);
 }
 
 // sums split-K slabs in fixed order and applies the epilogue
@@ -779,6 +813,20 @@ extern "C" int twog_gemm_f32(const twog_gemm_t* problems, int n_problems, int a_
         for (int i = 0; i < n; ++i) grouped = grouped || (a_kmajor && pr[i].A.inner > 1) || (b_kmajor && pr[i].B.inner > 1);
         g_last_class = (big ? TWOG_GEMM_CLASS_TILE128 : 0) | (big && w8 && !grouped ? TWOG_GEMM_CLASS_WAVES8 : 0) |
                        (grouped ? TWOG_GEMM_CLASS_KG : 0) | (g.splitk > 1 ? TWOG_GEMM_CLASS_SPLITK : 0);
+        // few 64x64 tiles (at most ~1.5 per CU) with a reduction worth splitting: 8-wave workgroups, k-split inside
+        static const int ks_on = getenv("TWOG_GEMM_KS") ? atoi(getenv("TWOG_GEMM_KS")) : 1;
+        int kmax_ = 0;
+        for (int i = 0; i < n; ++i) kmax_ = pr[i].K > kmax_ ? pr[i].K : kmax_;
+        const bool ks = ks_on && !big && !a_kmajor && !grouped && g.splitk == 1 && g.total_tiles <= 384 && kmax_ >= 256;
+        if (ks) {
+            g_last_class |= TWOG_GEMM_CLASS_KSPLIT;
+            dim3 grid(g.total_tiles, 1), block(512);
+            if (b_kmajor) hipLaunchKernelGGL((gemm_ks_kernel<true, 2>), grid, block, 0, st, g);
+            else hipLaunchKernelGGL((gemm_ks_kernel<false, 2>), grid, block, 0, st, g);
+            TWOG_CHECK_LAUNCH();
+            done += n;
+            continue;
+        }
         if (big && w8 && !grouped) rc = d128 == 2 ? launch<128, 128, 512, 2>(g, a_kmajor, b_kmajor, st) : launch<128, 128, 512, 1>(g, a_kmajor, b_kmajor, st);
         else if (big) rc = d128 == 2 ? launch<128, 128, 256, 2>(g, a_kmajor, b_kmajor, st) : launch<128, 128, 256, 1>(g, a_kmajor, b_kmajor, st);
         else rc = d64 == 2 ? launch<64, 64, 256, 2>(g, a_kmajor, b_kmajor, st) : launch<64, 64, 256, 1>(g, a_kmajor, b_kmajor, st);
@@ -837,6 +885,15 @@ int twog_internal_gemm_gate_bwd(const twog_gemm_t* pr, int n, const twog_gru_ste
     const int d64 = depth ? ((depth >> 2) & 3) : 2;
     dim3 grid(g.total_tiles, 1), block(256);
     g_last_class = TWOG_GEMM_CLASS_GATE;
+    static const int ks_on = getenv("TWOG_GEMM_KS") ? atoi(getenv("TWOG_GEMM_KS")) : 1;
+    int kmax = 0;
+    for (int i = 0; i < n; ++i) kmax = pr[i].K > kmax ? pr[i].K : kmax;
+    if (ks_on && g.total_tiles <= 384 && kmax >= 256) {
+        g_last_class |= TWOG_GEMM_CLASS_KSPLIT;
+        hipLaunchKernelGGL(gemm_gate_bwd_ks_kernel<2>, grid, dim3(512), 0, (hipStream_t)stream, g, ga);
+        TWOG_CHECK_LAUNCH();
+        return 0;
+    }
     if (d64 == 2) hipLaunchKernelGGL(gemm_gate_bwd_kernel<2>, grid, block, 0, (hipStream_t)stream, g, ga);
     else hipLaunchKernelGGL(gemm_gate_bwd_kernel<1>, grid, block, 0, (hipStream_t)stream, g, ga);
     TWOG_CHECK_LAUNCH();

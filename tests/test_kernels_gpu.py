@@ -926,3 +926,29 @@ def test_bigru_forward_graph_capture_and_replay_at_baseline_width(K):
         for (_, bufs), want in zip(keep, wants):
             close(bufs['out'], want, rtol=1e-4, atol=1e-5, what=f'bigru rep {rep}')
     assert K.graph_cache_stats()[0] == n0 + 1   # the loop was captured (and replayed twice)
+
+
+@pytest.mark.parametrize('bkm', [False, True])
+def test_gemm_ksplit_class(K, bkm):
+    """Few 64x64 tiles with a reduction worth splitting (the recurrent chains' launches): 8-wave workgroups whose two
+    wave groups take alternate k-chunks and add their partial tiles through LDS. Checked against fp64; the class bit is
+    asserted, as for the 128x128 class."""
+    for (M, N, K_, bias, act, acc) in ((640, 1024, 512, True, 1, False), (1280, 512, 1536, False, 0, True),
+                                      (130, 200, 288, True, 0, True)):
+        g = torch.Generator().manual_seed(M + N)
+        A = torch.randn(M, K_, generator=g).to(DEV)
+        B = ((torch.randn(K_, N, generator=g) if bkm else torch.randn(N, K_, generator=g)) * 0.1).to(DEV)
+        b = torch.randn(N, generator=g).to(DEV) if bias else None
+        C0 = torch.randn(M, N, generator=g).to(DEV)
+        Cg = C0.clone()
+        K.gemm([dict(A=A, B=B, C=Cg, bias=b, act=act, accumulate=acc)], b_kmajor=bkm)
+        cls = K.gemm_last_class()
+        assert cls & K.GEMM_KSPLIT and not cls & K.GEMM_TILE128, hex(cls)
+        ref = A.double() @ (B.double() if bkm else B.double().t())
+        if bias:
+            ref = ref + b.double()
+        if acc:
+            ref = ref + C0.double()
+        if act:
+            ref = torch.relu(ref)
+        assert (Cg.double() - ref).abs().max().item() <= 3e-5 * ref.abs().max().item()
