@@ -87,10 +87,22 @@ class GemmProfiler:
     """HIP-event timing of every GEMM launch issued by the host composition (on torch's current stream, which is the
     stream the kernels are enqueued on). Launches are classed by the tile variant the library picks."""
 
-    def __init__(self, K):
+    def __init__(self, K, pool=None):
+        """pool: pre-created timing events (created OUTSIDE the timed region: on a fresh box the first few hundred
+        hipEventCreate calls of a process cost milliseconds each -- measured: 245 ms steps instead of 86)."""
         self.K, self.orig, self.records, self.shapes = K, K.gemm, [], []
         self.orig_attn = (K.attn_fwd, K.attn_bwd)
         self.attn = {'fwd': [], 'bwd': []}   # HIP events around the frame-level attention launches
+        self.pool, self.used = pool if pool is not None else [], 0
+
+    def event(self):
+        if self.used < len(self.pool):
+            e = self.pool[self.used]
+        else:
+            e = torch.cuda.Event(enable_timing=True)
+            self.pool.append(e)
+        self.used += 1
+        return e
 
     def __enter__(self):
         def timed(kind, fn):
@@ -98,7 +110,7 @@ class GemmProfiler:
                 d = descs[0] if kind == 'fwd' else descs[0]['f']
                 if d['inst_per_clip'] <= 1:          # (segment-level calls happen inside the library's time loop)
                     return fn(descs)
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0, e1 = self.event(), self.event()
                 e0.record()
                 fn(descs)
                 e1.record()
@@ -119,7 +131,7 @@ class GemmProfiler:
                 tiles128 += nb * math.ceil(M / 128) * math.ceil(Nn / 128)
                 kmax = max(kmax, Kk)
                 wide = wide and M >= 96 and Nn >= 96
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0, e1 = self.event(), self.event()
             e0.record()
             self.orig(problems, a_kmajor, b_kmajor, split_k_workspace)
             e1.record()
@@ -374,17 +386,32 @@ def main():
         step()
         torch.cuda.synchronize()
         log(f'warmup step {i}: {time.perf_counter() - tw:.3f} s')
+    # one more untimed step under the event wrappers: counts the events a step records, so that every event of the timed
+    # region exists before it starts (and the wrappers' code paths are warm)
+    with GemmProfiler(K) as dry:
+        step()
     torch.cuda.synchronize()
+    pool = [torch.cuda.Event(enable_timing=True) for _ in range(dry.used * args.steps + 64)]
+    for e in pool[:64]:
+        e.record()
+    torch.cuda.synchronize()
+    import gc
+    gc.collect()
+    gc.disable()          # no collector pauses inside the timed region
     barrier()
     torch.cuda.synchronize()
-    with GemmProfiler(K) as prof:
+    step_ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    with GemmProfiler(K, pool) as prof:
         t0 = time.perf_counter()
-        for _ in range(args.steps):
+        step_ev[0].record()
+        for i in range(args.steps):
             loss = step()
+            step_ev[i + 1].record()
         torch.cuda.synchronize()
         barrier()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+    gc.enable()
     if world > 1:
         tmax = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -392,7 +419,8 @@ def main():
     agg = prof.summary()
     if os.environ.get('TWOG_BENCH_GEMM_DETAIL') and rank == 0:
         prof.detail(args.steps)
-    log(f'timed region done: {dt / args.steps * 1e3:.1f} ms/step')
+    log(f'timed region done: {dt / args.steps * 1e3:.1f} ms/step; per step (device): '
+        + ' '.join(f'{step_ev[i].elapsed_time(step_ev[i + 1]):.0f}' for i in range(args.steps)))
 
     # secondary roofline: the geometric-level GCN forward alone (the kernel group the north star's HBM-roofline target
     # names), HIP events around its launches; algorithmic bytes T*(16N + 512N) per clip

@@ -941,7 +941,8 @@ def test_gemm_ksplit_class(K, bkm):
         b = torch.randn(N, generator=g).to(DEV) if bias else None
         C0 = torch.randn(M, N, generator=g).to(DEV)
         Cg = C0.clone()
-        K.gemm([dict(A=A, B=B, C=Cg, bias=b, act=act, accumulate=acc)], b_kmajor=bkm)
+        # (no split-K workspace: the form the time loops use)
+        K.gemm([dict(A=A, B=B, C=Cg, bias=b, act=act, accumulate=acc)], b_kmajor=bkm, split_k_workspace=False)
         cls = K.gemm_last_class()
         assert cls & K.GEMM_KSPLIT and not cls & K.GEMM_TILE128, hex(cls)
         ref = A.double() @ (B.double() if bkm else B.double().t())
