@@ -1018,7 +1018,10 @@ def tggcn_forward(K, plan: Plan, P, x_human, x_objects, objects_mask, human_seg,
                head('object_recognition_mlp', R_o, O, p.n_aff, cat_o), head('object_prediction_mlp', R_o, O, p.n_aff, cat_o)]
         outputs = [gates['h']['hard'], gates['o']['hard'], gates['h']['soft'], gates['o']['soft'],
                    y_h[0], y_h[1], y_o[0], y_o[1], y_h[2], y_h[3], y_o[2], y_o[3]]
-    S['outputs'] = outputs
+    # (detached aliases: the returned tensors get this node as their grad_fn, and the node keeps S alive -- holding the
+    # tensors themselves would close a reference cycle that only the cyclic collector could free, one batch of saved
+    # buffers per step late)
+    S['outputs'] = [o.detach() for o in outputs]
     return outputs, S
 
 

@@ -371,6 +371,22 @@ def main():
     # steady rate (measured: 190-240 ms instead of 86 for the first dozen steps -- clocks, page-in, allocator growth, graph
     # captures). Steps are repeated until three in a row agree within 3 % (at most 40); the W warm-up steps and the K
     # timed steps follow.
+    if os.environ.get('TWOG_BENCH_DEBUG'):   # where a step spends its time, phase by phase (host clock, synchronised)
+        for i in range(3):
+            ts = [time.perf_counter()]
+            dp.zero_grad()
+            out = model(x_human, x_objects, mask, human_segmentation=seg)
+            ts.append(time.perf_counter()); torch.cuda.synchronize(); ts.append(time.perf_counter())
+            loss = sum(criterion(out, loss_targets))
+            torch.cuda.synchronize(); ts.append(time.perf_counter())
+            loss.backward()
+            ts.append(time.perf_counter()); torch.cuda.synchronize(); ts.append(time.perf_counter())
+            dp.all_reduce_gradients()
+            opt.step(dp.grad_scale)
+            torch.cuda.synchronize(); ts.append(time.perf_counter())
+            d = [(b - a) * 1e3 for a, b in zip(ts[:-1], ts[1:])]
+            log(f'debug step {i}: forward enqueue {d[0]:.1f} + drain {d[1]:.1f}, loss {d[2]:.1f}, backward enqueue {d[3]:.1f} + '
+                f'drain {d[4]:.1f}, adam {d[5]:.1f} ms')
     hist = []
     for i in range(40):
         tw = time.perf_counter()
@@ -395,9 +411,6 @@ def main():
     for e in pool[:64]:
         e.record()
     torch.cuda.synchronize()
-    import gc
-    gc.collect()
-    gc.disable()          # no collector pauses inside the timed region
     barrier()
     torch.cuda.synchronize()
     step_ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
@@ -411,7 +424,6 @@ def main():
         barrier()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-    gc.enable()
     if world > 1:
         tmax = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)

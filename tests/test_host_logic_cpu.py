@@ -283,3 +283,26 @@ def test_gradient_sink_route_is_opt_in(fake_backend):
         g = ref[id(p)]
         if g is not None:
             assert float((p.grad - g).abs().max()) <= 1e-5 * (float(g.abs().max()) + 1e-12)
+
+
+def test_no_reference_cycle_keeps_saved_buffers_alive(fake_backend):
+    """The autograd node must not sit in a reference cycle with its saved state: after the step's tensors go out of
+    scope every saved buffer is freed by reference counting alone (no cyclic-GC pass) -- otherwise each training step
+    leaves gigabytes of buffers behind until the collector happens to run."""
+    import gc
+    import weakref
+    z, meta = load_g4('c2_stage1')
+    m = build_model(meta)
+    m.train()
+    noise = torch.from_numpy(z['gumbel_noise'])
+    m._gumbel_noise_override = noise if len(noise) else None
+    gc.disable()
+    try:
+        out = m(**g4_inputs(z))
+        node = next(o.grad_fn for o in out if o.grad_fn is not None)
+        probe = weakref.ref(node.S['HUM'])
+        sum((o * o).sum() for o in out if o.requires_grad).backward()
+        del out, node
+        assert probe() is None, 'saved buffers survived without a GC pass: reference cycle through the autograd node'
+    finally:
+        gc.enable()
