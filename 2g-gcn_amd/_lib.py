@@ -161,6 +161,7 @@ SIGNATURES = {
     'twog_relation_fwd': [C.POINTER(Relation), _P],
     'twog_relation_bwd': [C.POINTER(RelationBwd), _P],
     'twog_ssp_fwd': [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    'twog_ssp_gather': [_P, _L, _P, _L, _L, _I, _P, _I, _I, _I, _I, _I, _P],
     'twog_ssp_bwd': [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     'twog_gate_fwd': [C.POINTER(Gate), _P],
     'twog_gate_bwd': [C.POINTER(Gate), _P, _P, _P, _P, _P],

@@ -106,7 +106,48 @@ __global__ __launch_bounds__(256) void ssp_bwd_kernel(const float* dgi, const fl
     }
 }
 
+// gather only, arbitrary placement of the weights and of the gradient rows (the segment level keeps its attention
+// weights [time][clip][natt] and the two directions side by side in the d_gi rows):
+//   qh[(inst, h)][c] = sum_k att(inst)[att_off + k*H + h] * dgi[(inst*O + k) * dgi_ld + c]
+__global__ __launch_bounds__(256) void ssp_gather_kernel(const float* dgi, int64_t dgi_ld, const float* att,
+                                                         int64_t att_ld_clip, int64_t att_ld_frame, int att_off,
+                                                         float* qh, int inst_per_clip, int H, int O, int cols) {
+    const int inst = blockIdx.x;
+    const int clip = inst / inst_per_clip, frame = inst - clip * inst_per_clip;
+    const float* w = att + clip * att_ld_clip + frame * att_ld_frame + att_off;
+    const int c4 = cols >> 2;
+    for (int i = threadIdx.x; i < c4; i += blockDim.x) {
+        float4 q4[4];
+#pragma unroll
+        for (int h = 0; h < 4; ++h) q4[h] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int k = 0; k < O; ++k) {
+            const float4 g = reinterpret_cast<const float4*>(dgi + ((int64_t)inst * O + k) * dgi_ld)[i];
+#pragma unroll
+            for (int h = 0; h < 4; ++h) {
+                if (h >= H) break;
+                const float wk = w[k * H + h];
+                q4[h].x = fmaf(wk, g.x, q4[h].x); q4[h].y = fmaf(wk, g.y, q4[h].y);
+                q4[h].z = fmaf(wk, g.z, q4[h].z); q4[h].w = fmaf(wk, g.w, q4[h].w);
+            }
+        }
+        for (int h = 0; h < H && h < 4; ++h) reinterpret_cast<float4*>(qh + ((int64_t)inst * H + h) * cols)[i] = q4[h];
+    }
+}
+
 }  // namespace
+
+extern "C" int twog_ssp_gather(const float* dgi, int64_t dgi_ld, const float* att, int64_t att_ld_clip,
+                               int64_t att_ld_frame, int att_off, float* qh, int n_inst, int inst_per_clip, int H, int O,
+                               int cols, void* stream) {
+    if (n_inst <= 0 || O <= 0 || H <= 0) return 0;
+    if ((cols & 3) || (dgi_ld & 3) || H > 4 || O > 16 || inst_per_clip <= 0 || !att || !qh ||
+        (reinterpret_cast<uintptr_t>(dgi) & 15))
+        return -2;
+    hipLaunchKernelGGL(ssp_gather_kernel, dim3(n_inst), dim3(256), 0, (hipStream_t)stream, dgi, dgi_ld, att, att_ld_clip,
+                       att_ld_frame, att_off, qh, inst_per_clip, H, O, cols);
+    TWOG_CHECK_LAUNCH();
+    return 0;
+}
 
 extern "C" int twog_ssp_fwd(float* gi, const float* ph, const float* ps, const float* att, const float* mask, int n_inst,
                             int inst_per_clip, int H, int O, int cols, int natt, int att_off, void* stream) {

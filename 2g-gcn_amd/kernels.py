@@ -509,6 +509,17 @@ class HipKernels:
         self._check(self.lib.twog_ssp_fwd(gi.data_ptr(), _ptr(ph), _ptr(ps), _ptr(att), _ptr(mask), n_inst, inst_per_clip,
                                           H, O, cols, natt, att_off, self._stream()), 'twog_ssp_fwd')
 
+    def ssp_gather(self, dgi, att, att_ld_clip, att_ld_frame, att_off, n_inst, inst_per_clip, H, O):
+        """dgi: (n_inst*O, cols) view with unit column stride (row stride free) -> qh (n_inst*H, cols) =
+        sum_k att(inst)[att_off + k*H + h] * dgi[(inst, k)]."""
+        assert dgi.dim() == 2 and dgi.stride(1) == 1
+        cols = dgi.shape[1]
+        qh = torch.empty(n_inst * H, cols, dtype=torch.float32, device=dgi.device)
+        self._check(self.lib.twog_ssp_gather(dgi.data_ptr(), dgi.stride(0), att.data_ptr(), att_ld_clip, att_ld_frame,
+                                             att_off, qh.data_ptr(), n_inst, inst_per_clip, H, O, cols, self._stream()),
+                    'twog_ssp_gather')
+        return qh
+
     def ssp_bwd(self, dgi, ph, att, mask, n_inst, inst_per_clip, H, O, att_off, want_qs, dw=None):
         """Returns (qh (n_inst*H, cols) or None, qs (n_inst, cols) or None); fills dw[:, att_off : att_off + O*H] if given."""
         cols = dgi.shape[-1]

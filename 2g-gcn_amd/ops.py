@@ -14,6 +14,7 @@ buffers laid out for those kernels:
 No torch math is used on the data path (torch owns memory, streams, and the autograd graph edge).
 """
 import math
+import os
 
 import torch
 
@@ -1159,7 +1160,25 @@ def tggcn_backward(K, plan: Plan, P, S, x_human, x_objects, objects_mask, d_outp
                     K.gemm([dict(A=q_d, B=msgs[:, i_ * h:(i_ + 1) * h], C=dW_ih[:, cc:cc + h])], a_kmajor=True, b_kmajor=True)
                     K.gemm([dict(A=q_d, B=w_ih[:, cc:cc + h], C=dm, accumulate=True)], b_kmajor=True)
             if w_ih.shape[1] > fw:
-                K.gemm([dict(A=dgi_d, B=_v2(mg[d]), C=dW_ih[:, fw:])], a_kmajor=True, b_kmajor=True)
+                seg_rels_k = p.seg_mh if kind == 'h' else p.seg_mo
+                ssp_seg = (kind == 'o' and 'ho' in seg_rels_k and H < O and not p.general_segment()
+                           and not os.environ.get('TWOG_NO_SSP'))
+                if not ssp_seg:
+                    K.gemm([dict(A=dgi_d, B=_v2(mg[d]), C=dW_ih[:, fw:])], a_kmajor=True, b_kmajor=True)
+                else:
+                    # sender-side form of the human->object block (see ssp.hip): mg_ho[k] = sum_h att[k][h] msrc_ho[h], so
+                    # its weight gradient reduces over the H sender rows of every (clip, step) with q = sum_k att d_gi
+                    mgv = _v2(mg[d])
+                    for i_, rel_ in enumerate(seg_rels_k):
+                        blk = dW_ih[:, fw + i_ * h:fw + (i_ + 1) * h]
+                        if rel_ != 'ho':
+                            K.gemm([dict(A=dgi_d, B=mgv[:, i_ * h:(i_ + 1) * h], C=blk)], a_kmajor=True, b_kmajor=True)
+                            continue
+                        natt = sb['att'].shape[-1]
+                        qh = K.ssp_gather(dgi_d, sb['att'][d], natt, bs * natt, H * H + H * O, nF, T, H, O)
+                        i_s = S['seg_rels'][0].index('ho')
+                        K.gemm([dict(A=qh, B=_v2(sb['msrc_h'][d])[:, i_s * h:(i_s + 1) * h], C=blk)],
+                               a_kmajor=True, b_kmajor=True)
             G.add(c + '.weight_ih', dW_ih)
             G.add(c + '.bias_ih', K.colsum(dgi_d))
             # dW_hh = sum over steps with a previous state: forward chain pairs (t, t-1), backward chain (t, t+1)

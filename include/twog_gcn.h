@@ -309,6 +309,11 @@ int twog_scale_rows(twog_rows_t x, const float* s, int rows, int cols, void* str
  * =============================================================================================================== */
 int twog_ssp_fwd(float* gi, const float* ph, const float* ps, const float* att, const float* mask, int n_inst,
                  int inst_per_clip, int H, int O, int cols, int natt, int att_off, void* stream);
+/* gather alone, with arbitrary placement: qh[(inst,h)][c] = sum_k att(inst)[att_off + k*H + h] * dgi[(inst*O + k)*dgi_ld + c],
+ * att(inst) = att + clip*att_ld_clip + frame*att_ld_frame. Used for the segment-level human->object message block of the
+ * objects' W_ih gradient (its weights are stored [time][clip][natt], the two directions share the d_gi rows). */
+int twog_ssp_gather(const float* dgi, int64_t dgi_ld, const float* att, int64_t att_ld_clip, int64_t att_ld_frame,
+                    int att_off, float* qh, int n_inst, int inst_per_clip, int H, int O, int cols, void* stream);
 int twog_ssp_bwd(const float* dgi, const float* ph, const float* att, const float* mask, float* qh, float* qs, float* dw,
                  int n_inst, int inst_per_clip, int H, int O, int cols, int natt, int att_off, void* stream);
 

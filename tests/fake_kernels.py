@@ -583,6 +583,18 @@ class FakeKernels:
             add = add + ps.view(n_inst, 1, cols)
         gi.add_((m * add).view(gi.shape))
 
+    def ssp_gather(self, dgi, att, att_ld_clip, att_ld_frame, att_off, n_inst, inst_per_clip, H, O):
+        cols = dgi.shape[1]
+        flat = att.reshape(-1)
+        qh = torch.zeros(n_inst, H, cols)
+        g = dgi.reshape(n_inst, O, cols)
+        for inst in range(n_inst):
+            c, f = divmod(inst, inst_per_clip)
+            base = c * att_ld_clip + f * att_ld_frame + att_off
+            w = flat[base:base + O * H].view(O, H)
+            qh[inst] = w.t() @ g[inst]
+        return qh.reshape(n_inst * H, cols)
+
     def ssp_bwd(self, dgi, ph, att, mask, n_inst, inst_per_clip, H, O, att_off, want_qs, dw=None):
         cols = dgi.shape[-1]
         m = (mask.repeat_interleave(inst_per_clip, 0) if mask is not None else torch.ones(n_inst, O)).view(n_inst, O, 1)

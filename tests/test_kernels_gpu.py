@@ -953,3 +953,19 @@ def test_gemm_ksplit_class(K, bkm):
         if act:
             ref = torch.relu(ref)
         assert (Cg.double() - ref).abs().max().item() <= 3e-5 * ref.abs().max().item()
+
+
+def test_ssp_gather_with_segment_level_placement(K):
+    """Weights stored [time][clip][natt] and the gradient rows a column block of wider rows (the segment level's layout)."""
+    bs, T, H, O, cols = 3, 5, 2, 8, 48
+    natt = H * H + 2 * H * O + O * O
+    att = torch.softmax(rnd(T, bs, natt, seed=1), -1)
+    dgi_full = rnd(bs * T * O, 2 * cols, seed=2)
+    off = H * H + H * O
+    qc = F.ssp_gather(dgi_full[:, cols:], att, natt, bs * natt, off, bs * T, T, H, O)
+    qg = K.ssp_gather(dgi_full.to(DEV)[:, cols:], att.to(DEV), natt, bs * natt, off, bs * T, T, H, O)
+    close(qg, qc, what='ssp_gather')
+    # against the definition
+    w = att.permute(1, 0, 2)[..., off:off + O * H].reshape(bs * T, O, H)
+    ref = torch.einsum('nkh,nkc->nhc', w, dgi_full[:, cols:].reshape(bs * T, O, cols)).reshape(bs * T * H, cols)
+    close(qc, ref, what='specification vs definition')
