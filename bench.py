@@ -393,7 +393,12 @@ def main():
         step()
         torch.cuda.synchronize()
         hist.append(time.perf_counter() - tw)
-        if len(hist) >= 4 and max(hist[-3:]) <= 1.03 * min(hist[-3:]):
+        settled = len(hist) >= 4 and max(hist[-3:]) <= 1.03 * min(hist[-3:])
+        if world > 1:   # every rank must run the same number of steps (each holds a collective): stop when ALL have settled
+            flag = torch.tensor([1.0 if settled else 0.0], device=device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            settled = bool(flag.item() > 0.5)
+        if settled:
             break
     log(f'device warm-up: {len(hist)} steps, last {hist[-1] * 1e3:.1f} ms')
     log('model + data ready; warmup')

@@ -38,7 +38,9 @@ def boundary_layers(model, out):
     found = {}
 
     def check(layer, x):
-        w = P[layer + '.weight']
+        w = P.get(layer + '.weight')
+        if w is None or x is None or x.shape[-1] != w[0].numel():
+            return   # a configuration without this layer / with another operand layout (general relations): not covered
         units = _boundary_units(x.reshape(-1, x.shape[-1]), w.view(w.shape[0], -1), P.get(layer + '.bias'))
         idx = units.nonzero().flatten()
         if len(idx):
@@ -49,14 +51,14 @@ def boundary_layers(model, out):
         if O:
             check('object_embedding_mlp.0', x_objects.view(nF * O, -1))
         check('geometry_embedding_mlp.0', S['Gout'].view(nF, 128 * N))
-        check('geometry_embedding_mlp.2', S['t1'])
-        check('geometry_embedding_gcn.joint_embed.cnn.3.cnn', S['e1'])
+        check('geometry_embedding_mlp.2', S.get('t1'))
+        check('geometry_embedding_gcn.joint_embed.cnn.3.cnn', S.get('e1'))
         for kind, Ev, hfr in (('human', HUMv, S['HFR'][0]), ('object', OBJv, S['HFR'][1]), ('geometry', GEOv, S['HFR'][2])):
             check(kind + '_bd_embedding_mlp.0', hfr)
         for Ev, rels in ((HUMv, plan.snd_h), (OBJv, plan.snd_o), (GEOv, plan.snd_s)):
             for rel in rels:
                 check(ops._FRAME_MLP[rel] + '.0', Ev[:, :2 * h])
-        if plan.msg_segment and T > 1:
+        if plan.msg_segment and T > 1 and 'seg_rels' in S:
             sb = S['seg_bufs']
             for rels, hs in ((S['seg_rels'][0], sb['hs_h']), (S['seg_rels'][1], sb['hs_o'])):
                 prev = torch.cat([hs[:, :T - 1, :, :h].reshape(-1, h), hs[:, 1:, :, h:].reshape(-1, h)], 0)
