@@ -872,7 +872,9 @@ def tggcn_forward(K, plan: Plan, P, x_human, x_objects, objects_mask, human_seg,
             # 'same_as_human' with one human (models.py:1523-1525): every object takes the human's decisions; the
             # forced end at the last (padded) step is applied to the objects' copies as well (:744-745)
             gh = gates['h']
-            hard = gh['hard'].expand(bs, T, O).contiguous()
+            # (own storage: with H == O == 1 the expanded view IS the human's tensor -- for a given segmentation the
+            # caller's input -- and the forced end below must not write into it)
+            hard = gh['hard'].expand(bs, T, O).clone(memory_format=torch.contiguous_format)
             soft = gh['soft'].expand(bs, T, O).contiguous()
             if T > 0 and O > 0:
                 hard[:, T - 1].fill_(1.0)

@@ -306,3 +306,26 @@ def test_no_reference_cycle_keeps_saved_buffers_alive(fake_backend):
         assert probe() is None, 'saved buffers survived without a GC pass: reference cycle through the autograd node'
     finally:
         gc.enable()
+
+
+@pytest.mark.parametrize('strategy', ['sah', 'coh', 'ind'])
+@pytest.mark.parametrize('filt', [False, True])
+def test_callers_inputs_are_never_written(strategy, filt, fake_backend):
+    """One human, one object, one frame: every expanded (bs, T, O) view of the human's decisions has the shape of the
+    tensor itself. A given human segmentation must come back untouched (the forced end of the objects' copy of it was
+    once written through such a view) and equal output 0, as in the reference (vhoi/models.py:738-745)."""
+    torch.manual_seed(3)
+    N, bs, T, H, O = 19, 4, 1, 1, 1
+    m = TGGCN(input_size=(2048 + 4 * N, 2048), num_classes=(13, None), hidden_size=16, gcn_node=N,
+              object_segment_update_strategy=strategy, filter_discrete_updates=filt, update_segment_threshold=0.3)
+    m.train()
+    x_h, x_o = torch.rand(bs, T, H, 2048 + 4 * N), torch.rand(bs, T, O, 2048)
+    mask = torch.ones(bs, O)
+    seg = torch.tensor([1.0, 0.0, 1.0, 0.0]).view(bs, T, H)
+    keep = [t.clone() for t in (x_h, x_o, mask, seg)]
+    out = m(x_h, x_o, mask, human_segmentation=seg)
+    sum((o * o).sum() for o in out if o.requires_grad).backward()
+    for t, k in zip((x_h, x_o, mask, seg), keep):
+        assert torch.equal(t, k)
+    if not filt:
+        assert torch.equal(out[0], keep[3])
