@@ -119,7 +119,10 @@ __device__ __forceinline__ void store_tile(const TileRegs<ROWS, COLS, NT>& t, fl
 // every SIMD and halves the dependent MFMA chain of a tile: +1 % on the bs64 step, +7 % at 8 clips per GPU. (The
 // k-loop of such a launch is NOT bound by its MFMAs or by load latency -- a prefetch distance of 4 changed nothing --
 // but by the ~27 GB/s a lone 64x64 tile pulls through its CU's L2 port at 16 FLOP/B; measured)
-template <int BM, int BN, int NT, bool AKM, bool BKM, bool FAST, int TM, int TN, int D, bool KG, int KS = 1>
+// G3 (fused GRU forward step, gemm_gru_fwd_kernel): B holds the three gate blocks of a GRU weight, [3N][K] rows r | z | n,
+// and the tile's 192 columns are 64 hidden units x 3 gates laid out so that accumulator b of every wave is gate b of
+// the SAME 32 units: tile column c -> gate (c % 96) / 32, unit n0 + 32 * (c / 96) + c % 32. N counts hidden units.
+template <int BM, int BN, int NT, bool AKM, bool BKM, bool FAST, int TM, int TN, int D, bool KG, int KS = 1, bool G3 = false>
 __device__ __forceinline__ void gemm_mainloop(const twog_rows_t A, const twog_rows_t B, int M, int N, int a_vec,
                                               int b_vec, int m0, int n0, int k_begin, int k_end, float* smem,
                                               f32x16 (&acc)[TM][TN]) {
@@ -157,7 +160,11 @@ __device__ __forceinline__ void gemm_mainloop(const twog_rows_t A, const twog_ro
 #pragma unroll
         for (int i = 0; i < BRegs::PASSES; ++i) {
             const int rr = tid / BRegs::F4_PER_ROW + i * BRegs::ROWS_PER_PASS, cc = (tid % BRegs::F4_PER_ROW) * 4;
-            if constexpr (BKM) ob[i] = 4u * (uint32_t)((int64_t)rr * B.ld_outer + min(n0 + cc, N - 4));
+            if constexpr (G3) {
+                static_assert(!G3 || (FAST && !BKM && !KG && BN == 192 && TN == 3), "gate-aware column map: 64 x 192 tiles");
+                const int gate = (rr % 96) / 32, unit = n0 + 32 * (rr / 96) + (rr & 31);
+                ob[i] = 4u * (uint32_t)(twog_row_off(B, gate * N + min(unit, N - 1)) + cc);
+            } else if constexpr (BKM) ob[i] = 4u * (uint32_t)((int64_t)rr * B.ld_outer + min(n0 + cc, N - 4));
             else ob[i] = 4u * (uint32_t)(twog_row_off(B, min(n0 + rr, N - 1)) + cc);
         }
     }
@@ -616,6 +623,130 @@ __global__ __launch_bounds__(512, 2) void gemm_gate_bwd_ks_kernel(const Group g,
     gemm_tile<64, 64, 512, false, true, D, false, true, 2>(g, &ga);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Fused GRU forward step of the recurrent chains (gru.hip, segrnn.hip): one launch per chain step computes
+//   [r | z | n_h] = h_prev W_hh^T            (and  [r | z | n_i] += m W_ih[:, msg]^T  at the segment level)
+// on 64-row x (64 units x 3 gates) tiles and finishes the step in the epilogue -- sigmoid / tanh, the blend with h_prev,
+// the segment gate u -- from the accumulators: no gh round trip through memory, no gate launch. Same arithmetic as
+// gru_step_fwd_kernel (gru.hip); r, z, n and W_hn h + b_hn are saved for the backward chain as before.
+// A workgroup stages 64 + 192 operand rows per k-tile (24 FLOP/B instead of the 64x64 tile's 16 -- these launches are
+// bound by the L2 port of their CU) and the unit tile index is the block's XCD, so each L2 keeps
+// one 192-row slice of every weight.
+struct GruFwdProb {
+    twog_rows_t A, B, A2, B2;      // previous states x W_hh; aggregated messages x W_ih[:, msg] (K2 == 0: absent)
+    twog_rows_t gi, h_out, save;  // W_ih x + b_ih of this step [rows][3h]; new state; saved gates [rows][4h]
+    const float* b_hh;            // [3h] or nullptr
+    const float* u;               // segment gate per row or nullptr
+    int u_ld_outer, u_ld_inner;
+    int K2, rows, has_prev, rt_start, inner;
+};
+struct GruFwdGroup {
+    GruFwdProb p[MAXP];
+    int n, tiles_n, hidden;
+};
+
+template <int D, int KS>
+__global__ __launch_bounds__(256 * KS, 1) void gemm_gru_fwd_kernel(const GruFwdGroup g) {
+    constexpr int BM = 64, BN = 192, NT = 256 * KS, TM = 1, TN = 3;
+    __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * (BK + 4)];
+    const int ut = blockIdx.x % g.tiles_n, rt = blockIdx.x / g.tiles_n;
+    int pi = 0;
+#pragma unroll 1
+    for (int i = 1; i < g.n; ++i)
+        if (rt >= g.p[i].rt_start) pi = i;
+    const GruFwdProb& P = g.p[pi];
+    const int H = g.hidden, M = P.rows, m0 = (rt - P.rt_start) * BM, n0 = ut * 64;
+    const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) & 3, kgrp = threadIdx.x >> 8;   // KS == 2: two k-groups
+    const int li = lane & 31, kh = lane >> 5;
+    const int wm = (wave >> 1) * 32;
+    const int unit = n0 + (wave & 1) * 32 + li, unitc = min(unit, H - 1);
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[0][b][r] = 0.f;
+
+    // epilogue operands: requested next to the first operand tiles, they arrive under the reduction loop
+    const bool has_u = P.u != nullptr, has_hp = P.has_prev != 0;
+    const int inner = P.inner;
+    const float inv_inner = 1.0f / (float)inner;
+    const float b_r = P.b_hh ? P.b_hh[unitc] : 0.f, b_z = P.b_hh ? P.b_hh[H + unitc] : 0.f, b_n = P.b_hh ? P.b_hh[2 * H + unitc] : 0.f;
+    float e_r[16], e_z[16], e_n[16], e_h0[16], e_u[16];
+    if (kgrp == 0) {
+        const float* hp_ptr = has_hp ? P.A.ptr : P.gi.ptr;
+        const int hp_lo = has_hp ? (int)P.A.ld_outer : (int)P.gi.ld_outer, hp_li = has_hp ? (int)P.A.ld_inner : (int)P.gi.ld_inner;
+        const float* u_ptr = has_u ? P.u : P.gi.ptr;
+        const int u_lo = has_u ? P.u_ld_outer : 0, u_li = has_u ? P.u_ld_inner : 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int rowc = min(m0 + wm + (r & 3) + 8 * (r >> 2) + 4 * kh, M - 1);
+            const int o = (int)(((float)rowc + 0.5f) * inv_inner), i = rowc - o * inner;
+            const float* gi = P.gi.ptr + (o * (int)P.gi.ld_outer + i * (int)P.gi.ld_inner);
+            e_r[r] = gi[unitc];
+            e_z[r] = gi[H + unitc];
+            e_n[r] = gi[2 * H + unitc];
+            e_h0[r] = hp_ptr[o * hp_lo + i * hp_li + unitc];
+            e_u[r] = u_ptr[o * u_lo + i * u_li];
+        }
+    }
+
+    gemm_mainloop<BM, BN, NT, false, false, true, TM, TN, D, false, KS, true>(P.A, P.B, M, H, 1, 1, m0, n0, 0, H, smem, acc);
+    f32x16 hn = acc[0][2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[0][2][r] = 0.f;
+    if (P.K2 > 0) {   // uniform per workgroup: the message columns of W_ih; their n block stays on the input side of the gate
+        __syncthreads();   // every wave is done with the operand tiles of the first product
+        gemm_mainloop<BM, BN, NT, false, false, true, TM, TN, D, false, KS, true>(P.A2, P.B2, M, H, 1, 1, m0, n0, 0, P.K2, smem, acc);
+    }
+    if constexpr (KS == 2) {
+        // add the two k-groups' partial tiles (fixed order: group 0 + group 1) through LDS; group 0 runs the epilogue
+        __syncthreads();
+        float* red = smem + ((wave * 64) << 6) + lane;   // 4 accumulators x 16 registers per lane, lane-contiguous
+        if (kgrp == 1) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                red[r << 6] = acc[0][0][r];
+                red[(16 + r) << 6] = acc[0][1][r];
+                red[(32 + r) << 6] = acc[0][2][r];
+                red[(48 + r) << 6] = hn[r];
+            }
+        }
+        __syncthreads();
+        if (kgrp == 1) return;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            acc[0][0][r] += red[r << 6];
+            acc[0][1][r] += red[(16 + r) << 6];
+            acc[0][2][r] += red[(32 + r) << 6];
+            hn[r] += red[(48 + r) << 6];
+        }
+    }
+    if (unit >= H) return;
+    // C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm + (r & 3) + 8 * (r >> 2) + 4 * kh;
+        if (row >= M) continue;
+        const float ir = e_r[r] + acc[0][0][r], hr = b_r;
+        const float iz = e_z[r] + acc[0][1][r], hz = b_z;
+        const float in_ = e_n[r] + acc[0][2][r], hnv = hn[r] + b_n;
+        const float rg = 1.0f / (1.0f + expf(-(ir + hr)));
+        const float z = 1.0f / (1.0f + expf(-(iz + hz)));
+        const float n = tanhf(in_ + rg * hnv);
+        const float h0 = has_hp ? e_h0[r] : 0.f;
+        const float gnew = (1.0f - z) * n + z * h0;
+        const float uu = e_u[r];
+        const int o = (int)(((float)row + 0.5f) * inv_inner), i = row - o * inner;
+        P.h_out.ptr[o * (int)P.h_out.ld_outer + i * (int)P.h_out.ld_inner + unit] = has_u ? uu * gnew + (1.0f - uu) * h0 : gnew;
+        float* sv = P.save.ptr + (o * (int)P.save.ld_outer + i * (int)P.save.ld_inner);
+        sv[unit] = rg;
+        sv[H + unit] = z;
+        sv[2 * H + unit] = n;
+        sv[3 * H + unit] = hnv;
+    }
+}
+
 // sums split-K slabs in fixed order and applies the epilogue
 template <int BM, int BN>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const Group g) {
@@ -896,6 +1027,72 @@ int twog_internal_gemm_gate_bwd(const twog_gemm_t* pr, int n, const twog_gru_ste
     }
     if (d64 == 2) hipLaunchKernelGGL(gemm_gate_bwd_kernel<2>, grid, block, 0, (hipStream_t)stream, g, ga);
     else hipLaunchKernelGGL(gemm_gate_bwd_kernel<1>, grid, block, 0, (hipStream_t)stream, g, ga);
+    TWOG_CHECK_LAUNCH();
+    return 0;
+}
+
+// Fused forward step of the recurrent chains (gemm_gru_fwd_kernel). Problem i: gh[i] is the launch the unfused path would
+// make for W_hh h_prev + b_hh (A = previous states, B = W_hh [3h][h], bias = b_hh); gim[i] the one for the aggregated
+// messages (M == 0: none; A = messages, B = W_ih[:, msg]); st[i] the gate step that would follow (its gh / gi2 operands
+// are not read: the products stay in the accumulators). Returns 1 without launching when the shapes are not served
+// (hidden size or message width not a multiple of the 32-wide k-tile, unaligned operands, mixed row groupings).
+int twog_internal_gemm_gru_fwd(const twog_gemm_t* gh, const twog_gemm_t* gim, const twog_gru_step_t* st, int n,
+                               int dry_run, void* stream) {
+    // TWOG_GRU_FWD_FUSION: bit 0 = chains without message products (frame-level BiGRU), bit 1 = with (segment level).
+    // Measured at BASELINE size (bs64, 85.3 ms step): BiGRU fused -0.4 ms; segment level fused +2.5 ms -- its 160 tiles
+    // of K = 1536 leave 96 CUs idle for 61 us of MFMA work per tile, where the 480 64x64 tiles of the unfused GEMM fill
+    // two rounds of 20 us. Default: the frame level only.
+    static const int mode = getenv("TWOG_GRU_FWD_FUSION") ? atoi(getenv("TWOG_GRU_FWD_FUSION")) : 1;
+    static const int ksplit = getenv("TWOG_GRU_FWD_KS") ? atoi(getenv("TWOG_GRU_FWD_KS")) : 2;
+    const bool with_msgs = gim != nullptr;
+    if (!(mode & (with_msgs ? 2 : 1)) || n <= 0 || n > MAXP) return 1;
+    const int h = st[0].hidden;
+    if (h < 32 || h % BK) return 1;
+    auto span31 = [](const twog_rows_t& m, int rows, int64_t width) {
+        const int inner = m.inner > 1 ? m.inner : 1;
+        const int64_t last = (int64_t)((rows - 1) / inner) * m.ld_outer + (int64_t)((rows - 1) % inner) * (m.inner > 1 ? m.ld_inner : 0) + width;
+        return m.ld_outer >= 0 && m.ld_inner >= 0 && last < (int64_t(1) << 31);
+    };
+    GruFwdGroup g;
+    g.n = n; g.hidden = h; g.tiles_n = (h + 63) / 64;
+    int rt = 0;
+    for (int i = 0; i < n; ++i) {
+        const twog_gemm_t& q = gh[i];
+        const twog_gru_step_t& S = st[i];
+        if (S.hidden != h || S.rows <= 0 || S.rows != q.M || S.rows >= (1 << 22)) return 1;
+        if (q.N != 3 * h || q.K != h || q.act || q.accumulate || q.batch > 1 || q.B.inner > 1) return 1;
+        if (!vec_ok(q.A, 0, h, q.M) || !vec_ok(q.B, 0, h, 3 * h)) return 1;
+        const bool m2 = gim && gim[i].M > 0;
+        if (m2) {
+            const twog_gemm_t& q2 = gim[i];
+            if (q2.M != q.M || q2.N != 3 * h || q2.K <= 0 || q2.K % BK || q2.act || q2.batch > 1 || q2.B.inner > 1 || q2.bias) return 1;
+            if (!vec_ok(q2.A, 0, q2.K, q2.M) || !vec_ok(q2.B, 0, q2.K, 3 * h)) return 1;
+        }
+        const int inner = S.gi.inner > 1 ? S.gi.inner : 1;
+        auto same = [&](const twog_rows_t& m) { return (m.inner > 1 ? m.inner : 1) == inner; };
+        if (!same(S.h_out) || !same(S.save) || (S.h_prev.ptr && !same(S.h_prev))) return 1;
+        if (S.h_prev.ptr && (S.h_prev.ptr != q.A.ptr || S.h_prev.ld_outer != q.A.ld_outer || S.h_prev.ld_inner != q.A.ld_inner)) return 1;
+        if (S.u && (S.u_inner > 1 ? S.u_inner : 1) != inner) return 1;
+        if (!span31(S.gi, S.rows, 3 * h) || !span31(S.h_out, S.rows, h) || !span31(S.save, S.rows, 4 * h) ||
+            (S.h_prev.ptr && !span31(S.h_prev, S.rows, h)))
+            return 1;
+        if (S.u && ((int64_t)((S.rows - 1) / inner) * S.u_ld_outer + (int64_t)((S.rows - 1) % inner) * S.u_ld_inner >= (int64_t(1) << 31)))
+            return 1;
+        GruFwdProb& P = g.p[i];
+        P.A = q.A; P.B = q.B;
+        if (m2) { P.A2 = gim[i].A; P.B2 = gim[i].B; P.K2 = gim[i].K; }
+        else { P.A2 = q.A; P.B2 = q.B; P.K2 = 0; }
+        P.gi = S.gi; P.h_out = S.h_out; P.save = S.save;
+        P.b_hh = q.bias; P.u = S.u;
+        P.u_ld_outer = (int)S.u_ld_outer; P.u_ld_inner = (int)S.u_ld_inner;
+        P.rows = S.rows; P.has_prev = S.h_prev.ptr ? 1 : 0; P.rt_start = rt; P.inner = inner;
+        rt += (S.rows + 63) / 64;
+    }
+    if (dry_run) return 0;
+    for (int i = n; i < MAXP; ++i) { g.p[i] = g.p[0]; g.p[i].rt_start = 0x7fffffff; }
+    g_last_class = TWOG_GEMM_CLASS_GRUFWD;
+    if (ksplit == 2) hipLaunchKernelGGL((gemm_gru_fwd_kernel<2, 2>), dim3(rt * g.tiles_n), dim3(512), 0, (hipStream_t)stream, g);
+    else hipLaunchKernelGGL((gemm_gru_fwd_kernel<2, 1>), dim3(rt * g.tiles_n), dim3(256), 0, (hipStream_t)stream, g);
     TWOG_CHECK_LAUNCH();
     return 0;
 }

@@ -212,7 +212,12 @@ static int bigru_fwd_impl(const twog_bigru_t* types, int n_types, int bs, int T,
                 ++n;
             }
         }
-        int rc = twog_gemm_f32(gm, n, 0, 0, nullptr, 0, stream);
+        // one launch: the W_hh products on gate-aware tiles with the gate math in the epilogue (gemm_f32.hip); shapes it
+        // does not serve (hidden size not a multiple of the k-tile) take the GEMM + gate kernel pair
+        int rc = twog_internal_gemm_gru_fwd(gm, nullptr, st, n, 0, stream);
+        if (rc < 0) return rc;
+        if (rc == 0) continue;
+        rc = twog_gemm_f32(gm, n, 0, 0, nullptr, 0, stream);
         if (rc) return rc;
         rc = twog_gru_step_fwd(st, n, stream);
         if (rc) return rc;

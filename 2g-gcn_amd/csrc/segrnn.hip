@@ -125,6 +125,7 @@ static int segrnn_fwd_impl(const twog_segrnn_t* desc, void* stream) {
         // (3) projections of messages and previous state, then the gates
         n = 0;
         twog_gru_step_t st[4];
+        twog_gemm_t ghp[4], gimp[4];
         int ns = 0;
         for (int dir = 0; dir < 2; ++dir) {
             const int t = dir == 0 ? s : T - 1 - s, tp = dir == 0 ? t - 1 : t + 1;
@@ -139,13 +140,16 @@ static int segrnn_fwd_impl(const twog_segrnn_t* desc, void* stream) {
                 float* tmp_gim = (kind == 0 ? S.tmp_gim_h : S.tmp_gim_o) + (int64_t)dir * rows * 3 * h;
                 const float* whh = kind == 0 ? S.w_hh_h[dir] : S.w_hh_o[dir];
                 const float* bhh = kind == 0 ? S.b_hh_h[dir] : S.b_hh_o[dir];
-                gemm_set(gm[n++], hprev, rows_plain(whh, h), rows_plain(tmp_gh, 3 * h), bhh, rows, 3 * h, h, 0, 0);
+                gemm_set(gm[n], hprev, rows_plain(whh, h), rows_plain(tmp_gh, 3 * h), bhh, rows, 3 * h, h, 0, 0);
+                ghp[ns] = gm[n++];
+                gimp[ns].M = 0;
                 if (msg && nm) {
                     const float* mg = (kind == 0 ? S.mg_h : S.mg_o) + ((int64_t)dir * d.bs * T * E + (int64_t)t * E) * nm * h;
                     const float* wim = kind == 0 ? S.w_ihm_h[dir] : S.w_ihm_o[dir];
                     const int64_t ldw = kind == 0 ? S.ld_ih_h : S.ld_ih_o;
-                    gemm_set(gm[n++], rows_be(mg, E, nm * h, T), rows_plain(wim, ldw), rows_plain(tmp_gim, 3 * h),
+                    gemm_set(gm[n], rows_be(mg, E, nm * h, T), rows_plain(wim, ldw), rows_plain(tmp_gim, 3 * h),
                              nullptr, rows, 3 * h, nm * h, 0, 0);
+                    gimp[ns] = gm[n++];
                 }
                 twog_gru_step_t& G = st[ns++];
                 const float* gi = kind == 0 ? S.gi_h : S.gi_o;
@@ -161,6 +165,10 @@ static int segrnn_fwd_impl(const twog_segrnn_t* desc, void* stream) {
                 G.rows = rows; G.hidden = h;
             }
         }
+        // both products and the gates in one launch where the shapes allow it (gemm_gru_fwd_kernel, gemm_f32.hip)
+        rc = twog_internal_gemm_gru_fwd(ghp, gimp, st, ns, 0, stream);
+        if (rc < 0) return rc;
+        if (rc == 0) continue;
         rc = twog_gemm_f32(gm, n, 0, 0, nullptr, 0, stream);
         if (rc) return rc;
         rc = twog_gru_step_fwd(st, ns, stream);

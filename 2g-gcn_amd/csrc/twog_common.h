@@ -29,6 +29,10 @@ inline void twog_allow_dynamic_lds(K kernel, int bytes, std::atomic<uint32_t>& d
 int twog_internal_gemm_gate_bwd(const twog_gemm_t* problems, int n, const twog_gru_step_bwd_t* gates,
                                 float* const* du_part, int dry_run, void* stream);
 
+// library-internal (gemm_f32.hip): one launch for the W_hh (and message) products of a forward chain step AND its gates
+int twog_internal_gemm_gru_fwd(const twog_gemm_t* gh, const twog_gemm_t* gim, const twog_gru_step_t* steps, int n,
+                               int dry_run, void* stream);
+
 // address of row r in a twog_rows_t (see include/twog_gcn.h)
 __device__ __forceinline__ int64_t twog_row_off(const twog_rows_t& m, int r) {
     if (m.inner <= 1) return (int64_t)r * m.ld_outer;

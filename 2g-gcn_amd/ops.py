@@ -335,6 +335,21 @@ class _Grads:
             self.g[name] = t
 
 
+def _gru_bias_grads(K, G, b_ih, b_hh, dgi, dgh, h):
+    """Bias gradients of a GRU (cell): column sums of d_gi [rows][3h] and d_gh [rows][3h]. The r and z thirds of the two
+    are the same numbers (the gate backward writes one value to both; only the n third differs, by the factor r), so
+    d_gh is read for its n third only."""
+    if not (G.has(b_ih) or G.has(b_hh)):
+        return
+    db_ih = K.colsum(dgi)
+    if G.has(b_hh):
+        db_hh = torch.empty(3 * h, dtype=torch.float32, device=dgi.device)
+        db_hh[:2 * h].copy_(db_ih[:2 * h])
+        K.colsum(dgh[:, 2 * h:], out=db_hh[2 * h:])
+        G.add(b_hh, db_hh)
+    G.add(b_ih, db_ih)
+
+
 def _lin_w_grads(K, G, wname, bname, dY, X, cols=None, total=None):
     """dW = dY^T X (tall reduction -> k-major x k-major GEMM with split-K), db = column sums of dY.
     cols=(c0, c1), total: X pairs with the column block [c0, c1) of a weight that is `total` columns wide."""
@@ -1182,7 +1197,7 @@ def tggcn_backward(K, plan: Plan, P, S, x_human, x_objects, objects_mask, d_outp
                         K.gemm([dict(A=qh, B=_v2(sb['msrc_h'][d])[:, i_s * h:(i_s + 1) * h], C=blk)],
                                a_kmajor=True, b_kmajor=True)
             G.add(c + '.weight_ih', dW_ih)
-            G.add(c + '.bias_ih', K.colsum(dgi_d))
+            _gru_bias_grads(K, G, c + '.bias_ih', c + '.bias_hh', dgi_d, dghv[:, d * 3 * h:(d + 1) * 3 * h], h)
             # dW_hh = sum over steps with a previous state: forward chain pairs (t, t-1), backward chain (t, t+1)
             dW_hh = empty(3 * h, h)
             if T > 1:
@@ -1197,7 +1212,6 @@ def tggcn_backward(K, plan: Plan, P, S, x_human, x_objects, objects_mask, d_outp
             else:
                 dW_hh.zero_()
             G.add(c + '.weight_hh', dW_hh)
-            G.add(c + '.bias_hh', K.colsum(dghv[:, d * 3 * h:(d + 1) * 3 * h]))
             # d xx (frame-level part of the GRUCell input) -> entity-row gradient columns [h, h+fw)
             if ssp is None:
                 K.gemm([dict(A=dgi_d, B=w_ih[:, :fw], C=dEv[:, h:h + fw], accumulate=True)], b_kmajor=True)
@@ -1403,7 +1417,9 @@ def tggcn_backward(K, plan: Plan, P, S, x_human, x_objects, objects_mask, d_outp
         dgiv, dghv = _v2(dgi), _v2(dgh)
         for d, sfx in enumerate(('', '_reverse')):
             dgi_d = dgiv[:, d * 3 * h:(d + 1) * 3 * h]
-            _lin_w_grads(K, G, f'{name}_bd_rnn.weight_ih_l0{sfx}', f'{name}_bd_rnn.bias_ih_l0{sfx}', dgi_d, Ev[:, :h])
+            _lin_w_grads(K, G, f'{name}_bd_rnn.weight_ih_l0{sfx}', None, dgi_d, Ev[:, :h])
+            _gru_bias_grads(K, G, f'{name}_bd_rnn.bias_ih_l0{sfx}', f'{name}_bd_rnn.bias_hh_l0{sfx}', dgi_d,
+                            dghv[:, d * 3 * h:(d + 1) * 3 * h], h)
             dW_hh = empty(3 * h, h)
             if T > 1:
                 if d == 0:
@@ -1416,7 +1432,6 @@ def tggcn_backward(K, plan: Plan, P, S, x_human, x_objects, objects_mask, d_outp
             else:
                 dW_hh.zero_()
             G.add(f'{name}_bd_rnn.weight_hh_l0{sfx}', dW_hh)
-            G.add(f'{name}_bd_rnn.bias_hh_l0{sfx}', K.colsum(dghv[:, d * 3 * h:(d + 1) * 3 * h]))
             K.gemm([dict(A=dgi_d, B=P[f'{name}_bd_rnn.weight_ih_l0{sfx}'], C=dEv[:, :h], accumulate=True)], b_kmajor=True)
 
     _stage_done(p, 1)

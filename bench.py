@@ -416,6 +416,21 @@ def main():
     for e in pool[:64]:
         e.record()
     torch.cuda.synchronize()
+    # The interpreter's start-up heap (torch's modules, ~1e6 objects) leaves the collector's generations: a full
+    # collection that falls into the timed region then walks only what the steps allocated (microseconds) instead of
+    # everything (tens of ms of a stalled launch queue). Collection stays ENABLED -- a leak would still show.
+    import gc
+    gc.collect()
+    if not os.environ.get('TWOG_BENCH_NO_GC_FREEZE'):
+        gc.freeze()
+    gc_log, gc_t0 = [], [0.0]
+
+    def _gc_watch(phase, info):
+        if phase == 'start':
+            gc_t0[0] = time.perf_counter()
+        else:
+            gc_log.append((info['generation'], (time.perf_counter() - gc_t0[0]) * 1e3))
+    gc.callbacks.append(_gc_watch)
     barrier()
     torch.cuda.synchronize()
     step_ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
@@ -433,6 +448,10 @@ def main():
         tmax = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
+    gc.callbacks.remove(_gc_watch)
+    log('collector passes inside the timed region (generation: ms): '
+        + (' '.join(f'{g}:{ms:.1f}' for g, ms in gc_log if ms >= 0.5 or g == 2) or 'none above 0.5 ms')
+        + f' ({len(gc_log)} passes)')
     agg = prof.summary()
     if os.environ.get('TWOG_BENCH_GEMM_DETAIL') and rank == 0:
         prof.detail(args.steps)

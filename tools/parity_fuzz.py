@@ -32,8 +32,11 @@ BASE = dict(attention_style='v3', discrete_optimization_strategy='gs', filter_di
 def _stage_branch(name):
     """(forward stage, branch) of a parameter: which tensors lie upstream of which (ReLU-boundary rule below).
     Branch g / h / o = geometry / human / object stream before the streams mix in the segment level (stage >= 6)."""
-    if name.startswith('geometry_embedding_gcn.'):
-        return 0, 'g'
+    if name.startswith('geometry_embedding_gcn.'):   # inside the GCN: BatchNorm -> 1x1 conv -> 1x1 conv -> attention, weight
+        for sub, st in (('joint_embed.cnn.0.', 0.0), ('joint_embed.cnn.1.', 0.1), ('joint_embed.cnn.3.', 0.2)):
+            if sub in name:
+                return st, 'g'
+        return 0.3, 'g'
     if name.startswith('geometry_embedding_mlp.0'):
         return 1, 'g'
     if name.startswith('geometry_embedding_mlp.2'):
