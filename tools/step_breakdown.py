@@ -19,8 +19,12 @@ t0, t1 = int(step[0]['Start_Timestamp']), int(step[-1]['End_Timestamp'])
 def cls(r):
     n = re.sub(r'\(anonymous namespace\)::', '', r['Kernel_Name'])
     g = int(r['Grid_Size_X']) // max(int(r['Workgroup_Size_X']), 1)
-    if 'gemm_gate_bwd_kernel' in n:
+    if 'gemm_gate_bwd' in n:
         return 'recurrence: 64x64 GEMM NT + fused gate backward'
+    if 'gemm_gru_fwd' in n:
+        return 'recurrence: frame-level GRU step (W_hh product + gates, one launch)'
+    if 'gemm_ks_kernel' in n:
+        return 'recurrence: 64x64 GEMM, 8 waves (k-split in the workgroup)'
     if 'gemm_kernel<64' in n:
         return 'recurrence: 64x64 GEMM ' + ('NN' if 'false, false' in n else 'NT' if 'false, true' in n else 'TT/TN')
     if 'gemm_kernel<128' in n:
