@@ -46,6 +46,7 @@ struct Group {
     int cls_start[MAXP], cls_ntiles[MAXP], cls_rot[MAXP];
     int splitk;      // >= 1
     int k_per_split; // multiple of BK
+    int group;       // tile order inside a problem: groups of `group` panels of the major dimension (tile_coords)
     float* slabs;    // split-K partials: [problem-tile-major] see below
 };
 
@@ -57,6 +58,33 @@ struct GateArgs {
     float* du_part[MAXP];  // [2 * tiles_n][rows] partial row sums of d * (gru - h_prev) for this step, or nullptr
     int gate_of[MAXP];     // per (sorted) problem: index into s, -1 = plain epilogue
 };
+
+// Tile index -> (row panel, column panel) of a problem. Plain order: major panel by major panel (row panels; column
+// panels for n_major problems), minor index fastest -- the tiles that share the major panel start together and meet its
+// k-slices in L2. When the minor dimension is WIDE (>= 12 panels) the list is walked in groups of `group` major panels
+// instead, major index fastest inside the group: the 64 tiles an XCD has in flight (32 CUs x 2 workgroups) then cover
+// about 8 x 8 panels instead of 2 x 34, so its L2 is not asked for every minor panel again for each major panel.
+// Measured per launch at the L2<->fabric boundary (rocprofv3 FETCH_SIZE, bs64 step): dX of the geometry MLP
+// (7 680 x 4 352 x 2 048, 60 x 34 tiles) 2 273 -> 920 MB of reads for 232 MB of operands; the 12-panel-wide forward
+// launches -12...-15 %; with 4 or 8 minor panels grouping made it WORSE (+25...+40 %: the tiles sharing a row panel no
+// longer start together), hence the width test. Time is unchanged either way (the class is MFMA-bound).
+__device__ __forceinline__ void tile_coords(const Prob& P, int tile, int group, int& tm, int& tn) {
+    const int major = P.n_major ? P.tiles_n : P.tiles_m, minor = P.n_major ? P.tiles_m : P.tiles_n;
+    int a, b;
+    if (group <= 1 || minor < 12) {
+        a = tile / minor;
+        b = tile - a * minor;
+    } else {
+        const int per_group = group * minor;
+        const int grp = tile / per_group, first = grp * group;
+        const int gsize = min(major - first, group);
+        const int r = tile - grp * per_group;
+        b = r / gsize;
+        a = first + (r - b * gsize);
+    }
+    if (P.n_major) { tn = a; tm = b; }
+    else { tm = a; tn = b; }
+}
 
 // tile of ROWS x COLS (COLS contiguous in memory) -> registers; out-of-range elements read as 0
 template <int ROWS, int COLS, int NT>
@@ -402,8 +430,7 @@ __device__ __forceinline__ void gemm_tile(const Group& g, const GateArgs* ga) {
     const int M = G.M, N = G.N, K = G.K, a_vec = G.a_vec, b_vec = G.b_vec, act = G.act, accumulate = G.accumulate;
     const float* bias = G.bias;
     int tm_idx, tn_idx;
-    if (G.n_major) { tn_idx = tile / G.tiles_m; tm_idx = tile - tn_idx * G.tiles_m; }
-    else { tm_idx = tile / G.tiles_n; tn_idx = tile - tm_idx * G.tiles_n; }
+    tile_coords(G, tile, g.group, tm_idx, tn_idx);
     const int m0 = tm_idx * BM, n0 = tn_idx * BN;
     const int split = blockIdx.y;
     const int k_begin = split * g.k_per_split;
@@ -762,8 +789,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const Group g) {
     twog_rows_t C = P.C;
     C.ptr += bi * P.c_bs;
     int tm_idx, tn_idx;
-    if (P.n_major) { tn_idx = tile / P.tiles_m; tm_idx = tile - tn_idx * P.tiles_m; }
-    else { tm_idx = tile / P.tiles_n; tn_idx = tile - tm_idx * P.tiles_n; }
+    tile_coords(P, tile, g.group, tm_idx, tn_idx);
     const int m0 = tm_idx * BM, n0 = tn_idx * BN;
     // grid.y slices the tile so that small-output / deep-split problems still spread over the chip
     const int chunk = (BM * BN) / gridDim.y;
@@ -893,6 +919,10 @@ static void prepare_group(const twog_gemm_t* pr, int n, int a_kmajor, int b_kmaj
         rot += g.cls_ntiles[c] & 7;
     }
     g.total_tiles = t;
+    // grouped tile order for the 128x128 class (TWOG_GEMM_GROUP=0: plain order; the 64x64 chain launches keep it)
+    static const int group = getenv("TWOG_GEMM_GROUP") ? atoi(getenv("TWOG_GEMM_GROUP")) : 8;
+    static const int group64 = getenv("TWOG_GEMM_GROUP64") ? atoi(getenv("TWOG_GEMM_GROUP64")) : 0;
+    g.group = big ? group : group64;
     g.splitk = 1;
     g.k_per_split = ((kmax + BK - 1) / BK) * BK;
     g.slabs = nullptr;
@@ -1036,13 +1066,16 @@ int twog_internal_gemm_gate_bwd(const twog_gemm_t* pr, int n, const twog_gru_ste
 // messages (M == 0: none; A = messages, B = W_ih[:, msg]); st[i] the gate step that would follow (its gh / gi2 operands
 // are not read: the products stay in the accumulators). Returns 1 without launching when the shapes are not served
 // (hidden size or message width not a multiple of the 32-wide k-tile, unaligned operands, mixed row groupings).
+int twog_internal_gru_fwd_mode(void) {
+    const char* e = getenv("TWOG_GRU_FWD_FUSION");
+    return e ? atoi(e) : 3;
+}
+
 int twog_internal_gemm_gru_fwd(const twog_gemm_t* gh, const twog_gemm_t* gim, const twog_gru_step_t* st, int n,
                                int dry_run, void* stream) {
-    // TWOG_GRU_FWD_FUSION: bit 0 = chains without message products (frame-level BiGRU), bit 1 = with (segment level).
-    // Measured at BASELINE size (bs64, 85.3 ms step): BiGRU fused -0.4 ms; segment level fused +2.5 ms -- its 160 tiles
-    // of K = 1536 leave 96 CUs idle for 61 us of MFMA work per tile, where the 480 64x64 tiles of the unfused GEMM fill
-    // two rounds of 20 us. Default: the frame level only.
-    static const int mode = getenv("TWOG_GRU_FWD_FUSION") ? atoi(getenv("TWOG_GRU_FWD_FUSION")) : 1;
+    // TWOG_GRU_FWD_FUSION: bit 0 = chains without message products (frame-level BiGRU), bit 1 = with (segment level),
+    // bit 2 = always (skip the cost model below). Default 3: both levels, each launch decided by the model.
+    const int mode = twog_internal_gru_fwd_mode();   // read per call: tests switch it inside one process
     static const int ksplit = getenv("TWOG_GRU_FWD_KS") ? atoi(getenv("TWOG_GRU_FWD_KS")) : 2;
     const bool with_msgs = gim != nullptr;
     if (!(mode & (with_msgs ? 2 : 1)) || n <= 0 || n > MAXP) return 1;
@@ -1087,6 +1120,22 @@ int twog_internal_gemm_gru_fwd(const twog_gemm_t* gh, const twog_gemm_t* gim, co
         P.u_ld_outer = (int)S.u_ld_outer; P.u_ld_inner = (int)S.u_ld_inner;
         P.rows = S.rows; P.has_prev = S.h_prev.ptr ? 1 : 0; P.rt_start = rt; P.inner = inner;
         rt += (S.rows + 63) / 64;
+    }
+    if (!(mode & 4)) {
+        // Cost model (us of fp32 MFMA work per CU at 614 GFLOP/s, tiles dealt in rounds over 256 CUs; measured at BASELINE
+        // size): the fused launch runs rounds of 64 x 192 x K tiles, the pair it replaces rounds of
+        // 64 x 64 x K tiles plus a gate launch (~7 us). bs64, h = 512: frame level 20.5 vs 3 x 6.8 + 7 -> fused (measured
+        // 39 vs 43 us); segment level (K = 1 536, 160 tiles) 61 vs 2 x 20.5 + 7 -> unfused (measured +2.5 ms per step
+        // fused); 8 clips: 20.5 vs 6.8 + 7 -> unfused (measured 31.5 vs 39.7 ms per step forced). Short reductions stay
+        // unfused whatever the model says: at h = 64 (Bimanual layout) the 8-wave tile with its k-group exchange costs
+        // more than the two small launches it replaces (measured 20.7 vs 19.3 ms per step).
+        int kmax = h;
+        for (int i = 0; i < n; ++i) kmax = (h + g.p[i].K2) > kmax ? (h + g.p[i].K2) : kmax;
+        const double per_tile = 64.0 * 64.0 * kmax * 2.0 / 614.0e3;   // us for a 64 x 64 x K tile
+        const int unfused_tiles = rt * ((3 * h + 63) / 64), fused_tiles = rt * g.tiles_n;
+        const double fused = 3.0 * per_tile * ((fused_tiles + 255) / 256);
+        const double unfused = per_tile * ((unfused_tiles + 255) / 256) + 7.0;
+        if (fused > unfused || kmax < 256) return 1;
     }
     if (dry_run) return 0;
     for (int i = n; i < MAXP; ++i) { g.p[i] = g.p[0]; g.p[i].rt_start = 0x7fffffff; }

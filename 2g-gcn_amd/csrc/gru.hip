@@ -300,7 +300,7 @@ static int bigru_bwd_impl(const twog_bigru_bwd_t* types, int n_types, int bs, in
 
 extern "C" int twog_bigru_fwd(const twog_bigru_t* types, int n_types, int bs, int T, int hidden, void* stream) {
     if (n_types > 4 || n_types < 0) return -1;
-    const int dims[5] = {0x11, n_types, bs, T, hidden};
+    const int dims[6] = {0x11, n_types, bs, T, hidden, twog_internal_gru_fwd_mode()};
     twog_graph::Desc key;
     key.pod(dims).add(types, sizeof(twog_bigru_t) * n_types);
     return twog_graph::run(key, (hipStream_t)stream,

@@ -368,7 +368,7 @@ static int segrnn_bwd_impl(const twog_segrnn_t* desc, const twog_segrnn_bwd_t* b
 }
 
 extern "C" int twog_segrnn_fwd(const twog_segrnn_t* desc, void* stream) {
-    const int tag = 0x33;
+    const int tag[2] = {0x33, twog_internal_gru_fwd_mode()};
     twog_graph::Desc key;
     key.pod(tag).pod(*desc);
     return twog_graph::run(key, (hipStream_t)stream, [&](hipStream_t st) { return segrnn_fwd_impl(desc, st); });

@@ -33,6 +33,8 @@ int twog_internal_gemm_gate_bwd(const twog_gemm_t* problems, int n, const twog_g
 int twog_internal_gemm_gru_fwd(const twog_gemm_t* gh, const twog_gemm_t* gim, const twog_gru_step_t* steps, int n,
                                int dry_run, void* stream);
 
+int twog_internal_gru_fwd_mode(void);   // TWOG_GRU_FWD_FUSION (part of the chains' hipGraph keys: it changes what is captured)
+
 // address of row r in a twog_rows_t (see include/twog_gcn.h)
 __device__ __forceinline__ int64_t twog_row_off(const twog_rows_t& m, int r) {
     if (m.inner <= 1) return (int64_t)r * m.ld_outer;

@@ -161,7 +161,10 @@ class GemmProfiler:
             a[2] += 1
         rows = sorted(agg.items(), key=lambda kv: -kv[1][1])
         for (kind, akm, bkm, shp), (fl, sec, n) in rows:
-            log(f'{kind} {"T" if akm else "N"}{"T" if bkm else "N"} {n / steps:5.1f}/step {sec / n * 1e3:8.3f} ms {fl / sec / 1e12:6.1f} TF  {list(shp)[:4]}')
+            t128 = sum(b * math.ceil(m / 128) * math.ceil(nn / 128) for m, nn, _, b in shp)
+            amb = sum(4.0 * (m * k + nn * k + m * nn) * b for m, nn, k, b in shp) / 1e6
+            log(f'{kind} {"T" if akm else "N"}{"T" if bkm else "N"} {n / steps:5.1f}/step {sec / n * 1e3:8.3f} ms {fl / sec / 1e12:6.1f} TF  '
+                f'tiles128 {t128:5d}  algorithmic {amb:8.1f} MB  {list(shp)[:4]}')
 
     def summary(self):
         torch.cuda.synchronize()

@@ -302,9 +302,11 @@ def test_gcn_kernels(K, N):
 
 # --------------------------------------------------------------------------------------------------------------- BiGRU
 # h = 16, 72: GEMM + gate kernel per step; 32, 96 (a partial second unit tile), 512: the fused step (gemm_gru_fwd_kernel)
+@pytest.mark.parametrize('fusion', ['0', '7'])   # TWOG_GRU_FWD_FUSION: GEMM + gate kernel per step / the fused step forced
 @pytest.mark.parametrize('h,bs,T', [(16, 3, 5), (72, 3, 5), (32, 5, 4), (96, 30, 4), (512, 40, 3),
                                     (512, 8, 120)])   # last: BASELINE T and width
-def test_bigru(K, h, bs, T):
+def test_bigru(K, h, bs, T, fusion, monkeypatch):
+    monkeypatch.setenv('TWOG_GRU_FWD_FUSION', fusion)   # read per call by the library; part of the chain's graph key
     types_c, types_g = [], []
     ws = 0.2 if T < 100 else 0.2 * math.sqrt(64.0 / h)   # long chains: keep the hidden pre-activations O(1)
     for i, E in enumerate((2, 3, 1)):
@@ -314,8 +316,9 @@ def test_bigru(K, h, bs, T):
         types_g.append({k: v.to(DEV) for k, v in d.items()})
     res_c = F.bigru_fwd(types_c, bs, T, h)
     res_g = K.bigru_fwd(types_g, bs, T, h)
-    if h % 32 == 0:   # the variant that ran (the last step's launch): one fused launch per step
-        assert K.gemm_last_class() == K.GEMM_GRUFWD, hex(K.gemm_last_class())
+    # the variant that ran (the forward chain's last launch): the fused step where forced and served, else the gate kernel's
+    # GEMM partner
+    assert (K.gemm_last_class() == K.GEMM_GRUFWD) == (fusion == '7' and h % 32 == 0), hex(K.gemm_last_class())
     for (oc, sc), (og, sg) in zip(res_c, res_g):
         close(og, oc, rtol=1e-4, atol=1e-5, what='bigru out')
         close(sg, sc, rtol=1e-4, atol=1e-5, what='bigru save')
@@ -428,14 +431,14 @@ def _seg_params(dev, bs, T, H, O, h, rels, msg_segment=True, seed=0):
                                                  (24, 3, 2, 8, 512, (True, True, True, True), False),
                                                  # BASELINE length and width: a 120-step chain, forward and BPTT
                                                  (4, 120, 2, 8, 512, (True, True, True, True), True)])
-def test_segment_recurrence(K, bs, T, H, O, h, rels, msg):
+@pytest.mark.parametrize('fusion', ['0', '7'])
+def test_segment_recurrence(K, bs, T, H, O, h, rels, msg, fusion, monkeypatch):
+    monkeypatch.setenv('TWOG_GRU_FWD_FUSION', fusion)
     pc = _seg_params('cpu', bs, T, H, O, h, rels, msg)
     pg = _seg_params(DEV, bs, T, H, O, h, rels, msg)
     bc = F.segrnn_fwd(pc)
     bg = K.segrnn_fwd(pg)
-    import os
-    if os.environ.get('TWOG_GRU_FWD_FUSION') == '3' and h % 32 == 0:   # the opt-in test below: the fused step really ran
-        assert K.gemm_last_class() == K.GEMM_GRUFWD, hex(K.gemm_last_class())
+    assert (K.gemm_last_class() == K.GEMM_GRUFWD) == (fusion == '7' and h % 32 == 0), hex(K.gemm_last_class())
     keys = ['hs_h', 'hs_o', 'save_h', 'save_o'] + (['msrc_h', 'msrc_o', 'mg_h', 'mg_o', 'att'] if msg else [])
     for k in keys:
         close(bg[k], bc[k], rtol=2e-4, atol=2e-5, what='segrnn fwd ' + k)
@@ -451,20 +454,6 @@ def test_segment_recurrence(K, bs, T, H, O, h, rels, msg):
         if k.startswith('d_pre') and not msg:
             continue  # unused scratch when message_segment is off
         close(og[k], oc[k], rtol=3e-4, atol=3e-5, what='segrnn bwd ' + k)
-
-
-def test_segment_recurrence_with_the_fused_forward_step_opt_in():
-    """TWOG_GRU_FWD_FUSION=3 also runs the segment level's W_hh and message products on the gate-aware tiles (off by
-    default: slower at BASELINE size). The switch is read once per process, so the cases above run again in a child."""
-    import os
-    import subprocess
-    import sys
-    env = dict(os.environ, TWOG_GRU_FWD_FUSION='3')
-    r = subprocess.run([sys.executable, '-m', 'pytest', os.path.abspath(__file__), '-x', '-q', '-k',
-                        'test_segment_recurrence and not opt_in'], env=env, capture_output=True, text=True, timeout=600,
-                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    assert ' passed' in r.stdout
 
 
 # --------------------------------------------------------------------------------------------------------------- gates

@@ -36,8 +36,32 @@ def load(d):
     return out, cnt
 
 
+def by_launch(root, dst):
+    """128x128-class launches grouped by (kernel variant, grid size): grid = tiles x split-K x workgroup size identifies the
+    shape; read / write bytes per dispatch at the L2<->fabric boundary (join with TWOG_BENCH_GEMM_DETAIL=1 of bench.py)."""
+    agg = collections.defaultdict(lambda: [set(), 0.0, 0.0])
+    for sub, col, mul in (('f', 1, 2.0 * 1024), ('w', 2, 1024.0)):
+        for f in glob.glob(root + '/' + sub + '/*/*_counter_collection.csv'):
+            for r in csv.DictReader(open(f)):
+                k = short(r['Kernel_Name'])
+                if not k.startswith('gemm_kernel<128, 128') or r['Counter_Name'] not in ('FETCH_SIZE', 'WRITE_SIZE'):
+                    continue
+                a = agg[(k, int(r['Grid_Size']), int(r['Workgroup_Size']))]
+                if sub == 'f':
+                    a[0].add(r['Dispatch_Id'])
+                a[col] += float(r['Counter_Value']) * mul
+    with open(dst, 'w', newline='') as fo:
+        wri = csv.writer(fo)
+        wri.writerow(['kernel', 'workgroups', 'dispatches', 'read_MB_per_dispatch', 'write_MB_per_dispatch'])
+        for (k, grid, wg), (ids, rd, wr) in sorted(agg.items(), key=lambda kv: -(kv[1][1] + kv[1][2])):
+            n = max(len(ids), 1)
+            wri.writerow([k, grid // max(wg, 1), n, round(rd / n / 1e6, 1), round(wr / n / 1e6, 1)])
+
+
 def main():
     root, dst = sys.argv[1], sys.argv[2]
+    if len(sys.argv) > 4:
+        by_launch(root, sys.argv[4])
     f, nf = load(root + '/f')
     w, _ = load(root + '/w')
     s, _ = load(root + '/s')
