@@ -774,6 +774,18 @@ __global__ __launch_bounds__(256 * KS, 1) void gemm_gru_fwd_kernel(const GruFwdG
     }
 }
 
+// 32 x 64 tiles, 4 waves = two k-groups of a 1 x 2 wave grid: launches with so few rows that even 32-row tiles leave one
+// tile per CU (8 clips per GPU: 16 / 32 rows per entity type and direction). A 64 x 64 tile there is half padding and
+// keeps every SIMD busy for the whole K/2-instruction MFMA chain twice; here each wave runs half the chain once.
+template <bool BKM, int D>
+__global__ __launch_bounds__(256, 2) void gemm_ks32_kernel(const Group g) {
+    gemm_tile<32, 64, 256, false, BKM, D, false, false, 2>(g, nullptr);
+}
+template <int D>
+__global__ __launch_bounds__(256, 2) void gemm_gate_bwd_ks32_kernel(const Group g, const GateArgs ga) {
+    gemm_tile<32, 64, 256, false, true, D, false, true, 2>(g, &ga);
+}
+
 // sums split-K slabs in fixed order and applies the epilogue
 template <int BM, int BN>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const Group g) {
@@ -864,7 +876,7 @@ extern "C" int twog_gemm_last_class(void) { return g_last_class; }
 // Builds the launch descriptor of one chunk (<= MAXP problems): tile class, class-sorted problem list (order[i] = index of
 // the caller's problem that became sorted problem i), XCD map, split-K. Shared by the plain and the gate-fused launch.
 static void prepare_group(const twog_gemm_t* pr, int n, int a_kmajor, int b_kmajor, void* workspace,
-                          size_t workspace_bytes, Group& g, int* order, bool& big) {
+                          size_t workspace_bytes, Group& g, int* order, bool& big, int& bm) {
     // tile choice: 128x128 tiles (4 MFMA tiles per wave, half the LDS traffic per FLOP) whenever the problems are
     // at least one tile wide and -- possibly with split-K -- still fill the chip; 64x64 for the skinny ones.
     int64_t tiles128 = 0;
@@ -883,6 +895,20 @@ static void prepare_group(const twog_gemm_t* pr, int n, int a_kmajor, int b_kmaj
     if (force_tile == 128) big = true;
     if (force_tile == 64) big = false;
     const int BMN = big ? 128 : 64;
+    // 32-row tiles (gemm_ks32_kernel) for the in-library chain launches (no workspace) of small batches: one tile per CU
+    // even at 32 rows, a reduction worth splitting between two waves, no grouped k-major rows
+    bm = BMN;
+    {
+        static const int bm32_on = getenv("TWOG_GEMM_BM32") ? atoi(getenv("TWOG_GEMM_BM32")) : 1;
+        static const int ks_allowed = getenv("TWOG_GEMM_KS") ? atoi(getenv("TWOG_GEMM_KS")) : 1;
+        int64_t tiles32 = 0;
+        bool plain = true;
+        for (int i = 0; i < n; ++i) {
+            tiles32 += (int64_t)((pr[i].M + 31) / 32) * ((pr[i].N + 63) / 64);
+            plain = plain && pr[i].batch <= 1 && !(b_kmajor && pr[i].B.inner > 1);
+        }
+        if (bm32_on && ks_allowed && !big && !a_kmajor && !workspace && plain && kmax >= 256 && tiles32 <= 256) bm = 32;
+    }
     g.n = n;
     // longest reductions first, equal K adjacent (stable: the caller's order within a class is kept)
     for (int i = 0; i < n; ++i) order[i] = i;
@@ -896,7 +922,7 @@ static void prepare_group(const twog_gemm_t* pr, int n, int a_kmajor, int b_kmaj
         P.A = q.A; P.B = q.B; P.C = q.C; P.bias = q.bias;
         P.M = q.M; P.N = q.N; P.K = q.K;
         P.act = q.act; P.accumulate = q.accumulate;
-        P.tiles_m = (P.M + BMN - 1) / BMN;
+        P.tiles_m = (P.M + bm - 1) / bm;
         P.tiles_n = (P.N + BMN - 1) / BMN;
         P.tile_start = t;
         P.batch = q.batch > 0 ? q.batch : 1;
@@ -962,7 +988,8 @@ extern "C" int twog_gemm_f32(const twog_gemm_t* problems, int n_problems, int a_
         Group g;
         int order[MAXP];
         bool big;
-        prepare_group(pr, n, a_kmajor, b_kmajor, workspace, workspace_bytes, g, order, big);
+        int bm;
+        prepare_group(pr, n, a_kmajor, b_kmajor, workspace, workspace_bytes, g, order, big, bm);
         static const int depth = getenv("TWOG_GEMM_DEPTH") ? atoi(getenv("TWOG_GEMM_DEPTH")) : 0;  // tuning knob
         const int d128 = depth ? (depth & 3) : 2, d64 = depth ? ((depth >> 2) & 3) : 2;
         int rc;
@@ -979,6 +1006,15 @@ extern "C" int twog_gemm_f32(const twog_gemm_t* problems, int n_problems, int a_
         int kmax_ = 0;
         for (int i = 0; i < n; ++i) kmax_ = pr[i].K > kmax_ ? pr[i].K : kmax_;
         const bool ks = ks_on && !big && !a_kmajor && !grouped && g.splitk == 1 && g.total_tiles <= 384 && kmax_ >= 256;
+        if (bm == 32) {   // decided in prepare_group; implies the conditions of `ks`
+            g_last_class |= TWOG_GEMM_CLASS_KSPLIT | TWOG_GEMM_CLASS_ROWS32;
+            dim3 grid(g.total_tiles, 1), block(256);
+            if (b_kmajor) hipLaunchKernelGGL((gemm_ks32_kernel<true, 2>), grid, block, 0, st, g);
+            else hipLaunchKernelGGL((gemm_ks32_kernel<false, 2>), grid, block, 0, st, g);
+            TWOG_CHECK_LAUNCH();
+            done += n;
+            continue;
+        }
         if (ks) {
             g_last_class |= TWOG_GEMM_CLASS_KSPLIT;
             dim3 grid(g.total_tiles, 1), block(512);
@@ -1008,7 +1044,8 @@ int twog_internal_gemm_gate_bwd(const twog_gemm_t* pr, int n, const twog_gru_ste
     Group g;
     int order[MAXP];
     bool big;
-    prepare_group(pr, n, 0, 1, nullptr, 0, g, order, big);
+    int bm;
+    prepare_group(pr, n, 0, 1, nullptr, 0, g, order, big, bm);
     if (big || g.splitk != 1) return 1;
     auto span31 = [](const twog_rows_t& m, int rows, int64_t width) {  // largest element offset fits 31 bits
         const int inner = m.inner > 1 ? m.inner : 1;
@@ -1049,6 +1086,12 @@ int twog_internal_gemm_gate_bwd(const twog_gemm_t* pr, int n, const twog_gru_ste
     static const int ks_on = getenv("TWOG_GEMM_KS") ? atoi(getenv("TWOG_GEMM_KS")) : 1;
     int kmax = 0;
     for (int i = 0; i < n; ++i) kmax = pr[i].K > kmax ? pr[i].K : kmax;
+    if (bm == 32) {
+        g_last_class |= TWOG_GEMM_CLASS_KSPLIT | TWOG_GEMM_CLASS_ROWS32;
+        hipLaunchKernelGGL(gemm_gate_bwd_ks32_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, g, ga);
+        TWOG_CHECK_LAUNCH();
+        return 0;
+    }
     if (ks_on && g.total_tiles <= 384 && kmax >= 256) {
         g_last_class |= TWOG_GEMM_CLASS_KSPLIT;
         hipLaunchKernelGGL(gemm_gate_bwd_ks_kernel<2>, grid, dim3(512), 0, (hipStream_t)stream, g, ga);

@@ -123,7 +123,7 @@ class HipKernels:
         rc = self.lib.twog_gemm_f32(arr, n, int(a_kmajor), int(b_kmajor), ws_ptr, ws_bytes, self._stream())
         self._check(rc, 'twog_gemm_f32')
 
-    GEMM_TILE128, GEMM_WAVES8, GEMM_KG, GEMM_SPLITK, GEMM_GATE, GEMM_KSPLIT, GEMM_GRUFWD = 1, 2, 4, 8, 16, 32, 64  # TWOG_GEMM_CLASS_*
+    GEMM_TILE128, GEMM_WAVES8, GEMM_KG, GEMM_SPLITK, GEMM_GATE, GEMM_KSPLIT, GEMM_GRUFWD, GEMM_ROWS32 = 1, 2, 4, 8, 16, 32, 64, 128  # TWOG_GEMM_CLASS_*
 
     def gemm_last_class(self):
         """Bit field (GEMM_*) of the kernel variant the most recent gemm() chunk of this thread selected."""

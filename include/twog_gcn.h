@@ -66,6 +66,7 @@ int twog_gemm_f32(const twog_gemm_t* problems, int n_problems, int a_kmajor, int
 #define TWOG_GEMM_CLASS_GATE    16 /* gate backward fused into the epilogue             */
 #define TWOG_GEMM_CLASS_KSPLIT  32 /* 64x64 tiles, 8 waves, k-split inside the workgroup */
 #define TWOG_GEMM_CLASS_GRUFWD  64 /* 64 x (64 units x 3 gates) tiles, GRU forward step in the epilogue */
+#define TWOG_GEMM_CLASS_ROWS32  128 /* 32 x 64 tiles (chain launches of small batches)           */
 int twog_gemm_last_class(void);
 
 /* ===============================================================================================================

@@ -946,7 +946,9 @@ def test_gemm_ksplit_class(K, bkm):
     wave groups take alternate k-chunks and add their partial tiles through LDS. Checked against fp64; the class bit is
     asserted, as for the 128x128 class."""
     for (M, N, K_, bias, act, acc) in ((640, 1024, 512, True, 1, False), (1280, 512, 1536, False, 0, True),
-                                      (130, 200, 288, True, 0, True)):
+                                      (130, 200, 288, True, 0, True),
+                                      # at most 256 tiles of 32 x 64: the 32-row variant of small batches (8 clips)
+                                      (176, 512, 1536, False, 0, True), (48, 1536, 512, True, 1, False), (33, 70, 256, True, 0, False)):
         g = torch.Generator().manual_seed(M + N)
         A = torch.randn(M, K_, generator=g).to(DEV)
         B = ((torch.randn(K_, N, generator=g) if bkm else torch.randn(N, K_, generator=g)) * 0.1).to(DEV)
@@ -957,6 +959,7 @@ def test_gemm_ksplit_class(K, bkm):
         K.gemm([dict(A=A, B=B, C=Cg, bias=b, act=act, accumulate=acc)], b_kmajor=bkm, split_k_workspace=False)
         cls = K.gemm_last_class()
         assert cls & K.GEMM_KSPLIT and not cls & K.GEMM_TILE128, hex(cls)
+        assert bool(cls & K.GEMM_ROWS32) == (-(-M // 32) * -(-N // 64) <= 256), (hex(cls), M, N)
         ref = A.double() @ (B.double() if bkm else B.double().t())
         if bias:
             ref = ref + b.double()

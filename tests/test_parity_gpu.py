@@ -181,6 +181,14 @@ def test_oracle_parity_full_width_forward_backward():
     _oracle_vs_hip(bs=2, T=120, H=2, O=8, N=34, h=512, backward=True, seed=7)
 
 
+def test_oracle_parity_bench_batch_short_clips():
+    """The bench's batch (64 clips of the configs[2] layout, h = 512) at T = 3: every launch has the bench's tile counts, so
+    the variants the tile-count policies pick only there -- the fused frame-level GRU step (22 row tiles x 8 unit tiles),
+    the 128x128 class with split-K for the weight gradients, the grouped tile order -- run against the oracle, forward and
+    backward."""
+    _oracle_vs_hip(bs=64, T=3, H=2, O=8, N=34, h=512, backward=True, seed=11)
+
+
 def test_oracle_parity_c2_full_size():
     """BASELINE configs[1] at size: MPHOI layout (H=2, O=4, N=26), hs512, bs8, T=120, forward + backward."""
     _oracle_vs_hip(bs=8, T=120, H=2, O=4, N=26, h=512, backward=True, seed=9)

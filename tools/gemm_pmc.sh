@@ -15,7 +15,7 @@ csv.field_size_limit(1 << 30)
 tot = collections.defaultdict(float); n = collections.Counter()
 for f in glob.glob('gpurun_out/gpmc/p*/*/*_counter_collection.csv'):
     for r in csv.DictReader(open(f)):
-        if 'gemm_kernel' in r['Kernel_Name']:
+        if 'gemm_' in r['Kernel_Name']:
             tot[r['Counter_Name']] += float(r['Counter_Value']); n[r['Counter_Name']] += 1
 for k in sorted(tot):
     print(f'{k:32s} {tot[k] / n[k]:16.0f} per dispatch ({n[k]} dispatches)')
