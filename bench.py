@@ -364,7 +364,11 @@ def main():
         loss.backward()
         dp.all_reduce_gradients()
         opt.step(dp.grad_scale)
-        return loss
+        # detached: a caller that keeps the returned loss must not keep the step's autograd node (and the ~3 GB of buffers
+        # it saved) alive into the next step -- the next step's buffers would land at other addresses, i.e. under other
+        # hipGraph keys: first-sighting launches and a fresh capture of every time loop inside the timed region
+        # (seen as one 190 ms step in a default run)
+        return loss.detach()
 
     def barrier():
         if world > 1:
