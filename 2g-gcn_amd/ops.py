@@ -1516,6 +1516,52 @@ def attention_scores(plan, S):
     return [a_f, a_s[0], a_s[1]]
 
 
+class _Ref:
+    """Placeholder of a tensor inside the packed state (index into ctx.saved_tensors)."""
+    __slots__ = ('i',)
+
+    def __init__(self, i):
+        self.i = i
+
+
+def _pack_state(obj, tensors, seen=None):
+    """Nested dict / list / tuple -> the same structure with every tensor replaced by a _Ref; the tensors are appended to
+    `tensors` (one entry per distinct tensor object)."""
+    if seen is None:
+        seen = {}
+    if torch.is_tensor(obj):
+        i = seen.get(id(obj))
+        if i is None:
+            i = seen[id(obj)] = len(tensors)
+            tensors.append(obj)
+        return _Ref(i)
+    if isinstance(obj, dict):
+        return {k: _pack_state(v, tensors, seen) for k, v in obj.items()}
+    if isinstance(obj, list):
+        return [_pack_state(v, tensors, seen) for v in obj]
+    if isinstance(obj, tuple):
+        return tuple(_pack_state(v, tensors, seen) for v in obj)
+    return obj
+
+
+def _unpack_state(obj, tensors):
+    if isinstance(obj, _Ref):
+        return tensors[obj.i]
+    if isinstance(obj, dict):
+        return {k: _unpack_state(v, tensors) for k, v in obj.items()}
+    if isinstance(obj, list):
+        return [_unpack_state(v, tensors) for v in obj]
+    if isinstance(obj, tuple):
+        return tuple(_unpack_state(v, tensors) for v in obj)
+    return obj
+
+
+def saved_state(node):
+    """The forward pass's saved state of an autograd node of TGGCNFunction (`out.grad_fn`), as the dict the backward
+    pass works on. Raises like any access to freed saved tensors once backward has run without retain_graph."""
+    return _unpack_state(node.state_skeleton, node.saved_tensors)
+
+
 class TGGCNFunction(torch.autograd.Function):
     """One autograd node for the whole hot path. Inputs after the fixed ones are the parameters in the order of
     ``used_parameter_names(plan)``."""
@@ -1527,8 +1573,15 @@ class TGGCNFunction(torch.autograd.Function):
         P = dict(zip(names, params))
         outputs, S = tggcn_forward(K, plan, P, x_human, x_objects, objects_mask, human_seg, object_seg, noise,
                                    training, bn_bufs)
-        ctx.plan, ctx.names, ctx.S, ctx.P = plan, names, S, P
+        ctx.plan, ctx.names, ctx.P = plan, names, P
         ctx.inputs = (x_human, x_objects, objects_mask)
+        # The saved state goes through save_for_backward: the autograd engine owns its lifetime, as for any torch op -- the
+        # ~3 GB of buffers are released when backward has run (unless retain_graph), not when the caller lets go of the
+        # loss, and outputs saved here cannot form a reference cycle with the node.
+        tensors = []
+        ctx.state_skeleton = _pack_state(S, tensors)
+        ctx.save_for_backward(*tensors)
+        ctx.gate_learned = {k: bool(v['learned']) for k, v in S['gates'].items()}
         n_gate = 2 if plan.n_aff is None else 4
         hard = outputs[:n_gate // 2]
         ctx.mark_non_differentiable(*[o for o, gk in zip(hard, ('h', 'o')) if not S['gates'][gk]['learned']])
@@ -1547,12 +1600,11 @@ class TGGCNFunction(torch.autograd.Function):
         plan = ctx.plan
         x_human, x_objects, objects_mask = ctx.inputs
         d_outputs = list(d_outputs)[:len(d_outputs) - ctx.n_extra]
-        gates = ctx.S['gates']
         # a gate tensor that was given as an input (not learned) carries no gradient
         n_gate = 2 if plan.n_aff is None else 4
         kinds = ['h', 'h'] if plan.n_aff is None else ['h', 'o', 'h', 'o']
         for i in range(n_gate):
-            if not gates[kinds[i]]['learned']:
+            if not ctx.gate_learned[kinds[i]]:
                 d_outputs[i] = None
         # OPT-IN in-place gradient route (enable_grad_sinks; distributed.FlatParameters turns it on for its flat
         # gradient views): such a parameter receives `grad += g` from the producing kernels themselves and autograd gets
@@ -1568,11 +1620,12 @@ class TGGCNFunction(torch.autograd.Function):
                     and not getattr(prm, '_backward_hooks', None)
                     and not getattr(prm, '_post_accumulate_grad_hooks', None)):
                 sinks[n] = g
-        grads = tggcn_backward(K, plan, ctx.P, ctx.S, x_human, x_objects, objects_mask, d_outputs, sinks)
+        S = _unpack_state(ctx.state_skeleton, ctx.saved_tensors)
+        grads = tggcn_backward(K, plan, ctx.P, S, x_human, x_objects, objects_mask, d_outputs, sinks)
         out = [None] * 11
         for n in ctx.names:
             g = grads.get(n)
             if g is not None:
                 g = g.reshape(ctx.P[n].shape)
             out.append(g)
-        return tuple(out)   # ctx.S lives as long as the graph does (retain_graph=True may run this again)
+        return tuple(out)   # (retain_graph=True may run this again: the engine keeps the saved tensors then)

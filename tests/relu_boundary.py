@@ -30,7 +30,7 @@ def boundary_layers(model, out):
     {layer name (as in the state_dict, without '.weight'): tensor of unit indices with boundary rows}."""
     from twog_gcn_amd import ops
     node = next(o.grad_fn for o in out if o.grad_fn is not None)
-    S, plan, P = node.S, node.plan, dict(model.named_parameters())
+    S, plan, P = ops.saved_state(node), node.plan, dict(model.named_parameters())
     x_human, x_objects, _ = node.inputs
     bs, T, H, O, N, h = plan.bs, plan.T, plan.H, plan.O, plan.N, plan.h
     nF = bs * T

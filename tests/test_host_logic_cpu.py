@@ -300,7 +300,7 @@ def test_no_reference_cycle_keeps_saved_buffers_alive(fake_backend):
     try:
         out = m(**g4_inputs(z))
         node = next(o.grad_fn for o in out if o.grad_fn is not None)
-        probe = weakref.ref(node.S['HUM'])
+        probe = weakref.ref(ops.saved_state(node)['HUM'])
         sum((o * o).sum() for o in out if o.requires_grad).backward()
         del out, node
         assert probe() is None, 'saved buffers survived without a GC pass: reference cycle through the autograd node'
@@ -329,3 +329,35 @@ def test_callers_inputs_are_never_written(strategy, filt, fake_backend):
         assert torch.equal(t, k)
     if not filt:
         assert torch.equal(out[0], keep[3])
+
+
+def test_saved_state_is_released_by_backward_not_by_the_loss(fake_backend):
+    """Lifetime of the saved state follows torch's rule for saved tensors: gone when backward has run (without
+    retain_graph) even though the caller still holds the outputs, reachable again and again with retain_graph."""
+    import gc
+    import weakref
+    z, meta = load_g4('c2_stage1')
+    m = build_model(meta)
+    m.train()
+    noise = torch.from_numpy(z['gumbel_noise'])
+    m._gumbel_noise_override = noise if len(noise) else None
+    gc.disable()
+    try:
+        out = m(**g4_inputs(z))
+        node = next(o.grad_fn for o in out if o.grad_fn is not None)
+        probe = weakref.ref(ops.saved_state(node)['HUM'])
+        loss = sum((o * o).sum() for o in out if o.requires_grad)
+        loss.backward(retain_graph=True)
+        g1 = {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
+        assert probe() is not None
+        m.zero_grad()
+        loss.backward()                      # second run on the retained state, then the engine lets go of it
+        for n, p in m.named_parameters():
+            if p.grad is not None:
+                assert torch.equal(p.grad, g1[n]), n
+        assert probe() is None, 'saved buffers outlived backward while the caller still holds loss and outputs'
+        with pytest.raises(RuntimeError):
+            ops.saved_state(node)
+        assert out[0].shape[0] > 0 and loss.item() == loss.item()   # outputs and loss stay valid
+    finally:
+        gc.enable()

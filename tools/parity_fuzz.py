@@ -202,7 +202,7 @@ def one_case(rng, idx, dev=DEV, dry=False):
             rtol, atol, grad_ref = 2e-5, 1e-8, 'fp64|fp32'
         else:
             rtol, atol, grad_ref = 2e-2, 5e-6, 'fp32 (gates differ in fp64)'
-        sum((o * r.to(dev)).sum() for o, r in zip(out, rs) if o.requires_grad).backward()
+        sum((o * r.to(dev)).sum() for o, r in zip(out, rs) if o.requires_grad).backward(retain_graph=True)   # state kept for boundary_layers
         off = []
         for pname, p in m.named_parameters():
             g32 = osd[pname].grad
