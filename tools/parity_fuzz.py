@@ -74,6 +74,27 @@ def _is_owner_or_upstream(t, owner):
     return st < so and (bt == bo or bt is None or bo is None)
 
 
+def _decision_margin(aux, ref, cfg, given_seg, cad):
+    """Smallest distance of a LEARNED soft gate of the oracle run to what its hard decision is compared with: the
+    threshold and, with the local-maximum filter (vhoi/models.py:1637-1664), the neighbouring time steps."""
+    thr, filt = cfg['update_segment_threshold'], cfg['filter_discrete_updates']
+    series = []   # (T, n) tensors of soft values
+    if not given_seg:
+        soft_h = ref[2 if cad else 1].detach()                       # y_hss (bs, T, H)
+        series.append(soft_h.permute(1, 0, 2).reshape(soft_h.shape[1], -1))
+    for per in aux.get('ux_oss', []) or []:                          # per object: list over time of (bs, 1)
+        if isinstance(per, (list, tuple)) and len(per) and torch.is_tensor(per[0]):
+            series.append(torch.stack([x.detach().reshape(-1) for x in per]))
+    best = float('inf')
+    for S in series:
+        if not ((S != 0) & (S != 1)).any():   # a GIVEN segmentation (exact 0 / 1 on both sides): no rounding involved
+            continue
+        best = min(best, float((S - thr).abs().min()))
+        if filt and S.shape[0] > 1:
+            best = min(best, float((S[1:] - S[:-1]).abs().min()))
+    return best
+
+
 def one_case(rng, idx, dev=DEV, dry=False):
     H = rng.choice([1, 2, 2])
     cfg = dict(BASE)
@@ -162,7 +183,9 @@ def one_case(rng, idx, dev=DEV, dry=False):
     noise = torch.distributions.gumbel.Gumbel(0.0, 1.0).sample((T * max(n_gated, 1), bs, 2))
     osd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and 'running' not in k else v.clone())
            for k, v in sd.items()}
-    ref = cpu_ref.tggcn_forward(osd, dict(m.cfg), x_human, x_objects, mask, training=training, gumbel_noise=noise, **kw)
+    ref_aux = {}
+    ref = cpu_ref.tggcn_forward(osd, dict(m.cfg), x_human, x_objects, mask, training=training, gumbel_noise=noise,
+                                aux=ref_aux, **kw)
     if os.environ.get('TWOG_FUZZ_ORACLE_ONLY'):   # dry run of the case generator + oracle (no GPU)
         return dict(desc, worst_output_rel=0.0, worst_grad_rel=0.0)
     m = m.to(dev)
@@ -173,14 +196,30 @@ def one_case(rng, idx, dev=DEV, dry=False):
     except NotImplementedError as e:   # a configuration the gfx950 path declares unsupported (loudly): not a parity case
         raise AssertionError(f'the generator only draws supported configurations: {e}')
     assert len(out) == len(ref)
-    worst_out = 0.0
+    worst_out, flipped = 0.0, None
     for i, (o, r) in enumerate(zip(out, ref)):
         got, want = o.detach().cpu(), r.detach()
         assert got.shape == want.shape, (i, got.shape, want.shape)
         assert not torch.isnan(got).any(), ('nan', i)
         err = (got - want).abs().max().item() / max(1.0, want.abs().max().item())
+        if err >= 1e-4 and flipped is None:
+            # A hard decision on the rounding boundary: a learned soft gate within a few ulp of the threshold or -- with
+            # the local-maximum filter -- of its neighbour in time (seed 43 #285: two consecutive soft values 5.96e-8 = one
+            # ulp apart decide which of the two frames ends a segment). The reference's own result then depends on the
+            # order of its fp32 sums. Accepted only if the oracle's soft gates show such a margin; recorded with the
+            # margin, and the gradients are not judged.
+            margin = _decision_margin(ref_aux, ref, cfg, given_seg, cad)
+            flipped = dict(output=i, kernels_vs_oracle=err, smallest_decision_margin=margin)
+            assert margin < 4e-7, ('output', i, err, 'smallest decision margin', margin)
+        if flipped is not None:
+            assert err < 0.5, ('output', i, err, flipped)   # a flipped segment end moves the segment level, nothing explodes
+            continue
         worst_out = max(worst_out, err)
         assert err < 1e-4, ('output', i, err)
+    if flipped is not None:
+        desc.update(decision_on_rounding_boundary=flipped, worst_output_rel=worst_out, worst_grad_rel=0.0,
+                    worst_grad_rel_ill_conditioned=0.0, tensors_judged_by_conditioning=0, grad_ref='not judged')
+        return desc
     worst_g, worst_cond, n_cond, grad_ref = 0.0, 0.0, 0, 'none'
     st_learned = cfg['discrete_optimization_strategy'] == 'st' and n_gated > 0
     if training and not st_learned:   # 'st' with learned gates: the reference's backward raises (upstream bug), forward only
@@ -296,6 +335,7 @@ def main():
                    worst_grad_rel_ill_conditioned=max((r.get('worst_grad_rel_ill_conditioned', 0.0) for r in ok), default=0.0),
                    tensors_judged_by_conditioning=sum(r.get('tensors_judged_by_conditioning', 0) for r in ok),
                    cases_with_a_relu_unit_on_the_other_side_of_zero=sum(1 for r in ok if r.get('relu_boundary')),
+                   cases_with_a_hard_decision_on_the_rounding_boundary=sum(1 for r in ok if r.get('decision_on_rounding_boundary')),
                    seconds=time.time() - t0)
     os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
     json.dump(dict(summary=summary, failures=failures, results=results),
