@@ -22,7 +22,7 @@ namespace {
 constexpr int MAX_H = 4, MAX_O = 12, MAX_E = MAX_H + MAX_O;
 constexpr int NATT_MAX = MAX_H * MAX_H + 2 * MAX_H * MAX_O + MAX_O * MAX_O;
 constexpr int MAXG = 4;
-struct FwdGroup { twog_attn_t a[MAXG]; int staged; };
+struct FwdGroup { twog_attn_t a[MAXG]; int staged; int columns; };
 struct BwdGroup { twog_attn_bwd_t a[MAXG]; int staged; };
 
 // the n rows (inst*n .. inst*n+n-1) of a twog_rows_t resolved to base + e*step  (host guarantees inner <= 1 or == n)
@@ -88,6 +88,82 @@ __device__ __forceinline__ void softmax_row(const float* score, float* w, int S,
 }
 
 constexpr int GRAM_PART = 1024;   // floats of LDS scratch for the partial dot products
+__device__ __forceinline__ void weights_from_gram(const twog_attn_t& A, const float* sG, float* sW, const float* sMask);
+
+// Gram matrix of the throughput regime (frame level: thousands of instances, 2h-wide features), column-parallel: every
+// thread owns feature columns (two floats at a time), loads the E values of a column from global memory ONCE, and keeps
+// the E(E-1)/2 pair products in registers -- no staging of the feature rows in LDS, no re-reading them once per pair
+// partner (10 rows x 1028 floats staged and 451 KB read back per instance in the row-parallel form). The per-thread
+// partials are summed over the 64 lanes with a reduce-scatter butterfly (every exchange step halves the number of live
+// values: PP - 1 exchanges per lane instead of 6 per value), the waves' results are added in fixed order through sP.
+// N live values per lane, exchange distance M: the lane with bit M set keeps the upper half of its N values and receives
+// its partner's contribution to them, the other lane the lower half; with one value left the steps are plain all-reduces
+template <int PP, int N, int M>
+__device__ __forceinline__ void lane_reduce_scatter(float (&acc)[PP], int lane) {
+    if constexpr (M >= 1) {
+        if constexpr (N > 1) {
+            constexpr int half = N / 2;
+            const bool upper = (lane & M) != 0;
+#pragma unroll
+            for (int i = 0; i < half; ++i) {
+                const float send = upper ? acc[i] : acc[i + half];
+                const float keep = upper ? acc[i + half] : acc[i];
+                acc[i] = keep + __shfl_xor(send, M, 64);
+            }
+            lane_reduce_scatter<PP, half, M / 2>(acc, lane);
+        } else {
+            acc[0] += __shfl_xor(acc[0], M, 64);
+            lane_reduce_scatter<PP, 1, M / 2>(acc, lane);
+        }
+    }
+}
+
+template <int EMAX, int PP>
+__device__ __forceinline__ void gram_columns(const twog_attn_t& A, const RowSet& fh, const RowSet& fo, float* sG, float* sP) {
+    constexpr int P = EMAX * (EMAX - 1) / 2;
+    static_assert(P <= PP && (PP & (PP - 1)) == 0 && PP <= 64, "pairs padded to a power of two <= 64");
+    const int H = A.H, O = A.O, E = H + O, D = A.D;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    float acc[PP];
+#pragma unroll
+    for (int i = 0; i < PP; ++i) acc[i] = 0.f;
+    const float* rows[EMAX];
+#pragma unroll
+    for (int e = 0; e < EMAX; ++e) rows[e] = e < H ? fh.row(e) : (e < E ? fo.row(e - H) : fh.row(0));
+    for (int c2 = threadIdx.x; c2 < (D >> 1); c2 += blockDim.x) {
+        float2 x[EMAX];
+#pragma unroll
+        for (int e = 0; e < EMAX; ++e) {
+            x[e] = *reinterpret_cast<const float2*>(rows[e] + 2 * c2);
+            if (e >= E) x[e] = make_float2(0.f, 0.f);
+        }
+        int p = 0;
+#pragma unroll
+        for (int a = 0; a < EMAX; ++a)
+#pragma unroll
+            for (int b = a + 1; b < EMAX; ++b) {
+                acc[p] = fmaf(x[a].x, x[b].x, fmaf(x[a].y, x[b].y, acc[p]));
+                ++p;
+            }
+    }
+    // reduce-scatter over the lanes: after the halving steps lane L holds pair (L >> shift), summed over all 64 lanes
+    lane_reduce_scatter<PP, PP, 32>(acc, lane);
+    constexpr int LANES_PER_VALUE = 64 / PP;
+    if ((lane & (LANES_PER_VALUE - 1)) == 0) sP[wave * PP + lane / LANES_PER_VALUE] = acc[0];
+    __syncthreads();
+    const int t = threadIdx.x;
+    if (t < P) {
+        int p = t, a = 0;
+        while (p >= EMAX - 1 - a) { p -= EMAX - 1 - a; ++a; }
+        const int b = a + 1 + p;
+        float v = 0.f;
+        for (int w = 0; w < nw; ++w) v += sP[w * PP + t];   // fixed order: deterministic
+        v *= A.scale;
+        if (a < E && b < E) { sG[a * E + b] = v; sG[b * E + a] = v; }
+    }
+    if (t < E) sG[t * E + t] = 0.f;   // never read (a receiver is excluded from its own senders)
+    __syncthreads();
+}
 
 // pairwise scores + the four masked softmaxes. sF: [E][ldf] features in LDS (ldf = D + 4: consecutive rows start 4 banks
 // apart, so lanes that read different rows at the same column never collide); sG: [E][E] scratch; sP: GRAM_PART floats of
@@ -134,7 +210,13 @@ __device__ __forceinline__ void compute_weights(const twog_attn_t& A, const floa
         sG[b * E + a] = acc;
     }
     __syncthreads();
-    // one thread per (relation, receiver): scores are row pieces of sG, weights go to sW
+    weights_from_gram(A, sG, sW, sMask);
+}
+
+// the four masked softmaxes over rows of the scaled Gram matrix sG [E][E]: one thread per (relation, receiver); ends with
+// a barrier
+__device__ __forceinline__ void weights_from_gram(const twog_attn_t& A, const float* sG, float* sW, const float* sMask) {
+    const int H = A.H, O = A.O, E = H + O;
     const int i = threadIdx.x;
     if (i < 2 * H + 2 * O) {
         const float* sc;
@@ -159,55 +241,15 @@ __device__ __forceinline__ void compute_weights(const twog_attn_t& A, const floa
     __syncthreads();
 }
 
-__global__ __launch_bounds__(1024) void attn_fwd_kernel(const FwdGroup g) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];
-    const twog_attn_t& A = g.a[blockIdx.y];
-    const int inst = blockIdx.x;
-    if (inst >= A.n_inst) return;
-    const int H = A.H, O = A.O, E = H + O, D = A.D, hid = A.hidden;
-    const int ldf = D + 4;     // padded feature rows (see compute_weights)
-    float* sF = sm;            // [E][ldf]
-    float* sG = sF + E * ldf;  // [E][E]
-    float* sW = sG + MAX_E * MAX_E;
-    float* sMask = sW + NATT_MAX;
-    float* sP = sMask + MAX_O + 4;   // [GRAM_PART]
-    const int clip = inst / A.inst_per_clip;
-    const RowSet fh = rowset(A.feat_h, inst, H), fo = rowset(A.feat_o, inst, O);
-    RowSet m_hh = rowset(A.msg_hh, inst, H), m_ho = rowset(A.msg_ho, inst, H);
-    RowSet m_oh = rowset(A.msg_oh, inst, O), m_oo = rowset(A.msg_oo, inst, O);
-    RowSet m_so = rowset(A.msg_so, inst, 1), m_sh = rowset(A.msg_sh, inst, 1);
-    const RowSet o_hh = rowset(A.out_hh, inst, H), o_oh = rowset(A.out_oh, inst, H), o_sh = rowset(A.out_sh, inst, H);
-    const RowSet o_ho = rowset(A.out_ho, inst, O), o_so = rowset(A.out_so, inst, O), o_oo = rowset(A.out_oo, inst, O);
-    if (threadIdx.x < O) sMask[threadIdx.x] = A.obj_mask ? A.obj_mask[(int64_t)clip * O + threadIdx.x] : 1.f;
-    {   // features -> LDS
-        const int d4 = D >> 2;
-        for (int i = threadIdx.x; i < E * d4; i += blockDim.x) {
-            const int e = i / d4, c = (i - e * d4) * 4;
-            const float* src = e < H ? fh.row(e) : fo.row(e - H);
-            *reinterpret_cast<float4*>(sF + e * ldf + c) = *reinterpret_cast<const float4*>(src + c);
-        }
-    }
-    // latency regime: the instance is shared by gridDim.z = 2 workgroups -- both compute the (cheap) weights, half 0
-    // produces the messages to humans and the human / geometry messages to objects, half 1 the object -> object ones
-    const int half = blockIdx.z, nhalf = gridDim.z;
-    const bool do01 = nhalf == 1 || half == 0, do23 = nhalf == 1 || half == 1;
-    if (g.staged) {
-        float* cur = sP + GRAM_PART;
-        cur = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(cur) + 15) & ~uintptr_t(15));
-        if (do01) {
-            stage_rowset(m_hh, H, hid, cur);
-            stage_rowset(m_ho, H, hid, cur);
-            stage_rowset(m_oh, O, hid, cur);
-            stage_rowset(m_so, 1, hid, cur);
-            stage_rowset(m_sh, 1, hid, cur);
-        }
-        if (do23) stage_rowset(m_oo, O, hid, cur);
-    }
-    __syncthreads();
-    compute_weights(A, sF, ldf, sG, sP, sW, sMask);
-    const int natt = H * H + 2 * H * O + O * O;
-    if (A.att && half == 0)
-        for (int i = threadIdx.x; i < natt; i += blockDim.x) A.att[(int64_t)inst * natt + i] = sW[i];
+// weighted sums of one instance from the weights in sW (phase 3 of both forward kernels)
+struct FwdRows {
+    RowSet m_hh, m_ho, m_oh, m_oo, m_so, m_sh, o_hh, o_oh, o_sh, o_ho, o_so, o_oo;
+};
+__device__ __forceinline__ void attn_outputs(const twog_attn_t& A, const float* sW, const float* sMask, const FwdRows& R,
+                                             bool do01, bool do23) {
+    const int H = A.H, O = A.O, hid = A.hidden;
+    const RowSet &m_hh = R.m_hh, &m_ho = R.m_ho, &m_oh = R.m_oh, &m_oo = R.m_oo, &m_so = R.m_so, &m_sh = R.m_sh;
+    const RowSet &o_hh = R.o_hh, &o_oh = R.o_oh, &o_sh = R.o_sh, &o_ho = R.o_ho, &o_so = R.o_so, &o_oo = R.o_oo;
     // weighted sums: one (group, column) item per thread, lane-contiguous loads/stores. Groups are independent pieces of
     // work of similar size -- 0: messages to humans (hh, oh, sh); 1: human/geometry messages to objects (ho, so);
     // 2, 3: object->object messages for the first / second half of the receivers.
@@ -277,6 +319,87 @@ __global__ __launch_bounds__(1024) void attn_fwd_kernel(const FwdGroup g) {
             }
         }
     }
+}
+
+__global__ __launch_bounds__(1024) void attn_fwd_kernel(const FwdGroup g) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const twog_attn_t& A = g.a[blockIdx.y];
+    const int inst = blockIdx.x;
+    if (inst >= A.n_inst) return;
+    const int H = A.H, O = A.O, E = H + O, D = A.D, hid = A.hidden;
+    const int ldf = D + 4;     // padded feature rows (see compute_weights)
+    float* sG = sm;            // [E][E]
+    float* sW = sG + MAX_E * MAX_E;
+    float* sMask = sW + NATT_MAX;
+    float* sP = sMask + MAX_O + 4;   // [GRAM_PART]
+    float* sF = sP + GRAM_PART;      // [E][ldf] (row-parallel Gram only), then the staged message rows
+    const int clip = inst / A.inst_per_clip;
+    const RowSet fh = rowset(A.feat_h, inst, H), fo = rowset(A.feat_o, inst, O);
+    RowSet m_hh = rowset(A.msg_hh, inst, H), m_ho = rowset(A.msg_ho, inst, H);
+    RowSet m_oh = rowset(A.msg_oh, inst, O), m_oo = rowset(A.msg_oo, inst, O);
+    RowSet m_so = rowset(A.msg_so, inst, 1), m_sh = rowset(A.msg_sh, inst, 1);
+    const RowSet o_hh = rowset(A.out_hh, inst, H), o_oh = rowset(A.out_oh, inst, H), o_sh = rowset(A.out_sh, inst, H);
+    const RowSet o_ho = rowset(A.out_ho, inst, O), o_so = rowset(A.out_so, inst, O), o_oo = rowset(A.out_oo, inst, O);
+    if (threadIdx.x < O) sMask[threadIdx.x] = A.obj_mask ? A.obj_mask[(int64_t)clip * O + threadIdx.x] : 1.f;
+    {   // features -> LDS
+        const int d4 = D >> 2;
+        for (int i = threadIdx.x; i < E * d4; i += blockDim.x) {
+            const int e = i / d4, c = (i - e * d4) * 4;
+            const float* src = e < H ? fh.row(e) : fo.row(e - H);
+            *reinterpret_cast<float4*>(sF + e * ldf + c) = *reinterpret_cast<const float4*>(src + c);
+        }
+    }
+    // latency regime: the instance is shared by gridDim.z = 2 workgroups -- both compute the (cheap) weights, half 0
+    // produces the messages to humans and the human / geometry messages to objects, half 1 the object -> object ones
+    const int half = blockIdx.z, nhalf = gridDim.z;
+    const bool do01 = nhalf == 1 || half == 0, do23 = nhalf == 1 || half == 1;
+    if (g.staged) {
+        float* cur = sF + E * ldf;
+        cur = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(cur) + 15) & ~uintptr_t(15));
+        if (do01) {
+            stage_rowset(m_hh, H, hid, cur);
+            stage_rowset(m_ho, H, hid, cur);
+            stage_rowset(m_oh, O, hid, cur);
+            stage_rowset(m_so, 1, hid, cur);
+            stage_rowset(m_sh, 1, hid, cur);
+        }
+        if (do23) stage_rowset(m_oo, O, hid, cur);
+    }
+    __syncthreads();
+    compute_weights(A, sF, ldf, sG, sP, sW, sMask);
+    const int natt = H * H + 2 * H * O + O * O;
+    if (A.att && half == 0)
+        for (int i = threadIdx.x; i < natt; i += blockDim.x) A.att[(int64_t)inst * natt + i] = sW[i];
+    FwdRows R{m_hh, m_ho, m_oh, m_oo, m_so, m_sh, o_hh, o_oh, o_sh, o_ho, o_so, o_oo};
+    attn_outputs(A, sW, sMask, R, do01, do23);
+}
+
+// Throughput regime with at most ten entities per instance: the Gram matrix comes column-parallel from global memory
+// (gram_columns), no feature rows in LDS -- the workgroup needs 6 KB of LDS instead of 47 KB. 80 VGPRs keep three
+// 512-thread workgroups on a CU (6 waves per SIMD).
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 8))) void attn_fwd_cols_kernel(const FwdGroup g) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const twog_attn_t& A = g.a[blockIdx.y];
+    const int inst = blockIdx.x;
+    if (inst >= A.n_inst) return;
+    const int H = A.H, O = A.O, E = H + O;
+    float* sG = sm;
+    float* sW = sG + MAX_E * MAX_E;
+    float* sMask = sW + NATT_MAX;
+    float* sP = sMask + MAX_O + 4;
+    const int clip = inst / A.inst_per_clip;
+    const RowSet fh = rowset(A.feat_h, inst, H), fo = rowset(A.feat_o, inst, O);
+    FwdRows R{rowset(A.msg_hh, inst, H), rowset(A.msg_ho, inst, H), rowset(A.msg_oh, inst, O), rowset(A.msg_oo, inst, O),
+              rowset(A.msg_so, inst, 1), rowset(A.msg_sh, inst, 1), rowset(A.out_hh, inst, H), rowset(A.out_oh, inst, H),
+              rowset(A.out_sh, inst, H), rowset(A.out_ho, inst, O), rowset(A.out_so, inst, O), rowset(A.out_oo, inst, O)};
+    if (threadIdx.x < O) sMask[threadIdx.x] = A.obj_mask ? A.obj_mask[(int64_t)clip * O + threadIdx.x] : 1.f;
+    if (E <= 6) gram_columns<6, 16>(A, fh, fo, sG, sP);
+    else gram_columns<10, 64>(A, fh, fo, sG, sP);
+    weights_from_gram(A, sG, sW, sMask);
+    const int natt = H * H + 2 * H * O + O * O;
+    if (A.att)
+        for (int i = threadIdx.x; i < natt; i += blockDim.x) A.att[(int64_t)inst * natt + i] = sW[i];
+    attn_outputs(A, sW, sMask, R, true, true);
 }
 
 // wave-level dot product of two rows of length n (n % 4 == 0, 16-byte aligned)
@@ -541,8 +664,8 @@ inline size_t n_dout_rows(const twog_attn_t& a) {
     return (size_t)(a.msg_hh.ptr ? a.H : 0) + (a.msg_oh.ptr ? a.H : 0) + (a.msg_sh.ptr ? a.H : 0) +
            (a.msg_ho.ptr ? a.O : 0) + (a.msg_so.ptr ? a.O : 0) + (a.msg_oo.ptr ? a.O : 0);
 }
-inline size_t lds_fwd(const twog_attn_t& a, bool staged) {
-    size_t f = (size_t)(a.H + a.O) * (a.D + 4) + MAX_E * MAX_E + NATT_MAX + MAX_O + 8 + GRAM_PART;
+inline size_t lds_fwd(const twog_attn_t& a, bool staged, bool columns = false) {
+    size_t f = (columns ? 0 : (size_t)(a.H + a.O) * (a.D + 4)) + MAX_E * MAX_E + NATT_MAX + MAX_O + 8 + GRAM_PART;
     if (staged) f += n_msg_rows(a) * (a.hidden + 4);
     return sizeof(float) * f;
 }
@@ -598,9 +721,27 @@ extern "C" int twog_attn_fwd(const twog_attn_t* a, int n, void* stream) {
     }
     if (lds > LDS_LIMIT) return -3;
     g.staged = staged ? 1 : 0;
+    // throughput regime with at most ten entities per instance: column-parallel Gram, no feature rows in LDS
+    static const int cols_on = getenv("TWOG_ATTN_COLUMNS") ? atoi(getenv("TWOG_ATTN_COLUMNS")) : 1;
+    bool columns = !staged && cols_on;
+    for (int i = 0; i < n; ++i) columns = columns && (a[i].H + a[i].O) <= 10 && (a[i].D & 1) == 0;
+    g.columns = columns ? 1 : 0;
+    if (columns) {
+        lds = 0;
+        for (int i = 0; i < n; ++i) lds = lds_fwd(a[i], false, true) > lds ? lds_fwd(a[i], false, true) : lds;
+    }
     static std::atomic<uint32_t> lds_attr_done{0};
     twog_allow_dynamic_lds(attn_fwd_kernel, (int)LDS_LIMIT, lds_attr_done);
     // throughput regime: 512 threads (the LDS feature tile limits a CU to 3 workgroups: 24 waves instead of 12)
+    if (columns) {
+        // 256 threads: the butterfly costs the same per wave whatever the workgroup size, and six small workgroups per
+        // CU overlap their phases better than three large ones (measured at the BASELINE shape: 0.262 ms with 512
+        // threads, 0.231 with 256, 0.250 with 128; the row-parallel kernel: 0.283)
+        static const int cols_threads = getenv("TWOG_ATTN_COLS_THREADS") ? atoi(getenv("TWOG_ATTN_COLS_THREADS")) : 256;
+        hipLaunchKernelGGL(attn_fwd_cols_kernel, dim3(maxinst, n, 1), dim3(cols_threads), lds, (hipStream_t)stream, g);
+        TWOG_CHECK_LAUNCH();
+        return 0;
+    }
     hipLaunchKernelGGL(attn_fwd_kernel, dim3(maxinst, n, staged ? 2 : 1), dim3(staged ? 1024 : 512), lds, (hipStream_t)stream, g);
     TWOG_CHECK_LAUNCH();
     return 0;

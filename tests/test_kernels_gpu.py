@@ -695,6 +695,36 @@ def test_mul_and_scale_rows(K):
     close(xg, xc, what='scale_rows on a column block')
 
 
+@pytest.mark.parametrize('H,O,D,h,geo', [(2, 4, 64, 32, True),      # 6 entities: 15 pairs in 16 slots
+                                         (1, 1, 32, 32, False),     # one pair
+                                         (1, 5, 40, 16, True),      # fewer column pairs than threads
+                                         (2, 7, 96, 48, True),      # 9 entities in the 10-entity variant
+                                         (2, 8, 200, 64, False),    # 10 entities, a column count that is no power of two
+                                         (2, 9, 128, 64, True)])    # 11 entities: the row-parallel (LDS) Gram
+def test_entity_attention_streaming_regime(K, H, O, D, h, geo):
+    """More than 1024 instances (the frame-level call of a real batch): the forward kernel whose Gram matrix is computed
+    column-parallel from global memory (at most ten entities), and its fall-back; forward only (the backward kernel
+    is the same in both regimes and is covered above)."""
+    n_inst, ipc = 1100, 10
+    dc = _attn_case('cpu', H, O, D, h, n_inst, ipc, geo, 1, seed=5)
+    dg = _attn_case(DEV, H, O, D, h, n_inst, ipc, geo, 1, seed=5)
+    if H == 1:
+        for d in (dc, dg):
+            d['msg_hh'] = None
+            d.pop('out_hh')
+    if O == 1:
+        for d in (dc, dg):
+            d['msg_oo'] = None
+            d.pop('out_oo')
+    F.attn_fwd([dc])
+    K.attn_fwd([dg])
+    close(dg['att'], dc['att'], rtol=1e-4, atol=1e-6, what='att weights')
+    for k in dc:
+        if k.startswith('out_'):
+            close(dg[k], dc[k], rtol=1e-4, atol=1e-5, what=k)
+    assert not torch.isnan(dg['att']).any()
+
+
 @pytest.mark.parametrize('n_inst,ipc', [(240, 120), (1200, 120)])   # LDS-staged (latency) path and streaming path
 def test_entity_attention_product_layout_full_size(K, n_inst, ipc):
     """The frame-level call exactly as ops.py lays it out at the BASELINE shape (H=2, O=8, h=512, T=120): features and
