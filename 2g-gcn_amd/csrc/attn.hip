@@ -417,7 +417,35 @@ __device__ __forceinline__ float wave_dot(const float* a, const float* b, int n,
     return wave_sum(acc);
 }
 
-__global__ __launch_bounds__(1024) void attn_bwd_kernel(const BwdGroup g) {
+// dL/dw of one relation, column-parallel (the throughput regime of the backward kernel): the thread's columns of the R
+// gradient rows and the S sender-message rows are loaded once, the R x S products stay in registers, the lanes add
+// them with the reduce-scatter butterfly, the waves' sums meet in sP [wave][PP]; the caller adds them in fixed order.
+template <int RMAX, int SMAX, int PP>
+__device__ __forceinline__ void dw_columns(const RowSet& dr, const RowSet& mr, int R, int S, int hid, float* sP) {
+    static_assert(RMAX * SMAX <= PP && PP <= 64, "one slot per (receiver, sender)");
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float acc[PP];
+#pragma unroll
+    for (int i = 0; i < PP; ++i) acc[i] = 0.f;
+    for (int c2 = threadIdx.x; c2 < (hid >> 1); c2 += blockDim.x) {
+        float2 d[RMAX], m[SMAX];
+#pragma unroll
+        for (int r = 0; r < RMAX; ++r) d[r] = r < R ? *reinterpret_cast<const float2*>(dr.row(r) + 2 * c2) : make_float2(0.f, 0.f);
+#pragma unroll
+        for (int s = 0; s < SMAX; ++s) m[s] = s < S ? *reinterpret_cast<const float2*>(mr.row(s) + 2 * c2) : make_float2(0.f, 0.f);
+#pragma unroll
+        for (int r = 0; r < RMAX; ++r)
+#pragma unroll
+            for (int s = 0; s < SMAX; ++s)
+                acc[r * SMAX + s] = fmaf(d[r].x, m[s].x, fmaf(d[r].y, m[s].y, acc[r * SMAX + s]));
+    }
+    lane_reduce_scatter<PP, PP, 32>(acc, lane);
+    constexpr int LANES_PER_VALUE = 64 / PP;
+    if ((lane & (LANES_PER_VALUE - 1)) == 0) sP[wave * PP + lane / LANES_PER_VALUE] = acc[0];
+}
+
+template <bool COLS>
+__device__ __forceinline__ void attn_bwd_body(const BwdGroup& g) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const twog_attn_bwd_t& B = g.a[blockIdx.y];
     const twog_attn_t& A = B.f;
@@ -515,6 +543,37 @@ __global__ __launch_bounds__(1024) void attn_bwd_kernel(const BwdGroup g) {
             for (int q = 0; q < Q; ++q) v += sP[q * natt + t];
             sdW[t] = B.dw_extra ? v + B.dw_extra[(int64_t)inst * natt + t] : v;
         }
+    } else if (COLS && do_feat) {
+        // (at most 2 humans and 8 objects, checked by the host) one relation after the other; slot (r, s) of a relation
+        // sits at r * SMAX + s of its butterfly, the waves' partial sums at sP [wave][64]
+        // receivers [r0, r0 + R) of a relation; skip_diag: receiver r0 + r is excluded from its own senders
+        auto relation = [&](auto tag, RowSet dr, const RowSet& mr, int r0, int R, int S, int off, bool skip_diag, bool recv_masked) {
+            constexpr int RMAX = decltype(tag)::R, SMAX = decltype(tag)::S, PP = decltype(tag)::PP;
+            if (R <= 0) return;   // uniform
+            if (dr.on()) dr.base += (int64_t)r0 * dr.step;
+            if (mr.on()) dw_columns<RMAX, SMAX, PP>(dr, mr, R, S, hid, sP);
+            __syncthreads();
+            for (int t = threadIdx.x; t < R * S; t += blockDim.x) {
+                const int r = t / S, s_ = t - r * S;
+                float v = 0.f;
+                if (mr.on() && !(skip_diag && r0 + r == s_)) {
+                    for (int w = 0; w < nw; ++w) v += sP[w * PP + r * SMAX + s_];   // fixed order: deterministic
+                    if (recv_masked) v *= sMask[r0 + r];
+                }
+                const int slot = off + r0 * S + t;
+                sdW[slot] = B.dw_extra ? v + B.dw_extra[(int64_t)inst * natt + slot] : v;
+            }
+            __syncthreads();
+        };
+        struct T22 { enum { R = 2, S = 2, PP = 4 }; };
+        struct T28 { enum { R = 2, S = 8, PP = 16 }; };
+        struct T82 { enum { R = 8, S = 2, PP = 16 }; };
+        struct T48 { enum { R = 4, S = 8, PP = 32 }; };
+        relation(T22{}, d_hh, m_hh, 0, H, H, att_off_hh(H, O), true, false);
+        relation(T28{}, d_oh, m_oh, 0, H, O, att_off_oh(H, O), false, false);
+        relation(T82{}, d_ho, m_ho, 0, O, H, att_off_ho(H, O), false, rmask);
+        relation(T48{}, d_oo, m_oo, 0, min(O, 4), O, att_off_oo(H, O), true, false);   // two halves: 32 products in
+        relation(T48{}, d_oo, m_oo, 4, O - 4, O, att_off_oo(H, O), true, false);        // registers instead of 64
     } else if (do_feat)
     for (int p = wv; p < natt; p += nw) {
         float v = 0.f;
@@ -655,6 +714,10 @@ __global__ __launch_bounds__(1024) void attn_bwd_kernel(const BwdGroup g) {
     }
 }
 
+__global__ __launch_bounds__(1024) void attn_bwd_kernel(const BwdGroup g) { attn_bwd_body<false>(g); }
+// throughput regime, at most 2 humans and 8 objects: dL/dw column-parallel (dw_columns)
+__global__ __launch_bounds__(256) void attn_bwd_cols_kernel(const BwdGroup g) { attn_bwd_body<true>(g); }
+
 constexpr int STAGE_MAX_INST = 1024;  // calls with at most this many instances use the LDS-staged (latency) path
 inline size_t n_msg_rows(const twog_attn_t& a) {
     return (size_t)(a.msg_hh.ptr ? a.H : 0) + (a.msg_ho.ptr ? a.H : 0) + (a.msg_oh.ptr ? a.O : 0) +
@@ -769,6 +832,14 @@ extern "C" int twog_attn_bwd(const twog_attn_bwd_t* a, int n, void* stream) {
     g.staged = staged ? 1 : 0;
     static std::atomic<uint32_t> lds_attr_done{0};
     twog_allow_dynamic_lds(attn_bwd_kernel, (int)LDS_LIMIT, lds_attr_done);
+    static const int cols_on = getenv("TWOG_ATTN_COLUMNS") ? atoi(getenv("TWOG_ATTN_COLUMNS")) : 1;
+    bool columns = !staged && cols_on;
+    for (int i = 0; i < n; ++i) columns = columns && a[i].f.H <= 2 && a[i].f.O <= 8 && (a[i].f.hidden & 1) == 0;
+    if (columns) {
+        hipLaunchKernelGGL(attn_bwd_cols_kernel, dim3(maxinst, n, 1), dim3(256), lds, (hipStream_t)stream, g);
+        TWOG_CHECK_LAUNCH();
+        return 0;
+    }
     hipLaunchKernelGGL(attn_bwd_kernel, dim3(maxinst, n, staged ? 2 : 1), dim3(staged ? 1024 : 256), lds, (hipStream_t)stream, g);
     TWOG_CHECK_LAUNCH();
     return 0;

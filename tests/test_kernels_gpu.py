@@ -703,8 +703,8 @@ def test_mul_and_scale_rows(K):
                                          (2, 9, 128, 64, True)])    # 11 entities: the row-parallel (LDS) Gram
 def test_entity_attention_streaming_regime(K, H, O, D, h, geo):
     """More than 1024 instances (the frame-level call of a real batch): the forward kernel whose Gram matrix is computed
-    column-parallel from global memory (at most ten entities), and its fall-back; forward only (the backward kernel
-    is the same in both regimes and is covered above)."""
+    column-parallel from global memory (at most ten entities) and the backward kernel whose dL/dw is (at most 2 humans,
+    8 objects), and their row-parallel fall-backs (11 entities / 9 objects)."""
     n_inst, ipc = 1100, 10
     dc = _attn_case('cpu', H, O, D, h, n_inst, ipc, geo, 1, seed=5)
     dg = _attn_case(DEV, H, O, D, h, n_inst, ipc, geo, 1, seed=5)
@@ -723,6 +723,27 @@ def test_entity_attention_streaming_regime(K, H, O, D, h, geo):
         if k.startswith('out_'):
             close(dg[k], dc[k], rtol=1e-4, atol=1e-5, what=k)
     assert not torch.isnan(dg['att']).any()
+
+    def bwd(dev, d, seed=200):
+        t = lambda *s, sd=0: rnd(*s, seed=seed + sd).to(dev)
+        natt = H * H + 2 * H * O + O * O
+        b = dict(f=d, dfeat_accumulate=1, relu_mask_dmsg=1, dfeat_h=t(n_inst * H, D, sd=1), dfeat_o=t(n_inst * O, D, sd=2),
+                 dw_extra=t(n_inst, natt, sd=3) if geo else None)
+        for i, (rel, R) in enumerate((('hh', H), ('oh', H), ('ho', O), ('oo', O), ('so', O), ('sh', H))):
+            if d.get('msg_' + rel) is None:
+                continue
+            b['dout_' + rel] = t(n_inst * R, h, sd=10 + i)
+            S_ = {'hh': H, 'ho': H, 'oh': O, 'oo': O, 'so': 0, 'sh': 0}[rel]
+            b['dmsg_' + rel] = torch.zeros(n_inst * S_ if S_ else n_inst, h, device=dev)
+        return b
+
+    dc['att'], dg['att'] = dc['att'].clone(), dc['att'].to(DEV)   # same saved weights on both sides
+    bc, bg = bwd('cpu', dc), bwd(DEV, dg)
+    F.attn_bwd([bc])
+    K.attn_bwd([bg])
+    for k in bc:
+        if k.startswith('dmsg_') or k.startswith('dfeat_h') or k.startswith('dfeat_o'):
+            close(bg[k], bc[k], rtol=2e-4, atol=2e-5, what=k)
 
 
 @pytest.mark.parametrize('n_inst,ipc', [(240, 120), (1200, 120)])   # LDS-staged (latency) path and streaming path
