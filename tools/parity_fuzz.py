@@ -299,14 +299,20 @@ def one_case(rng, idx, dev=DEV, dry=False, run_seed=0):
             # contribution is a third of the row); an unconfirmed one keeps the 30 % cap of the signature rule.
             from tests.relu_boundary import boundary_layers
             found = boundary_layers(m, out)
+            # Several units can sit on the boundary in one case (the larger the layout, the likelier): every off tensor
+            # must be explained by SOME candidate -- a confirmed one where it can be, which lifts its cap.
             confirmed = [o for o in owners if o.rsplit('.', 1)[0] in found]
-            cap = 1.0 if confirmed else 0.3
-            cands = confirmed or owners
-            ok = same_gates and max(e for _, e, _ in off) < cap and any(
-                all(_is_owner_or_upstream(t, own_) for t, _, _ in off) for own_ in cands)
-            assert ok, ('grad', sorted(off, key=lambda o: -o[1])[:6], 'candidate owners', owners[:4],
-                        'boundary units found in', list(found))
-            desc['relu_boundary'] = cands[:4]
+            unexplained = []
+            for t, e, _ in off:
+                by_conf = any(_is_owner_or_upstream(t, own_) for own_ in confirmed)
+                by_any = by_conf or any(_is_owner_or_upstream(t, own_) for own_ in owners)
+                if not (by_any and e < (1.0 if by_conf else 0.3)):
+                    unexplained.append((t, e))
+            ok = same_gates and not unexplained
+            assert ok, ('grad', sorted(off, key=lambda o: -o[1])[:6], 'unexplained', unexplained[:6], 'candidate owners',
+                        owners[:6], 'boundary units found in', list(found))
+            cands = confirmed + [o for o in owners if o not in confirmed]
+            desc['relu_boundary'] = cands[:6]
             desc['relu_boundary_confirmed'] = bool(confirmed)
             desc['relu_boundary_worst_rel'] = max(e for _, e, _ in off)
     desc['grad_ref'] = grad_ref
@@ -334,8 +340,8 @@ def main():
         except NotImplementedError as e:   # a configuration the gfx950 path declares unsupported: not a parity failure
             results.append(dict(idx=i, skipped=str(e)[:200]))
         except Exception as e:  # noqa: BLE001
-            failures.append(dict(idx=i, error=repr(e)[:500], rng_state_hash=hash(state) & 0xffffffff))
-            print('FAIL', i, repr(e)[:500], flush=True)
+            failures.append(dict(idx=i, error=repr(e)[:2500], rng_state_hash=hash(state) & 0xffffffff))
+            print("FAIL", i, repr(e)[:2500], flush=True)
     ok = [r for r in results if 'worst_output_rel' in r and 'skipped' not in r]
     summary = dict(cases=n - first, first_case=first, passed=len(ok), skipped=len(results) - len(ok), failed=len(failures), seed=seed,
                    worst_output_rel=max((r['worst_output_rel'] for r in ok), default=0.0),
