@@ -23,7 +23,7 @@ constexpr int MAX_H = 4, MAX_O = 12, MAX_E = MAX_H + MAX_O;
 constexpr int NATT_MAX = MAX_H * MAX_H + 2 * MAX_H * MAX_O + MAX_O * MAX_O;
 constexpr int MAXG = 4;
 struct FwdGroup { twog_attn_t a[MAXG]; int staged; int columns; };
-struct BwdGroup { twog_attn_bwd_t a[MAXG]; int staged; };
+struct BwdGroup { twog_attn_bwd_t a[MAXG]; int staged; int wave_groups; };
 
 // the n rows (inst*n .. inst*n+n-1) of a twog_rows_t resolved to base + e*step  (host guarantees inner <= 1 or == n)
 struct RowSet {
@@ -420,14 +420,17 @@ __device__ __forceinline__ float wave_dot(const float* a, const float* b, int n,
 // dL/dw of one relation, column-parallel (the throughput regime of the backward kernel): the thread's columns of the R
 // gradient rows and the S sender-message rows are loaded once, the R x S products stay in registers, the lanes add
 // them with the reduce-scatter butterfly, the waves' sums meet in sP [wave][PP]; the caller adds them in fixed order.
+// (tid, nthreads: this thread's index in and the size of the thread group that shares the relation -- the workgroup, or
+// one of its wave groups in the latency regime)
 template <int RMAX, int SMAX, int PP>
-__device__ __forceinline__ void dw_columns(const RowSet& dr, const RowSet& mr, int R, int S, int hid, float* sP) {
+__device__ __forceinline__ void dw_columns(const RowSet& dr, const RowSet& mr, int R, int S, int hid, float* sP,
+                                           int tid, int nthreads) {
     static_assert(RMAX * SMAX <= PP && PP <= 64, "one slot per (receiver, sender)");
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = tid & 63, wave = tid >> 6;
     float acc[PP];
 #pragma unroll
     for (int i = 0; i < PP; ++i) acc[i] = 0.f;
-    for (int c2 = threadIdx.x; c2 < (hid >> 1); c2 += blockDim.x) {
+    for (int c2 = tid; c2 < (hid >> 1); c2 += nthreads) {
         float2 d[RMAX], m[SMAX];
 #pragma unroll
         for (int r = 0; r < RMAX; ++r) d[r] = r < R ? *reinterpret_cast<const float2*>(dr.row(r) + 2 * c2) : make_float2(0.f, 0.f);
@@ -473,7 +476,15 @@ __device__ __forceinline__ void attn_bwd_body(const BwdGroup& g) {
     for (int i = threadIdx.x; i < natt; i += blockDim.x) sW[i] = A.att[(int64_t)inst * natt + i];
     if (threadIdx.x < O) sMask[threadIdx.x] = A.obj_mask ? A.obj_mask[(int64_t)clip * O + threadIdx.x] : 1.f;
     float* sP = sMask + MAX_O + 4;   // [GRAM_PART] partial dot products (latency regime)
-    if (g.staged) {
+    // latency regime (gridDim.z = 2): half 0 produces the sender-message gradients, half 1 the feature gradients
+    const int half = blockIdx.z, nhalf = gridDim.z;
+    const bool do_feat = nhalf == 1 || half == 1, do_msg = nhalf == 1 || half == 0;
+    // Half 1 with at most 2 humans and 8 objects computes dL/dw column-parallel straight from global memory, four wave
+    // groups of 256 threads taking the relations side by side: it stages nothing (the 12 row sets are ~100 KB per
+    // instance: 7 of the 20 us of this launch, cycle stamps) and its critical path loses the LDS round trip.
+    const bool wg_dw = g.staged && nhalf == 2 && half == 1 && blockDim.x == 1024 && H <= 2 && O <= 8 && (hid & 1) == 0 &&
+                       g.wave_groups != 0;
+    if (g.staged && !wg_dw) {
         float* cur = sP + GRAM_PART;
         cur = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(cur) + 15) & ~uintptr_t(15));
         stage_rowset(m_hh, H, hid, cur);
@@ -490,9 +501,6 @@ __device__ __forceinline__ void attn_bwd_body(const BwdGroup& g) {
         if (m_oo.on()) stage_rowset(d_oo, O, hid, cur);
     }
     __syncthreads();
-    // latency regime (gridDim.z = 2): half 0 produces the sender-message gradients, half 1 the feature gradients
-    const int half = blockIdx.z, nhalf = gridDim.z;
-    const bool do_feat = nhalf == 1 || half == 1, do_msg = nhalf == 1 || half == 0;
     // dL/dw[r][s] = recv_mask_r * <dout[r], msg[s]>
     // latency regime (rows staged in LDS): thread -> (pair p, column chunk q) partial dot products, then one ordered add
     // per pair -- no chain of per-pair cross-lane reductions (see compute_weights)
@@ -513,7 +521,42 @@ __device__ __forceinline__ void attn_bwd_body(const BwdGroup& g) {
             if (m_oo.on() && r != s_) { dr = d_oo.row(r); mr = m_oo.row(s_); }
         }
     };
-    if (do_feat && g.staged) {
+    if (wg_dw) {
+        // wave group 0 / 1: object->object, receivers 0..3 / 4..7; group 2: human->object then human->human; group 3:
+        // object->human. Partial sums of a group's 4 waves at sP [group][wave][32], slot (r, s) at r * SMAX + s.
+        const int grp = threadIdx.x >> 8, tg = threadIdx.x & 255;
+        float* sPg = sP + grp * 4 * 32;
+        auto shifted = [](RowSet rs, int r0) { if (rs.on()) rs.base += (int64_t)r0 * rs.step; return rs; };
+        if (grp == 0) { if (m_oo.on()) dw_columns<4, 8, 32>(d_oo, m_oo, min(O, 4), O, hid, sPg, tg, 256); }
+        else if (grp == 1) { if (m_oo.on() && O > 4) dw_columns<4, 8, 32>(shifted(d_oo, 4), m_oo, O - 4, O, hid, sPg, tg, 256); }
+        else if (grp == 2) { if (m_ho.on()) dw_columns<8, 2, 16>(d_ho, m_ho, O, H, hid, sPg, tg, 256); }
+        else { if (m_oh.on()) dw_columns<2, 8, 16>(d_oh, m_oh, H, O, hid, sPg, tg, 256); }
+        if (grp == 2 && m_hh.on()) dw_columns<2, 2, 4>(d_hh, m_hh, H, H, hid, sPg + 4 * 16, tg, 256);
+        __syncthreads();
+        for (int p = threadIdx.x; p < natt; p += blockDim.x) {
+            float v = 0.f;
+            if (p < H * H) {
+                const int r = p / H, s_ = p - r * H;
+                if (m_hh.on() && r != s_)
+                    for (int w = 0; w < 4; ++w) v += sP[2 * 128 + 64 + w * 4 + r * 2 + s_];
+            } else if (p < H * H + H * O) {
+                const int q = p - H * H, r = q / O, s_ = q - r * O;
+                if (m_oh.on())
+                    for (int w = 0; w < 4; ++w) v += sP[3 * 128 + w * 16 + r * 8 + s_];
+            } else if (p < H * H + 2 * H * O) {
+                const int q = p - H * H - H * O, r = q / H, s_ = q - r * H;
+                if (m_ho.on()) {
+                    for (int w = 0; w < 4; ++w) v += sP[2 * 128 + w * 16 + r * 2 + s_];
+                    if (rmask) v *= sMask[r];
+                }
+            } else {
+                const int q = p - H * H - 2 * H * O, r = q / O, s_ = q - r * O;
+                if (m_oo.on() && r != s_)
+                    for (int w = 0; w < 4; ++w) v += sP[(r >> 2) * 128 + w * 32 + (r & 3) * 8 + s_];
+            }
+            sdW[p] = B.dw_extra ? v + B.dw_extra[(int64_t)inst * natt + p] : v;
+        }
+    } else if (do_feat && g.staged) {
         int Q = (int)blockDim.x / natt;
         if (Q > GRAM_PART / natt) Q = GRAM_PART / natt;
         if (Q < 1) Q = 1;
@@ -551,7 +594,7 @@ __device__ __forceinline__ void attn_bwd_body(const BwdGroup& g) {
             constexpr int RMAX = decltype(tag)::R, SMAX = decltype(tag)::S, PP = decltype(tag)::PP;
             if (R <= 0) return;   // uniform
             if (dr.on()) dr.base += (int64_t)r0 * dr.step;
-            if (mr.on()) dw_columns<RMAX, SMAX, PP>(dr, mr, R, S, hid, sP);
+            if (mr.on()) dw_columns<RMAX, SMAX, PP>(dr, mr, R, S, hid, sP, (int)threadIdx.x, (int)blockDim.x);
             __syncthreads();
             for (int t = threadIdx.x; t < R * S; t += blockDim.x) {
                 const int r = t / S, s_ = t - r * S;
@@ -830,6 +873,8 @@ extern "C" int twog_attn_bwd(const twog_attn_bwd_t* a, int n, void* stream) {
     }
     if (lds > LDS_LIMIT) return -3;
     g.staged = staged ? 1 : 0;
+    static const int wg_on = getenv("TWOG_ATTN_WAVE_GROUPS") ? atoi(getenv("TWOG_ATTN_WAVE_GROUPS")) : 1;
+    g.wave_groups = wg_on;
     static std::atomic<uint32_t> lds_attr_done{0};
     twog_allow_dynamic_lds(attn_bwd_kernel, (int)LDS_LIMIT, lds_attr_done);
     static const int cols_on = getenv("TWOG_ATTN_COLUMNS") ? atoi(getenv("TWOG_ATTN_COLUMNS")) : 1;
