@@ -745,14 +745,26 @@ __device__ __forceinline__ void attn_bwd_body(const BwdGroup& g) {
 #pragma unroll
         for (int b = 0; b < MAX_E; ++b) f[b] = b < E ? (b < H ? fh.row(b) : fo.row(b - H))[d] : 0.f;
         const int a0 = grp == 0 ? 0 : e_half, a1 = grp == 0 ? e_half : E;
-        for (int a = a0; a < a1; ++a) {
-            const float* c = sC + a * MAX_E;
-            float acc = 0.f;
+        // the previous gradient values of all of this item's rows are requested up front: written as one
+        // read-modify-write after the other, every load would wait for the store before it (the compiler cannot rule out
+        // that the rows alias) -- five dependent round trips instead of one
+        float prev[MAX_E / 2];
 #pragma unroll
-            for (int b = 0; b < MAX_E; ++b)
-                if (b < E) acc = fmaf(c[b], f[b], acc);
-            float* dst = (a < H ? df_h.row(a) : df_o.row(a - H)) + d;
-            *dst = accum ? *dst + acc : acc;
+        for (int i = 0; i < MAX_E / 2; ++i) {
+            const int a = a0 + i;
+            prev[i] = (accum && a < a1) ? (a < H ? df_h.row(a) : df_o.row(a - H))[d] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < MAX_E / 2; ++i) {
+            const int a = a0 + i;
+            if (a < a1) {
+                const float* c = sC + a * MAX_E;
+                float acc = prev[i];
+#pragma unroll
+                for (int b = 0; b < MAX_E; ++b)
+                    if (b < E) acc = fmaf(c[b], f[b], acc);
+                (a < H ? df_h.row(a) : df_o.row(a - H))[d] = acc;
+            }
         }
     }
 }
