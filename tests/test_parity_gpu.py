@@ -190,6 +190,13 @@ def test_oracle_parity_bench_batch_short_clips():
     _oracle_vs_hip(bs=64, T=3, H=2, O=8, N=34, h=512, backward=True, seed=11)
 
 
+def test_oracle_parity_streaming_attention_kernels():
+    """More than 1 024 (clip, frame) instances with ten entities each (9 clips x 120 frames, H=2, O=8): the frame-level
+    attention runs its throughput-regime kernels -- column-parallel Gram forward, column-parallel dL/dw backward --
+    inside the full path, forward and backward against the oracle (h=64 keeps the oracle at a minute)."""
+    _oracle_vs_hip(bs=9, T=120, H=2, O=8, N=34, h=64, backward=True, seed=17)
+
+
 def test_oracle_parity_c2_full_size():
     """BASELINE configs[1] at size: MPHOI layout (H=2, O=4, N=26), hs512, bs8, T=120, forward + backward."""
     _oracle_vs_hip(bs=8, T=120, H=2, O=4, N=26, h=512, backward=True, seed=9)
