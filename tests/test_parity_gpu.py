@@ -197,6 +197,11 @@ def test_oracle_parity_streaming_attention_kernels():
     _oracle_vs_hip(bs=9, T=120, H=2, O=8, N=34, h=64, backward=True, seed=17)
 
 
+def test_oracle_parity_streaming_attention_kernels_six_entities():
+    """The same regime at the MPHOI layout (H=2, O=4): the 16-slot variant of the column-parallel Gram."""
+    _oracle_vs_hip(bs=9, T=120, H=2, O=4, N=26, h=64, backward=True, seed=19)
+
+
 def test_oracle_parity_c2_full_size():
     """BASELINE configs[1] at size: MPHOI layout (H=2, O=4, N=26), hs512, bs8, T=120, forward + backward."""
     _oracle_vs_hip(bs=8, T=120, H=2, O=4, N=26, h=512, backward=True, seed=9)
