@@ -86,7 +86,9 @@ def test_golden_reference_vectors(name):
     print(f'{name}: worst relative gradient error {worst:.2e}')
 
 
-def _synthetic(bs, T, H, O, N, seed=0):
+def _synthetic(bs, T, H, O, N, seed=0, virtual='clip1'):
+    """virtual = 'clip1': the last two objects of clip 1 are virtual; 'half': the last two objects are virtual on every
+    second clip (SURVEY 8d's input variant of the bench batch)."""
     g = torch.Generator().manual_seed(seed)
     vis = torch.relu(torch.randn(bs, T, H, 2048, generator=g))
     pos = torch.rand(bs, T, N, 2, generator=g)
@@ -95,40 +97,91 @@ def _synthetic(bs, T, H, O, N, seed=0):
     x_human = torch.cat([vis, geo], -1).contiguous()
     x_objects = torch.relu(torch.randn(bs, T, O, 2048, generator=g))
     mask = torch.ones(bs, O)
-    if bs > 1:
+    if virtual == 'half':
+        mask[1::2, O - 2:] = 0.0
+    elif bs > 1:
         mask[1, O - 2:] = 0.0
-        x_objects[1, :, O - 2:] = 0.0
+    x_objects = x_objects * mask[:, None, :, None]
     return x_human, x_objects, mask
 
 
-def _oracle_vs_hip(bs, T, H, O, N, h, backward, seed=3, n_sub=13):
+GRAD_REL, GRAD_ABS = 5e-4, 5e-6      # the hard gate on every parameter gradient (of the tensor's scale, against the oracle)
+MAX_YARDSTICK_TENSORS = 4            # tensors that may fall back on the fp64 yardstick (ill-conditioned, see below)
+_RECORDS = []
+
+
+def _record(**kw):
+    """One line per full-path comparison in gpurun_out/parity_oracle_vs_hip.jsonl (what was nudged, what was measured)."""
+    import json
+    import os
+    _RECORDS.append(kw)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    try:
+        os.makedirs(os.path.join(root, 'gpurun_out'), exist_ok=True)
+        with open(os.path.join(root, 'gpurun_out', 'parity_oracle_vs_hip.jsonl'), 'a') as f:
+            f.write(json.dumps(kw) + '\n')
+    except OSError:
+        pass
+
+
+def _oracle_vs_hip(bs, T, H, O, N, h, backward, seed=3, n_sub=13, n_aff=None, both_given=False, virtual='clip1'):
+    """The full path on the HIP kernels against the CPU oracle on the same weights, inputs and noise: every output at
+    1e-4, every parameter gradient at 5e-4 of its scale -- no escape clause.
+
+    A ReLU unit whose pre-activation is below the rounding error of its own dot product would land on different sides of
+    zero in the two implementations (different summation orders) and move its row of the gradient by percents. Such
+    units exist in most full-size cases, so the CASE is moved off them first (tests/relu_boundary.py::condition_case
+    nudges the bias of every such unit by a few band widths and re-checks; the nudged weights feed both sides). What
+    remains beyond 5e-4 can only be conditioning (BatchNorm over few frames in front of the GCN parameters: both fp32
+    implementations then sit ~1e-3 from the exact gradient): such a tensor must be no further from the oracle run in
+    fp64 than three times the fp32 oracle itself is (+ 2e-5 of its scale), and at most MAX_YARDSTICK_TENSORS may need
+    that."""
+    from tests.relu_boundary import condition_case
+    cfg = dict(STAGE1)
+    if H == 1:
+        cfg['message_humans_to_human'] = False
     torch.manual_seed(seed)
-    m = TGGCN(input_size=(2048 + 4 * N, 2048), num_classes=(n_sub, None), hidden_size=h, gcn_node=N, **STAGE1)
-    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
-    x_human, x_objects, mask = _synthetic(bs, T, H, O, N, seed)
-    seg = torch.ones(bs, T, H)
-    noise = torch.distributions.gumbel.Gumbel(0.0, 1.0).sample((T * O, bs, 2))
+    m = TGGCN(input_size=(2048 + 4 * N, 2048), num_classes=(n_sub, n_aff), hidden_size=h, gcn_node=N, **cfg)
+    buffers = {k: v.detach().clone() for k, v in m.state_dict().items() if 'running_' in k or 'num_batches' in k}
+    x_human, x_objects, mask = _synthetic(bs, T, H, O, N, seed, virtual)
+    g = torch.Generator().manual_seed(seed + 100)
+    if both_given:   # CAD-120 semantics: both segmentations come from the annotation (vhoi/data_loading.py:1254-1256)
+        kw = dict(human_segmentation=(torch.rand(bs, T, H, generator=g) < 0.3).float(),
+                  objects_segmentation=(torch.rand(bs, T, O, generator=g) < 0.3).float())
+        noise = None
+    else:
+        kw = dict(human_segmentation=torch.ones(bs, T, H))
+        noise = torch.distributions.gumbel.Gumbel(0.0, 1.0).sample((T * O, bs, 2))
+    m = m.to(DEV).train()
+    m._gumbel_noise_override = noise
+    dkw = {k: v.to(DEV) for k, v in kw.items()}
+    xh_d, xo_d, mask_d = x_human.to(DEV), x_objects.to(DEV), mask.to(DEV)
+
+    def fwd():
+        return m(xh_d, xo_d, mask_d, **dkw)
+
+    rounds, nudged = condition_case(m, fwd) if backward else (0, {})
+    m.load_state_dict(buffers, strict=False)   # the conditioning passes moved the BatchNorm running statistics
+    sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
     # oracle (CPU)
     osd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and 'running' not in k else v.clone())
            for k, v in sd.items()}
-    ref = cpu_ref.tggcn_forward(osd, dict(m.cfg), x_human, x_objects, mask, human_segmentation=seg, training=True,
-                                gumbel_noise=noise)
+    ref = cpu_ref.tggcn_forward(osd, dict(m.cfg), x_human, x_objects, mask, training=True, gumbel_noise=noise, **kw)
     # HIP
-    m = m.to(DEV).train()
-    m._gumbel_noise_override = noise
-    out = m(x_human.to(DEV), x_objects.to(DEV), mask.to(DEV), human_segmentation=seg.to(DEV))
-    soft_ref = None
+    out = fwd()
+    assert len(out) == len(ref) == (12 if n_aff is not None else 6)
+    worst_out = 0.0
     for i, (o, r) in enumerate(zip(out, ref)):
         got, want = o.detach().cpu(), r.detach()
         assert got.shape == want.shape
-        err = (got - want).abs().max().item()
-        assert err < REL * max(1.0, want.abs().max().item()), (i, err)
+        err = (got - want).abs().max().item() / max(1.0, want.abs().max().item())
+        worst_out = max(worst_out, err)
+        assert err < REL, (i, err)
     if not backward:
         return
     rs = [torch.randn(o.shape, generator=torch.Generator().manual_seed(i)) for i, o in enumerate(ref)]
     sum((o * r).sum() for o, r in zip(ref, rs) if o.requires_grad).backward()
-    # (retain_graph: a deviation below is explained from the state the forward pass saved, tests/relu_boundary.py)
-    sum((o * r.to(DEV)).sum() for o, r in zip(out, rs) if o.requires_grad).backward(retain_graph=True)
+    sum((o * r.to(DEV)).sum() for o, r in zip(out, rs) if o.requires_grad).backward()
     worst, off = 0.0, []
     for pname, p in m.named_parameters():
         g_ref = osd[pname].grad
@@ -137,33 +190,36 @@ def _oracle_vs_hip(bs, T, H, O, N, h, backward, seed=3, n_sub=13):
             continue
         assert p.grad is not None, pname
         scale = max(g_ref.abs().max().item(), 1e-6)
-        diff = (p.grad.cpu() - g_ref).abs()
-        err = diff.max().item()
-        if err < 5e-4 * scale + 5e-6:
+        err = (p.grad.cpu() - g_ref).abs().max().item()
+        if err < GRAD_REL * scale + GRAD_ABS:
             worst = max(worst, err / scale)
-            continue
-        per_unit = diff.reshape(diff.shape[0], -1).max(dim=1).values if diff.dim() > 1 else diff
-        off.append((pname, err / scale, (per_unit >= 5e-4 * scale + 5e-6).nonzero().flatten().tolist()))
-    print(f'worst relative gradient error within tolerance {worst:.2e}; tensors beyond it: {[(n, f"{e:.1e}") for n, e, _ in off]}')
+        else:
+            off.append((pname, err / scale))
+    yard = []
     if off:
-        # Beyond rounding. The one legitimate cause: a ReLU unit whose pre-activation is below the rounding error of its
-        # own dot product -- oracle and kernels sum in different orders and land on different sides of zero. Accept a
-        # deviation ONLY where such a unit is FOUND (tests/relu_boundary.py recomputes every ReLU layer's pre-activations
-        # in fp64): each off tensor must be that layer's own parameter -- deviating in boundary units only -- or lie
-        # upstream of it; everything is bounded, and the outputs matched above.
-        from tests.relu_boundary import boundary_layers
-        from tools.parity_fuzz import _is_owner_or_upstream
-        found = boundary_layers(m, out)
-        print('ReLU layers with units on the boundary:', {k: v.tolist()[:8] for k, v in found.items()})
-        assert found, ('gradients off and no ReLU unit on the boundary', off[:6])
-        for pname, e, units in off:
-            assert e < 3e-2, (pname, e)
-            owners = [ly for ly in found if _is_owner_or_upstream(pname, ly + '.weight')]
-            assert owners, (pname, e, 'not upstream of any boundary layer', list(found))
-            own = pname.rsplit('.', 1)[0]
-            if own in found and not any(ly != own and _is_owner_or_upstream(pname, ly + '.weight') for ly in found):
-                # the owning layer itself (and nothing downstream explains it): only the boundary units may move
-                assert set(units) <= set(found[own].tolist()), (pname, units[:8], found[own].tolist()[:8])
+        assert len(off) <= MAX_YARDSTICK_TENSORS, ('gradients beyond 5e-4 of their scale', sorted(off, key=lambda t: -t[1])[:8])
+        f64 = torch.float64
+        osd64 = {k: (v.detach().to(f64).requires_grad_(True) if v.is_floating_point() and 'running' not in k
+                     else (v.detach().to(f64) if v.is_floating_point() else v.clone())) for k, v in sd.items()}
+        ref64 = cpu_ref.tggcn_forward(osd64, dict(m.cfg), x_human.to(f64), x_objects.to(f64), mask.to(f64), training=True,
+                                      gumbel_noise=None if noise is None else noise.to(f64),
+                                      **{k: v.to(f64) for k, v in kw.items()})
+        n_hard = 2 if n_aff is not None else 1
+        assert all(torch.equal(ref64[i].float(), ref[i].detach()) for i in range(n_hard)), 'hard gates differ in fp64'
+        sum((o * r.to(f64)).sum() for o, r in zip(ref64, rs) if o.requires_grad).backward()
+        for pname, e in off:
+            g64, g32 = osd64[pname].grad, osd[pname].grad
+            scale = max(g32.abs().max().item(), 1e-6)
+            own = (g32.to(f64) - g64).abs().max().item()
+            err64 = (dict(m.named_parameters())[pname].grad.cpu().to(f64) - g64).abs().max().item()
+            yard.append((pname, e, err64 / scale, own / scale))
+            assert err64 <= 3.0 * own + 2e-5 * scale, ('beyond the fp64 yardstick', pname, e, err64 / scale, own / scale)
+    print(f'worst output {worst_out:.2e}; worst gradient within 5e-4: {worst:.2e}; judged by the fp64 yardstick: '
+          f'{[(n, f"{e:.1e}", f"hip-fp64 {a:.1e}", f"oracle32-fp64 {b:.1e}") for n, e, a, b in yard]}; '
+          f'ReLU-boundary units nudged in {rounds} round(s): {nudged}')
+    _record(case=dict(bs=bs, T=T, H=H, O=O, N=N, h=h, seed=seed, n_aff=n_aff, both_given=both_given, virtual=virtual),
+            worst_output_rel=worst_out, worst_grad_rel_within_tolerance=worst, tensors_on_fp64_yardstick=yard,
+            conditioning_rounds=rounds, relu_units_nudged=nudged)
 
 
 def test_oracle_parity_c3_layout_reduced_width():
@@ -188,6 +244,19 @@ def test_oracle_parity_bench_batch_short_clips():
     the 128x128 class with split-K for the weight gradients, the grouped tile order -- run against the oracle, forward and
     backward."""
     _oracle_vs_hip(bs=64, T=3, H=2, O=8, N=34, h=512, backward=True, seed=11)
+
+
+def test_oracle_parity_bench_batch_virtual_objects_on_half_the_clips():
+    """SURVEY 8d's input variant at the bench batch: the last two objects are virtual on every second clip (masked
+    senders and receivers inside every attention instance, masked gate rows), T = 3, forward and backward."""
+    _oracle_vs_hip(bs=64, T=3, H=2, O=8, N=34, h=512, backward=True, seed=23, virtual='half')
+
+
+def test_oracle_parity_c1_full_width():
+    """BASELINE configs[0] (CAD-120) at full width on the GPU: one human, five objects, N = 19, h = 512, classes
+    (10, 12) -> the 12-output order with the object heads, BOTH segmentations given (no gate is learned, no noise;
+    vhoi/models.py:631-633, :909-926), T = 120, forward and backward."""
+    _oracle_vs_hip(bs=2, T=120, H=1, O=5, N=19, h=512, backward=True, seed=21, n_sub=10, n_aff=12, both_given=True)
 
 
 def test_oracle_parity_streaming_attention_kernels():
