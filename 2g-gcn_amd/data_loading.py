@@ -99,14 +99,15 @@ def ignore_last_step_end_flag_general(x):
 def smooth_segmentation(x, sigma: float):
     """Budget targets (reference behaviour: vhoi/data_loading.py:544-559): the 0/1 end flags blurred along time with a
     unit-mass Gaussian (zero beyond the clip ends), rescaled by 2.5 sigma and clipped to [0, 1]; missing (-1) frames
-    contribute nothing and stay -1. sigma == 0: unchanged."""
+    contribute nothing and stay -1 in the result. sigma == 0: unchanged. Bit-compatible with the reference: the product is
+    evaluated as (blurred * 2.5) * sigma in the array's precision, and -- as there -- the missing entries of the CALLER'S
+    array are zeroed in place (a caller that reuses its array sees 0, not -1, at those frames)."""
     if not sigma:
         return x
     from scipy.ndimage import gaussian_filter1d
     missing = x == -1.0
-    flags = np.where(missing, np.float32(0.0), x).astype(x.dtype, copy=False)
-    blurred = gaussian_filter1d(flags, sigma=sigma, axis=1, mode='constant')
-    out = np.minimum(np.maximum(blurred * (2.5 * sigma), 0.0), 1.0).astype(x.dtype, copy=False)
+    x[missing] = 0.0
+    out = np.clip(gaussian_filter1d(x, sigma=sigma, axis=1, mode='constant') * 2.5 * sigma, 0.0, 1.0)
     out[missing] = -1.0
     return out
 

@@ -9,6 +9,8 @@ averaging is folded into the fused Adam kernel (no extra pass over the gradients
 
 BatchNorm statistics of the geometry branch stay local to each rank (standard DDP semantics); Gumbel noise is drawn
 per rank. Dead parameters (constructed by the reference but never used) keep a zero gradient.
+The three cross-sample couplings of SURVEY 8e have an exact-equivalence switch each: sync_bn (a), count_weighted_loss
+(b), global_noise_seed (c).
 """
 import torch
 import torch.distributed as dist
@@ -79,44 +81,70 @@ class DataParallel:
         dp.zero_grad(); loss = f(dp.model(...)); loss.backward(); dp.all_reduce_gradients(); opt.step(dp.grad_scale)"""
 
     def __init__(self, model: torch.nn.Module, process_group=None, bucket_mb: int = 64, broadcast: bool = True,
-                 sync_bn: bool = False, global_noise_seed: int = None, overlap: bool = True):
+                 sync_bn: bool = False, global_noise_seed: int = None, overlap: bool = True,
+                 count_weighted_loss: bool = False, force_collectives: bool = False):
         """sync_bn: the geometric-level BatchNorm uses the statistics of the GLOBAL batch (one all-reduce of 2*4N fp64
-        sums per step). global_noise_seed: every rank draws the Gumbel noise of the global batch from a
-        generator seeded with this value and keeps its shard (8e (c)). With both (and equal shard sizes) W ranks compute
-        what one process computes on the whole batch; the throughput default keeps them off (standard DDP semantics)."""
+        sums per step). count_weighted_loss: every term of the criterion (losses.multi_task_loss) is
+        normalised by the GLOBAL number of valid (non-ignored) targets instead of the rank's own (one all-reduce of the
+        6-12 per-term counts per step; 8e (b)) -- with ragged clips (-1 targets) the averaged rank gradients are then the
+        gradient of the global mean, not a mean of per-rank means. global_noise_seed: every rank draws the Gumbel noise of
+        the global batch from a generator seeded with this value and keeps its shard (8e (c)). With all three (and equal
+        shard sizes) W ranks compute what one process computes on the whole batch; the throughput default keeps them off
+        (standard DDP semantics; equal-length synthetic clips make the counts equal anyway).
+        force_collectives: run every collective (broadcast, stage-hooked asynchronous all-reduces, count / statistics
+        reductions) even in a process group of ONE rank, where they are identities -- lets a single-GPU box execute the
+        RCCL path itself (tests/test_distributed_gpu.py)."""
         self.model = model
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
-        rank = dist.get_rank(process_group) if self.world > 1 else 0
+        if force_collectives and not (dist.is_available() and dist.is_initialized()):
+            raise RuntimeError('force_collectives needs an initialised process group')
+        self.collective = self.world > 1 or bool(force_collectives)
+        rank = dist.get_rank(process_group) if self.collective else 0
         self._works, self._launched = [], set()
+        self.collective_calls = 0   # collectives issued so far (tests assert the path really ran)
+        from . import ops
         if sync_bn:
-            def reduce_stats(sums, n_frames, world=self.world, group=process_group):
-                if world > 1:
+            def reduce_stats(sums, n_frames, world=self.world, group=process_group, on=self.collective, me=self):
+                if on:
                     dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
+                    me.collective_calls += 1
                 return sums, n_frames * world
-            model._bn_stats_reduce = reduce_stats
+            ops.set_model_extra(model, 'bn_stats_reduce', reduce_stats)
+        if count_weighted_loss:
+            def reduce_counts(counts, world=self.world, group=process_group, on=self.collective, me=self):
+                """counts: fp64 [terms] valid targets of this rank -> global count / W (the rank losses are averaged)."""
+                if on:
+                    dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=group)
+                    me.collective_calls += 1
+                return counts / world
+            from . import losses
+            losses.set_count_reducer(reduce_counts)
+            self._count_reducer = reduce_counts
         if global_noise_seed is not None:
-            model._noise_shard = (rank, self.world, torch.Generator().manual_seed(int(global_noise_seed)))
+            ops.set_model_extra(model, 'noise_shard',
+                                (rank, self.world, torch.Generator().manual_seed(int(global_noise_seed))))
         # gradients are laid out in the order the backward pass finishes them (ops.grad_ready_stage), so that each
         # stage's all-reduce can start from inside the backward pass and overlap with the rest of it
-        from . import ops
         self.flat = FlatParameters(model, stage_of=ops.grad_ready_stage if overlap else None)
         self.bucket = max(1, bucket_mb) * (1 << 20) // 4
-        if overlap and self.world > 1:
+        if overlap and self.collective:
             ops.set_grad_stage_hook(model, self._stage_ready)   # scoped to this model; close() removes it
-        if self.world > 1 and broadcast:
+        if self.collective and broadcast:
             dist.broadcast(self.flat.flat, src=0, group=self.group)
             for b in model.buffers():
                 dist.broadcast(b, src=0, group=self.group)
+            self.collective_calls += 1
 
     def close(self):
-        """Detaches this wrapper from the model (stage hook, sync-BN / noise-shard settings)."""
-        from . import ops
-        if getattr(self.model, '_twog_grad_stage_hook', None) == self._stage_ready:
+        """Detaches this wrapper from the model (stage hook, sync-BN / noise-shard / loss-count settings)."""
+        from . import ops, losses
+        if ops.get_model_extra(self.model, 'stage_hook') == self._stage_ready:
             ops.set_grad_stage_hook(self.model, None)
-        for attr in ('_bn_stats_reduce', '_noise_shard'):
-            if hasattr(self.model, attr):
-                delattr(self.model, attr)
+        for key in ('bn_stats_reduce', 'noise_shard'):
+            ops.set_model_extra(self.model, key, None)
+        if getattr(self, '_count_reducer', None) is not None and losses.get_count_reducer() is self._count_reducer:
+            losses.set_count_reducer(None)
 
     @property
     def grad_scale(self):
@@ -131,6 +159,7 @@ class DataParallel:
         for off in range(begin, end, self.bucket):
             self._works.append(dist.all_reduce(g[off:min(off + self.bucket, end)], op=dist.ReduceOp.SUM,
                                                group=self.group, async_op=True))
+            self.collective_calls += 1
 
     def _stage_ready(self, stage):
         """Called from inside this model's backward pass (ops.set_grad_stage_hook): every gradient of `stage` is final, start its
@@ -143,7 +172,7 @@ class DataParallel:
     def all_reduce_gradients(self):
         """Sum-all-reduce of the flat gradient buffer: whatever the backward pass has not started yet is launched here
         (a few large chunks, back to back), then everything is waited for. One backward pass per call to zero_grad()."""
-        if self.world == 1:
+        if not self.collective:
             return
         if self.flat.stage_ranges:
             for stage in sorted(self.flat.stage_ranges):
@@ -156,6 +185,6 @@ class DataParallel:
 
     def shard(self, tensor, rank=None):
         """This rank's contiguous slice [r*bs/W, (r+1)*bs/W) of a global batch."""
-        rank = dist.get_rank(self.group) if rank is None and self.world > 1 else (rank or 0)
+        rank = dist.get_rank(self.group) if rank is None and self.collective else (rank or 0)
         n = tensor.shape[0] // self.world
         return tensor[rank * n:(rank + 1) * n]

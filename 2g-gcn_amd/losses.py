@@ -36,6 +36,23 @@ def budget_loss(input, target, ignore_value=-1, reduction='mean'):
 
 _KIND = {nll_loss: _NLL, F.nll_loss: _NLL, binary_cross_entropy_loss: _BCE, budget_loss: _BUDGET}
 
+# Data-parallel normalisation: every term is a sum over the valid (non-ignored) targets divided by their
+# number (pyrutils/torch/losses.py:13-21, :30-36; F.nll_loss reduction='mean', :47). With ragged clips the ranks hold
+# different numbers of valid targets, and the average of per-rank means is not the global mean. A registered reducer
+# (distributed.DataParallel(count_weighted_loss=True)) maps this rank's per-term counts [terms] (fp64, on the device) to
+# (global count) / W: the term becomes sum_rank / (count_global / W), whose average over the W ranks -- and so the
+# averaged gradient -- is the global-batch value. No reducer: the reference's single-process arithmetic.
+_count_reducer = None
+
+
+def set_count_reducer(fn):
+    global _count_reducer
+    _count_reducer = fn
+
+
+def get_count_reducer():
+    return _count_reducer
+
 
 class _MultiTaskLoss(torch.autograd.Function):
     @staticmethod
@@ -48,6 +65,16 @@ class _MultiTaskLoss(torch.autograd.Function):
             y = (y.to(torch.int64) if k == _NLL else y.to(torch.float32)).contiguous()
             terms.append(dict(kind=k, input=x, target=y, weight=w, ignore=ignore))
         losses, stats = K.multitask_loss_fwd(terms)
+        if _count_reducer is not None:
+            # six to twelve scalars: sum_rank / (count_global / W) per term, 0 / 0 -> NaN for NLL like torch's mean over an
+            # empty selection, 0 for the BCE / budget terms (pyrutils/torch/losses.py:15-16, :32-33)
+            eff = _count_reducer(stats[:, 1].clone())
+            val = stats[:, 0] / eff
+            soft = torch.tensor([k != _NLL for k in kinds], device=val.device)
+            val = torch.where(soft & (eff <= 0), torch.zeros_like(val), val)
+            w = torch.tensor([float(x) for x in weights], dtype=torch.float64, device=val.device)
+            losses = (w * val).to(torch.float32)
+            stats = torch.stack([stats[:, 0], eff], 1).contiguous()
         ctx.terms, ctx.stats = terms, stats
         return losses
 

@@ -261,7 +261,7 @@ class TGGCN(nn.Module):
         n_sub, n_aff = self.num_classes
         plan = ops.Plan(self.cfg, bs, T, H, O, self.gcn_node, x_objects.shape[-1], n_sub, n_aff,
                         human_segmentation is not None, objects_segmentation is not None)
-        plan.stage_hook = getattr(self, '_twog_grad_stage_hook', None)   # data-parallel overlap (ops.set_grad_stage_hook)
+        plan.stage_hook = ops.get_model_extra(self, 'stage_hook')   # data-parallel overlap (ops.set_grad_stage_hook)
         plan.dists = dists or None
         plan.steps = None
         if steps_per_example is not None and (plan.time_s or plan.time_u or plan.seglen):
@@ -271,10 +271,10 @@ class TGGCN(nn.Module):
         if plan.gs and n_gated:
             if self._gumbel_noise_override is not None:
                 noise = self._gumbel_noise_override
-            elif getattr(self, '_noise_shard', None) is not None:
+            elif ops.get_model_extra(self, 'noise_shard') is not None:
                 # data-parallel equivalence mode (distributed.DataParallel(global_noise=True)): every rank draws the noise
                 # of the GLOBAL batch from an identically seeded generator and keeps its own clips
-                rank, world, gen = self._noise_shard
+                rank, world, gen = ops.get_model_extra(self, 'noise_shard')
                 u = torch.rand(T * n_gated, world * bs, 2, generator=gen).clamp_(1e-10, 1.0 - 1e-7)
                 noise = (-torch.log(-torch.log(u)))[:, rank * bs:(rank + 1) * bs]
             else:
@@ -288,7 +288,7 @@ class TGGCN(nn.Module):
         params = [sd[n] for n in names]
         bn = self.geometry_embedding_gcn.joint_embed.cnn[0].bn
         bn_bufs = dict(running_mean=bn.running_mean, running_var=bn.running_var,
-                       num_batches_tracked=bn.num_batches_tracked, stats_reduce=getattr(self, '_bn_stats_reduce', None))
+                       num_batches_tracked=bn.num_batches_tracked, stats_reduce=ops.get_model_extra(self, 'bn_stats_reduce'))
         hs = human_segmentation.float() if human_segmentation is not None else None
         osg = objects_segmentation.float() if objects_segmentation is not None else None
         out = ops.TGGCNFunction.apply(plan, names, self.training, bn_bufs, x_human, x_objects, objects_mask, hs, osg,

@@ -15,14 +15,18 @@ No torch math is used on the data path (torch owns memory, streams, and the auto
 """
 import math
 import os
+import weakref
 
 import torch
 
 from .kernels import get_kernels
 
-SUPPORTED_NOTE = ("the HIP path implements message_type 'v2' + message_granularity 'v1' + message_aggregation 'att' "
-                  "(attention_style 'v2'/'v3') or 'mp' (a superset of every configuration shipped in the reference's "
-                  "conf/models/)")
+SUPPORTED_NOTE = ("the HIP path implements every constructor configuration of the reference's TGGCN: message_type "
+                  "'v1' (relational) / 'v2', message_granularity 'v1' / 'v2', aggregation 'att' / 'mp', attention_style "
+                  "'v1'..'v4', distance-based attention, every gate strategy and position feature. Sender-only messages "
+                  "with dot-product attention or mean pooling (every configuration shipped in the reference's "
+                  "conf/models/) run on the tuned kernels (attn.hip, segrnn.hip), the other forms on the general "
+                  "single-relation kernels (relation.hip)")
 
 
 def _v2(t, width=None):
@@ -128,6 +132,9 @@ class Plan:
         self.seg_mo = [r for r, on in (('ho', self.rel_ho), ('oo', self.rel_oo)) if on] if self.msg_segment else []
         self.fw_h = self.fw_end_h - h  # width of the frame-level part xx_hs of the human GRUCell input
         self.fw_o = self.fw_end_o - h
+        # tuning / test switch, read ONCE per forward call: the backward pass of this call follows the same decision even
+        # if the variable changes in between (it reads what the forward saved for exactly that form)
+        self.no_ssp = bool(os.environ.get('TWOG_NO_SSP'))
 
     def general_frame(self):
         """True when the frame-level messages need the general single-relation kernels (relation.hip) instead of the
@@ -147,8 +154,7 @@ class Plan:
         result is scattered over the O receivers with the attention weights. Returns the (first, end) columns of those
         blocks in the object rows -- they sit side by side right behind h_f -- or None when the form does not apply
         (general message forms keep their own layout; no gain unless there are fewer senders than receivers)."""
-        import os
-        if self.general_frame() or self.O == 0 or os.environ.get('TWOG_NO_SSP'):
+        if self.general_frame() or self.O == 0 or self.no_ssp:
             return None
         n = int(self.rel_ho and self.H < self.O) + int(self.rel_so)
         if n == 0 or (self.rel_ho and self.rel_so and not self.H < self.O):
@@ -263,11 +269,30 @@ def used_parameter_names(plan: Plan):
 
 # ---- gradient readiness (data-parallel overlap): the backward pass finishes the parameter gradients in three stages;
 # distributed.DataParallel lays its flat buffer out in this order and starts each stage's all-reduce from the hook
+_MODEL_EXTRAS = weakref.WeakKeyDictionary()   # module -> {'stage_hook', 'bn_stats_reduce', 'noise_shard', ...}
+
+
+def set_model_extra(model, key, value):
+    """Per-module settings of the data-parallel wrapper (stage hook, sync-BN reducer, global-noise shard). They live in a
+    weak-keyed side table, NOT in the module's __dict__: copy.deepcopy(model) / torch.save(model) -- the usual way to
+    make an EMA copy or a checkpoint -- must not drag the wrapper, its flat buffers and its process group along (a bound
+    method stored on the module would), and the copy must not inherit the hook. None removes the entry."""
+    d = _MODEL_EXTRAS.setdefault(model, {})
+    if value is None:
+        d.pop(key, None)
+    else:
+        d[key] = value
+
+
+def get_model_extra(model, key):
+    return _MODEL_EXTRAS.get(model, {}).get(key)
+
+
 def set_grad_stage_hook(model, fn):
     """fn(stage) is called from inside the backward pass of THIS model's forward calls as soon as every gradient of
     `stage` (see grad_ready_stage) is final; None removes the hook. The hook is scoped to the module (it travels with
     each forward's Plan), so a second model in the process -- an EMA copy, a discarded wrapper -- never triggers it."""
-    model._twog_grad_stage_hook = fn
+    set_model_extra(model, 'stage_hook', fn)
 
 
 def grad_ready_stage(name: str) -> int:
@@ -1179,7 +1204,7 @@ def tggcn_backward(K, plan: Plan, P, S, x_human, x_objects, objects_mask, d_outp
             if w_ih.shape[1] > fw:
                 seg_rels_k = p.seg_mh if kind == 'h' else p.seg_mo
                 ssp_seg = (kind == 'o' and 'ho' in seg_rels_k and H < O and not p.general_segment()
-                           and not os.environ.get('TWOG_NO_SSP'))
+                           and not p.no_ssp)
                 if not ssp_seg:
                     K.gemm([dict(A=dgi_d, B=_v2(mg[d]), C=dW_ih[:, fw:])], a_kmajor=True, b_kmajor=True)
                 else:

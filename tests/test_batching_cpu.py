@@ -113,3 +113,24 @@ def test_fetcher_and_feeder_match_reference(kind):
     assert dl.determine_num_classes('2G-GCN', 'multiple', 'mphoi') == (13, None)
     assert dl.determine_num_classes('2G-GCN', 'multiple', 'bimanual') == (14, None)
     assert dl.determine_num_classes('2G-GCN', 'multiple', 'cad120') == (10, 12)
+
+
+def test_segmentation_helpers_bit_exact_with_reference():
+    """Golden G11 (tools/make_golden.py::g11_segmentation_helpers, outputs of the reference's own helpers): end flags from
+    labels, the Gaussian budget targets -- bit for bit, including what the call leaves in the caller's array -- and the
+    cleared last end flag."""
+    z = np.load(os.path.join(GOLDEN, 'g11_segmentation_helpers.npz'))
+    for ci in range(3):
+        labels = z[f'c{ci}_labels']
+        for style in ('input', 'output'):
+            got = dl.segmentation_from_output_class(labels.copy(), segmentation_type=style)
+            assert np.array_equal(np.asarray(got, dtype=np.float32), z[f'c{ci}_seg_{style}'].astype(np.float32)), (ci, style)
+        seg = z[f'c{ci}_seg_output'].astype(np.float32)
+        for sigma in (0.0, 1.0, 2.0, 3.5):
+            arg = seg.copy()
+            res = dl.smooth_segmentation(arg, sigma)
+            want = z[f'c{ci}_smooth_{sigma}']
+            assert res.dtype == want.dtype and np.array_equal(res, want), (ci, sigma, float(np.abs(res - want).max()))
+            assert np.array_equal(arg, z[f'c{ci}_smooth_{sigma}_arg_after']), (ci, sigma, 'caller array')
+        got = dl.ignore_last_step_end_flag(z[f'c{ci}_seg_input'].astype(np.float32).copy())
+        assert np.array_equal(got, z[f'c{ci}_ignore_last'])

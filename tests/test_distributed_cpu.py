@@ -147,3 +147,125 @@ def test_sync_bn_and_global_noise_reproduce_the_full_batch_step():
             assert torch.allclose(ret[r][2], bn.running_var, rtol=1e-5, atol=1e-7)
     finally:
         kernels._set_backend_for_tests(None)
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# count-weighted loss normalisation: ragged clips (-1 targets), every term of the reference's criterion on
+def _ragged_targets(bs, T=4, H=2, seed=3):
+    g = torch.Generator().manual_seed(seed)
+    lengths = [T, 1, 2, T][:bs]                     # rank 0 gets clips of 4 + 1 valid frames, rank 1 of 2 + 4
+    cls = torch.randint(0, 13, (bs, T, H), generator=g)
+    seg = (torch.rand(bs, T, H, generator=g) < 0.5).float()
+    for b, n in enumerate(lengths):
+        cls[b, n:] = -1
+        seg[b, n:] = -1.0
+    return cls, seg
+
+
+def _criterion_loss(model, xh, xo, mask, cls, seg, noise):
+    """The product criterion (losses.select_loss: budget + BCE on the learned human gates, four NLL terms), all weights on."""
+    from twog_gcn_amd.losses import select_loss
+    crit, _ = select_loss('2G-GCN', 'multiple', 'mphoi', dict(misc=dict(budget_loss=dict(add=True, human_weight=0.7),
+                                                                          segmentation_loss=dict(add=True, weight=1.3),
+                                                                          first_level_loss_weight=0.5)))
+    model._gumbel_noise_override = noise
+    model.eval()
+    out = model(xh, xo, mask)                       # human AND object gates learned
+    return sum(crit(out, [seg, seg, cls, cls, cls, cls]))
+
+
+def _noise_all(bs, T=4, H=2, O=3):
+    torch.manual_seed(4321)
+    return torch.distributions.gumbel.Gumbel(0.0, 1.0).sample((T * (H + O), bs, 2))
+
+
+def _worker_counts(rank, world, port, ret, weighted):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import twog_gcn_amd  # noqa: F401
+    from twog_gcn_amd import kernels
+    from twog_gcn_amd.distributed import DataParallel
+    from tests.fake_kernels import FakeKernels
+    kernels._set_backend_for_tests(FakeKernels())
+    torch.set_num_threads(2)
+    model = _tiny_model(seed=0)
+    dp = DataParallel(model, bucket_mb=1, count_weighted_loss=weighted)
+    xh, xo, mask, _, _ = _batch(4)
+    cls, seg = _ragged_targets(4)
+    noise = _noise_all(4)
+    sl = slice(rank * 2, rank * 2 + 2)
+    dp.zero_grad()
+    loss = _criterion_loss(model, xh[sl], xo[sl], mask[sl], cls[sl], seg[sl], noise[:, sl])
+    loss.backward()
+    dp.all_reduce_gradients()
+    ret[rank] = (dp.flat.grad.clone() * dp.grad_scale, float(loss.detach()), dp.collective_calls)
+    dp.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('weighted', [True, False])
+def test_count_weighted_loss_reproduces_the_global_mean(weighted):
+    """Two ranks with different numbers of valid targets: with count_weighted_loss the averaged rank gradients (and the
+    averaged rank losses) are those of ONE process on the whole batch; without it they are a mean of per-rank means --
+    measurably different here, which is what makes the positive case meaningful."""
+    import twog_gcn_amd  # noqa: F401
+    from twog_gcn_amd import kernels, losses
+    from twog_gcn_amd.distributed import DataParallel
+    from tests.fake_kernels import FakeKernels
+    port = 35500 + os.getpid() % 2000 + (7 if weighted else 0)
+    ret = mp.Manager().dict()
+    mp.spawn(_worker_counts, args=(2, port, ret, weighted), nprocs=2, join=True)
+    kernels._set_backend_for_tests(FakeKernels())
+    try:
+        assert losses.get_count_reducer() is None
+        model = _tiny_model(seed=0)
+        dp = DataParallel(model)
+        xh, xo, mask, _, _ = _batch(4)
+        cls, seg = _ragged_targets(4)
+        dp.zero_grad()
+        loss = _criterion_loss(model, xh, xo, mask, cls, seg, _noise_all(4))
+        loss.backward()
+        ref, scale = dp.flat.grad, max(1.0, float(dp.flat.grad.abs().max()))
+        err = max(float((ret[r][0] - ref).abs().max()) for r in (0, 1))
+        mean_loss = 0.5 * (ret[0][1] + ret[1][1])
+        if weighted:
+            assert err < 2e-5 * scale, err
+            assert abs(mean_loss - float(loss.detach())) < 1e-5 * max(1.0, abs(float(loss.detach())))
+            assert ret[0][2] > 1   # the count reduction + the gradient buckets
+        else:
+            assert err > 1e-3 * scale, ('the ragged batch should make the unweighted average differ', err)
+    finally:
+        kernels._set_backend_for_tests(None)
+
+
+def test_model_deepcopy_does_not_drag_the_wrapper_along():
+    """An EMA copy (copy.deepcopy) or torch.save of a wrapped model must not copy the DataParallel wrapper, its flat
+    buffers or its hooks: they live in ops' weak side table, not in the module's __dict__."""
+    import copy
+    import io
+    import twog_gcn_amd  # noqa: F401
+    from twog_gcn_amd import kernels, ops
+    from twog_gcn_amd.distributed import DataParallel
+    from tests.fake_kernels import FakeKernels
+    kernels._set_backend_for_tests(FakeKernels())
+    try:
+        model = _tiny_model(seed=0)
+        dp = DataParallel(model, sync_bn=True, global_noise_seed=5)
+        calls = []
+        ops.set_grad_stage_hook(model, lambda stage: calls.append(stage))
+        assert not any(k.startswith('_twog') or k in ('_bn_stats_reduce', '_noise_shard') for k in vars(model))
+        ema = copy.deepcopy(model)
+        assert ops.get_model_extra(ema, 'stage_hook') is None and ops.get_model_extra(ema, 'bn_stats_reduce') is None
+        assert ops.get_model_extra(model, 'stage_hook') is not None
+        buf = io.BytesIO()
+        torch.save(model, buf)                      # pickles the module itself: nothing un-picklable hangs on it
+        xh, xo, mask, tgt, noise = _batch(2)
+        ema._gumbel_noise_override = noise
+        out = ema(xh, xo, mask, human_segmentation=torch.ones(xh.shape[:3]))
+        torch.nn.functional.nll_loss(out[4], tgt).backward()
+        assert calls == []                          # the copy's backward never triggers the original's hook
+        dp.close()
+        assert ops.get_model_extra(model, 'bn_stats_reduce') is None and ops.get_model_extra(model, 'noise_shard') is None
+    finally:
+        kernels._set_backend_for_tests(None)

@@ -58,3 +58,55 @@ def test_two_ranks_on_one_gpu_match_single_process():
             assert float((g - ref).abs().max()) < 2e-5 * scale
         assert torch.equal(ret[r][0], ret[r][1]) and torch.equal(ret[r][1], ret[r][2])  # deterministic, graphs included
     assert torch.equal(ret[0][0], ret[1][0])
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# RCCL itself on this one-GPU box: a process group of ONE rank over the nccl backend (= RCCL on ROCm) with
+# DataParallel(force_collectives=True) -- RCCL init with device_id, the broadcast, the stage-hooked asynchronous
+# all-reduces issued from inside the backward pass, the sync-BN and loss-count reductions all execute on the device; with
+# one rank they are identities, so the result must equal the collective-free step bit for bit.
+def _nccl_worker(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+    torch.cuda.set_device(0)
+    dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', 0))
+    import twog_gcn_amd  # noqa: F401
+    from twog_gcn_amd.distributed import DataParallel, FusedAdam
+    from twog_gcn_amd.losses import select_loss
+    crit, _ = select_loss('2G-GCN', 'multiple', 'mphoi', dict(misc={}))
+    xh, xo, mask, tgt, noise = (t.to(DEV) for t in _batch(4))
+    seg_t = torch.zeros(xh.shape[:3], device=DEV)
+    res = {}
+    for forced in (True, False):
+        model = _tiny_model(seed=0).to(DEV).train()
+        dp = DataParallel(model, bucket_mb=1, sync_bn=True, count_weighted_loss=True, global_noise_seed=11,
+                          force_collectives=forced)
+        opt = FusedAdam(dp.flat, lr=1e-2)
+        grads = []
+        for _ in range(3):
+            dp.zero_grad()
+            out = model(xh, xo, mask, human_segmentation=torch.ones(xh.shape[:3], device=DEV))
+            sum(crit(out, [seg_t, seg_t, tgt, tgt, tgt, tgt])).backward()
+            dp.all_reduce_gradients()
+            grads.append(dp.flat.grad.clone().cpu())
+            opt.step(dp.grad_scale)
+        torch.cuda.synchronize()
+        res[forced] = (grads, dp.flat.flat.clone().cpu(), dp.collective_calls)
+        dp.close()
+    ret['backend'] = dist.get_backend()
+    ret['forced'], ret['plain'] = res[True], res[False]
+    dist.destroy_process_group()
+
+
+def test_rccl_single_rank_collective_path_on_the_device():
+    port = 36500 + os.getpid() % 2000
+    ret = mp.Manager().dict()
+    mp.spawn(_nccl_worker, args=(1, port, ret), nprocs=1, join=True)
+    assert ret['backend'] == 'nccl'
+    (g_f, p_f, calls_f), (g_p, p_p, calls_p) = ret['forced'], ret['plain']
+    # per step: 1 sync-BN reduction + 1 loss-count reduction + >= 3 gradient buckets (three stages), + the broadcast
+    assert calls_f >= 1 + 3 * 5 and calls_p == 0, (calls_f, calls_p)
+    for a, b in zip(g_f, g_p):
+        assert torch.equal(a, b)                  # a one-rank all-reduce is the identity
+    assert torch.equal(p_f, p_p)
+    assert all(torch.isfinite(g).all() for g in g_f)

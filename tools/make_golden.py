@@ -481,9 +481,43 @@ def g8_postprocess():
     print('g8: ', len(out), 'arrays')
 
 
+def g11_segmentation_helpers():
+    """G11: the segmentation helpers of vhoi/data_loading.py on seeded label matrices with missing (-1) frames, bit for
+    bit: smooth_segmentation (:544-559; result AND what it leaves in the caller's array), segmentation_from_output_class
+    (:885-896), ignore_last_step_end_flag (:524-533)."""
+    import types
+    sys.modules.setdefault('zarr', types.ModuleType('zarr'))
+    tb = types.ModuleType('torch.utils.tensorboard')
+    tb.SummaryWriter = object
+    sys.modules.setdefault('torch.utils.tensorboard', tb)
+    import vhoi.data_loading as ref_dl
+    rng = np.random.RandomState(11)
+    out = {}
+    for ci, (n, steps) in enumerate(((5, 40), (3, 17), (2, 6))):
+        labels = np.repeat(rng.randint(0, 4, size=(n, steps // 3 + 1)), 3, axis=1)[:, :steps].astype(np.int64)
+        labels[0, steps - 4:] = -1                       # trailing padding
+        labels[-1, 1:3] = -1                             # missing frames inside a clip
+        out[f'c{ci}_labels'] = labels
+        for style in ('input', 'output'):
+            seg = ref_dl.segmentation_from_output_class(labels.copy(), segmentation_type=style)
+            out[f'c{ci}_seg_{style}'] = np.asarray(seg)
+        seg = np.asarray(out[f'c{ci}_seg_output'], dtype=np.float32)
+        for sigma in (0.0, 1.0, 2.0, 3.5):
+            arg = seg.copy()
+            res = ref_dl.smooth_segmentation(arg, sigma)
+            out[f'c{ci}_smooth_{sigma}'] = np.asarray(res)
+            out[f'c{ci}_smooth_{sigma}_arg_after'] = arg
+        out[f'c{ci}_ignore_last'] = ref_dl.ignore_last_step_end_flag(np.asarray(out[f'c{ci}_seg_input'], dtype=np.float32).copy())
+    np.savez_compressed(os.path.join(OUT, 'g11_segmentation_helpers.npz'), **out)
+    print('g11:', len(out), 'arrays')
+
+
 if __name__ == '__main__':
     torch.set_num_threads(8)
     os.makedirs(OUT, exist_ok=True)
+    if len(sys.argv) > 1 and sys.argv[1] == 'g11':
+        g11_segmentation_helpers()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'g4':   # python tools/make_golden.py g4 [case ...]
         g4_full(only=set(sys.argv[2:]) or None)
         sys.exit(0)
@@ -494,3 +528,4 @@ if __name__ == '__main__':
     g7_losses()
     g6_batching()
     g8_postprocess()
+    g11_segmentation_helpers()
