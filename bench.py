@@ -228,7 +228,9 @@ def cpu_baseline(sample_frames=None, sample_clips=4, repeats=3):
     med = lambda v: sorted(v)[len(v) // 2]
     clips = nb * Ts / T
     return dict(value=clips / med(t_all), unit='clips/s', cores=cores, kind='port', cpu_model=_cpu_model(),
-                threads=cores, repeats=repeats, warmup=1,
+                threads=cores, repeats=repeats, warmup=1, sample_clips=nb, sample_frames=Ts,
+                protocol='r02: 1 warm-up + 3 timed forward+backward passes of 4 full-length clips, median (round 1 timed ONE '
+                         'pass of 8 clips: values are not comparable across that change)',
                 sample=f'{nb} clips x {Ts} of {T} frames (H={H},O={O},N={N_NODES},h={CFG["hidden_size"]}); 1 warm-up + '
                        f'{repeats} timed forward+backward passes, median {med(t_all):.1f} s (all: '
                        f'{", ".join(f"{t:.1f}" for t in t_all)})' + ('' if Ts == T else ', scaled linearly in frames'),
@@ -287,6 +289,7 @@ def main():
                          'GLOBAL batch, batch / N clips per GPU (SURVEY 8e: fixed global bs64 = 8 x 8 at N = 8)')
     args = ap.parse_args()
     wl = select_workload(args.workload)
+    args.workload_batch = args.batch   # as given (None = the workload's): the other scaling mode is derived from it
     if args.batch is None:
         args.batch = BS
     if args.cpu_baseline_only:
@@ -348,27 +351,33 @@ def main():
     dp = DataParallel(model)
     opt = FusedAdam(dp.flat, lr=1e-4)
     bs = args.batch
-    x_human, x_objects, mask, targets = synthetic_batch(bs, device, seed=1234 + rank)
-    seg = torch.ones(bs, T, H, device=device)  # feeder semantics: impose_segmentation_pattern == 1
     # the reference's criterion for this model (vhoi/losses.py:8-61) with the stage-1 configuration: the budget, BCE and
     # frame-level NLL terms weigh 0, the two segment-level NLL terms weigh 1; all six terms run in one fused launch
     from twog_gcn_amd.losses import select_loss
     criterion, loss_names = select_loss('2G-GCN', 'multiple', 'mphoi', dict(misc={}))
-    seg_target = torch.zeros(bs, T, H, device=device)
-    loss_targets = [seg_target, seg_target, targets[0], targets[1], targets[0], targets[1]]
 
-    def step():
-        dp.zero_grad()
-        out = model(x_human, x_objects, mask, human_segmentation=seg)
-        loss = sum(criterion(out, loss_targets))
-        loss.backward()
-        dp.all_reduce_gradients()
-        opt.step(dp.grad_scale)
-        # detached: a caller that keeps the returned loss must not keep the step's autograd node (and the ~3 GB of buffers
-        # it saved) alive into the next step -- the next step's buffers would land at other addresses, i.e. under other
-        # hipGraph keys: first-sighting launches and a fresh capture of every time loop inside the timed region
-        # (seen as one 190 ms step in a default run)
-        return loss.detach()
+    def make_step(nb):
+        """One training step on `nb` resident clips per GPU: returns (step function, the tensors it reads)."""
+        x_human, x_objects, mask, targets = synthetic_batch(nb, device, seed=1234 + rank)
+        seg = torch.ones(nb, T, H, device=device)  # feeder semantics: impose_segmentation_pattern == 1
+        seg_target = torch.zeros(nb, T, H, device=device)
+        loss_targets = [seg_target, seg_target, targets[0], targets[1], targets[0], targets[1]]
+
+        def step():
+            dp.zero_grad()
+            out = model(x_human, x_objects, mask, human_segmentation=seg)
+            loss = sum(criterion(out, loss_targets))
+            loss.backward()
+            dp.all_reduce_gradients()
+            opt.step(dp.grad_scale)
+            # detached: a caller that keeps the returned loss must not keep the step's autograd node (and the ~3 GB of
+            # buffers it saved) alive into the next step -- the next step's buffers would land at other addresses, i.e.
+            # under other hipGraph keys: first-sighting launches and a fresh capture of every time loop inside the timed
+            # region (seen as one 190 ms step in a default run)
+            return loss.detach()
+        return step, (x_human, x_objects, mask, seg, loss_targets)
+
+    step, (x_human, x_objects, mask, seg, loss_targets) = make_step(bs)
 
     def barrier():
         if world > 1:
@@ -394,19 +403,23 @@ def main():
             d = [(b - a) * 1e3 for a, b in zip(ts[:-1], ts[1:])]
             log(f'debug step {i}: forward enqueue {d[0]:.1f} + drain {d[1]:.1f}, loss {d[2]:.1f}, backward enqueue {d[3]:.1f} + '
                 f'drain {d[4]:.1f}, adam {d[5]:.1f} ms')
-    hist = []
-    for i in range(40):
-        tw = time.perf_counter()
-        step()
-        torch.cuda.synchronize()
-        hist.append(time.perf_counter() - tw)
-        settled = len(hist) >= 4 and max(hist[-3:]) <= 1.03 * min(hist[-3:])
-        if world > 1:   # every rank must run the same number of steps (each holds a collective): stop when ALL have settled
-            flag = torch.tensor([1.0 if settled else 0.0], device=device)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            settled = bool(flag.item() > 0.5)
-        if settled:
-            break
+    def settle(step_fn):
+        hist = []
+        for i in range(40):
+            tw = time.perf_counter()
+            step_fn()
+            torch.cuda.synchronize()
+            hist.append(time.perf_counter() - tw)
+            settled = len(hist) >= 4 and max(hist[-3:]) <= 1.03 * min(hist[-3:])
+            if world > 1:   # every rank must run the same number of steps (each holds a collective): stop when ALL have settled
+                flag = torch.tensor([1.0 if settled else 0.0], device=device)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                settled = bool(flag.item() > 0.5)
+            if settled:
+                break
+        return hist
+
+    hist = settle(step)
     log(f'device warm-up: {len(hist)} steps, last {hist[-1] * 1e3:.1f} ms')
     log('model + data ready; warmup')
     for i in range(args.warmup):
@@ -464,6 +477,39 @@ def main():
         prof.detail(args.steps)
     log(f'timed region done: {dt / args.steps * 1e3:.1f} ms/step; per step (device): '
         + ' '.join(f'{step_ev[i].elapsed_time(step_ev[i + 1]):.0f}' for i in range(args.steps)))
+
+    # ---- N > 1: the OTHER scaling mode in the same line (SURVEY 8e asks for both). `value` is the mode --scaling names
+    # (default weak: the workload's 64 clips on every GPU); the secondary run keeps everything else and changes only the
+    # clips per GPU: strong = BASELINE configs[3]'s fixed GLOBAL batch of 64 (64 / N per GPU), weak = 64 per GPU.
+    other_scaling = None
+    if world > 1:
+        other = 'strong' if args.scaling == 'weak' else 'weak'
+        base = BS if args.workload_batch is None else args.workload_batch
+        nb2 = base // world if other == 'strong' else base
+        if nb2 >= 1 and (other == 'weak' or base % world == 0):
+            del step
+            step2, _keep = make_step(nb2)
+            h2 = settle(step2)
+            for _ in range(args.warmup):
+                step2()
+            torch.cuda.synchronize()
+            barrier()
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            for _ in range(args.steps):
+                step2()
+            torch.cuda.synchronize()
+            barrier()
+            torch.cuda.synchronize()
+            dt2 = time.perf_counter() - t2
+            tmax = torch.tensor([dt2], device=device, dtype=torch.float64)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt2 = float(tmax.item())
+            other_scaling = {'scaling': other, 'value': nb2 * world * args.steps / dt2, 'unit': 'clips/s',
+                             'ms_per_step': dt2 / args.steps * 1e3, 'per_gpu_batch': nb2, 'global_batch': nb2 * world,
+                             'steps': args.steps, 'warmup': args.warmup, 'device_warmup_steps': len(h2)}
+            log(f'{other} scaling: {nb2} clips per GPU, {dt2 / args.steps * 1e3:.1f} ms/step')
+            del step2, _keep
 
     # secondary roofline: the geometric-level GCN forward alone (the kernel group the north star's HBM-roofline target
     # names), HIP events around its launches; algorithmic bytes T*(16N + 512N) per clip
@@ -566,6 +612,12 @@ def main():
         }
         if fwd_only is not None:
             result['forward_only_clips_per_s'] = fwd_only
+        if world > 1:
+            # both scaling modes in one line: `value` / `scaling` above are the mode --scaling names, this is the other
+            result['value_is'] = (f'{args.scaling} scaling: {bs} clips per GPU, global batch {bs * world}')
+            result['other_scaling'] = other_scaling
+            key = 'strong_scaling' if args.scaling == 'weak' else 'weak_scaling'
+            result[key] = other_scaling
         if world == 1 and not args.no_cpu_baseline:
             log('cpu baseline ...')
             result['cpu_baseline'] = cpu_baseline_in_child(args.workload)

@@ -32,6 +32,10 @@ def test_bench_gpus_2_launches_two_ranks_weak():
     assert d['config']['collective_backend'] == 'gloo'
     assert d['value'] > 0 and d['forward_only_clips_per_s'] > 0
     assert abs(d['value'] - 32 * 2 / (d['ms_per_step'] * 2e-3)) < 1e-6 * d['value']
+    # the same line carries the other scaling mode: fixed GLOBAL batch of the workload (16 clips -> 8 per GPU)
+    st = d['strong_scaling']
+    assert st['scaling'] == 'strong' and st['per_gpu_batch'] == 8 and st['global_batch'] == 16 and st['value'] > 0
+    assert 'weak scaling' in d['value_is']
 
 
 def test_bench_strong_scaling_splits_the_global_batch():
@@ -39,6 +43,8 @@ def test_bench_strong_scaling_splits_the_global_batch():
                '--no-cpu-baseline')
     assert d['n_gpus'] == 2 and d['scaling'] == 'strong'
     assert d['config']['per_gpu_batch'] == 8 and d['config']['global_batch'] == 16
+    wk = d['weak_scaling']
+    assert wk['scaling'] == 'weak' and wk['per_gpu_batch'] == 16 and wk['global_batch'] == 32 and wk['value'] > 0
 
 
 def test_bench_world_size_mismatch_is_refused():
