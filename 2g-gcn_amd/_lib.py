@@ -131,6 +131,8 @@ _I, _L, _F, _P = C.c_int, C.c_int64, C.c_float, C.c_void_p
 SIGNATURES = {
     'twog_gemm_f32': [C.POINTER(Gemm), _I, _I, _I, _P, C.c_size_t, _P],
     'twog_gemm_last_class': [],
+    'twog_chain_workspace_bytes': [],
+    'twog_gemm_f32_chain': [C.POINTER(Gemm), _I, _I, _I, _P, C.c_size_t, _P],
     'twog_gcn_max_nodes': [],
     'twog_bn_stats': [_P, _L, _I, _I, _P, _I, _P],
     'twog_bn_finalize': [_P, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _P, _P],
@@ -143,13 +145,13 @@ SIGNATURES = {
     'twog_gcn_attn2_bwd': [_P, _P, _P, _P, _I, _I, _P, _P, _I, _P],
     'twog_gru_step_fwd': [C.POINTER(GruStep), _I, _P],
     'twog_gru_step_bwd': [C.POINTER(GruStepBwd), _I, _P],
-    'twog_bigru_fwd': [C.POINTER(BiGru), _I, _I, _I, _I, _P],
-    'twog_bigru_bwd': [C.POINTER(BiGruBwd), _I, _I, _I, _I, _P],
+    'twog_bigru_fwd': [C.POINTER(BiGru), _I, _I, _I, _I, _P, C.c_size_t, _P],
+    'twog_bigru_bwd': [C.POINTER(BiGruBwd), _I, _I, _I, _I, _P, C.c_size_t, _P],
     'twog_attn_fwd': [C.POINTER(Attn), _I, _P],
     'twog_attn_limits': [C.POINTER(C.c_int), C.POINTER(C.c_int)],
     'twog_attn_bwd': [C.POINTER(AttnBwd), _I, _P],
-    'twog_segrnn_fwd': [C.POINTER(SegRnn), _P],
-    'twog_segrnn_bwd': [C.POINTER(SegRnn), C.POINTER(SegRnnBwd), _P],
+    'twog_segrnn_fwd': [C.POINTER(SegRnn), _P, C.c_size_t, _P],
+    'twog_segrnn_bwd': [C.POINTER(SegRnn), C.POINTER(SegRnnBwd), _P, C.c_size_t, _P],
     'twog_graph_cache_stats': [c_int64_p, c_int64_p],
     'twog_pos_embed_fwd': [_P, _P, _I, _I, _I, _I, _P, _P, _I, _I, Rows, _P, _P],
     'twog_periodic_embed_bwd': [Rows, _P, _I, _I, _P, _P],
@@ -197,6 +199,7 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing
         fn.argtypes = argtypes
         fn.restype = C.c_int
+    lib.twog_chain_workspace_bytes.restype = C.c_size_t
     lib.twog_version.restype = C.c_char_p
     lib.twog_version.argtypes = []
     _lib = lib

@@ -48,6 +48,9 @@ struct Group {
     int k_per_split; // multiple of BK
     int group;       // tile order inside a problem: groups of `group` panels of the major dimension (tile_coords)
     float* slabs;    // split-K partials: [problem-tile-major] see below
+    unsigned* xcnt;  // XS kernels (split-K over workgroups, combined in the launch): arrival ticket per tile, zero between launches
+    int xs_early;    // XS: every slice requests the epilogue operands before its reduction loop (small launches: the
+                     // combining workgroup then has them when it draws the last ticket; large ones fetch them once, late)
 };
 
 // Fused "next gate step" epilogue of the recurrent backward chains (gru.hip / segrnn.hip): the launch that adds the last
@@ -382,7 +385,16 @@ __device__ __forceinline__ void gemm_mainloop(const twog_rows_t A, const twog_ro
     }
 }
 
-template <int BM, int BN, int NT, bool AKM, bool BKM, int D, bool KG, bool GATE, int KS = 1>
+// XS (recurrent-chain launches with fewer tiles than the chip has CUs): the reduction is ALSO split over workgroups
+// (blockIdx.y = k-slice) and combined inside the launch, without a grid barrier and without waiting: every workgroup
+// writes its partial tile write-through (16-byte sc1 stores, so no release fence), drains them, and one lane draws an
+// agent-scope ticket; the workgroup whose ticket is the last one re-reads all slices' partials with sc1 loads (they
+// bypass its L1: no acquire), adds them in SLICE order -- bit-identical whoever arrives last -- and runs the epilogue
+// (bias / accumulate / the fused gate backward) exactly as the unsplit kernel does. It also resets the ticket, so the
+// counters are zero again at the launch boundary (graph replays need no memset node). The hand-off form is the
+// guide's split-K recipe (cdna_hip_programming.md section 5 item 2 / MI355X_MICROARCH.md "Valid forms": sc1 payload,
+// every storing wave drained, workgroup barrier, one relaxed agent atomic; the last arriver's loads all sc1).
+template <int BM, int BN, int NT, bool AKM, bool BKM, int D, bool KG, bool GATE, int KS = 1, bool XS = false>
 __device__ __forceinline__ void gemm_tile(const Group& g, const GateArgs* ga) {
     constexpr int NTG = NT / KS;
     constexpr int WM = BM / (NTG / 128), WN = BN / 2;  // per-wave tile; the waves of a k-group in a (NTG/128) x 2 grid
@@ -435,6 +447,9 @@ __device__ __forceinline__ void gemm_tile(const Group& g, const GateArgs* ga) {
     const int split = blockIdx.y;
     const int k_begin = split * g.k_per_split;
     const int k_end = min(K, k_begin + g.k_per_split);
+    // XS: slices of THIS problem (a grouped launch mixes reduction lengths; the grid has the longest one's count)
+    const int xs_slices = XS ? min(g.splitk, (K + g.k_per_split - 1) / g.k_per_split) : 1;
+    if (XS && split >= xs_slices) return;   // whole workgroup, before any barrier
 
     const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) % (NTG / 64), kgrp = (threadIdx.x >> 6) / (NTG / 64);
     const int li = lane & 31, kh = lane >> 5;
@@ -451,27 +466,12 @@ __device__ __forceinline__ void gemm_tile(const Group& g, const GateArgs* ga) {
 
     // epilogue operands are fetched BEFORE the reduction loop so their latency hides under it (it is a visible share of
     // the short recurrent launches: 16 k-tiles): the bias of this lane's columns and, for the single-accumulator
-    // 64x64 class, the previous C values of accumulate launches
+    // 64x64 class, the previous C values of accumulate launches. XS kernels fetch them only in the workgroup that
+    // combines the slices (next to its slab loads), not in every slice.
     constexpr bool PREFETCH_C = (TM * TN == 1);
+    const bool epi_here = XS || g.splitk == 1;
     float bv[TN];
-#pragma unroll
-    for (int b = 0; b < TN; ++b)
-        bv[b] = (PREFETCH_C && bias && g.splitk == 1 && kgrp == 0) ? bias[min(n0 + wn + b * 32 + li, N - 1)] : 0.f;
     float cprev[PREFETCH_C ? 16 : 1];
-    if constexpr (PREFETCH_C) {
-        if (accumulate && g.splitk == 1 && kgrp == 0) {
-            const int col = min(n0 + wn + li, N - 1);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = min(m0 + wm + (r & 3) + 8 * (r >> 2) + 4 * kh, M - 1);
-                cprev[r] = C.ptr[twog_row_off(C, row) + col];
-            }
-        } else {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) cprev[r] = 0.f;
-        }
-    }
-
     // fused gate epilogue: its operands do not depend on this launch, so they are requested here, next to the first
     // operand tiles, and arrive under the reduction loop (the tile has the registers: these launches run one or two
     // workgroups per CU). Addressing as checked by the host (twog_internal_gemm_gate_bwd): dh, save, h_prev, dgi, dgh and
@@ -481,34 +481,54 @@ __device__ __forceinline__ void gemm_tile(const Group& g, const GateArgs* ga) {
     constexpr int GN = GATE ? 16 : 1;
     float g_dh[GN], g_rg[GN], g_z[GN], g_n[GN], g_hn[GN], g_h0[GN], g_uu[GN];
     int gidx = -1;
-    if constexpr (GATE) {
-        gidx = ga->gate_of[pi];
-        if (gidx >= 0 && kgrp == 0) {
-            const twog_gru_step_bwd_t& S = ga->s[gidx];
-            const int H = S.hidden;
-            const int colc = min(n0 + wn + li, N - 1);
-            const bool has_u = S.u != nullptr, has_hp = S.h_prev.ptr != nullptr;
-            const int inner = S.dh.inner > 1 ? S.dh.inner : 1;
-            const float inv_inner = 1.0f / (float)inner;
-            const float* hp_ptr = has_hp ? S.h_prev.ptr : S.dh.ptr;
-            const int hp_lo = has_hp ? (int)S.h_prev.ld_outer : (int)S.dh.ld_outer, hp_li = has_hp ? (int)S.h_prev.ld_inner : (int)S.dh.ld_inner;
-            const float* u_ptr = has_u ? S.u : S.dh.ptr;
-            const int u_lo = has_u ? (int)S.u_ld_outer : 0, u_li = has_u ? (int)S.u_ld_inner : 0;
+    if constexpr (GATE) gidx = ga->gate_of[pi];
+    auto fetch_epilogue = [&]() {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int rowc = min(m0 + wm + (r & 3) + 8 * (r >> 2) + 4 * kh, M - 1);
-                const int o = (int)(((float)rowc + 0.5f) * inv_inner), i = rowc - o * inner;
-                const float* sv = S.save.ptr + (o * (int)S.save.ld_outer + i * (int)S.save.ld_inner);
-                g_dh[r] = S.dh.ptr[o * (int)S.dh.ld_outer + i * (int)S.dh.ld_inner + colc];
-                g_rg[r] = sv[colc];
-                g_z[r] = sv[H + colc];
-                g_n[r] = sv[2 * H + colc];
-                g_hn[r] = sv[3 * H + colc];
-                g_h0[r] = hp_ptr[o * hp_lo + i * hp_li + colc];
-                g_uu[r] = u_ptr[o * u_lo + i * u_li];
+        for (int b = 0; b < TN; ++b)
+            bv[b] = (PREFETCH_C && bias && epi_here && kgrp == 0) ? bias[min(n0 + wn + b * 32 + li, N - 1)] : 0.f;
+        if constexpr (PREFETCH_C) {
+            if (accumulate && epi_here && kgrp == 0) {
+                const int col = min(n0 + wn + li, N - 1);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = min(m0 + wm + (r & 3) + 8 * (r >> 2) + 4 * kh, M - 1);
+                    cprev[r] = C.ptr[twog_row_off(C, row) + col];
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) cprev[r] = 0.f;
             }
         }
-    }
+        if constexpr (GATE) {
+            if (gidx >= 0 && kgrp == 0) {
+                const twog_gru_step_bwd_t& S = ga->s[gidx];
+                const int H = S.hidden;
+                const int colc = min(n0 + wn + li, N - 1);
+                const bool has_u = S.u != nullptr, has_hp = S.h_prev.ptr != nullptr;
+                const int inner = S.dh.inner > 1 ? S.dh.inner : 1;
+                const float inv_inner = 1.0f / (float)inner;
+                const float* hp_ptr = has_hp ? S.h_prev.ptr : S.dh.ptr;
+                const int hp_lo = has_hp ? (int)S.h_prev.ld_outer : (int)S.dh.ld_outer, hp_li = has_hp ? (int)S.h_prev.ld_inner : (int)S.dh.ld_inner;
+                const float* u_ptr = has_u ? S.u : S.dh.ptr;
+                const int u_lo = has_u ? (int)S.u_ld_outer : 0, u_li = has_u ? (int)S.u_ld_inner : 0;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int rowc = min(m0 + wm + (r & 3) + 8 * (r >> 2) + 4 * kh, M - 1);
+                    const int o = (int)(((float)rowc + 0.5f) * inv_inner), i = rowc - o * inner;
+                    const float* sv = S.save.ptr + (o * (int)S.save.ld_outer + i * (int)S.save.ld_inner);
+                    g_dh[r] = S.dh.ptr[o * (int)S.dh.ld_outer + i * (int)S.dh.ld_inner + colc];
+                    g_rg[r] = sv[colc];
+                    g_z[r] = sv[H + colc];
+                    g_n[r] = sv[2 * H + colc];
+                    g_hn[r] = sv[3 * H + colc];
+                    g_h0[r] = hp_ptr[o * hp_lo + i * hp_li + colc];
+                    g_uu[r] = u_ptr[o * u_lo + i * u_li];
+                }
+            }
+        }
+    };
+    const bool early = !XS || xs_slices == 1 || g.xs_early;
+    if (early) fetch_epilogue();
 
     // uniform per workgroup: aligned operands and a reduction range made of whole k-tiles -> branch-free staging
     const bool fast = a_vec && b_vec && ((k_end - k_begin) % BK == 0);
@@ -530,8 +550,60 @@ __device__ __forceinline__ void gemm_tile(const Group& g, const GateArgs* ga) {
         for (int r = 0; r < 16; ++r) acc[0][0][r] += red[r << 6];
     }
 
+    if constexpr (XS) {
+        static_assert(!XS || (TM * TN == 1 && KS == 2), "the in-launch combine is written for the k-split 64x64 / 32x64 classes");
+        const int S = xs_slices;
+        if (S > 1) {   // uniform over the workgroup
+            // partial tile of slice `split`: [wave][4 register quads][lane] x 16 bytes -- every store / load instruction
+            // of a wave covers 1 KB of whole 128-byte lines; the layout is private to this kernel
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(g.slabs, 0, 0xffffffff, 0x00020000);
+            const uint32_t tile_bytes = BM * BN * 4u;
+            const uint32_t slice_stride = (uint32_t)g.total_tiles * tile_bytes;
+            const int tile_off = (int)((uint32_t)bid * tile_bytes);
+            const int lane_off = (int)(((uint32_t)wave * 4u * 64u + (uint32_t)lane) * 16u);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                f32x4 v = {acc[0][0][4 * q], acc[0][0][4 * q + 1], acc[0][0][4 * q + 2], acc[0][0][4 * q + 3]};
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, v), rs,
+                                                       lane_off + q * 1024, tile_off + (int)((uint32_t)split * slice_stride), 16);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains its write-through stores
+            __syncthreads();
+            unsigned* flag = reinterpret_cast<unsigned*>(smem + 4096);   // beyond the k-group exchange area
+            if (threadIdx.x == 0)
+                *flag = __hip_atomic_fetch_add(g.xcnt + bid, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+            if (*flag != (unsigned)(S - 1)) return;
+            if (threadIdx.x == 0) __hip_atomic_store(g.xcnt + bid, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (!early) fetch_epilogue();   // in flight together with the slab loads below
+            f32x4 sum[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) sum[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+            int s0 = 0;
+            for (; s0 + 1 < S; s0 += 2) {   // two slices' loads in flight; added in slice order
+                f32x4 va[4], vb[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    va[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, lane_off + q * 1024, tile_off + (int)((uint32_t)s0 * slice_stride), 16));
+                    vb[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, lane_off + q * 1024, tile_off + (int)((uint32_t)(s0 + 1) * slice_stride), 16));
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { sum[q] += va[q]; sum[q] += vb[q]; }
+            }
+            if (s0 < S) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    sum[q] += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, lane_off + q * 1024, tile_off + (int)((uint32_t)s0 * slice_stride), 16));
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                acc[0][0][4 * q] = sum[q].x; acc[0][0][4 * q + 1] = sum[q].y; acc[0][0][4 * q + 2] = sum[q].z; acc[0][0][4 * q + 3] = sum[q].w;
+            }
+        }
+    }
+
     // epilogue. C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
-    if (g.splitk > 1) {
+    if (!XS && g.splitk > 1) {
         // raw partials: slab[split][tile][BM][BN]
         float* slab = g.slabs + ((int64_t)split * g.total_tiles + bid) * (BM * BN);
 #pragma unroll
@@ -774,6 +846,24 @@ __global__ __launch_bounds__(256 * KS, 1) void gemm_gru_fwd_kernel(const GruFwdG
     }
 }
 
+// the same four kernels with the reduction also split over workgroups and combined in the launch (XS, see gemm_tile)
+template <bool BKM, int D>
+__global__ __launch_bounds__(512, 2) void gemm_xs_kernel(const Group g) {
+    gemm_tile<64, 64, 512, false, BKM, D, false, false, 2, true>(g, nullptr);
+}
+template <int D>
+__global__ __launch_bounds__(512, 2) void gemm_gate_bwd_xs_kernel(const Group g, const GateArgs ga) {
+    gemm_tile<64, 64, 512, false, true, D, false, true, 2, true>(g, &ga);
+}
+template <bool BKM, int D>
+__global__ __launch_bounds__(256, 2) void gemm_xs32_kernel(const Group g) {
+    gemm_tile<32, 64, 256, false, BKM, D, false, false, 2, true>(g, nullptr);
+}
+template <int D>
+__global__ __launch_bounds__(256, 2) void gemm_gate_bwd_xs32_kernel(const Group g, const GateArgs ga) {
+    gemm_tile<32, 64, 256, false, true, D, false, true, 2, true>(g, &ga);
+}
+
 // 32 x 64 tiles, 4 waves = two k-groups of a 1 x 2 wave grid: launches with so few rows that even 32-row tiles leave one
 // tile per CU (8 clips per GPU: 16 / 32 rows per entity type and direction). A 64 x 64 tile there is half padding and
 // keeps every SIMD busy for the whole K/2-instruction MFMA chain twice; here each wave runs half the chain once.
@@ -952,6 +1042,8 @@ static void prepare_group(const twog_gemm_t* pr, int n, int a_kmajor, int b_kmaj
     g.splitk = 1;
     g.k_per_split = ((kmax + BK - 1) / BK) * BK;
     g.slabs = nullptr;
+    g.xcnt = nullptr;
+    g.xs_early = 0;
     // deterministic split-K when the grid would leave CUs idle and the reduction is long
     if (t < 4096 && kmax >= 1024 && workspace) {
         // pick the split that fills whole "rounds" of resident workgroups (2 per CU for 128-tiles, 4 for 64-tiles)
@@ -977,8 +1069,77 @@ static void prepare_group(const twog_gemm_t* pr, int n, int a_kmajor, int b_kmaj
     }
 }
 
+// Split of the reduction over workgroups for a chain launch (XS kernels). Model: a k-tile of one tile costs `unit` us of
+// fp32 MFMA on a CU (64x64: 16 x 64-cycle MFMAs per SIMD = 0.49 us at the ~2.1 GHz the part sustains; 32x64: half), the
+// workgroups of a launch are dealt over 256 CUs, a CU works its workgroups off one after the other, and a launch with
+// S > 1 pays the hand-off (slab stores, ticket, the last arriver's S slab loads). TWOG_GEMM_XSPLIT: 0 = this model,
+// 1 = never split, n > 1 = always n slices (tuning / tests).
+constexpr size_t XS_COUNTER_BYTES = 16384;   // 4096 tickets at the start of the chain workspace
+static int pick_xsplit(int tiles, int kmax, int bm, size_t ws_bytes) {
+    static const int force = getenv("TWOG_GEMM_XSPLIT") ? atoi(getenv("TWOG_GEMM_XSPLIT")) : 0;
+    if (force == 1 || tiles <= 0 || tiles > 4096 || ws_bytes <= XS_COUNTER_BYTES) return 1;
+    const int kt = (kmax + BK - 1) / BK;
+    const size_t tile_bytes = (size_t)bm * 64 * sizeof(float);
+    const int by_ws = (int)((ws_bytes - XS_COUNTER_BYTES) / (tile_bytes * (size_t)tiles));
+    const double unit = bm == 32 ? 0.25 : 0.49;
+    auto cost = [&](int S) {
+        const int per_cu = (tiles * S + 255) / 256, kts = (kt + S - 1) / S;
+        return per_cu * kts * unit + (S > 1 ? 3.0 + 0.35 * S : 0.0);
+    };
+    int best = 1;
+    double best_c = cost(1);
+    static const int cand[] = {2, 3, 4, 6, 8, 12, 16};
+    for (int S : cand) {
+        if (S > by_ws || kt / S < 2) break;
+        const double c = force > 1 ? (S == force ? -1.0 : 1e30) : cost(S);
+        if (c < best_c - 1.0) { best_c = c; best = S; }
+    }
+    return best;
+}
+
+// launches the XS variant when the chain workspace allows a split that pays; returns false when the caller should use
+// the unsplit kernels
+template <class LaunchFn>
+static bool try_xsplit(Group& g, int bm, int kmax, void* chain_ws, size_t chain_ws_bytes, LaunchFn launch_fn) {
+    if (!chain_ws) return false;
+    const int S = pick_xsplit(g.total_tiles, kmax, bm, chain_ws_bytes);
+    if (S <= 1) return false;
+    const int kt = (kmax + BK - 1) / BK;
+    g.k_per_split = ((kt + S - 1) / S) * BK;
+    g.splitk = (kmax + g.k_per_split - 1) / g.k_per_split;
+    if (g.splitk <= 1) { g.splitk = 1; g.k_per_split = kt * BK; return false; }
+    g.xcnt = reinterpret_cast<unsigned*>(chain_ws);
+    g.slabs = reinterpret_cast<float*>(reinterpret_cast<char*>(chain_ws) + XS_COUNTER_BYTES);
+    // epilogue operands (previous C, gate operands: up to 8 values per output element) in every slice: only while the
+    // launch is latency-bound, i.e. its outputs are a few hundred KB (8 clips per GPU: 48 rows x 512)
+    static const int early_tiles = getenv("TWOG_GEMM_XS_EARLY") ? atoi(getenv("TWOG_GEMM_XS_EARLY")) : 96;
+    g.xs_early = g.total_tiles <= early_tiles ? 1 : 0;
+    launch_fn(dim3(g.total_tiles, g.splitk));
+    return true;
+}
+
+static int gemm_impl(const twog_gemm_t* problems, int n_problems, int a_kmajor, int b_kmajor, void* workspace,
+                     size_t workspace_bytes, void* chain_ws, size_t chain_ws_bytes, void* stream);
+
 extern "C" int twog_gemm_f32(const twog_gemm_t* problems, int n_problems, int a_kmajor, int b_kmajor, void* workspace,
                              size_t workspace_bytes, void* stream) {
+    return gemm_impl(problems, n_problems, a_kmajor, b_kmajor, workspace, workspace_bytes, nullptr, 0, stream);
+}
+
+// The launches of a recurrent chain (few tiles, K = h ... 3h, each dependent on the previous one): `chain_ws` (>= 16 KB
+// of tickets, ZERO when first handed over and then left to the library, + room for the partial tiles; see
+// twog_chain_workspace_bytes) lets the library split the reduction over workgroups and combine it inside the launch.
+extern "C" int twog_gemm_f32_chain(const twog_gemm_t* problems, int n_problems, int a_kmajor, int b_kmajor, void* chain_ws,
+                                   size_t chain_ws_bytes, void* stream) {
+    return gemm_impl(problems, n_problems, a_kmajor, b_kmajor, nullptr, 0, chain_ws, chain_ws_bytes, stream);
+}
+
+extern "C" size_t twog_chain_workspace_bytes(void) {
+    return XS_COUNTER_BYTES + (size_t)48 * 1024 * 1024;   // tickets + 3 072 partial 64x64 tiles
+}
+
+static int gemm_impl(const twog_gemm_t* problems, int n_problems, int a_kmajor, int b_kmajor, void* workspace,
+                     size_t workspace_bytes, void* chain_ws, size_t chain_ws_bytes, void* stream) {
     if (n_problems <= 0) return 0;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     int done = 0;
@@ -1008,6 +1169,15 @@ extern "C" int twog_gemm_f32(const twog_gemm_t* problems, int n_problems, int a_
         const bool ks = ks_on && !big && !a_kmajor && !grouped && g.splitk == 1 && g.total_tiles <= 384 && kmax_ >= 256;
         if (bm == 32) {   // decided in prepare_group; implies the conditions of `ks`
             g_last_class |= TWOG_GEMM_CLASS_KSPLIT | TWOG_GEMM_CLASS_ROWS32;
+            if (try_xsplit(g, 32, kmax_, chain_ws, chain_ws_bytes, [&](dim3 grid) {
+                    if (b_kmajor) hipLaunchKernelGGL((gemm_xs32_kernel<true, 2>), grid, dim3(256), 0, st, g);
+                    else hipLaunchKernelGGL((gemm_xs32_kernel<false, 2>), grid, dim3(256), 0, st, g);
+                })) {
+                g_last_class |= TWOG_GEMM_CLASS_XSPLIT;
+                TWOG_CHECK_LAUNCH();
+                done += n;
+                continue;
+            }
             dim3 grid(g.total_tiles, 1), block(256);
             if (b_kmajor) hipLaunchKernelGGL((gemm_ks32_kernel<true, 2>), grid, block, 0, st, g);
             else hipLaunchKernelGGL((gemm_ks32_kernel<false, 2>), grid, block, 0, st, g);
@@ -1017,6 +1187,15 @@ extern "C" int twog_gemm_f32(const twog_gemm_t* problems, int n_problems, int a_
         }
         if (ks) {
             g_last_class |= TWOG_GEMM_CLASS_KSPLIT;
+            if (try_xsplit(g, 64, kmax_, chain_ws, chain_ws_bytes, [&](dim3 grid) {
+                    if (b_kmajor) hipLaunchKernelGGL((gemm_xs_kernel<true, 2>), grid, dim3(512), 0, st, g);
+                    else hipLaunchKernelGGL((gemm_xs_kernel<false, 2>), grid, dim3(512), 0, st, g);
+                })) {
+                g_last_class |= TWOG_GEMM_CLASS_XSPLIT;
+                TWOG_CHECK_LAUNCH();
+                done += n;
+                continue;
+            }
             dim3 grid(g.total_tiles, 1), block(512);
             if (b_kmajor) hipLaunchKernelGGL((gemm_ks_kernel<true, 2>), grid, block, 0, st, g);
             else hipLaunchKernelGGL((gemm_ks_kernel<false, 2>), grid, block, 0, st, g);
@@ -1039,7 +1218,7 @@ extern "C" int twog_gemm_f32(const twog_gemm_t* problems, int n_problems, int a_
 // buffer; the gate's dh2 is taken from the accumulators, not from memory). Returns 1 without launching when this chunk
 // is not served by the fused kernel (tile class, grouped rows, too many partial slots) -- dry_run only asks that.
 int twog_internal_gemm_gate_bwd(const twog_gemm_t* pr, int n, const twog_gru_step_bwd_t* gates, float* const* du_part,
-                                int dry_run, void* stream) {
+                                int dry_run, void* chain_ws, size_t chain_ws_bytes, void* stream) {
     if (n <= 0 || n > MAXP) return 1;
     Group g;
     int order[MAXP];
@@ -1088,12 +1267,26 @@ int twog_internal_gemm_gate_bwd(const twog_gemm_t* pr, int n, const twog_gru_ste
     for (int i = 0; i < n; ++i) kmax = pr[i].K > kmax ? pr[i].K : kmax;
     if (bm == 32) {
         g_last_class |= TWOG_GEMM_CLASS_KSPLIT | TWOG_GEMM_CLASS_ROWS32;
+        if (try_xsplit(g, 32, kmax, chain_ws, chain_ws_bytes, [&](dim3 xgrid) {
+                hipLaunchKernelGGL(gemm_gate_bwd_xs32_kernel<2>, xgrid, dim3(256), 0, (hipStream_t)stream, g, ga);
+            })) {
+            g_last_class |= TWOG_GEMM_CLASS_XSPLIT;
+            TWOG_CHECK_LAUNCH();
+            return 0;
+        }
         hipLaunchKernelGGL(gemm_gate_bwd_ks32_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, g, ga);
         TWOG_CHECK_LAUNCH();
         return 0;
     }
     if (ks_on && g.total_tiles <= 384 && kmax >= 256) {
         g_last_class |= TWOG_GEMM_CLASS_KSPLIT;
+        if (try_xsplit(g, 64, kmax, chain_ws, chain_ws_bytes, [&](dim3 xgrid) {
+                hipLaunchKernelGGL(gemm_gate_bwd_xs_kernel<2>, xgrid, dim3(512), 0, (hipStream_t)stream, g, ga);
+            })) {
+            g_last_class |= TWOG_GEMM_CLASS_XSPLIT;
+            TWOG_CHECK_LAUNCH();
+            return 0;
+        }
         hipLaunchKernelGGL(gemm_gate_bwd_ks_kernel<2>, grid, dim3(512), 0, (hipStream_t)stream, g, ga);
         TWOG_CHECK_LAUNCH();
         return 0;

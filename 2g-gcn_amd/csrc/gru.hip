@@ -176,7 +176,8 @@ extern "C" int twog_gru_step_bwd(const twog_gru_step_bwd_t* steps, int n_steps, 
 // ---------------------------------------------------------------------------------------------------------------
 // Frame-level BiGRU recurrence for up to 4 entity types at once (humans, objects, geometry).
 // ---------------------------------------------------------------------------------------------------------------
-static int bigru_fwd_impl(const twog_bigru_t* types, int n_types, int bs, int T, int hidden, void* stream) {
+static int bigru_fwd_impl(const twog_bigru_t* types, int n_types, int bs, int T, int hidden, void* chain_ws,
+                          size_t chain_ws_bytes, void* stream) {
     if (n_types > 4) return -1;
     const int h = hidden;
     for (int s = 0; s < T; ++s) {
@@ -217,7 +218,7 @@ static int bigru_fwd_impl(const twog_bigru_t* types, int n_types, int bs, int T,
         int rc = twog_internal_gemm_gru_fwd(gm, nullptr, st, n, 0, stream);
         if (rc < 0) return rc;
         if (rc == 0) continue;
-        rc = twog_gemm_f32(gm, n, 0, 0, nullptr, 0, stream);
+        rc = twog_gemm_f32_chain(gm, n, 0, 0, chain_ws, chain_ws_bytes, stream);
         if (rc) return rc;
         rc = twog_gru_step_fwd(st, n, stream);
         if (rc) return rc;
@@ -227,7 +228,8 @@ static int bigru_fwd_impl(const twog_bigru_t* types, int n_types, int bs, int T,
 
 // Backward through time. d_out: gradient wrt `out` [bs][T][E][2h]; writes d_gi [bs][T][E][6h] and
 // d_gh [bs][T][E][6h] (the caller turns them into dX / dW_ih / dW_hh / biases with large GEMMs).
-static int bigru_bwd_impl(const twog_bigru_bwd_t* types, int n_types, int bs, int T, int hidden, void* stream) {
+static int bigru_bwd_impl(const twog_bigru_bwd_t* types, int n_types, int bs, int T, int hidden, void* chain_ws,
+                          size_t chain_ws_bytes, void* stream) {
     if (n_types > 4) return -1;
     const int h = hidden;
     // gate descriptors + the carry GEMM of chain step s, one pair per (type, direction)
@@ -284,34 +286,38 @@ static int bigru_bwd_impl(const twog_bigru_bwd_t* types, int n_types, int bs, in
             rc = 1;
             if (fuse) {
                 make_step(s - 1, nxt, nullptr);
-                rc = twog_internal_gemm_gate_bwd(gm, n, nxt, nullptr, 0, stream);
+                rc = twog_internal_gemm_gate_bwd(gm, n, nxt, nullptr, 0, chain_ws, chain_ws_bytes, stream);
                 if (rc < 0) return rc;
                 if (rc == 1) {  // shape not served by the fused kernel: decided at the first step
                     if (s != T - 1) return -120;
                     fuse = false;
                 }
             }
-            if (rc == 1) rc = twog_gemm_f32(gm, n, 0, 1, nullptr, 0, stream);
+            if (rc == 1) rc = twog_gemm_f32_chain(gm, n, 0, 1, chain_ws, chain_ws_bytes, stream);
             if (rc) return rc;
         }
     }
     return 0;
 }
 
-extern "C" int twog_bigru_fwd(const twog_bigru_t* types, int n_types, int bs, int T, int hidden, void* stream) {
+extern "C" int twog_bigru_fwd(const twog_bigru_t* types, int n_types, int bs, int T, int hidden, void* chain_ws,
+                              size_t chain_ws_bytes, void* stream) {
     if (n_types > 4 || n_types < 0) return -1;
     const int dims[6] = {0x11, n_types, bs, T, hidden, twog_internal_gru_fwd_mode()};
     twog_graph::Desc key;
-    key.pod(dims).add(types, sizeof(twog_bigru_t) * n_types);
-    return twog_graph::run(key, (hipStream_t)stream,
-                           [&](hipStream_t st) { return bigru_fwd_impl(types, n_types, bs, T, hidden, st); });
+    key.pod(dims).add(types, sizeof(twog_bigru_t) * n_types).pod(chain_ws).pod(chain_ws_bytes);
+    return twog_graph::run(key, (hipStream_t)stream, [&](hipStream_t st) {
+        return bigru_fwd_impl(types, n_types, bs, T, hidden, chain_ws, chain_ws_bytes, st);
+    });
 }
 
-extern "C" int twog_bigru_bwd(const twog_bigru_bwd_t* types, int n_types, int bs, int T, int hidden, void* stream) {
+extern "C" int twog_bigru_bwd(const twog_bigru_bwd_t* types, int n_types, int bs, int T, int hidden, void* chain_ws,
+                              size_t chain_ws_bytes, void* stream) {
     if (n_types > 4 || n_types < 0) return -1;
     const int dims[5] = {0x22, n_types, bs, T, hidden};
     twog_graph::Desc key;
-    key.pod(dims).add(types, sizeof(twog_bigru_bwd_t) * n_types);
-    return twog_graph::run(key, (hipStream_t)stream,
-                           [&](hipStream_t st) { return bigru_bwd_impl(types, n_types, bs, T, hidden, st); });
+    key.pod(dims).add(types, sizeof(twog_bigru_bwd_t) * n_types).pod(chain_ws).pod(chain_ws_bytes);
+    return twog_graph::run(key, (hipStream_t)stream, [&](hipStream_t st) {
+        return bigru_bwd_impl(types, n_types, bs, T, hidden, chain_ws, chain_ws_bytes, st);
+    });
 }

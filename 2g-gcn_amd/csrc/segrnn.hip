@@ -83,7 +83,7 @@ inline void fill_attn(twog_attn_t& A, const twog_segrnn_t& S, const Dims& d, int
 
 }  // namespace
 
-static int segrnn_fwd_impl(const twog_segrnn_t* desc, void* stream) {
+static int segrnn_fwd_impl(const twog_segrnn_t* desc, void* chain_ws, size_t chain_ws_bytes, void* stream) {
     const twog_segrnn_t& S = *desc;
     const Dims d = dims_of(S);
     const int h = d.h, T = d.T;
@@ -111,7 +111,7 @@ static int segrnn_fwd_impl(const twog_segrnn_t* desc, void* stream) {
                              d.bs * d.O, d.nso * h, h, 1, 0);
                 }
             }
-            rc = twog_gemm_f32(gm, n, 0, 0, nullptr, 0, stream);
+            rc = twog_gemm_f32_chain(gm, n, 0, 0, chain_ws, chain_ws_bytes, stream);
             if (rc) return rc;
             // (2) attention + weighted sums
             twog_attn_t at[2];
@@ -169,7 +169,7 @@ static int segrnn_fwd_impl(const twog_segrnn_t* desc, void* stream) {
         rc = twog_internal_gemm_gru_fwd(ghp, gimp, st, ns, 0, stream);
         if (rc < 0) return rc;
         if (rc == 0) continue;
-        rc = twog_gemm_f32(gm, n, 0, 0, nullptr, 0, stream);
+        rc = twog_gemm_f32_chain(gm, n, 0, 0, chain_ws, chain_ws_bytes, stream);
         if (rc) return rc;
         rc = twog_gru_step_fwd(st, ns, stream);
         if (rc) return rc;
@@ -193,7 +193,8 @@ __global__ __launch_bounds__(256) void du_reduce_kernel(const float* part, float
     du[i] += acc;
 }
 
-static int segrnn_bwd_impl(const twog_segrnn_t* desc, const twog_segrnn_bwd_t* bdesc, void* stream) {
+static int segrnn_bwd_impl(const twog_segrnn_t* desc, const twog_segrnn_bwd_t* bdesc, void* chain_ws, size_t chain_ws_bytes,
+                           void* stream) {
     const twog_segrnn_t& S = *desc;
     const twog_segrnn_bwd_t& B = *bdesc;
     const Dims d = dims_of(S);
@@ -287,14 +288,14 @@ static int segrnn_bwd_impl(const twog_segrnn_t* desc, const twog_segrnn_bwd_t* b
         if (n) {
             rc = 1;
             if (fuse && fuse_b && !first) {  // problems are exactly the four W_hh GEMMs, in (dir, kind) order
-                rc = twog_internal_gemm_gate_bwd(gm, n, nxt, nxt_part, 0, stream);
+                rc = twog_internal_gemm_gate_bwd(gm, n, nxt, nxt_part, 0, chain_ws, chain_ws_bytes, stream);
                 if (rc < 0) return rc;
                 if (rc == 1) {  // shape not served by the fused kernel: decided at the first step, cannot change later
                     if (s != T - 1) return -120;
                     fuse = false;
                 }
             }
-            if (rc == 1) rc = twog_gemm_f32(gm, n, 0, 1, nullptr, 0, stream);
+            if (rc == 1) rc = twog_gemm_f32_chain(gm, n, 0, 1, chain_ws, chain_ws_bytes, stream);
             if (rc) return rc;
         }
         if (!msg) continue;
@@ -346,14 +347,14 @@ static int segrnn_bwd_impl(const twog_segrnn_t* desc, const twog_segrnn_bwd_t* b
         }
         rc = 1;
         if (fuse && fuse_e) {  // problems are exactly (dir, kind) = the order of make_gates
-            rc = twog_internal_gemm_gate_bwd(gm, n, nxt, nxt_part, 0, stream);
+            rc = twog_internal_gemm_gate_bwd(gm, n, nxt, nxt_part, 0, chain_ws, chain_ws_bytes, stream);
             if (rc < 0) return rc;
             if (rc == 1) {
                 if (s != T - 1) return -122;
                 fuse = false;
             }
         }
-        if (rc == 1) rc = twog_gemm_f32(gm, n, 0, 1, nullptr, 0, stream);
+        if (rc == 1) rc = twog_gemm_f32_chain(gm, n, 0, 1, chain_ws, chain_ws_bytes, stream);
         if (rc) return rc;
     }
     if (fuse) {
@@ -367,19 +368,21 @@ static int segrnn_bwd_impl(const twog_segrnn_t* desc, const twog_segrnn_bwd_t* b
     return 0;
 }
 
-extern "C" int twog_segrnn_fwd(const twog_segrnn_t* desc, void* stream) {
+extern "C" int twog_segrnn_fwd(const twog_segrnn_t* desc, void* chain_ws, size_t chain_ws_bytes, void* stream) {
     const int tag[2] = {0x33, twog_internal_gru_fwd_mode()};
     twog_graph::Desc key;
-    key.pod(tag).pod(*desc);
-    return twog_graph::run(key, (hipStream_t)stream, [&](hipStream_t st) { return segrnn_fwd_impl(desc, st); });
+    key.pod(tag).pod(*desc).pod(chain_ws).pod(chain_ws_bytes);
+    return twog_graph::run(key, (hipStream_t)stream,
+                           [&](hipStream_t st) { return segrnn_fwd_impl(desc, chain_ws, chain_ws_bytes, st); });
 }
 
-extern "C" int twog_segrnn_bwd(const twog_segrnn_t* desc, const twog_segrnn_bwd_t* bdesc, void* stream) {
+extern "C" int twog_segrnn_bwd(const twog_segrnn_t* desc, const twog_segrnn_bwd_t* bdesc, void* chain_ws,
+                               size_t chain_ws_bytes, void* stream) {
     const int tag = 0x44;
     twog_graph::Desc key;
-    key.pod(tag).pod(*desc).pod(*bdesc);
+    key.pod(tag).pod(*desc).pod(*bdesc).pod(chain_ws).pod(chain_ws_bytes);
     return twog_graph::run(key, (hipStream_t)stream,
-                           [&](hipStream_t st) { return segrnn_bwd_impl(desc, bdesc, st); });
+                           [&](hipStream_t st) { return segrnn_bwd_impl(desc, bdesc, chain_ws, chain_ws_bytes, st); });
 }
 
 extern "C" int twog_graph_cache_stats(int64_t* entries, int64_t* collisions) {

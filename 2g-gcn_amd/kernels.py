@@ -77,14 +77,27 @@ class HipKernels:
             self._ws[k] = buf
         return buf
 
+    def chain_workspace(self, device):
+        """(pointer, bytes) of the chain workspace of the CURRENT stream on `device` (include/twog_gcn.h,
+        twog_gemm_f32_chain): arrival tickets (zeroed here, once; every launch returns them to zero) + room for the
+        partial tiles of a reduction split over workgroups. One buffer per (device, stream): launches that share it are
+        ordered by the stream."""
+        k = (str(device), 'chain', int(self._stream() or 0))
+        buf = self._ws.get(k)
+        if buf is None:
+            buf = torch.zeros(int(self.lib.twog_chain_workspace_bytes()) // 4, dtype=torch.float32, device=device)
+            self._ws[k] = buf
+        return buf.data_ptr(), buf.numel() * 4
+
     def version(self):
         return self.lib.twog_version().decode()
 
     # ---------------------------------------------------------------- GEMM
-    def gemm(self, problems, a_kmajor=False, b_kmajor=False, split_k_workspace=True):
+    def gemm(self, problems, a_kmajor=False, b_kmajor=False, split_k_workspace=True, chain=False):
         """problems: list of dicts with keys A, B, C (row-strided views), bias (1-D or None), act (0/1), accumulate.
         Logical shapes: A (M,K) [or stored (K,M) if a_kmajor], B (N,K) [or (K,N) if b_kmajor], C (M,N).
-        Optional 'batch': (n, a_stride, b_stride, c_stride) in elements."""
+        Optional 'batch': (n, a_stride, b_stride, c_stride) in elements. chain=True: a launch of a recurrent chain
+        (twog_gemm_f32_chain: the reduction may be split over workgroups and combined inside the launch)."""
         n = len(problems)
         if n == 0:
             return
@@ -116,6 +129,10 @@ class HipKernels:
                 g.batch, g.a_batch_stride, g.b_batch_stride, g.c_batch_stride = 1, 0, 0, 0
             else:
                 g.batch, g.a_batch_stride, g.b_batch_stride, g.c_batch_stride = b
+        if chain:
+            rc = self.lib.twog_gemm_f32_chain(arr, n, int(a_kmajor), int(b_kmajor), *self.chain_workspace(dev), self._stream())
+            self._check(rc, 'twog_gemm_f32_chain')
+            return
         ws_ptr, ws_bytes = 0, 0
         if split_k_workspace:
             ws = self.workspace(320 << 20, dev, 'splitk')
@@ -124,6 +141,7 @@ class HipKernels:
         self._check(rc, 'twog_gemm_f32')
 
     GEMM_TILE128, GEMM_WAVES8, GEMM_KG, GEMM_SPLITK, GEMM_GATE, GEMM_KSPLIT, GEMM_GRUFWD, GEMM_ROWS32 = 1, 2, 4, 8, 16, 32, 64, 128  # TWOG_GEMM_CLASS_*
+    GEMM_XSPLIT = 256
 
     def gemm_last_class(self):
         """Bit field (GEMM_*) of the kernel variant the most recent gemm() chunk of this thread selected."""
@@ -236,7 +254,7 @@ class HipKernels:
                                                              _ptr(y.get('b_hh_r')))
             a.out, a.save, a.tmp_gh, a.zeros, a.E = out.data_ptr(), save.data_ptr(), tmp.data_ptr(), zeros.data_ptr(), E
             outs.append((out, save))
-        self._check(self.lib.twog_bigru_fwd(arr, n, bs, T, h, self._stream()), 'twog_bigru_fwd')
+        self._check(self.lib.twog_bigru_fwd(arr, n, bs, T, h, *self.chain_workspace(dev), self._stream()), 'twog_bigru_fwd')
         return outs
 
     def bigru_bwd(self, types, bs, T, h):
@@ -258,7 +276,7 @@ class HipKernels:
             a.w_hh_f, a.w_hh_r = y['w_hh_f'].data_ptr(), y['w_hh_r'].data_ptr()
             a.d_gi, a.d_gh, a.carry, a.E = d_gi.data_ptr(), d_gh.data_ptr(), carry.data_ptr(), E
             outs.append((d_gi, d_gh))
-        self._check(self.lib.twog_bigru_bwd(arr, n, bs, T, h, self._stream()), 'twog_bigru_bwd')
+        self._check(self.lib.twog_bigru_bwd(arr, n, bs, T, h, *self.chain_workspace(dev), self._stream()), 'twog_bigru_bwd')
         return outs
 
     # ---------------------------------------------------------------- single GRU gate steps (general segment loop)
@@ -369,7 +387,7 @@ class HipKernels:
                     zeros=torch.zeros(bs * max(H, O, 1), h, dtype=torch.float32, device=dev))
         s = L.SegRnn()
         self._fill_seg(s, p, bufs)
-        self._check(self.lib.twog_segrnn_fwd(C.byref(s), self._stream()), 'twog_segrnn_fwd')
+        self._check(self.lib.twog_segrnn_fwd(C.byref(s), *self.chain_workspace(dev), self._stream()), 'twog_segrnn_fwd')
         return bufs
 
     def segrnn_bwd(self, p, bufs, d_hs_h, d_hs_o):
@@ -394,7 +412,7 @@ class HipKernels:
         b.d_hs_h, b.d_hs_o = _ptr(d_hs_h), _ptr(d_hs_o)
         for k, v in list(out.items()) + list(scratch.items()):
             setattr(b, k, _ptr(v))
-        self._check(self.lib.twog_segrnn_bwd(C.byref(s), C.byref(b), self._stream()), 'twog_segrnn_bwd')
+        self._check(self.lib.twog_segrnn_bwd(C.byref(s), C.byref(b), *self.chain_workspace(dev), self._stream()), 'twog_segrnn_bwd')
         return out
 
     def graph_cache_stats(self):

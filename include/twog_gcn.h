@@ -67,7 +67,20 @@ int twog_gemm_f32(const twog_gemm_t* problems, int n_problems, int a_kmajor, int
 #define TWOG_GEMM_CLASS_KSPLIT  32 /* 64x64 tiles, 8 waves, k-split inside the workgroup */
 #define TWOG_GEMM_CLASS_GRUFWD  64 /* 64 x (64 units x 3 gates) tiles, GRU forward step in the epilogue */
 #define TWOG_GEMM_CLASS_ROWS32  128 /* 32 x 64 tiles (chain launches of small batches)           */
+#define TWOG_GEMM_CLASS_XSPLIT  256 /* reduction split over workgroups, combined inside the launch (last arriver) */
 int twog_gemm_last_class(void);
+
+/* The dependent launches of the recurrent chains (vhoi/models.py:983-1002 frame-level BiGRUs, :785-880 segment loop:
+ * few output tiles, K = h ... 3h, every launch waiting for the previous one). `chain_ws` is a caller-owned scratch of
+ * twog_chain_workspace_bytes() bytes whose first 16 KB (arrival tickets) are ZERO when it is first handed over and are
+ * afterwards left to the library (every launch returns them to zero); with it the library may split the reduction of
+ * such a launch over workgroups and combine the partial tiles inside the launch -- each workgroup publishes its partial
+ * write-through and draws a ticket, the last arriver adds the partials in slice order (bit-reproducible) and runs the
+ * epilogue; no grid barrier, no waiting. NULL: never split. One chain workspace must not be used by launches that can
+ * run concurrently (different streams): give each stream its own. */
+size_t twog_chain_workspace_bytes(void);
+int twog_gemm_f32_chain(const twog_gemm_t* problems, int n_problems, int a_kmajor, int b_kmajor, void* chain_ws,
+                        size_t chain_ws_bytes, void* stream);
 
 /* ===============================================================================================================
  * Geometric-level GCN (pyrutils/torch/models_gcn.py:6-100; called at vhoi/models.py:640-645).
@@ -153,7 +166,8 @@ typedef struct {
     int32_t E;
     int32_t pad_;
 } twog_bigru_t;
-int twog_bigru_fwd(const twog_bigru_t* types, int n_types, int bs, int T, int hidden, void* stream);
+int twog_bigru_fwd(const twog_bigru_t* types, int n_types, int bs, int T, int hidden, void* chain_ws,
+                   size_t chain_ws_bytes, void* stream); /* chain_ws: see twog_gemm_f32_chain (NULL ok) */
 
 typedef struct {
     const float* d_out;  /* [bs][T][E][2h] gradient wrt out                                              */
@@ -167,7 +181,8 @@ typedef struct {
     int32_t E;
     int32_t pad_;
 } twog_bigru_bwd_t;
-int twog_bigru_bwd(const twog_bigru_bwd_t* types, int n_types, int bs, int T, int hidden, void* stream);
+int twog_bigru_bwd(const twog_bigru_bwd_t* types, int n_types, int bs, int T, int hidden, void* chain_ws,
+                   size_t chain_ws_bytes, void* stream);
 
 /* ===============================================================================================================
  * Fusion-level attention message passing (vhoi/models.py:1004-1475, :1693-1754) for message_type 'v2', granularity
@@ -248,7 +263,7 @@ typedef struct {
     float* tmp_gh_o;  /* scratch [2][bs*O][3h] */
     float* zeros;     /* [bs*max(H,O)][h] zeros */
 } twog_segrnn_t;
-int twog_segrnn_fwd(const twog_segrnn_t* desc, void* stream);
+int twog_segrnn_fwd(const twog_segrnn_t* desc, void* chain_ws, size_t chain_ws_bytes, void* stream); /* chain_ws: see twog_gemm_f32_chain */
 
 typedef struct {
     const float* d_hs_h; /* [bs][T][H][2h] gradient wrt hs_h */
@@ -272,7 +287,8 @@ typedef struct {
     float* du_part_h;
     float* du_part_o;
 } twog_segrnn_bwd_t;
-int twog_segrnn_bwd(const twog_segrnn_t* desc, const twog_segrnn_bwd_t* bdesc, void* stream);
+int twog_segrnn_bwd(const twog_segrnn_t* desc, const twog_segrnn_bwd_t* bdesc, void* chain_ws, size_t chain_ws_bytes,
+                    void* stream);
 /* hipGraph cache of the time loops (twog_bigru_*, twog_segrnn_*): number of captured loops and of hash-bucket hits whose
  * descriptor bytes differed (each was resolved by the byte compare; see csrc/graph_cache.h). Diagnostics / tests. */
 int twog_graph_cache_stats(int64_t* entries, int64_t* collisions);

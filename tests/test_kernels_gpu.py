@@ -2,6 +2,9 @@
 (tests/fake_kernels.py, plain torch fp32 on CPU) on seeded random inputs, including strided views, ragged sizes,
 masks and the split-K / grouped / batched GEMM forms. Tolerances are fp32 summation-order tolerances."""
 import math
+import os
+import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -13,6 +16,7 @@ from tests.fake_kernels import FakeKernels
 
 pytestmark = pytest.mark.gpu
 DEV = 'cuda:0'
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.fixture(scope='module')
@@ -578,7 +582,7 @@ def test_out_of_range_descriptors_are_rejected_before_any_launch(K):
     assert lib.twog_bn_stats(None, 0, 8, max_nodes + 1, None, 4, st) < 0
     assert lib.twog_bn_stats(None, 0, 8, 0, None, 4, st) < 0
     assert lib.twog_gcn_attn2_fwd(None, None, 8, max_nodes + 1, None, None, st) < 0
-    assert lib.twog_bigru_fwd(None, 5, 2, 3, 32, st) < 0
+    assert lib.twog_bigru_fwd(None, 5, 2, 3, 32, None, 0, st) < 0
     assert lib.twog_attn_fwd(None, 5, st) < 0                      # more descriptor groups than one launch carries
     g = _lib.Gate()
     g.bs, g.T, g.E, g.n_seg = 2, 3, 2, 9                             # more gate-input column segments than the struct holds
@@ -619,7 +623,7 @@ def _graph_collision_scenario():
     for rep in range(5):            # sighting, capture, replays -- interleaved between the two loops
         for bs, arr, bufs, d, want in cases:
             bufs['out'].fill_(float('nan'))
-            assert K.lib.twog_bigru_fwd(arr, 1, bs, T, h, st) == 0
+            assert K.lib.twog_bigru_fwd(arr, 1, bs, T, h, *K.chain_workspace(DEV), st) == 0
             close(bufs['out'], want, rtol=1e-4, atol=1e-5, what=f'bigru rep {rep} bs {bs}')
     return K.graph_cache_stats()
 
@@ -985,7 +989,7 @@ def test_bigru_forward_graph_capture_and_replay_at_baseline_width(K):
     for rep in range(4):
         for _, bufs in keep:
             bufs['out'].fill_(float('nan'))
-        assert K.lib.twog_bigru_fwd(arr, 3, bs, T, h, st) == 0
+        assert K.lib.twog_bigru_fwd(arr, 3, bs, T, h, *K.chain_workspace(DEV), st) == 0
         for (_, bufs), want in zip(keep, wants):
             close(bufs['out'], want, rtol=1e-4, atol=1e-5, what=f'bigru rep {rep}')
     assert K.graph_cache_stats()[0] == n0 + 1   # the loop was captured (and replayed twice)
@@ -1019,6 +1023,74 @@ def test_gemm_ksplit_class(K, bkm):
         if act:
             ref = torch.relu(ref)
         assert (Cg.double() - ref).abs().max().item() <= 3e-5 * ref.abs().max().item()
+
+
+@pytest.mark.parametrize('bkm', [False, True])
+@pytest.mark.parametrize('force', ['0', '2', '3', '8'])
+def test_gemm_chain_split_over_workgroups(K, bkm, force):
+    """Chain launches with the reduction split over WORKGROUPS and combined inside the launch by the last arriver
+    (TWOG_GEMM_CLASS_XSPLIT): 64x64 and 32x64 tiles, bias / ReLU / accumulate epilogues, ragged edges, a grouped launch
+    that mixes reduction lengths, the library's own choice of the slice count (force 0) and forced ones -- in a child
+    process per setting (the variable is read once). Against fp64; bit-identical from launch to launch (the partials are
+    added in slice order whoever arrives last); the tickets return to zero."""
+    code = r"""
+import sys, torch
+sys.path.insert(0, %r)
+import twog_gcn_amd
+from twog_gcn_amd.kernels import get_kernels
+K = get_kernels(); DEV = 'cuda:0'; bkm = %r; force = %r
+def run(probs, expect_xs):
+    outs = []
+    for rep in range(3):
+        ps = [dict(p, C=p['C0'].clone()) for p in probs]
+        K.gemm([{k: v for k, v in p.items() if k != 'C0'} for p in ps], b_kmajor=bkm, chain=True)
+        cls = K.gemm_last_class()
+        outs.append([p['C'] for p in ps])
+    assert bool(cls & K.GEMM_XSPLIT) == expect_xs, (hex(cls), expect_xs, [tuple(p['C'].shape) for p in ps])
+    for p, Cg in zip(probs, outs[0]):
+        A, B = p['A'], p['B']
+        ref = A.double() @ (B.double() if bkm else B.double().t())
+        if p.get('bias') is not None: ref = ref + p['bias'].double()
+        if p.get('accumulate'): ref = ref + p['C0'].double()
+        if p.get('act'): ref = torch.relu(ref)
+        err = (Cg.double() - ref).abs().max().item()
+        assert err <= 3e-5 * ref.abs().max().item(), (err, tuple(Cg.shape))
+    for o in outs[1:]:
+        for a, b in zip(outs[0], o):
+            assert torch.equal(a, b), 'launch-to-launch difference'
+    ptr, nbytes = K.chain_workspace(DEV)
+    tickets = K._ws[(str(DEV), 'chain', int(K._stream() or 0))][:4096].view(torch.int32)
+    assert int(tickets.abs().max()) == 0, 'tickets not returned to zero'
+def prob(M, N, K_, bias, act, acc, seed):
+    g = torch.Generator().manual_seed(seed)
+    A = torch.randn(M, K_, generator=g).to(DEV)
+    B = ((torch.randn(K_, N, generator=g) if bkm else torch.randn(N, K_, generator=g)) * 0.1).to(DEV)
+    return dict(A=A, B=B, C0=torch.randn(M, N, generator=g).to(DEV), bias=torch.randn(N, generator=g).to(DEV) if bias else None,
+                act=act, accumulate=acc)
+forced = force != '0'
+# (shape, does the library's own cost model split it?)
+for (M, N, K_, bias, act, acc), model_xs in (((1408, 512, 1536, False, 0, True), True),     # BiGRU backward carry, bs64: 176 tiles
+                                             ((176, 512, 1536, False, 0, True), True),      # 8 clips: 32-row tiles
+                                             ((176, 1536, 512, True, 1, False), False),     # 8 clips: W_hh projection (short K)
+                                             ((130, 200, 288, True, 0, True), False),       # ragged edges, 9 k-tiles
+                                             ((33, 70, 256, True, 1, False), False)):
+    if force == '8' and K_ < 512:
+        continue
+    run([prob(M, N, K_, bias, act, acc, M + N)], True if forced else model_xs)
+# grouped launch mixing reduction lengths (the segment level's projection step: K = h and K = 2h)
+K.gemm_last_class()
+probs = [prob(128, 1536, 512, True, 0, False, 1), prob(128, 1536, 1024, False, 0, False, 2),
+         prob(64, 1536, 512, True, 0, False, 3), prob(64, 1536, 1024, False, 0, True, 4)]
+if forced:
+    run(probs, True)
+else:   # whatever the model decides for this one, the result must be right and reproducible
+    K.gemm([dict({k: v for k, v in p.items() if k != 'C0'}, C=p['C0'].clone()) for p in probs], b_kmajor=bkm, chain=True)
+    run(probs, bool(K.gemm_last_class() & K.GEMM_XSPLIT))
+print('OK')
+""" % (ROOT, bkm, force)
+    env = dict(os.environ, TWOG_GEMM_XSPLIT=force)
+    r = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and 'OK' in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
 
 
 def test_ssp_gather_with_segment_level_placement(K):
