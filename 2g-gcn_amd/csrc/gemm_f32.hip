@@ -1081,6 +1081,15 @@ static int pick_xsplit(int tiles, int kmax, int bm, size_t ws_bytes) {
     const int kt = (kmax + BK - 1) / BK;
     const size_t tile_bytes = (size_t)bm * 64 * sizeof(float);
     const int by_ws = (int)((ws_bytes - XS_COUNTER_BYTES) / (tile_bytes * (size_t)tiles));
+    if (bm == 32 && force <= 1) {
+        // small batches (32-row tiles, at most one per CU): every launch is latency-bound and the hand-off costs about a
+        // microsecond at this scale; measured (tools/xs_sweep.sh, 8 clips): K = 1 536: 22 -> 12 us for 4 ... 8 slices,
+        // K = 1 024: 17 -> 11.5, K = 512: 10.4 ... 11.3 -> 8.6 ... 10.9 at 4 slices. Slices of four k-tiles, at most 8 of them,
+        // at most two workgroups per CU.
+        int S = kt / 4 < 8 ? kt / 4 : 8;
+        while (S > 1 && (tiles * S > 512 || S > by_ws)) --S;
+        return S < 1 ? 1 : S;
+    }
     const double unit = bm == 32 ? 0.25 : 0.49;
     auto cost = [&](int S) {
         const int per_cu = (tiles * S + 255) / 256, kts = (kt + S - 1) / S;
@@ -1092,7 +1101,7 @@ static int pick_xsplit(int tiles, int kmax, int bm, size_t ws_bytes) {
     for (int S : cand) {
         if (S > by_ws || kt / S < 2) break;
         const double c = force > 1 ? (S == force ? -1.0 : 1e30) : cost(S);
-        if (c < best_c - 1.0) { best_c = c; best = S; }
+        if (c < best_c - 2.5) { best_c = c; best = S; }   // a split must be worth more than the model's error
     }
     return best;
 }

@@ -1068,24 +1068,25 @@ def prob(M, N, K_, bias, act, acc, seed):
     return dict(A=A, B=B, C0=torch.randn(M, N, generator=g).to(DEV), bias=torch.randn(N, generator=g).to(DEV) if bias else None,
                 act=act, accumulate=acc)
 forced = force != '0'
-# (shape, does the library's own cost model split it?)
-for (M, N, K_, bias, act, acc), model_xs in (((1408, 512, 1536, False, 0, True), True),     # BiGRU backward carry, bs64: 176 tiles
+def auto(probs):   # the library's own decision for this launch
+    K.gemm([dict({k: v for k, v in p.items() if k != 'C0'}, C=p['C0'].clone()) for p in probs], b_kmajor=bkm, chain=True)
+    return bool(K.gemm_last_class() & K.GEMM_XSPLIT)
+# (shape, must the library's own model split it? None = either way)
+for (M, N, K_, bias, act, acc), model_xs in (((1408, 512, 1536, False, 0, True), None),     # BiGRU backward carry, bs64: 176 tiles
+                                             ((1280, 1024, 1536, False, 0, False), True),   # segment d_mg, bs64: 320 tiles
                                              ((176, 512, 1536, False, 0, True), True),      # 8 clips: 32-row tiles
-                                             ((176, 1536, 512, True, 1, False), False),     # 8 clips: W_hh projection (short K)
-                                             ((130, 200, 288, True, 0, True), False),       # ragged edges, 9 k-tiles
-                                             ((33, 70, 256, True, 1, False), False)):
+                                             ((176, 1536, 512, True, 1, False), True),      # 8 clips: W_hh projection
+                                             ((130, 200, 288, True, 0, True), None),        # ragged edges, 9 k-tiles
+                                             ((33, 70, 256, True, 1, False), None)):
     if force == '8' and K_ < 512:
         continue
-    run([prob(M, N, K_, bias, act, acc, M + N)], True if forced else model_xs)
+    p = [prob(M, N, K_, bias, act, acc, M + N)]
+    expect = True if forced else (model_xs if model_xs is not None else auto(p))
+    run(p, expect)
 # grouped launch mixing reduction lengths (the segment level's projection step: K = h and K = 2h)
-K.gemm_last_class()
 probs = [prob(128, 1536, 512, True, 0, False, 1), prob(128, 1536, 1024, False, 0, False, 2),
          prob(64, 1536, 512, True, 0, False, 3), prob(64, 1536, 1024, False, 0, True, 4)]
-if forced:
-    run(probs, True)
-else:   # whatever the model decides for this one, the result must be right and reproducible
-    K.gemm([dict({k: v for k, v in p.items() if k != 'C0'}, C=p['C0'].clone()) for p in probs], b_kmajor=bkm, chain=True)
-    run(probs, bool(K.gemm_last_class() & K.GEMM_XSPLIT))
+run(probs, True if forced else auto(probs))
 print('OK')
 """ % (ROOT, bkm, force)
     env = dict(os.environ, TWOG_GEMM_XSPLIT=force)
