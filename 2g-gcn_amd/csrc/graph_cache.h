@@ -1,10 +1,11 @@
 // hipGraph cache for the launch-bound time loops (frame-level BiGRU and segment-level recurrence, forward and
-// backward: 240-720 dependent launches per call).
-//
-// The loops are enqueued by host code in this library; at small batch the kernels are shorter than the host's launch
-// cost and the step becomes host-bound. A loop is therefore captured once into a hipGraph (stream capture of exactly the
-// launches the loop issues) and replayed with one hipGraphLaunch while its descriptor -- every pointer, shape and stride
-// -- stays the same, which is the steady state of a training loop under a caching allocator. The 64-bit hash of the
+// backward: 240-720 dependent launches per call). OPT-IN since round 3 (TWOG_GRAPHS=1; TWOG_NO_GRAPHS=1 still forces it
+// off): the loops' kernels are no longer shorter than the C++ launch path that issues them (fused gate epilogues, fewer
+// and longer launches), and a replayed node costs 0.8-1.6 us MORE than the same kernel launched directly on ROCm 7.2
+// (bench, graphs on -> off: bs64 84.8 -> 83.9 ms, 8 clips hs512 26.1 -> 24.7 ms, 16 clips h=64 20.9 -> 18.9 ms per step).
+// The graphs remain the remedy for a host-bound deployment (slow or shared host cores): then a loop is captured once
+// (stream capture of exactly the launches the loop issues) and replayed with one hipGraphLaunch while its descriptor --
+// every pointer, shape and stride -- stays the same, the steady state of a training loop under a caching allocator. The 64-bit hash of the
 // descriptor only picks the bucket: every entry keeps the descriptor BYTES and a hit is confirmed with a compare, so two
 // descriptors that collide can never replay each other's pointers (a mismatch probes on under a salted key and
 // captures its own graph). The cache is small (64 loops) and flushed when full. TWOG_NO_GRAPHS=1 turns it off;
@@ -61,8 +62,9 @@ inline uint64_t collisions() { return state().collisions; }
 // stream, which cannot be captured), fenced against the caller's stream with two events.
 template <class F>
 int run(const Desc& d, hipStream_t user, F enqueue) {
-    static const bool off = getenv("TWOG_NO_GRAPHS") != nullptr;
-    if (off) return enqueue(user);
+    // read per call (two getenv calls against hundreds of launches): tests switch it inside one process
+    const char* on_env = getenv("TWOG_GRAPHS");
+    if (!on_env || atoi(on_env) == 0 || getenv("TWOG_NO_GRAPHS") != nullptr) return enqueue(user);
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES) {
         (void)hipGetLastError();

@@ -635,7 +635,7 @@ def test_graph_cache_survives_hash_collisions():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     code = ('import tests.test_kernels_gpu as t; n, c = t._graph_collision_scenario(); '
             'assert c > 0, (n, c); assert n >= 2, (n, c); print("collisions resolved:", n, c)')
-    r = subprocess.run([sys.executable, '-c', code], cwd=root, env=dict(os.environ, TWOG_GRAPH_HASH_BITS='0'),
+    r = subprocess.run([sys.executable, '-c', code], cwd=root, env=dict(os.environ, TWOG_GRAPH_HASH_BITS='0', TWOG_GRAPHS='1'),
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and 'collisions resolved' in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
@@ -964,10 +964,11 @@ def test_attention_backward_takes_extra_weight_gradient(K):
     assert float((b0['dfeat_h'] - bc['dfeat_h']).abs().max()) > 1e-4   # the extra term does reach the features
 
 
-def test_bigru_forward_graph_capture_and_replay_at_baseline_width(K):
+def test_bigru_forward_graph_capture_and_replay_at_baseline_width(K, monkeypatch):
     """BASELINE-size BiGRU step (three entity types, 528 tiles): first sighting (direct launches), capture into a
-    hipGraph and two replays must all give the specification's result."""
+    hipGraph and two replays must all give the specification's result (the opt-in graph path: TWOG_GRAPHS=1)."""
     from twog_gcn_amd import _lib as L
+    monkeypatch.setenv('TWOG_GRAPHS', '1')
     bs, T, h = 64, 3, 512
     ws = 0.2 * math.sqrt(64.0 / h)
     arr = (L.BiGru * 3)()

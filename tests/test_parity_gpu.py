@@ -315,6 +315,41 @@ def test_full_size_determinism_and_batch_independence():
         assert err < REL * max(1.0, b.abs().max().item()), err
 
 
+def test_graph_replay_path_matches_direct_launches(monkeypatch):
+    """The opt-in hipGraph path of the four time loops (TWOG_GRAPHS=1: first sighting direct, then capture, then replays)
+    gives bit for bit what the default direct launches give, forward and backward, step after step."""
+    bs, T, H, O, N, h = 4, 12, 2, 4, 26, 64
+    torch.manual_seed(2)
+    m = TGGCN(input_size=(2048 + 4 * N, 2048), num_classes=(13, None), hidden_size=h, gcn_node=N, **STAGE1).to(DEV).train()
+    x_human, x_objects, mask = (t.to(DEV) for t in _synthetic(bs, T, H, O, N, 4))
+    seg = torch.ones(bs, T, H, device=DEV)
+    m._gumbel_noise_override = torch.distributions.gumbel.Gumbel(0.0, 1.0).sample((T * O, bs, 2))
+    bn = m.geometry_embedding_gcn.joint_embed.cnn[0].bn
+    stats0 = twog_kernels.get_kernels().graph_cache_stats()[0]
+
+    def step(check=None):
+        m.zero_grad(set_to_none=True)
+        bn.running_mean.zero_(); bn.running_var.fill_(1.0)
+        out = m(x_human, x_objects, mask, human_segmentation=seg)
+        (out[4].sum() + out[5].sum() + out[1].sum()).backward()
+        if check is None:
+            return [o.detach().clone() for o in out], {n_: p.grad.clone() for n_, p in m.named_parameters() if p.grad is not None}
+        # compared in place: no allocation that outlives the step, so every step sees the same buffer addresses -- the
+        # steady state of a training loop, and what the capture-on-second-sighting rule keys on
+        for a, b in zip(out, check[0]):
+            assert torch.equal(a.detach(), b)
+        for n_, g in check[1].items():
+            assert torch.equal(dict(m.named_parameters())[n_].grad, g), n_
+        return None
+
+    direct = step()
+    assert twog_kernels.get_kernels().graph_cache_stats()[0] == stats0
+    monkeypatch.setenv('TWOG_GRAPHS', '1')
+    for _ in range(5):
+        step(direct)
+    assert twog_kernels.get_kernels().graph_cache_stats()[0] > stats0, 'no loop was captured'
+
+
 # ------------------------------------------------------------------------------------------------- edge cases
 @pytest.mark.parametrize('bs,T,H,O,N,h,mask_mode', [
     (1, 1, 2, 4, 26, 32, 'all'),        # single clip, single frame (chain start == chain end, forced last gate)
