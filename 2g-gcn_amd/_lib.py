@@ -135,8 +135,9 @@ SIGNATURES = {
     'twog_gemm_f32_chain': [C.POINTER(Gemm), _I, _I, _I, _P, C.c_size_t, _P],
     'twog_gcn_max_nodes': [],
     'twog_bn_stats': [_P, _L, _I, _I, _P, _I, _P],
-    'twog_bn_finalize': [_P, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _P, _P],
+    'twog_bn_finalize': [_P, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P],
     'twog_gcn_embed1_fwd': [_P, _L, _I, _I, _P, _P, _P, _P, _P],
+    'twog_gcn_fused_fwd': [_P, _L, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     'twog_gcn_embed1_bwd': [_P, _L, _I, _I, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P],
     'twog_gcn_attn_fwd': [_P, _P, _I, _I, _P, _P, _P],
     'twog_gcn_attn_bwd': [_P, _P, _P, _P, _I, _I, _P, _P, _P],

@@ -24,49 +24,113 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float* x, int64_t f
     const int per = (n_frames + gridDim.x - 1) / gridDim.x;
     const int f0 = blockIdx.x * per, f1 = min(n_frames, f0 + per);
     if (pos >= nch) return;
-    double s = 0.0, q = 0.0;
-    for (int f = f0; f < f1; ++f) {
-        const double v = (double)x[(int64_t)f * fstride + pos];
-        s += v;
-        q += v * v;
+    // four frames in flight (the loop is bound by the latency of its loads, not by the two fp64 adds); the partial sums
+    // are combined in a fixed order: bit-reproducible
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0, q0 = 0.0, q1 = 0.0, q2 = 0.0, q3 = 0.0;
+    int f = f0;
+    for (; f + 4 <= f1; f += 4) {
+        const double v0 = (double)x[(int64_t)f * fstride + pos], v1 = (double)x[(int64_t)(f + 1) * fstride + pos];
+        const double v2 = (double)x[(int64_t)(f + 2) * fstride + pos], v3 = (double)x[(int64_t)(f + 3) * fstride + pos];
+        s0 += v0; q0 += v0 * v0;
+        s1 += v1; q1 += v1 * v1;
+        s2 += v2; q2 += v2 * v2;
+        s3 += v3; q3 += v3 * v3;
     }
+    for (; f < f1; ++f) {
+        const double v = (double)x[(int64_t)f * fstride + pos];
+        s0 += v; q0 += v * v;
+    }
+    const double s = (s0 + s1) + (s2 + s3), q = (q0 + q1) + (q2 + q3);
     const int ch = (pos & 3) * N + (pos >> 2);
     partials[((int64_t)blockIdx.x * 2 + 0) * nch + ch] = s;
     partials[((int64_t)blockIdx.x * 2 + 1) * nch + ch] = q;
 }
 
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const double* partials, int n_blocks, int n_frames, int nch,
-                                                          const float* gamma, const float* beta, float* rmean,
-                                                          float* rvar, long long* nbt, int training, float* ab,
-                                                          float* mean_invstd) {
-    const int ch = threadIdx.x;
-    if (ch == 0 && training && nbt) *nbt += 1;
-    if (ch >= nch) return;
-    float mean, var;
+// Workgroup 0 (1024 threads): thread = (channel, one of 4 partial lanes); lane p adds the blocks p, p + 4, ... of its
+// channel, the four sums meet in LDS in fixed order. Workgroups 1 .. 65 (md_out != NULL) fold the two similarity
+// projections of compute_similarity (models_gcn.py:95-100) for the fused forward kernel (geo_fused.hip):
+// md_out[n][k] = sum_o Wk[o][n] Wq[o][k] (n, k < 64), md_out[64][n] = sum_o Wk[o][n] bq[o]  (theta_i . phi_j = x_i^T M x_j
+// + d . x_j + terms constant in j) -- 0.5 MFLOP, not worth a launch of its own.
+__global__ __launch_bounds__(1024) void bn_finalize_kernel(const double* partials, int n_blocks, int n_frames, int nch,
+                                                           const float* gamma, const float* beta, float* rmean,
+                                                           float* rvar, long long* nbt, int training, float* ab,
+                                                           float* mean_invstd, const float* wq, const float* wk,
+                                                           const float* bq, float* md_out) {
+    __shared__ double red[2][4][256];
+    __shared__ float mred[16][64];
+    if (blockIdx.x > 0) {
+        // blocks 1 .. 65: row n = blockIdx.x - 1 of md (row 64 = d). Thread = (output k, one of 16 slices of the 128-term sum):
+        // eight independent loads per operand in flight, the 16 slice sums added in fixed order through LDS
+        const int n = blockIdx.x - 1, k = threadIdx.x & 63, sl = threadIdx.x >> 6;
+        float a[8], b[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int o = sl * 8 + u;
+            a[u] = n < 64 ? wk[o * 64 + n] : bq[o];
+            b[u] = n < 64 ? wq[o * 64 + k] : wk[o * 64 + k];
+        }
+        float acc = 0.f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc = fmaf(a[u], b[u], acc);
+        mred[sl][k] = acc;
+        __syncthreads();
+        if (sl == 0) {
+            float t = 0.f;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) t += mred[j][k];
+            md_out[n * 64 + k] = t;
+        }
+        return;
+    }
+    const int ch = threadIdx.x & 255, part = threadIdx.x >> 8;
+    if (threadIdx.x == 0 && training && nbt) *nbt += 1;
     if (training) {
         double s = 0.0, q = 0.0;
-        for (int b = 0; b < n_blocks; ++b) {
-            s += partials[((int64_t)b * 2 + 0) * nch + ch];
-            q += partials[((int64_t)b * 2 + 1) * nch + ch];
+        if (ch < nch) {
+            int b = part;
+            for (; b + 28 < n_blocks; b += 32) {   // eight blocks' partials in flight (latency-bound loads), added in order
+                double ps[8], pq[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    ps[u] = partials[((int64_t)(b + 4 * u) * 2 + 0) * nch + ch];
+                    pq[u] = partials[((int64_t)(b + 4 * u) * 2 + 1) * nch + ch];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { s += ps[u]; q += pq[u]; }
+            }
+            for (; b < n_blocks; b += 4) {
+                s += partials[((int64_t)b * 2 + 0) * nch + ch];
+                q += partials[((int64_t)b * 2 + 1) * nch + ch];
+            }
         }
-        const double m = s / n_frames;
-        double v = q / n_frames - m * m;
-        if (v < 0.0) v = 0.0;
-        mean = (float)m;
-        var = (float)v;
-        const double unb = n_frames > 1 ? v * ((double)n_frames / (n_frames - 1)) : v;
-        rmean[ch] = 0.9f * rmean[ch] + 0.1f * mean;  // momentum 0.1 (torch default, models_gcn.py:43)
-        rvar[ch] = 0.9f * rvar[ch] + 0.1f * (float)unb;
-    } else {
-        mean = rmean[ch];
-        var = rvar[ch];
+        red[0][part][ch] = s;
+        red[1][part][ch] = q;
     }
-    const float invstd = 1.0f / sqrtf(var + 1e-5f);
-    const float a = gamma[ch] * invstd;
-    ab[ch] = a;
-    ab[nch + ch] = beta[ch] - mean * a;
-    mean_invstd[ch] = mean;
-    mean_invstd[nch + ch] = invstd;
+    __syncthreads();
+    if (part == 0 && ch < nch) {
+        float mean, var;
+        if (training) {
+            const double s = (red[0][0][ch] + red[0][1][ch]) + (red[0][2][ch] + red[0][3][ch]);
+            const double q = (red[1][0][ch] + red[1][1][ch]) + (red[1][2][ch] + red[1][3][ch]);
+            const double m = s / n_frames;
+            double v = q / n_frames - m * m;
+            if (v < 0.0) v = 0.0;
+            mean = (float)m;
+            var = (float)v;
+            const double unb = n_frames > 1 ? v * ((double)n_frames / (n_frames - 1)) : v;
+            rmean[ch] = 0.9f * rmean[ch] + 0.1f * mean;  // momentum 0.1 (torch default, models_gcn.py:43)
+            rvar[ch] = 0.9f * rvar[ch] + 0.1f * (float)unb;
+        } else {
+            mean = rmean[ch];
+            var = rvar[ch];
+        }
+        const float invstd = 1.0f / sqrtf(var + 1e-5f);
+        const float a = gamma[ch] * invstd;
+        ab[ch] = a;
+        ab[nch + ch] = beta[ch] - mean * a;
+        mean_invstd[ch] = mean;
+        mean_invstd[nch + ch] = invstd;
+    }
 }
 
 // e1[(f,n)][j] = relu(sum_c W1[j][c] * (a[ch]*x[f][n][c] + b[ch]) + b1[j]); block = 4 rows x 64 outputs
@@ -81,10 +145,12 @@ __global__ __launch_bounds__(256) void embed1_fwd_kernel(const float* x, int64_t
     for (int64_t r = (int64_t)blockIdx.x * 4 + rl; r < rows; r += (int64_t)gridDim.x * 4) {
         const int f = (int)(r / N), n = (int)(r - (int64_t)f * N);
         const float4 v = *reinterpret_cast<const float4*>(x + (int64_t)f * fstride + n * 4);
-        const float x0 = ab[n] * v.x + ab[nch + n];
-        const float x1 = ab[N + n] * v.y + ab[nch + N + n];
-        const float x2 = ab[2 * N + n] * v.z + ab[nch + 2 * N + n];
-        const float x3 = ab[3 * N + n] * v.w + ab[nch + 3 * N + n];
+        // (explicit fused multiply-adds: bit-identical to the copy of this arithmetic inside gcn_fused_fwd_kernel,
+        // geo_fused.hip -- the backward pass recomputes e1 here and masks with its signs)
+        const float x0 = fmaf(ab[n], v.x, ab[nch + n]);
+        const float x1 = fmaf(ab[N + n], v.y, ab[nch + N + n]);
+        const float x2 = fmaf(ab[2 * N + n], v.z, ab[nch + 2 * N + n]);
+        const float x3 = fmaf(ab[3 * N + n], v.w, ab[nch + 3 * N + n]);
         float acc = bj;
         acc = fmaf(w.x, x0, acc);
         acc = fmaf(w.y, x1, acc);
@@ -325,11 +391,12 @@ extern "C" int twog_bn_stats(const float* x_geo, int64_t frame_stride, int n_fra
 extern "C" int twog_bn_finalize(const double* partials, int n_blocks, int n_frames, int n_nodes, const float* gamma,
                                 const float* beta, float* running_mean, float* running_var,
                                 int64_t* num_batches_tracked, int training, float* ab, float* mean_invstd,
-                                void* stream) {
+                                const float* wq, const float* wk, const float* bq, float* md_out, void* stream) {
     if (n_nodes > MAX_NODES || n_nodes < 1) return -1;
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partials, n_blocks, n_frames,
+    if (md_out && !(wq && wk && bq)) return -2;
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(md_out ? 66 : 1), dim3(1024), 0, (hipStream_t)stream, partials, n_blocks, n_frames,
                        4 * n_nodes, gamma, beta, running_mean, running_var, (long long*)num_batches_tracked, training,
-                       ab, mean_invstd);
+                       ab, mean_invstd, wq, wk, bq, md_out);
     TWOG_CHECK_LAUNCH();
     return 0;
 }

@@ -156,26 +156,31 @@ class HipKernels:
         return x_human.data_ptr() + 2048 * 4, H * Fh, bs * T
 
     def bn_fold(self, x_human, n_nodes, gamma, beta, running_mean, running_var, num_batches_tracked, training,
-                stats_reduce=None):
+                stats_reduce=None, fold=None):
         """stats_reduce (optional, sync-BN of distributed.DataParallel): callable (sums fp64 [2*4N], n_frames) ->
-        (sums reduced over the ranks, total frames); applied to the batch statistics before they are folded."""
+        (sums reduced over the ranks, total frames); applied to the batch statistics before they are folded.
+        fold = (wq [128,64], wk [128,64], bq [128]): the same launch also folds the similarity projections into
+        md [65,64] = [Mt | d] (see twog_bn_finalize); then returns (ab, mi, md)."""
         ptr, fstride, nf = self._geo(x_human)
         nch = 4 * n_nodes
-        ab = torch.empty(2, nch, dtype=torch.float32, device=x_human.device)
-        mi = torch.empty(2, nch, dtype=torch.float32, device=x_human.device)
-        nblk = 64
-        partials = torch.empty(nblk * 2 * nch, dtype=torch.float64, device=x_human.device)
+        dev = x_human.device
+        ab = torch.empty(2, nch, dtype=torch.float32, device=dev)
+        mi = torch.empty(2, nch, dtype=torch.float32, device=dev)
+        nblk = max(1, min(240, nf // 8))   # >= 8 frames per block, at most 240 blocks (the finalize kernel sums them 4-wide)
+        partials = torch.empty(nblk * 2 * nch, dtype=torch.float64, device=dev)
         if training:
             self._check(self.lib.twog_bn_stats(ptr, fstride, nf, n_nodes, partials.data_ptr(), nblk, self._stream()),
                         'twog_bn_stats')
             if stats_reduce is not None:
                 partials, nf = stats_reduce(partials.view(nblk, 2 * nch).sum(0), nf)
                 partials, nblk = partials.contiguous(), 1
+        md = torch.empty(65, 64, dtype=torch.float32, device=dev) if fold is not None else None
+        wq, wk, bq = fold if fold is not None else (None, None, None)
         self._check(self.lib.twog_bn_finalize(partials.data_ptr(), nblk, nf, n_nodes, gamma.data_ptr(),
                                               beta.data_ptr(), running_mean.data_ptr(), running_var.data_ptr(),
                                               _ptr(num_batches_tracked), int(training), ab.data_ptr(), mi.data_ptr(),
-                                              self._stream()), 'twog_bn_finalize')
-        return ab, mi
+                                              _ptr(wq), _ptr(wk), _ptr(bq), _ptr(md), self._stream()), 'twog_bn_finalize')
+        return (ab, mi) if fold is None else (ab, mi, md)
 
     def gcn_embed1_fwd(self, x_human, n_nodes, ab, w1, b1):
         ptr, fstride, nf = self._geo(x_human)
@@ -183,6 +188,18 @@ class HipKernels:
         self._check(self.lib.twog_gcn_embed1_fwd(ptr, fstride, nf, n_nodes, ab.data_ptr(), w1.data_ptr(),
                                                  b1.data_ptr(), e1.data_ptr(), self._stream()), 'twog_gcn_embed1_fwd')
         return e1
+
+    def gcn_fused_fwd(self, x_human, n_nodes, ab, w1, b1, w2, b2, md, save_x=True):
+        """Geo_gcn forward up to the aggregation in one kernel: returns (X or None, adj [F,N,N], Z [(f,n),64])."""
+        ptr, fstride, nf = self._geo(x_human)
+        dev = x_human.device
+        X = torch.empty(nf * n_nodes, 64, dtype=torch.float32, device=dev) if save_x else None
+        adj = torch.empty(nf, n_nodes, n_nodes, dtype=torch.float32, device=dev)
+        Z = torch.empty(nf * n_nodes, 64, dtype=torch.float32, device=dev)
+        self._check(self.lib.twog_gcn_fused_fwd(ptr, fstride, nf, n_nodes, ab.data_ptr(), w1.data_ptr(), b1.data_ptr(),
+                                                w2.data_ptr(), b2.data_ptr(), md.data_ptr(), _ptr(X), adj.data_ptr(),
+                                                Z.data_ptr(), self._stream()), 'twog_gcn_fused_fwd')
+        return X, adj, Z
 
     def gcn_embed1_bwd(self, x_human, n_nodes, ab, mean_invstd, w1, de1):
         ptr, fstride, nf = self._geo(x_human)

@@ -402,7 +402,7 @@ def _lin_w_grads(K, G, wname, bname, dY, X, cols=None, total=None):
             G.add(bname, K.colsum(dY))
 
 
-def geo_gcn_forward(K, P, x_human, bs, T, N, training, bn_bufs, S):
+def geo_gcn_forward(K, P, x_human, bs, T, N, training, bn_bufs, S, save_x=True):
     """Geo_gcn.forward (pyrutils/torch/models_gcn.py:30-37) on the geometry block of x_human; returns the (bs, 128, N, T)
     output and stores what the backward needs in S. Algorithmic HBM bytes: T*(16N + 512N) per clip."""
     dev, nF = x_human.device, bs * T
@@ -411,27 +411,25 @@ def geo_gcn_forward(K, P, x_human, bs, T, N, training, bn_bufs, S):
         return torch.empty(*shape, dtype=torch.float32, device=dev)
 
     g = 'geometry_embedding_gcn.'
-    ab, mi = K.bn_fold(x_human, N, P[g + 'joint_embed.cnn.0.bn.weight'], P[g + 'joint_embed.cnn.0.bn.bias'],
-                       bn_bufs['running_mean'], bn_bufs['running_var'], bn_bufs['num_batches_tracked'], training,
-                       stats_reduce=bn_bufs.get('stats_reduce'))
-    w1 = P[g + 'joint_embed.cnn.1.cnn.weight'].view(64, 4)
-    e1 = K.gcn_embed1_fwd(x_human, N, ab, w1, P[g + 'joint_embed.cnn.1.cnn.bias'])
-    w2 = P[g + 'joint_embed.cnn.3.cnn.weight'].view(64, 64)
-    X = empty(nF * N, 64)
-    K.gemm([dict(A=e1, B=w2, C=X, bias=P[g + 'joint_embed.cnn.3.cnn.bias'], act=1)])
-    # compute_similarity folded (geo_attn_mfma.hip): theta_i . phi_j = x_i^T (Wq^T Wk) x_j + (Wk^T bq) . x_j + terms constant
-    # in j, which the softmax over j cancels. md = [Mt | d], Mt[n][k] = sum_o Wk[o][n] Wq[o][k], d = Wk^T bq
+    # BatchNorm statistics folded into a per-channel scale / shift; the same launch folds compute_similarity's two
+    # projections (geo_attn_mfma.hip): theta_i . phi_j = x_i^T (Wq^T Wk) x_j + (Wk^T bq) . x_j + terms constant in j, which the
+    # softmax over j cancels. md = [Mt | d], Mt[n][k] = sum_o Wk[o][n] Wq[o][k], d = Wk^T bq
     wq, wk = P[g + 'get_s.s1.cnn.weight'].view(128, 64), P[g + 'get_s.s2.cnn.weight'].view(128, 64)
-    md = empty(65, 64)
-    K.gemm([dict(A=wk, B=wq, C=md[:64])], a_kmajor=True, b_kmajor=True)
-    K.colsum(wk, rowscale=P[g + 'get_s.s1.cnn.bias'], out=md[64])
-    adj, Z = K.gcn_attn2_fwd(X, md, nF, N)
+    ab, mi, md = K.bn_fold(x_human, N, P[g + 'joint_embed.cnn.0.bn.weight'], P[g + 'joint_embed.cnn.0.bn.bias'],
+                           bn_bufs['running_mean'], bn_bufs['running_var'], bn_bufs['num_batches_tracked'], training,
+                           stats_reduce=bn_bufs.get('stats_reduce'), fold=(wq, wk, P[g + 'get_s.s1.cnn.bias']))
+    w1 = P[g + 'joint_embed.cnn.1.cnn.weight'].view(64, 4)
+    w2 = P[g + 'joint_embed.cnn.3.cnn.weight'].view(64, 64)
+    # embed -> X -> similarity -> softmax -> aggregation in ONE kernel per group of frames (geo_fused.hip); e1 is never
+    # stored (the backward pass recomputes it from the geometry input), X only when a backward pass will read it
+    X, adj, Z = K.gcn_fused_fwd(x_human, N, ab, w1, P[g + 'joint_embed.cnn.1.cnn.bias'], w2,
+                                P[g + 'joint_embed.cnn.3.cnn.bias'], md, save_x=save_x)
     # Y = Z W, stored (bs, 128, N, T) with T fastest so that the reference's raw .view (models.py:644-645) is free
     Gout = empty(bs, 128, N, T)
     Zv = Z.view(bs, T, N, 64).permute(0, 2, 1, 3)  # (bs, N, T, 64) view
     K.gemm([dict(A=P[g + 'weight'], B=Zv[0], C=Gout[0].view(128, N * T), batch=(bs, 0, T * N * 64, 128 * N * T))],
            a_kmajor=True, b_kmajor=False)
-    S.update(ab=ab, mi=mi, e1=e1, X=X, md=md, adj=adj, Z=Z)
+    S.update(ab=ab, mi=mi, X=X, md=md, adj=adj, Z=Z)
     return Gout
 
 
@@ -1482,7 +1480,10 @@ def tggcn_backward(K, plan: Plan, P, S, x_human, x_objects, objects_mask, d_outp
 
     # ---- A. GCN backward
     g = 'geometry_embedding_gcn.'
-    Z, X, e1 = S['Z'], S['X'], S['e1']
+    Z, X = S['Z'], S['X']
+    # e1 = relu(W1 x^ + b1) recomputed from the geometry input (bit-identical to what the fused forward kernel multiplied)
+    e1 = K.gcn_embed1_fwd(x_human, N, S['ab'], P[g + 'joint_embed.cnn.1.cnn.weight'].view(64, 4),
+                          P[g + 'joint_embed.cnn.1.cnn.bias'])
     dZ = empty(nF * N, 64)
     dZv = dZ.view(bs, T, N, 64).permute(0, 2, 1, 3)
     K.gemm([dict(A=dGout[0].view(128, N * T), B=P[g + 'weight'], C=dZv[0], batch=(bs, 128 * N * T, 0, T * N * 64))],

@@ -97,7 +97,11 @@ int twog_bn_stats(const float* x_geo, int64_t frame_stride, int n_frames, int n_
  * num_batches_tracked += 1 (torch BatchNorm1d semantics); training == 0: running statistics. */
 int twog_bn_finalize(const double* partials, int n_blocks, int n_frames, int n_nodes, const float* gamma,
                      const float* beta, float* running_mean, float* running_var, int64_t* num_batches_tracked,
-                     int training, float* ab, float* mean_invstd, void* stream);
+                     int training, float* ab, float* mean_invstd, const float* wq, const float* wk, const float* bq,
+                     float* md_out, void* stream);
+/* (md_out != NULL: the same launch folds the two similarity projections of compute_similarity, models_gcn.py:95-100, for
+ * twog_gcn_fused_fwd: wq, wk [128][64] = get_s.s1 / s2 weights, bq [128] = get_s.s1 bias -> md_out [65][64] = [Mt | d],
+ * Mt[n][k] = sum_o wk[o][n] wq[o][k], d[n] = sum_o wk[o][n] bq[o].) */
 /* embed layer 1 (models_gcn.py:57-59): e1[(f,n)][64] = relu(W1 (a*x+b) + b1), W1 [64][4]. */
 int twog_gcn_embed1_fwd(const float* x_geo, int64_t frame_stride, int n_frames, int n_nodes, const float* ab,
                         const float* w1, const float* b1, float* e1, void* stream);
@@ -106,6 +110,14 @@ int twog_gcn_embed1_fwd(const float* x_geo, int64_t frame_stride, int n_frames, 
 int twog_gcn_embed1_bwd(const float* x_geo, int64_t frame_stride, int n_frames, int n_nodes, const float* ab,
                         const float* mean_invstd, const float* w1, const float* de1, float* partials, int n_blocks,
                         float* dw1, float* db1, float* dgamma, float* dbeta, void* stream);
+/* The forward pass up to the aggregation as ONE kernel (csrc/geo_fused.hip): x^ = a*x+b (norm_data folded, :45-50),
+ * e1 = relu(W1 x^ + b1) (:57-59, never stored), X = relu(W2 e1 + b2) (:60-63), S = softmax_j(x_i^T M x_j + d . x_j) -- the
+ * similarity of compute_similarity (:95-100) with M = Wq^T Wk, d = Wk^T bq folded by the caller into md [65][64] =
+ * [Mt | d] -- and Z = S X (:33-34). w1 [64][4], b1 [64], w2 [64][64], b2 [64]. Outputs: x_out [(f,n)][64] (NULL ok: only the
+ * backward pass reads it), adj [f][N][N], z [(f,n)][64]. */
+int twog_gcn_fused_fwd(const float* x_geo, int64_t frame_stride, int n_frames, int n_nodes, const float* ab,
+                       const float* w1, const float* b1, const float* w2, const float* b2, const float* md,
+                       float* x_out, float* adj, float* z, void* stream);
 /* compute_similarity + aggregation per frame (models_gcn.py:95-100, :33-34): qk [(f,n)][256] = [theta(x) | phi(x)],
  * x [(f,n)][64]; s_out [f][N][N] = softmax_j(q_i . k_j) (no 1/sqrt(d)); z [(f,n)][64] = S x. */
 int twog_gcn_attn_fwd(const float* qk, const float* x, int n_frames, int n_nodes, float* s_out, float* z,

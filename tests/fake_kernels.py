@@ -61,7 +61,12 @@ class FakeKernels:
         return x_human[:, :, 0, 2048:].reshape(bs * T, N, 4)
 
     def bn_fold(self, x_human, n_nodes, gamma, beta, running_mean, running_var, num_batches_tracked, training,
-                stats_reduce=None):
+                stats_reduce=None, fold=None):
+        if fold is not None:
+            wq, wk, bq = fold
+            ab, mi = self.bn_fold(x_human, n_nodes, gamma, beta, running_mean, running_var, num_batches_tracked, training,
+                                  stats_reduce=stats_reduce)
+            return ab, mi, torch.cat([wk.t() @ wq, (wk.t() @ bq).view(1, 64)], 0)
         N = n_nodes
         x = self._geo(x_human, N).double()  # (F, N, 4)
         xc = x.permute(2, 1, 0).reshape(4 * N, -1)  # channel c*N+n
@@ -92,6 +97,14 @@ class FakeKernels:
     def gcn_embed1_fwd(self, x_human, n_nodes, ab, w1, b1):
         xh = self._xhat(x_human, n_nodes, ab)
         return torch.relu(xh.reshape(-1, 4) @ w1.t() + b1)
+
+    def gcn_fused_fwd(self, x_human, n_nodes, ab, w1, b1, w2, b2, md, save_x=True):
+        """Executable spec of geo_fused.hip: embed -> X -> folded similarity -> softmax -> aggregation."""
+        e1 = self.gcn_embed1_fwd(x_human, n_nodes, ab, w1, b1)
+        X = torch.relu(e1 @ w2.t() + b2)
+        nf = X.shape[0] // n_nodes
+        adj, Z = self.gcn_attn2_fwd(X, md, nf, n_nodes)
+        return (X if save_x else None), adj, Z
 
     def gcn_embed1_bwd(self, x_human, n_nodes, ab, mean_invstd, w1, de1):
         N = n_nodes

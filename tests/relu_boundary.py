@@ -62,7 +62,11 @@ def _layers(model, out):
         xg = x_human.view(nF, H, -1)[:, 0, 2048:].reshape(nF, N, 4).double()
         xhat = xg * ab[0].t().unsqueeze(0) + ab[1].t().unsqueeze(0)
         items.append(item('geometry_embedding_gcn.joint_embed.cnn.1.cnn', xhat.reshape(nF * N, 4), GCN_CONV1_WIDTH_FACTOR))
-    items.append(item('geometry_embedding_gcn.joint_embed.cnn.3.cnn', S.get('e1')))
+        # the second convolution's input e1 = relu(W1 x^ + b1) is not stored by the fused forward kernel: recomputed here
+        c1 = 'geometry_embedding_gcn.joint_embed.cnn.1.cnn'
+        w1, b1 = P[c1 + '.weight'].view(64, 4).double(), P[c1 + '.bias'].double()
+        e1 = torch.relu(xhat.reshape(nF * N, 4) @ w1.t() + b1)
+        items.append(item('geometry_embedding_gcn.joint_embed.cnn.3.cnn', e1))
     for kind, hfr in (('human', S['HFR'][0]), ('object', S['HFR'][1]), ('geometry', S['HFR'][2])):
         items.append(item(kind + '_bd_embedding_mlp.0', hfr))
     for Ev, rels in ((HUMv, plan.snd_h), (OBJv, plan.snd_o), (GEOv, plan.snd_s)):

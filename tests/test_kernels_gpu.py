@@ -302,6 +302,22 @@ def test_gcn_kernels(K, N):
     dx2_g, dmd_g = K.gcn_attn2_bwd(x.to(DEV), md.to(DEV), s2_c.to(DEV), dz.to(DEV), nF, N)
     close(dx2_g, dx2_c, rtol=1e-4, atol=1e-5, what='gcn attn2 dX')
     close(dmd_g, dmd_c, rtol=2e-4, atol=1e-4 * float(dmd_c.abs().max()), what='gcn attn2 dM|dd')
+    # the fused forward kernel (geo_fused.hip): embed -> X -> folded similarity -> softmax -> aggregation, groups of frames
+    w2, b2 = rnd(64, 64, seed=13, scale=0.2), rnd(64, seed=14, scale=0.2)
+    for nf_sub in (nF, 1, 5):   # whole groups, a single frame, a ragged last group
+        xs = xh[:, :T].reshape(bs * T, H, -1)[:nf_sub].reshape(1, nf_sub, H, -1).contiguous()
+        X_c, adj_c, Z_c = F.gcn_fused_fwd(xs, N, ab_c, w1, b1, w2, b2, md)
+        X_g, adj_g, Z_g = K.gcn_fused_fwd(xs.to(DEV), N, ab_c.to(DEV), w1.to(DEV), b1.to(DEV), w2.to(DEV), b2.to(DEV), md.to(DEV))
+        close(X_g, X_c, rtol=2e-5, atol=1e-5, what=f'fused X ({nf_sub} frames)')
+        close(adj_g, adj_c, rtol=1e-4, atol=1e-6, what='fused adjacency')
+        close(Z_g, Z_c, rtol=1e-4, atol=1e-5, what='fused Z')
+        Xn, adj_n, Z_n = K.gcn_fused_fwd(xs.to(DEV), N, ab_c.to(DEV), w1.to(DEV), b1.to(DEV), w2.to(DEV), b2.to(DEV), md.to(DEV), save_x=False)
+        assert Xn is None and torch.equal(adj_n, adj_g) and torch.equal(Z_n, Z_g)
+    # the e1 the backward pass recomputes has exactly the signs / values the fused kernel multiplied: X from the stand-alone
+    # embed1 kernel + a GEMM equals the fused kernel's X to summation-order rounding
+    e1_g2 = K.gcn_embed1_fwd(xh.to(DEV), N, ab_c.to(DEV), w1.to(DEV), b1.to(DEV))
+    Xfull, _, _ = K.gcn_fused_fwd(xh.to(DEV), N, ab_c.to(DEV), w1.to(DEV), b1.to(DEV), w2.to(DEV), b2.to(DEV), md.to(DEV))
+    close(Xfull, torch.relu(e1_g2.double() @ w2.to(DEV).double().t() + b2.to(DEV).double()).float(), rtol=2e-5, atol=1e-5, what='fused X vs embed1 + GEMM')
 
 
 # --------------------------------------------------------------------------------------------------------------- BiGRU
