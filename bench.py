@@ -56,6 +56,13 @@ WORKLOADS = {
     'c3': dict(H=2, O=8, N=34, h=512, bs=64, classes=13, name='Synthetic T=120 N=34 C=512 (BASELINE configs[2])'),
     'c2': dict(H=2, O=4, N=26, h=512, bs=8, classes=13, name='MPHOI-72 layout hs512 bs8 (BASELINE configs[1])'),
     'c5': dict(H=2, O=9, N=30, h=64, bs=16, classes=14, name='Bimanual layout h=64, 16 clips per GPU (BASELINE configs[4])'),
+    # the constructor's OWN defaults (vhoi/models.py:179-190: relational + receiver-specific messages, concat attention, no
+    # segment-level messages, h = 128) and the same with segment-level messages: the general single-relation kernels
+    # (relation.hip) and the host-composed segment loop -- no shipped configuration uses them; informational
+    'defaults': dict(H=2, O=4, N=26, h=128, bs=8, classes=13, cfg={},
+                     name='TGGCN constructor defaults (relational / specific / concat, h=128), MPHOI layout bs8'),
+    'defaults_seg': dict(H=2, O=4, N=26, h=128, bs=8, classes=13, cfg=dict(message_segment=True),
+                         name='TGGCN constructor defaults + message_segment (general segment loop), MPHOI layout bs8'),
 }
 
 
@@ -63,6 +70,9 @@ def select_workload(name):
     global H, O, N_NODES, BS, N_CLASSES
     w = WORKLOADS[name]
     H, O, N_NODES, BS, N_CLASSES = w['H'], w['O'], w['N'], w['bs'], w['classes']
+    if 'cfg' in w:   # constructor defaults + the listed overrides instead of the 2G-GCN_stage1 parameters
+        CFG.clear()
+        CFG.update(w['cfg'])
     CFG['hidden_size'], CFG['gcn_node'] = w['h'], w['N']
     return w
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 FLOP/clk/CU
@@ -217,7 +227,7 @@ def cpu_baseline(sample_frames=None, sample_clips=4, repeats=3):
             if v.is_floating_point():
                 v.grad = None
         t0 = time.perf_counter()
-        out = cpu_ref.tggcn_forward(sd, CFG, x_human, x_objects, mask, human_segmentation=seg, training=True)
+        out = cpu_ref.tggcn_forward(sd, dict(m.cfg), x_human, x_objects, mask, human_segmentation=seg, training=True)
         t1 = time.perf_counter()
         loss = torch.nn.functional.nll_loss(out[4], tgt[0]) + torch.nn.functional.nll_loss(out[5], tgt[1])
         loss.backward()
@@ -574,7 +584,7 @@ def main():
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
             'higher_is_better': True, 'scaling': args.scaling, 'vs_baseline': None, 'dtype': 'fp32', 'data': 'synthetic',
             'config': {'workload': f'{wl["name"]}: bs{bs} per GPU, T={T}, H={H}, O={O}, N={N_NODES}, h={CFG["hidden_size"]}, '
-                                   f'classes {N_CLASSES}, 2G-GCN_stage1 parameters',
+                                   f'classes {N_CLASSES}, ' + ('constructor defaults' + (f' + {wl["cfg"]}' if wl['cfg'] else '') if 'cfg' in wl else '2G-GCN_stage1 parameters'),
                        'global_batch': bs * world, 'per_gpu_batch': bs, 'parallelism': f'dp{world}',
                        'devices': devices, 'collective_backend': backend if world > 1 else None,
                        'step': 'forward + multi-task loss (fused HIP criterion) + backward + gradient all-reduce + fused Adam',

@@ -1,5 +1,5 @@
 # Run on the GPU box: the evidence set of one round for the bs64 bench step.
-#   usage: bash tools/profile_round.sh r02b     (writes gpurun_out/<tag>_*; copy what is to be judged into profiles/)
+#   usage: bash tools/profile_round.sh r03     (writes gpurun_out/<tag>_*; copy what is to be judged into profiles/)
 TAG=${1:-rXX}
 export TMPDIR=/tmp
 rm -rf gpurun_out/prof_$TAG
@@ -11,6 +11,10 @@ bash tools/bench_pmc.sh
 cp gpurun_out/pmc_summary.csv gpurun_out/${TAG}_bench_bs64_pmc_summary.csv
 cp gpurun_out/gemm128_hbm_traffic.json gpurun_out/${TAG}_gemm128_hbm_traffic.json
 rm -rf gpurun_out/pmc
+bash tools/prof_c2.sh $TAG > /dev/null 2>&1
+for w in c2 c5 defaults defaults_seg; do
+  python3 bench.py --workload $w > gpurun_out/${TAG}_bench_$w.json 2> gpurun_out/${TAG}_bench_$w.err
+done
 python3 bench.py > gpurun_out/${TAG}_bench_line.json 2> gpurun_out/${TAG}_bench_line.err
 tail -3 gpurun_out/${TAG}_bench_line.err
 head -12 gpurun_out/${TAG}_bench_bs64_step_breakdown.txt

@@ -19,12 +19,16 @@ t0, t1 = int(step[0]['Start_Timestamp']), int(step[-1]['End_Timestamp'])
 def cls(r):
     n = re.sub(r'\(anonymous namespace\)::', '', r['Kernel_Name'])
     g = int(r['Grid_Size_X']) // max(int(r['Workgroup_Size_X']), 1)
+    if 'gemm_gate_bwd_xs' in n:
+        return 'recurrence: GEMM NT + fused gate backward, reduction split over workgroups'
     if 'gemm_gate_bwd' in n:
         return 'recurrence: 64x64 GEMM NT + fused gate backward'
     if 'gemm_gru_fwd' in n:
         return 'recurrence: frame-level GRU step (W_hh product + gates, one launch)'
-    if 'gemm_ks_kernel' in n:
-        return 'recurrence: 64x64 GEMM, 8 waves (k-split in the workgroup)'
+    if 'gemm_xs' in n:
+        return 'recurrence: GEMM with the reduction split over workgroups (in-launch combine)'
+    if 'gemm_ks_kernel' in n or 'gemm_ks32' in n:
+        return 'recurrence: 64x64 / 32x64 GEMM (k-split in the workgroup)'
     if 'gemm_kernel<64' in n:
         return 'recurrence: 64x64 GEMM ' + ('NN' if 'false, false' in n else 'NT' if 'false, true' in n else 'TT/TN')
     if 'gemm_kernel<128' in n:
