@@ -422,9 +422,15 @@ __device__ __forceinline__ float wave_dot(const float* a, const float* b, int n,
 // them with the reduce-scatter butterfly, the waves' sums meet in sP [wave][PP]; the caller adds them in fixed order.
 // (tid, nthreads: this thread's index in and the size of the thread group that shares the relation -- the workgroup, or
 // one of its wave groups in the latency regime)
+// gw != nullptr: the same pass also produces the gradient of the SENDER messages of this relation from the values it has
+// in registers anyway -- dmsg[s][c] = sum_r w[r][s] (mask_r) dout[r][c], times ReLU'(msg[s][c]) -- so the backward kernel
+// reads every dout / message row once instead of twice (the separate message-gradient phase re-read 58 rows of 2 KB per
+// instance at the BASELINE shape: 30 % of the kernel's traffic). Needs ALL receivers of the relation in this call.
+// gw: the relation's saved weights w[r * ldw + s] for this call's senders (LDS); gmask: receiver mask or nullptr.
 template <int RMAX, int SMAX, int PP>
 __device__ __forceinline__ void dw_columns(const RowSet& dr, const RowSet& mr, int R, int S, int hid, float* sP,
-                                           int tid, int nthreads) {
+                                           int tid, int nthreads, const float* gw = nullptr, int ldw = 0,
+                                           const RowSet* gr = nullptr, const float* gmask = nullptr, bool relu = false) {
     static_assert(RMAX * SMAX <= PP && PP <= 64, "one slot per (receiver, sender)");
     const int lane = tid & 63, wave = tid >> 6;
     float acc[PP];
@@ -441,6 +447,24 @@ __device__ __forceinline__ void dw_columns(const RowSet& dr, const RowSet& mr, i
 #pragma unroll
             for (int s = 0; s < SMAX; ++s)
                 acc[r * SMAX + s] = fmaf(d[r].x, m[s].x, fmaf(d[r].y, m[s].y, acc[r * SMAX + s]));
+        if (gw) {
+            if (gmask) {
+#pragma unroll
+                for (int r = 0; r < RMAX; ++r)
+                    if (r < R) { const float k = gmask[r]; d[r].x *= k; d[r].y *= k; }
+            }
+#pragma unroll
+            for (int s = 0; s < SMAX; ++s) {
+                if (s < S) {
+                    float gx = 0.f, gy = 0.f;
+#pragma unroll
+                    for (int r = 0; r < RMAX; ++r)
+                        if (r < R) { const float w = gw[r * ldw + s]; gx = fmaf(w, d[r].x, gx); gy = fmaf(w, d[r].y, gy); }
+                    if (relu) { if (!(m[s].x > 0.f)) gx = 0.f; if (!(m[s].y > 0.f)) gy = 0.f; }
+                    *reinterpret_cast<float2*>(gr->row(s) + 2 * c2) = make_float2(gx, gy);
+                }
+            }
+        }
     }
     lane_reduce_scatter<PP, PP, 32>(acc, lane);
     constexpr int LANES_PER_VALUE = 64 / PP;
@@ -590,20 +614,27 @@ __device__ __forceinline__ void attn_bwd_body(const BwdGroup& g) {
         // (at most 2 humans and 8 objects, checked by the host) one relation after the other; slot (r, s) of a relation
         // sits at r * SMAX + s of its butterfly, the waves' partial sums at sP [wave][64]
         // receivers [r0, r0 + R) of a relation; skip_diag: receiver r0 + r is excluded from its own senders
-        auto relation = [&](auto tag, RowSet dr, const RowSet& mr, int r0, int R, int S, int off, bool skip_diag, bool recv_masked) {
+        // receivers [0, R) (all of them), senders [s0, s0 + S) of a relation with Sfull senders; skip_diag: receiver r is
+        // excluded from its own senders (its saved weight is an exact zero). The pass also writes the relation's
+        // sender-message gradients (see dw_columns).
+        auto relation = [&](auto tag, const RowSet& dr, RowSet mr, RowSet gr, int R, int s0, int S, int Sfull, int off,
+                            bool skip_diag, bool recv_masked) {
             constexpr int RMAX = decltype(tag)::R, SMAX = decltype(tag)::S, PP = decltype(tag)::PP;
-            if (R <= 0) return;   // uniform
-            if (dr.on()) dr.base += (int64_t)r0 * dr.step;
-            if (mr.on()) dw_columns<RMAX, SMAX, PP>(dr, mr, R, S, hid, sP, (int)threadIdx.x, (int)blockDim.x);
+            if (S <= 0 || R <= 0) return;   // uniform
+            if (mr.on()) mr.base += (int64_t)s0 * mr.step;
+            if (gr.on()) gr.base += (int64_t)s0 * gr.step;
+            if (mr.on())
+                dw_columns<RMAX, SMAX, PP>(dr, mr, R, S, hid, sP, (int)threadIdx.x, (int)blockDim.x,
+                                           gr.on() ? sW + off + s0 : nullptr, Sfull, &gr, recv_masked ? sMask : nullptr, relu_mask);
             __syncthreads();
             for (int t = threadIdx.x; t < R * S; t += blockDim.x) {
                 const int r = t / S, s_ = t - r * S;
                 float v = 0.f;
-                if (mr.on() && !(skip_diag && r0 + r == s_)) {
+                if (mr.on() && !(skip_diag && r == s0 + s_)) {
                     for (int w = 0; w < nw; ++w) v += sP[w * PP + r * SMAX + s_];   // fixed order: deterministic
-                    if (recv_masked) v *= sMask[r0 + r];
+                    if (recv_masked) v *= sMask[r];
                 }
-                const int slot = off + r0 * S + t;
+                const int slot = off + r * Sfull + s0 + s_;
                 sdW[slot] = B.dw_extra ? v + B.dw_extra[(int64_t)inst * natt + slot] : v;
             }
             __syncthreads();
@@ -611,12 +642,12 @@ __device__ __forceinline__ void attn_bwd_body(const BwdGroup& g) {
         struct T22 { enum { R = 2, S = 2, PP = 4 }; };
         struct T28 { enum { R = 2, S = 8, PP = 16 }; };
         struct T82 { enum { R = 8, S = 2, PP = 16 }; };
-        struct T48 { enum { R = 4, S = 8, PP = 32 }; };
-        relation(T22{}, d_hh, m_hh, 0, H, H, att_off_hh(H, O), true, false);
-        relation(T28{}, d_oh, m_oh, 0, H, O, att_off_oh(H, O), false, false);
-        relation(T82{}, d_ho, m_ho, 0, O, H, att_off_ho(H, O), false, rmask);
-        relation(T48{}, d_oo, m_oo, 0, min(O, 4), O, att_off_oo(H, O), true, false);   // two halves: 32 products in
-        relation(T48{}, d_oo, m_oo, 4, O - 4, O, att_off_oo(H, O), true, false);        // registers instead of 64
+        struct T84 { enum { R = 8, S = 4, PP = 32 }; };
+        relation(T22{}, d_hh, m_hh, g_hh, H, 0, H, H, att_off_hh(H, O), true, false);
+        relation(T28{}, d_oh, m_oh, g_oh, H, 0, O, O, att_off_oh(H, O), false, false);
+        relation(T82{}, d_ho, m_ho, g_ho, O, 0, H, H, att_off_ho(H, O), false, rmask);
+        relation(T84{}, d_oo, m_oo, g_oo, O, 0, min(O, 4), O, att_off_oo(H, O), true, false);   // two halves of the SENDERS:
+        relation(T84{}, d_oo, m_oo, g_oo, O, 4, O - 4, O, att_off_oo(H, O), true, false);        // 32 products in registers
     } else if (do_feat)
     for (int p = wv; p < natt; p += nw) {
         float v = 0.f;
@@ -665,12 +696,13 @@ __device__ __forceinline__ void attn_bwd_body(const BwdGroup& g) {
     // gradient wrt sender messages: dmsg[s] = sum_r w[r][s] * recv_mask_r * dout[r]  (optionally times ReLU'(msg)),
     // one (group, column) item per thread; groups: 0: hh, oh, sh; 1: ho, so; 2, 3: oo senders first / second half
     const int o_half = (O + 1) / 2;
+    const bool ent_done = COLS && do_feat;   // (column regime: the entity relations' message gradients are already written)
     if (do_msg)
-    for (int idx = threadIdx.x; idx < 4 * hid; idx += blockDim.x) {
+    for (int idx = threadIdx.x; idx < (ent_done ? 2 : 4) * hid; idx += blockDim.x) {
         const int grp = idx / hid, j = idx - grp * hid;
         float gr[MAX_O];
         if (grp == 0) {
-            if (m_hh.on()) {
+            if (m_hh.on() && !ent_done) {
 #pragma unroll
                 for (int r = 0; r < MAX_H; ++r) gr[r] = r < H ? d_hh.row(r)[j] : 0.f;
                 for (int s = 0; s < H; ++s) {
@@ -682,7 +714,7 @@ __device__ __forceinline__ void attn_bwd_body(const BwdGroup& g) {
                     g_hh.row(s)[j] = acc;
                 }
             }
-            if (m_oh.on()) {
+            if (m_oh.on() && !ent_done) {
 #pragma unroll
                 for (int r = 0; r < MAX_H; ++r) gr[r] = r < H ? d_oh.row(r)[j] : 0.f;
                 for (int s = 0; s < O; ++s) {
@@ -701,7 +733,7 @@ __device__ __forceinline__ void attn_bwd_body(const BwdGroup& g) {
                 g_sh.row(0)[j] = acc;
             }
         } else if (grp == 1) {
-            if (m_ho.on()) {
+            if (m_ho.on() && !ent_done) {
 #pragma unroll
                 for (int r = 0; r < MAX_O; ++r) gr[r] = r < O ? (rmask ? sMask[r] : 1.f) * d_ho.row(r)[j] : 0.f;
                 for (int s = 0; s < H; ++s) {
