@@ -385,6 +385,180 @@ __device__ __forceinline__ void gemm_mainloop(const twog_rows_t A, const twog_ro
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// X3: the 128x128 class on the bf16 matrix cores with fp32-exact operands (TWOG_GEMM_X3, see twog_gemm_f32).
+//
+// Every fp32 operand element is split EXACTLY into three bf16 values, x = h + m + l: h = x truncated to its top 8
+// significant bits, m = (x - h) truncated, l = x - h - m (at most 8 significant bits are left: no rounding anywhere,
+// the 24-bit significand is three 8-bit chunks). A product a b = sum of nine chunk products; the six with weight
+// >= 2^-16 -- hh, hm, mh, mm, hl, lh -- run on v_mfma_f32_32x32x16_bf16 (bf16 x bf16 products are exact in the fp32
+// accumulator), the three dropped ones (ml, lm, ll) are <= 2^-23 |a b| in total: below the rounding of the fp32
+// accumulation itself, which is the same as in the native kernel. Six bf16 MFMAs of 16 k-steps cost 192 cycles per
+// 32x32 block where the fp32 MFMA (32x32x2) needs 512: 2.67x the matrix rate for the same result to fp32 rounding.
+//
+// Structure: same tile (128x128x32, 8 waves of 32x64), same branch-free 16-byte global loads into registers; the split
+// happens once per element on the way into LDS (5.5 VALU operations per element), LDS holds three bf16 planes per
+// operand, one stage (61 KB: two workgroups per CU) behind a register stage. Row-major operands ([row][k], k
+// contiguous) are stored as [row][32 k] rows of 80 bytes (64 + 16 pad: the ds_read_b128 fragment reads are
+// conflict-free); k-major operands ([k][row]) are stored as they come, [k][128 rows] rows of 256 bytes with 16-byte
+// chunks XOR-swizzled by the k row, and transposed on the way out by ds_read_b64_tr_b16 (each 16-lane group receives a
+// 4 k x 16 rows block column-major: the MFMA's k-contiguous fragment with no data movement of our own).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint32_t pack_hi16(uint32_t lo, uint32_t hi) {   // {hi[31:16], lo[31:16]}
+    return __builtin_amdgcn_perm(hi, lo, 0x07060302);
+}
+// four consecutive fp32 values -> their three bf16 planes (4 x 2 bytes each)
+__device__ __forceinline__ void split3(const f32x4 v, i32x2& ph, i32x2& pm, i32x2& pl) {
+    uint32_t x[4], r1[4], r2[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float f0 = v[i];   // (a scalar copy: __builtin_bit_cast applied to the vector ELEMENT v[i] reads element 0)
+        x[i] = __float_as_uint(f0);
+        const float f1 = f0 - __uint_as_float(x[i] & 0xffff0000u);
+        r1[i] = __float_as_uint(f1);
+        r2[i] = __float_as_uint(f1 - __uint_as_float(r1[i] & 0xffff0000u));
+    }
+    ph = i32x2{(int)pack_hi16(x[0], x[1]), (int)pack_hi16(x[2], x[3])};
+    pm = i32x2{(int)pack_hi16(r1[0], r1[1]), (int)pack_hi16(r1[2], r1[3])};
+    pl = i32x2{(int)pack_hi16(r2[0], r2[1]), (int)pack_hi16(r2[2], r2[3])};
+}
+
+constexpr int X3_RROW = 80;              // bytes per row of a [row][32 k] image
+constexpr int X3_RPLANE = 128 * X3_RROW; // 10 240
+constexpr int X3_TPLANE = 32 * 256;      // [32 k][128 rows] image: 8 192
+__device__ __forceinline__ int x3_swz(int k) { return ((k & 3) << 2) | ((k >> 2) & 3); }
+
+template <bool AKM, bool BKM>
+__device__ __forceinline__ void gemm_mainloop_x3(const twog_rows_t A, const twog_rows_t B, int M, int N, int m0, int n0,
+                                                 int k_begin, int k_end, float* smem, f32x16 (&acc)[1][2]) {
+    constexpr int BM = 128, BN = 128, NT = 512;
+    constexpr int A_BYTES = 3 * (AKM ? X3_TPLANE : X3_RPLANE);
+    char* ldsA = reinterpret_cast<char*>(smem);
+    char* ldsB = ldsA + A_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = (wave >> 1) * 32, wn = (wave & 1) * 64;
+    using ARegs = TileRegs<(AKM ? BK : BM), (AKM ? BM : BK), NT>;
+    using BRegs = TileRegs<(BKM ? BK : BN), (BKM ? BN : BK), NT>;
+    static_assert(ARegs::PASSES == 2 && BRegs::PASSES == 2, "two 16-byte loads per operand and thread");
+    // global addressing as in gemm_mainloop's FAST path (branch-free buffer loads, clamped edges)
+    uint32_t oa[2], ob[2];
+    int sa_off[2], sb_off[2];   // LDS byte offset (plane 0) of this thread's store for pass i
+    const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(A.ptr, 0, 0xffffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc(B.ptr, 0, 0xffffffff, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        {
+            const int rr = tid / ARegs::F4_PER_ROW + i * ARegs::ROWS_PER_PASS, cq = tid % ARegs::F4_PER_ROW;
+            if constexpr (AKM) {   // rr = k row of the tile, cq = quad of tile rows
+                oa[i] = 4u * (uint32_t)((int64_t)rr * A.ld_outer + min(m0 + cq * 4, M - 4));
+                sa_off[i] = 256 * rr + 16 * ((cq >> 1) ^ x3_swz(rr)) + 8 * (cq & 1);
+            } else {               // rr = tile row, cq = quad of k
+                oa[i] = 4u * (uint32_t)(twog_row_off(A, min(m0 + rr, M - 1)) + cq * 4);
+                sa_off[i] = rr * X3_RROW + cq * 8;
+            }
+        }
+        {
+            const int rr = tid / BRegs::F4_PER_ROW + i * BRegs::ROWS_PER_PASS, cq = tid % BRegs::F4_PER_ROW;
+            if constexpr (BKM) {
+                ob[i] = 4u * (uint32_t)((int64_t)rr * B.ld_outer + min(n0 + cq * 4, N - 4));
+                sb_off[i] = 256 * rr + 16 * ((cq >> 1) ^ x3_swz(rr)) + 8 * (cq & 1);
+            } else {
+                ob[i] = 4u * (uint32_t)(twog_row_off(B, min(n0 + rr, N - 1)) + cq * 4);
+                sb_off[i] = rr * X3_RROW + cq * 8;
+            }
+        }
+    }
+    f32x4 ra[2], rb[2];
+    auto gload = [&](int k0) {
+        const int sa = (int)(AKM ? (uint32_t)k0 * (uint32_t)A.ld_outer * 4u : (uint32_t)k0 * 4u);
+        const int sb = (int)(BKM ? (uint32_t)k0 * (uint32_t)B.ld_outer * 4u : (uint32_t)k0 * 4u);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, (int)oa[i], sa, 0));
+#pragma unroll
+        for (int i = 0; i < 2; ++i) rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_b, (int)ob[i], sb, 0));
+    };
+    auto split_store = [&]() {
+        constexpr int PA = AKM ? X3_TPLANE : X3_RPLANE, PB = BKM ? X3_TPLANE : X3_RPLANE;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            i32x2 ph, pm, pl;
+            split3(ra[i], ph, pm, pl);
+            *reinterpret_cast<i32x2*>(ldsA + sa_off[i]) = ph;
+            *reinterpret_cast<i32x2*>(ldsA + sa_off[i] + PA) = pm;
+            *reinterpret_cast<i32x2*>(ldsA + sa_off[i] + 2 * PA) = pl;
+            split3(rb[i], ph, pm, pl);
+            *reinterpret_cast<i32x2*>(ldsB + sb_off[i]) = ph;
+            *reinterpret_cast<i32x2*>(ldsB + sb_off[i] + PB) = pm;
+            *reinterpret_cast<i32x2*>(ldsB + sb_off[i] + 2 * PB) = pl;
+        }
+    };
+    // fragment addressing: lane l = (r = l & 31 row / column of the 32x32 block, h = l >> 5 half of the 16-deep k-step)
+    const int r32 = lane & 31, h = lane >> 5;
+    // row-major image: 16 bytes (k = 16 s + 8 h .. + 7) of row (block row + r)
+    const int fa_r = (wm + r32) * X3_RROW + 16 * h;
+    const int fb_r = (wn + r32) * X3_RROW + 16 * h;
+    // k-major image, transposed read: lane 4q + p of a 16-lane group g supplies block row k = 8 (g >> 1) + q (+ 4 for the second
+    // read), rows 16 (g & 1) + 4p .. 4p + 3 of the block: chunk (block row / 8) + 2 (g & 1) + (p >> 1), byte 8 (p & 1)
+    const int g16 = lane >> 4, q4 = (lane >> 2) & 3, p4 = lane & 3;
+    const int tk = 8 * (g16 >> 1) + q4;                     // k row inside a k-step (first read); second read: + 4
+    const int tchA = (wm >> 3) + 2 * (g16 & 1) + (p4 >> 1);
+    const int tchB = (wn >> 3) + 2 * (g16 & 1) + (p4 >> 1);  // block b: + 4 b
+    auto frag = [&](const char* base, bool kmaj, int plane, int s, int off_r, int tch) -> bf16x8 {
+        if (!kmaj) {
+            const i32x4 v = *reinterpret_cast<const i32x4*>(base + plane * X3_RPLANE + off_r + 32 * s);
+            return __builtin_bit_cast(bf16x8, v);
+        }
+        const int k0 = 16 * s + tk, k1 = k0 + 4;
+        const char* pl = base + plane * X3_TPLANE + 8 * (p4 & 1);
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) s16x4*)(pl + 256 * k0 + 16 * (tch ^ x3_swz(k0))));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) s16x4*)(pl + 256 * k1 + 16 * (tch ^ x3_swz(k1))));
+        typedef short s16x8 __attribute__((ext_vector_type(8)));
+        const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        return __builtin_bit_cast(bf16x8, v);
+    };
+    auto compute = [&]() {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            bf16x8 af[3], bf[2][3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) af[p] = frag(ldsA, AKM, p, s, fa_r, tchA);
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) bf[b][p] = frag(ldsB, BKM, p, s, fb_r + b * 32 * X3_RROW, tchB + 4 * b);
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                // smallest terms first: l h, h l, m m, then m h, h m, h h
+                acc[0][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2], bf[b][0], acc[0][b], 0, 0, 0);
+                acc[0][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[b][2], acc[0][b], 0, 0, 0);
+                acc[0][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[b][1], acc[0][b], 0, 0, 0);
+                acc[0][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[b][0], acc[0][b], 0, 0, 0);
+                acc[0][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[b][1], acc[0][b], 0, 0, 0);
+                acc[0][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[b][0], acc[0][b], 0, 0, 0);
+            }
+        }
+    };
+    const int nkt = (k_end - k_begin) / BK;
+    if (nkt <= 0) return;
+    gload(k_begin);
+    split_store();
+    __syncthreads();
+    for (int kt = 0; kt < nkt; ++kt) {
+        const bool more = kt + 1 < nkt;
+        if (more) gload(k_begin + (kt + 1) * BK);   // in flight under the MFMAs of this k-tile
+        compute();
+        __syncthreads();                            // every wave is done reading the k-tile
+        if (more) split_store();
+        __syncthreads();
+    }
+}
+
 // XS (recurrent-chain launches with fewer tiles than the chip has CUs): the reduction is ALSO split over workgroups
 // (blockIdx.y = k-slice) and combined inside the launch, without a grid barrier and without waiting: every workgroup
 // writes its partial tile write-through (16-byte sc1 stores, so no release fence), drains them, and one lane draws an
@@ -394,7 +568,7 @@ __device__ __forceinline__ void gemm_mainloop(const twog_rows_t A, const twog_ro
 // counters are zero again at the launch boundary (graph replays need no memset node). The hand-off form is the
 // guide's split-K recipe (cdna_hip_programming.md section 5 item 2 / MI355X_MICROARCH.md "Valid forms": sc1 payload,
 // every storing wave drained, workgroup barrier, one relaxed agent atomic; the last arriver's loads all sc1).
-template <int BM, int BN, int NT, bool AKM, bool BKM, int D, bool KG, bool GATE, int KS = 1, bool XS = false>
+template <int BM, int BN, int NT, bool AKM, bool BKM, int D, bool KG, bool GATE, int KS = 1, bool XS = false, bool X3 = false>
 __device__ __forceinline__ void gemm_tile(const Group& g, const GateArgs* ga) {
     constexpr int NTG = NT / KS;
     constexpr int WM = BM / (NTG / 128), WN = BN / 2;  // per-wave tile; the waves of a k-group in a (NTG/128) x 2 grid
@@ -532,7 +706,10 @@ __device__ __forceinline__ void gemm_tile(const Group& g, const GateArgs* ga) {
 
     // uniform per workgroup: aligned operands and a reduction range made of whole k-tiles -> branch-free staging
     const bool fast = a_vec && b_vec && ((k_end - k_begin) % BK == 0);
-    if (fast)
+    if constexpr (X3) {
+        static_assert(!X3 || (BM == 128 && BN == 128 && NT == 512 && !KG && !GATE && KS == 1 && !XS), "X3: the 8-wave 128x128 class");
+        gemm_mainloop_x3<AKM, BKM>(A, B, M, N, m0, n0, k_begin, k_end, smem, acc);   // (the host launches it for aligned operands and whole k-tiles only)
+    } else if (fast)
         gemm_mainloop<BM, BN, NT, AKM, BKM, true, TM, TN, D, KG, KS>(A, B, M, N, a_vec, b_vec, m0, n0, k_begin, k_end, smem, acc);
     else
         gemm_mainloop<BM, BN, NT, AKM, BKM, false, TM, TN, 1, false, KS>(A, B, M, N, a_vec, b_vec, m0, n0, k_begin, k_end, smem, acc);
@@ -704,6 +881,11 @@ __device__ __forceinline__ void gemm_tile(const Group& g, const GateArgs* ga) {
 template <int BM, int BN, int NT, bool AKM, bool BKM, int D, bool KG>
 __global__ __launch_bounds__(NT, 2) void gemm_kernel(const Group g) {
     gemm_tile<BM, BN, NT, AKM, BKM, D, KG, false>(g, nullptr);
+}
+
+template <bool AKM, bool BKM>
+__global__ __launch_bounds__(512, 2) void gemm_x3_kernel(const Group g) {
+    gemm_tile<128, 128, 512, AKM, BKM, 2, false, false, 1, false, true>(g, nullptr);
 }
 
 // 64x64 class, A row-major, B k-major (dX = dY W): the only form the recurrent backward chains use
@@ -936,12 +1118,34 @@ inline int vec_ok(const twog_rows_t& m, int64_t batch_stride, int contiguous_ext
     return (aligned && ld_ok && contiguous_extent >= 4 && contiguous_extent % 4 == 0) ? 1 : 0;
 }
 
+thread_local int g_last_class_x3 = 0;
+
 template <int BM, int BN, int NT, int D>
 int launch(Group& g, int akm, int bkm, hipStream_t st) {
+    g_last_class_x3 = 0;
     dim3 grid(g.total_tiles, g.splitk), block(NT);
     // KG variant: some k-major operand has (outer, inner) grouped rows
     bool kg = false;
     for (int i = 0; i < g.n; ++i) kg = kg || (akm && g.p[i].A.inner > 1) || (bkm && g.p[i].B.inner > 1);
+    if constexpr (BM == 128 && NT == 512) {
+        // X3 (fp32-exact operands on the bf16 matrix cores, gemm_mainloop_x3): aligned operands, whole k-tiles, plain rows
+        static const int x3_on = getenv("TWOG_GEMM_X3") ? atoi(getenv("TWOG_GEMM_X3")) : 0;
+        bool ok = x3_on != 0 && !kg && (g.k_per_split % BK) == 0;
+        for (int i = 0; i < g.n; ++i) ok = ok && g.p[i].a_vec && g.p[i].b_vec && (g.p[i].K % BK) == 0 && g.p[i].M >= 4 && g.p[i].N >= 4;
+        if (ok) {
+            if (!akm && !bkm) hipLaunchKernelGGL((gemm_x3_kernel<false, false>), grid, block, 0, st, g);
+            else if (!akm && bkm) hipLaunchKernelGGL((gemm_x3_kernel<false, true>), grid, block, 0, st, g);
+            else if (akm && bkm) hipLaunchKernelGGL((gemm_x3_kernel<true, true>), grid, block, 0, st, g);
+            else hipLaunchKernelGGL((gemm_x3_kernel<true, false>), grid, block, 0, st, g);
+            TWOG_CHECK_LAUNCH();
+            g_last_class_x3 = 1;
+            if (g.splitk > 1) {
+                hipLaunchKernelGGL((splitk_reduce_kernel<BM, BN>), dim3(g.total_tiles, (BM * BN) / 1024), dim3(256), 0, st, g);
+                TWOG_CHECK_LAUNCH();
+            }
+            return 0;
+        }
+    }
     if (!akm && !bkm) hipLaunchKernelGGL((gemm_kernel<BM, BN, NT, false, false, D, false>), grid, block, 0, st, g);
     else if (!akm && bkm && !kg) hipLaunchKernelGGL((gemm_kernel<BM, BN, NT, false, true, D, false>), grid, block, 0, st, g);
     else if (!akm && bkm) hipLaunchKernelGGL((gemm_kernel<BM, BN, NT, false, true, D, true>), grid, block, 0, st, g);
@@ -1216,6 +1420,7 @@ static int gemm_impl(const twog_gemm_t* problems, int n_problems, int a_kmajor, 
         else if (big) rc = d128 == 2 ? launch<128, 128, 256, 2>(g, a_kmajor, b_kmajor, st) : launch<128, 128, 256, 1>(g, a_kmajor, b_kmajor, st);
         else rc = d64 == 2 ? launch<64, 64, 256, 2>(g, a_kmajor, b_kmajor, st) : launch<64, 64, 256, 1>(g, a_kmajor, b_kmajor, st);
         if (rc) return rc;
+        if (g_last_class_x3) g_last_class |= TWOG_GEMM_CLASS_X3;
         done += n;
     }
     return 0;

@@ -142,6 +142,7 @@ class HipKernels:
 
     GEMM_TILE128, GEMM_WAVES8, GEMM_KG, GEMM_SPLITK, GEMM_GATE, GEMM_KSPLIT, GEMM_GRUFWD, GEMM_ROWS32 = 1, 2, 4, 8, 16, 32, 64, 128  # TWOG_GEMM_CLASS_*
     GEMM_XSPLIT = 256
+    GEMM_X3 = 512
 
     def gemm_last_class(self):
         """Bit field (GEMM_*) of the kernel variant the most recent gemm() chunk of this thread selected."""
