@@ -432,7 +432,7 @@ constexpr int X3_RPLANE = 128 * X3_RROW; // 10 240
 constexpr int X3_TPLANE = 32 * 256;      // [32 k][128 rows] image: 8 192
 __device__ __forceinline__ int x3_swz(int k) { return ((k & 3) << 2) | ((k >> 2) & 3); }
 
-template <bool AKM, bool BKM>
+template <bool AKM, bool BKM, bool KG>
 __device__ __forceinline__ void gemm_mainloop_x3(const twog_rows_t A, const twog_rows_t B, int M, int N, int m0, int n0,
                                                  int k_begin, int k_end, float* smem, f32x16 (&acc)[1][2]) {
     constexpr int BM = 128, BN = 128, NT = 512;
@@ -454,7 +454,7 @@ __device__ __forceinline__ void gemm_mainloop_x3(const twog_rows_t A, const twog
         {
             const int rr = tid / ARegs::F4_PER_ROW + i * ARegs::ROWS_PER_PASS, cq = tid % ARegs::F4_PER_ROW;
             if constexpr (AKM) {   // rr = k row of the tile, cq = quad of tile rows
-                oa[i] = 4u * (uint32_t)((int64_t)rr * A.ld_outer + min(m0 + cq * 4, M - 4));
+                oa[i] = KG ? 4u * (uint32_t)min(m0 + cq * 4, M - 4) : 4u * (uint32_t)((int64_t)rr * A.ld_outer + min(m0 + cq * 4, M - 4));
                 sa_off[i] = 256 * rr + 16 * ((cq >> 1) ^ x3_swz(rr)) + 8 * (cq & 1);
             } else {               // rr = tile row, cq = quad of k
                 oa[i] = 4u * (uint32_t)(twog_row_off(A, min(m0 + rr, M - 1)) + cq * 4);
@@ -464,7 +464,7 @@ __device__ __forceinline__ void gemm_mainloop_x3(const twog_rows_t A, const twog
         {
             const int rr = tid / BRegs::F4_PER_ROW + i * BRegs::ROWS_PER_PASS, cq = tid % BRegs::F4_PER_ROW;
             if constexpr (BKM) {
-                ob[i] = 4u * (uint32_t)((int64_t)rr * B.ld_outer + min(n0 + cq * 4, N - 4));
+                ob[i] = KG ? 4u * (uint32_t)min(n0 + cq * 4, N - 4) : 4u * (uint32_t)((int64_t)rr * B.ld_outer + min(n0 + cq * 4, N - 4));
                 sb_off[i] = 256 * rr + 16 * ((cq >> 1) ^ x3_swz(rr)) + 8 * (cq & 1);
             } else {
                 ob[i] = 4u * (uint32_t)(twog_row_off(B, min(n0 + rr, N - 1)) + cq * 4);
@@ -472,25 +472,64 @@ __device__ __forceinline__ void gemm_mainloop_x3(const twog_rows_t A, const twog
             }
         }
     }
-    f32x4 ra[2], rb[2];
-    auto gload = [&](int k0) {
-        const int sa = (int)(AKM ? (uint32_t)k0 * (uint32_t)A.ld_outer * 4u : (uint32_t)k0 * 4u);
-        const int sb = (int)(BKM ? (uint32_t)k0 * (uint32_t)B.ld_outer * 4u : (uint32_t)k0 * 4u);
+    struct Stage { f32x4 a[2], b[2]; };
+    // KG: a k-major operand whose rows (= k) are (outer, inner) grouped, e.g. "all but the first time step of every clip":
+    // the (outer, inner) position of each pass's row is carried from k-tile to k-tile (k only moves forward; the clamped tail
+    // repeats the last tile), no division in the loop. Offsets stay below 2^32 bytes (vec_ok).
+    int ka_o[KG ? 2 : 1], ka_i[KG ? 2 : 1], kb_o[KG ? 2 : 1], kb_i[KG ? 2 : 1], ka_k = k_begin, kb_k = k_begin;
+    const int a_in = A.inner <= 1 ? 0x7fffffff : A.inner, b_in = B.inner <= 1 ? 0x7fffffff : B.inner;
+    const uint32_t a_ldi = (uint32_t)(A.inner <= 1 ? A.ld_outer : A.ld_inner), b_ldi = (uint32_t)(B.inner <= 1 ? B.ld_outer : B.ld_inner);
+    if constexpr (KG) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, (int)oa[i], sa, 0));
+        for (int i = 0; i < 2; ++i) {
+            const int ra_ = k_begin + tid / ARegs::F4_PER_ROW + i * ARegs::ROWS_PER_PASS;
+            const int rb_ = k_begin + tid / BRegs::F4_PER_ROW + i * BRegs::ROWS_PER_PASS;
+            ka_o[i] = A.inner <= 1 ? 0 : ra_ / A.inner; ka_i[i] = A.inner <= 1 ? ra_ : ra_ - ka_o[i] * A.inner;
+            kb_o[i] = B.inner <= 1 ? 0 : rb_ / B.inner; kb_i[i] = B.inner <= 1 ? rb_ : rb_ - kb_o[i] * B.inner;
+        }
+    }
+    auto gload = [&](Stage& r, int k0) {
+        if constexpr (KG && AKM) {
+            const int delta = k0 - ka_k;
+            ka_k = k0;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_b, (int)ob[i], sb, 0));
+            for (int i = 0; i < 2; ++i) {
+                ka_i[i] += delta;
+                while (ka_i[i] >= a_in) { ka_i[i] -= a_in; ++ka_o[i]; }
+                const uint32_t off = 4u * ((uint32_t)ka_o[i] * (uint32_t)A.ld_outer + (uint32_t)ka_i[i] * a_ldi) + oa[i];
+                r.a[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, (int)off, 0, 0));
+            }
+        } else {
+            const int sa = (int)(AKM ? (uint32_t)k0 * (uint32_t)A.ld_outer * 4u : (uint32_t)k0 * 4u);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) r.a[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, (int)oa[i], sa, 0));
+        }
+        if constexpr (KG && BKM) {
+            const int delta = k0 - kb_k;
+            kb_k = k0;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                kb_i[i] += delta;
+                while (kb_i[i] >= b_in) { kb_i[i] -= b_in; ++kb_o[i]; }
+                const uint32_t off = 4u * ((uint32_t)kb_o[i] * (uint32_t)B.ld_outer + (uint32_t)kb_i[i] * b_ldi) + ob[i];
+                r.b[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_b, (int)off, 0, 0));
+            }
+        } else {
+            const int sb = (int)(BKM ? (uint32_t)k0 * (uint32_t)B.ld_outer * 4u : (uint32_t)k0 * 4u);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) r.b[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_b, (int)ob[i], sb, 0));
+        }
     };
-    auto split_store = [&]() {
+    auto split_store = [&](const Stage& r) {
         constexpr int PA = AKM ? X3_TPLANE : X3_RPLANE, PB = BKM ? X3_TPLANE : X3_RPLANE;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             i32x2 ph, pm, pl;
-            split3(ra[i], ph, pm, pl);
+            split3(r.a[i], ph, pm, pl);
             *reinterpret_cast<i32x2*>(ldsA + sa_off[i]) = ph;
             *reinterpret_cast<i32x2*>(ldsA + sa_off[i] + PA) = pm;
             *reinterpret_cast<i32x2*>(ldsA + sa_off[i] + 2 * PA) = pl;
-            split3(rb[i], ph, pm, pl);
+            split3(r.b[i], ph, pm, pl);
             *reinterpret_cast<i32x2*>(ldsB + sb_off[i]) = ph;
             *reinterpret_cast<i32x2*>(ldsB + sb_off[i] + PB) = pm;
             *reinterpret_cast<i32x2*>(ldsB + sb_off[i] + 2 * PB) = pl;
@@ -544,19 +583,31 @@ __device__ __forceinline__ void gemm_mainloop_x3(const twog_rows_t A, const twog
             }
         }
     };
+    // Two register stages: the loads of k-tile t + 2 are issued before the MFMAs of tile t and are split / stored a whole
+    // iteration later (one stage does not cover the HBM latency at this matrix rate). One LDS stage: a barrier after the
+    // MFMAs (every wave is done reading) and one after the stores. Loads past the last k-tile are clamped to it instead of
+    // branched around (see gemm_mainloop); the redundant tile is never stored.
     const int nkt = (k_end - k_begin) / BK;
     if (nkt <= 0) return;
-    gload(k_begin);
-    split_store();
+    const int k_last = k_begin + (nkt - 1) * BK;
+    Stage r0, r1;
+    gload(r0, k_begin);
+    gload(r1, min(k_begin + BK, k_last));
+    split_store(r0);
     __syncthreads();
-    for (int kt = 0; kt < nkt; ++kt) {
-        const bool more = kt + 1 < nkt;
-        if (more) gload(k_begin + (kt + 1) * BK);   // in flight under the MFMAs of this k-tile
-        compute();
-        __syncthreads();                            // every wave is done reading the k-tile
-        if (more) split_store();
+    for (int kt = 0; kt + 1 < nkt; kt += 2) {
+        gload(r0, min(k_begin + (kt + 2) * BK, k_last));
+        compute();                                   // k-tile kt
+        __syncthreads();
+        split_store(r1);                             // k-tile kt + 1
+        __syncthreads();
+        gload(r1, min(k_begin + (kt + 3) * BK, k_last));
+        compute();                                   // k-tile kt + 1
+        __syncthreads();
+        if (kt + 2 < nkt) split_store(r0);           // k-tile kt + 2 (uniform)
         __syncthreads();
     }
+    if (nkt & 1) compute();
 }
 
 // XS (recurrent-chain launches with fewer tiles than the chip has CUs): the reduction is ALSO split over workgroups
@@ -707,8 +758,8 @@ __device__ __forceinline__ void gemm_tile(const Group& g, const GateArgs* ga) {
     // uniform per workgroup: aligned operands and a reduction range made of whole k-tiles -> branch-free staging
     const bool fast = a_vec && b_vec && ((k_end - k_begin) % BK == 0);
     if constexpr (X3) {
-        static_assert(!X3 || (BM == 128 && BN == 128 && NT == 512 && !KG && !GATE && KS == 1 && !XS), "X3: the 8-wave 128x128 class");
-        gemm_mainloop_x3<AKM, BKM>(A, B, M, N, m0, n0, k_begin, k_end, smem, acc);   // (the host launches it for aligned operands and whole k-tiles only)
+        static_assert(!X3 || (BM == 128 && BN == 128 && NT == 512 && !GATE && KS == 1 && !XS), "X3: the 8-wave 128x128 class");
+        gemm_mainloop_x3<AKM, BKM, KG>(A, B, M, N, m0, n0, k_begin, k_end, smem, acc);   // (the host launches it for aligned operands and whole k-tiles only)
     } else if (fast)
         gemm_mainloop<BM, BN, NT, AKM, BKM, true, TM, TN, D, KG, KS>(A, B, M, N, a_vec, b_vec, m0, n0, k_begin, k_end, smem, acc);
     else
@@ -883,9 +934,9 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(const Group g) {
     gemm_tile<BM, BN, NT, AKM, BKM, D, KG, false>(g, nullptr);
 }
 
-template <bool AKM, bool BKM>
-__global__ __launch_bounds__(512, 2) void gemm_x3_kernel(const Group g) {
-    gemm_tile<128, 128, 512, AKM, BKM, 2, false, false, 1, false, true>(g, nullptr);
+template <bool AKM, bool BKM, bool KG>
+__global__ __launch_bounds__(512, 4) void gemm_x3_kernel(const Group g) {   // 4 waves per SIMD = two workgroups per CU: <= 128 VGPRs
+    gemm_tile<128, 128, 512, AKM, BKM, 2, KG, false, 1, false, true>(g, nullptr);
 }
 
 // 64x64 class, A row-major, B k-major (dX = dY W): the only form the recurrent backward chains use
@@ -1130,13 +1181,16 @@ int launch(Group& g, int akm, int bkm, hipStream_t st) {
     if constexpr (BM == 128 && NT == 512) {
         // X3 (fp32-exact operands on the bf16 matrix cores, gemm_mainloop_x3): aligned operands, whole k-tiles, plain rows
         static const int x3_on = getenv("TWOG_GEMM_X3") ? atoi(getenv("TWOG_GEMM_X3")) : 0;
-        bool ok = x3_on != 0 && !kg && (g.k_per_split % BK) == 0;
+        bool ok = x3_on != 0 && (g.k_per_split % BK) == 0;
         for (int i = 0; i < g.n; ++i) ok = ok && g.p[i].a_vec && g.p[i].b_vec && (g.p[i].K % BK) == 0 && g.p[i].M >= 4 && g.p[i].N >= 4;
         if (ok) {
-            if (!akm && !bkm) hipLaunchKernelGGL((gemm_x3_kernel<false, false>), grid, block, 0, st, g);
-            else if (!akm && bkm) hipLaunchKernelGGL((gemm_x3_kernel<false, true>), grid, block, 0, st, g);
-            else if (akm && bkm) hipLaunchKernelGGL((gemm_x3_kernel<true, true>), grid, block, 0, st, g);
-            else hipLaunchKernelGGL((gemm_x3_kernel<true, false>), grid, block, 0, st, g);
+            if (!akm && !bkm) hipLaunchKernelGGL((gemm_x3_kernel<false, false, false>), grid, block, 0, st, g);
+            else if (!akm && bkm && !kg) hipLaunchKernelGGL((gemm_x3_kernel<false, true, false>), grid, block, 0, st, g);
+            else if (!akm && bkm) hipLaunchKernelGGL((gemm_x3_kernel<false, true, true>), grid, block, 0, st, g);
+            else if (akm && bkm && !kg) hipLaunchKernelGGL((gemm_x3_kernel<true, true, false>), grid, block, 0, st, g);
+            else if (akm && bkm) hipLaunchKernelGGL((gemm_x3_kernel<true, true, true>), grid, block, 0, st, g);
+            else if (!kg) hipLaunchKernelGGL((gemm_x3_kernel<true, false, false>), grid, block, 0, st, g);
+            else hipLaunchKernelGGL((gemm_x3_kernel<true, false, true>), grid, block, 0, st, g);
             TWOG_CHECK_LAUNCH();
             g_last_class_x3 = 1;
             if (g.splitk > 1) {
