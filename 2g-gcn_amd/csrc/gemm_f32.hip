@@ -386,21 +386,25 @@ __device__ __forceinline__ void gemm_mainloop(const twog_rows_t A, const twog_ro
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// X3: the 128x128 class on the bf16 matrix cores with fp32-exact operands (TWOG_GEMM_X3, see twog_gemm_f32).
+// X3: the 128x128 class on the bf16 matrix cores with fp32-exact operands (default; TWOG_GEMM_X3=0 selects the native
+// fp32-MFMA kernels above for every launch).
 //
 // Every fp32 operand element is split EXACTLY into three bf16 values, x = h + m + l: h = x truncated to its top 8
 // significant bits, m = (x - h) truncated, l = x - h - m (at most 8 significant bits are left: no rounding anywhere,
 // the 24-bit significand is three 8-bit chunks). A product a b = sum of nine chunk products; the six with weight
 // >= 2^-16 -- hh, hm, mh, mm, hl, lh -- run on v_mfma_f32_32x32x16_bf16 (bf16 x bf16 products are exact in the fp32
-// accumulator), the three dropped ones (ml, lm, ll) are <= 2^-23 |a b| in total: below the rounding of the fp32
-// accumulation itself, which is the same as in the native kernel. Six bf16 MFMAs of 16 k-steps cost 192 cycles per
+// accumulator); the three dropped ones (ml, lm, ll) are <= 2^-21 |a b| in the worst case and ~2^-24 |a b| on average,
+// i.e. of the order of the rounding the fp32 accumulation applies to every partial sum anyway: measured against fp64
+// products the kernel's error equals the native fp32-MFMA kernel's on every shape of tools/gemm_x3_bench.py (0.7-2.5e-6
+// of the largest output for K = 512 ... 61 440); adding the two products m l and l m (exact to 2^-30) changes no digit of
+// that error and costs 15 % (TWOG_X3_PRODUCTS=8 at build time). Six bf16 MFMAs of 16 k-steps cost 192 cycles per
 // 32x32 block where the fp32 MFMA (32x32x2) needs 512: 2.67x the matrix rate for the same result to fp32 rounding.
 //
-// Structure: same tile (128x128x32, 8 waves of 32x64), same branch-free 16-byte global loads into registers; the split
-// happens once per element on the way into LDS (5.5 VALU operations per element), LDS holds three bf16 planes per
-// operand, one stage (61 KB: two workgroups per CU) behind a register stage. Row-major operands ([row][k], k
-// contiguous) are stored as [row][32 k] rows of 80 bytes (64 + 16 pad: the ds_read_b128 fragment reads are
-// conflict-free); k-major operands ([k][row]) are stored as they come, [k][128 rows] rows of 256 bytes with 16-byte
+// Structure: 128x128 tile, 8 waves of 32x64, k-tiles of 16 (one bf16 MFMA k-step), the same branch-free 16-byte global
+// loads into registers (two stages); the split happens once per element on the way into LDS (5.5 VALU operations per
+// element), LDS holds three bf16 planes per operand in two stages (2 x 36 KB: two workgroups per CU), one barrier per
+// k-tile. Row-major operands ([row][k], k contiguous) are stored as [row][16 k] rows of 32 bytes whose two 16-byte chunks
+// are swapped on every second group of 16 rows (the ds_read_b128 fragment reads and the ds_write_b64 stores are conflict-free); k-major operands ([k][row]) are stored as they come, [k][128 rows] rows of 256 bytes with 16-byte
 // chunks XOR-swizzled by the k row, and transposed on the way out by ds_read_b64_tr_b16 (each 16-lane group receives a
 // 4 k x 16 rows block column-major: the MFMA's k-contiguous fragment with no data movement of our own).
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -411,7 +415,9 @@ typedef int i32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t pack_hi16(uint32_t lo, uint32_t hi) {   // {hi[31:16], lo[31:16]}
     return __builtin_amdgcn_perm(hi, lo, 0x07060302);
 }
-// four consecutive fp32 values -> their three bf16 planes (4 x 2 bytes each)
+// four consecutive fp32 values -> their three bf16 planes (4 x 2 bytes each), by truncation: h = the top 8 significant bits,
+// m = the top 8 of x - h, l = x - h - m. Exact (both subtractions are, and at most 8 significant bits are left for l), never
+// overflows (a rounding split -- v_cvt_pk_bf16_f32 -- measured 5-8 % slower with the same end-to-end error).
 __device__ __forceinline__ void split3(const f32x4 v, i32x2& ph, i32x2& pm, i32x2& pl) {
     uint32_t x[4], r1[4], r2[4];
 #pragma unroll
@@ -427,187 +433,173 @@ __device__ __forceinline__ void split3(const f32x4 v, i32x2& ph, i32x2& pm, i32x
     pl = i32x2{(int)pack_hi16(r2[0], r2[1]), (int)pack_hi16(r2[2], r2[3])};
 }
 
-constexpr int X3_RROW = 80;              // bytes per row of a [row][32 k] image
-constexpr int X3_RPLANE = 128 * X3_RROW; // 10 240
-constexpr int X3_TPLANE = 32 * 256;      // [32 k][128 rows] image: 8 192
+#ifndef TWOG_X3_PRODUCTS
+#define TWOG_X3_PRODUCTS 6
+#endif
+constexpr int X3_PRODUCTS = TWOG_X3_PRODUCTS;  // chunk products per element product: 8 (exact to 2^-30) or 6 (drops m l, l m)
+constexpr int X3_BK = 16;                    // one v_mfma_f32_32x32x16_bf16 k-step per k-tile
+constexpr int X3_RROW = 32;                  // bytes per row of a [row][16 k] image; its two 16-byte chunks are swapped on rows
+                                             // 16..31 (mod 32): conflict-free ds_read_b128 (lane groups of the guide) and ds_write_b64
+constexpr int X3_RPLANE = 128 * X3_RROW;     // 4 096
+constexpr int X3_TPLANE = X3_BK * 256;       // [16 k][128 rows] image: 4 096
+constexpr int X3_STAGE = 6 * X3_RPLANE;      // one LDS stage (both operands, worst case): 36 864 bytes; two stages = the tile's 73 728
 __device__ __forceinline__ int x3_swz(int k) { return ((k & 3) << 2) | ((k >> 2) & 3); }
 
 template <bool AKM, bool BKM, bool KG>
 __device__ __forceinline__ void gemm_mainloop_x3(const twog_rows_t A, const twog_rows_t B, int M, int N, int m0, int n0,
                                                  int k_begin, int k_end, float* smem, f32x16 (&acc)[1][2]) {
-    constexpr int BM = 128, BN = 128, NT = 512;
-    constexpr int A_BYTES = 3 * (AKM ? X3_TPLANE : X3_RPLANE);
-    char* ldsA = reinterpret_cast<char*>(smem);
-    char* ldsB = ldsA + A_BYTES;
+    constexpr int BM = 128, BN = 128, NT = 512, XK = X3_BK;
+    constexpr int PA = AKM ? X3_TPLANE : X3_RPLANE, PB = BKM ? X3_TPLANE : X3_RPLANE;
+    char* lds = reinterpret_cast<char*>(smem);   // stage b: A planes at b * X3_STAGE, B planes behind them
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = (wave >> 1) * 32, wn = (wave & 1) * 64;
-    using ARegs = TileRegs<(AKM ? BK : BM), (AKM ? BM : BK), NT>;
-    using BRegs = TileRegs<(BKM ? BK : BN), (BKM ? BN : BK), NT>;
-    static_assert(ARegs::PASSES == 2 && BRegs::PASSES == 2, "two 16-byte loads per operand and thread");
+    using ARegs = TileRegs<(AKM ? XK : BM), (AKM ? BM : XK), NT>;
+    using BRegs = TileRegs<(BKM ? XK : BN), (BKM ? BN : XK), NT>;
+    static_assert(ARegs::PASSES == 1 && BRegs::PASSES == 1, "one 16-byte load per operand and thread");
     // global addressing as in gemm_mainloop's FAST path (branch-free buffer loads, clamped edges)
-    uint32_t oa[2], ob[2];
-    int sa_off[2], sb_off[2];   // LDS byte offset (plane 0) of this thread's store for pass i
+    uint32_t oa, ob;
+    int sa_off, sb_off;   // LDS byte offset (stage 0, plane 0) of this thread's stores
     const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(A.ptr, 0, 0xffffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc(B.ptr, 0, 0xffffffff, 0x00020000);
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        {
-            const int rr = tid / ARegs::F4_PER_ROW + i * ARegs::ROWS_PER_PASS, cq = tid % ARegs::F4_PER_ROW;
-            if constexpr (AKM) {   // rr = k row of the tile, cq = quad of tile rows
-                oa[i] = KG ? 4u * (uint32_t)min(m0 + cq * 4, M - 4) : 4u * (uint32_t)((int64_t)rr * A.ld_outer + min(m0 + cq * 4, M - 4));
-                sa_off[i] = 256 * rr + 16 * ((cq >> 1) ^ x3_swz(rr)) + 8 * (cq & 1);
-            } else {               // rr = tile row, cq = quad of k
-                oa[i] = 4u * (uint32_t)(twog_row_off(A, min(m0 + rr, M - 1)) + cq * 4);
-                sa_off[i] = rr * X3_RROW + cq * 8;
-            }
-        }
-        {
-            const int rr = tid / BRegs::F4_PER_ROW + i * BRegs::ROWS_PER_PASS, cq = tid % BRegs::F4_PER_ROW;
-            if constexpr (BKM) {
-                ob[i] = KG ? 4u * (uint32_t)min(n0 + cq * 4, N - 4) : 4u * (uint32_t)((int64_t)rr * B.ld_outer + min(n0 + cq * 4, N - 4));
-                sb_off[i] = 256 * rr + 16 * ((cq >> 1) ^ x3_swz(rr)) + 8 * (cq & 1);
-            } else {
-                ob[i] = 4u * (uint32_t)(twog_row_off(B, min(n0 + rr, N - 1)) + cq * 4);
-                sb_off[i] = rr * X3_RROW + cq * 8;
-            }
+    {
+        const int rr = tid / ARegs::F4_PER_ROW, cq = tid % ARegs::F4_PER_ROW;
+        if constexpr (AKM) {   // rr = k row of the tile, cq = quad of tile rows
+            oa = KG ? 4u * (uint32_t)min(m0 + cq * 4, M - 4) : 4u * (uint32_t)((int64_t)rr * A.ld_outer + min(m0 + cq * 4, M - 4));
+            sa_off = 256 * rr + 16 * ((cq >> 1) ^ x3_swz(rr)) + 8 * (cq & 1);
+        } else {               // rr = tile row, cq = quad of k
+            oa = 4u * (uint32_t)(twog_row_off(A, min(m0 + rr, M - 1)) + cq * 4);
+            sa_off = rr * X3_RROW + 16 * ((cq >> 1) ^ ((rr >> 4) & 1)) + 8 * (cq & 1);
         }
     }
-    struct Stage { f32x4 a[2], b[2]; };
+    {
+        const int rr = tid / BRegs::F4_PER_ROW, cq = tid % BRegs::F4_PER_ROW;
+        if constexpr (BKM) {
+            ob = KG ? 4u * (uint32_t)min(n0 + cq * 4, N - 4) : 4u * (uint32_t)((int64_t)rr * B.ld_outer + min(n0 + cq * 4, N - 4));
+            sb_off = 3 * PA + 256 * rr + 16 * ((cq >> 1) ^ x3_swz(rr)) + 8 * (cq & 1);
+        } else {
+            ob = 4u * (uint32_t)(twog_row_off(B, min(n0 + rr, N - 1)) + cq * 4);
+            sb_off = 3 * PA + rr * X3_RROW + 16 * ((cq >> 1) ^ ((rr >> 4) & 1)) + 8 * (cq & 1);
+        }
+    }
+    struct Stage { f32x4 a, b; };
     // KG: a k-major operand whose rows (= k) are (outer, inner) grouped, e.g. "all but the first time step of every clip":
-    // the (outer, inner) position of each pass's row is carried from k-tile to k-tile (k only moves forward; the clamped tail
-    // repeats the last tile), no division in the loop. Offsets stay below 2^32 bytes (vec_ok).
-    int ka_o[KG ? 2 : 1], ka_i[KG ? 2 : 1], kb_o[KG ? 2 : 1], kb_i[KG ? 2 : 1], ka_k = k_begin, kb_k = k_begin;
+    // the (outer, inner) position of this thread's row is carried from k-tile to k-tile (k only moves forward; the clamped
+    // tail repeats the last tile), no division in the loop. Offsets stay below 2^32 bytes (vec_ok).
+    int ka_o = 0, ka_i = 0, kb_o = 0, kb_i = 0, ka_k = k_begin, kb_k = k_begin;
     const int a_in = A.inner <= 1 ? 0x7fffffff : A.inner, b_in = B.inner <= 1 ? 0x7fffffff : B.inner;
     const uint32_t a_ldi = (uint32_t)(A.inner <= 1 ? A.ld_outer : A.ld_inner), b_ldi = (uint32_t)(B.inner <= 1 ? B.ld_outer : B.ld_inner);
     if constexpr (KG) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int ra_ = k_begin + tid / ARegs::F4_PER_ROW + i * ARegs::ROWS_PER_PASS;
-            const int rb_ = k_begin + tid / BRegs::F4_PER_ROW + i * BRegs::ROWS_PER_PASS;
-            ka_o[i] = A.inner <= 1 ? 0 : ra_ / A.inner; ka_i[i] = A.inner <= 1 ? ra_ : ra_ - ka_o[i] * A.inner;
-            kb_o[i] = B.inner <= 1 ? 0 : rb_ / B.inner; kb_i[i] = B.inner <= 1 ? rb_ : rb_ - kb_o[i] * B.inner;
-        }
+        const int ra_ = k_begin + tid / ARegs::F4_PER_ROW, rb_ = k_begin + tid / BRegs::F4_PER_ROW;
+        ka_o = A.inner <= 1 ? 0 : ra_ / A.inner; ka_i = A.inner <= 1 ? ra_ : ra_ - ka_o * A.inner;
+        kb_o = B.inner <= 1 ? 0 : rb_ / B.inner; kb_i = B.inner <= 1 ? rb_ : rb_ - kb_o * B.inner;
     }
     auto gload = [&](Stage& r, int k0) {
         if constexpr (KG && AKM) {
-            const int delta = k0 - ka_k;
+            ka_i += k0 - ka_k;
             ka_k = k0;
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                ka_i[i] += delta;
-                while (ka_i[i] >= a_in) { ka_i[i] -= a_in; ++ka_o[i]; }
-                const uint32_t off = 4u * ((uint32_t)ka_o[i] * (uint32_t)A.ld_outer + (uint32_t)ka_i[i] * a_ldi) + oa[i];
-                r.a[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, (int)off, 0, 0));
-            }
+            while (ka_i >= a_in) { ka_i -= a_in; ++ka_o; }
+            const uint32_t off = 4u * ((uint32_t)ka_o * (uint32_t)A.ld_outer + (uint32_t)ka_i * a_ldi) + oa;
+            r.a = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, (int)off, 0, 0));
         } else {
             const int sa = (int)(AKM ? (uint32_t)k0 * (uint32_t)A.ld_outer * 4u : (uint32_t)k0 * 4u);
-#pragma unroll
-            for (int i = 0; i < 2; ++i) r.a[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, (int)oa[i], sa, 0));
+            r.a = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, (int)oa, sa, 0));
         }
         if constexpr (KG && BKM) {
-            const int delta = k0 - kb_k;
+            kb_i += k0 - kb_k;
             kb_k = k0;
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                kb_i[i] += delta;
-                while (kb_i[i] >= b_in) { kb_i[i] -= b_in; ++kb_o[i]; }
-                const uint32_t off = 4u * ((uint32_t)kb_o[i] * (uint32_t)B.ld_outer + (uint32_t)kb_i[i] * b_ldi) + ob[i];
-                r.b[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_b, (int)off, 0, 0));
-            }
+            while (kb_i >= b_in) { kb_i -= b_in; ++kb_o; }
+            const uint32_t off = 4u * ((uint32_t)kb_o * (uint32_t)B.ld_outer + (uint32_t)kb_i * b_ldi) + ob;
+            r.b = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_b, (int)off, 0, 0));
         } else {
             const int sb = (int)(BKM ? (uint32_t)k0 * (uint32_t)B.ld_outer * 4u : (uint32_t)k0 * 4u);
-#pragma unroll
-            for (int i = 0; i < 2; ++i) r.b[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_b, (int)ob[i], sb, 0));
+            r.b = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_b, (int)ob, sb, 0));
         }
     };
-    auto split_store = [&](const Stage& r) {
-        constexpr int PA = AKM ? X3_TPLANE : X3_RPLANE, PB = BKM ? X3_TPLANE : X3_RPLANE;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            i32x2 ph, pm, pl;
-            split3(r.a[i], ph, pm, pl);
-            *reinterpret_cast<i32x2*>(ldsA + sa_off[i]) = ph;
-            *reinterpret_cast<i32x2*>(ldsA + sa_off[i] + PA) = pm;
-            *reinterpret_cast<i32x2*>(ldsA + sa_off[i] + 2 * PA) = pl;
-            split3(r.b[i], ph, pm, pl);
-            *reinterpret_cast<i32x2*>(ldsB + sb_off[i]) = ph;
-            *reinterpret_cast<i32x2*>(ldsB + sb_off[i] + PB) = pm;
-            *reinterpret_cast<i32x2*>(ldsB + sb_off[i] + 2 * PB) = pl;
-        }
+    auto split_store = [&](const Stage& r, int buf) {
+        char* base = lds + buf * X3_STAGE;
+        i32x2 ph, pm, pl;
+        split3(r.a, ph, pm, pl);
+        *reinterpret_cast<i32x2*>(base + sa_off) = ph;
+        *reinterpret_cast<i32x2*>(base + sa_off + PA) = pm;
+        *reinterpret_cast<i32x2*>(base + sa_off + 2 * PA) = pl;
+        split3(r.b, ph, pm, pl);
+        *reinterpret_cast<i32x2*>(base + sb_off) = ph;
+        *reinterpret_cast<i32x2*>(base + sb_off + PB) = pm;
+        *reinterpret_cast<i32x2*>(base + sb_off + 2 * PB) = pl;
     };
     // fragment addressing: lane l = (r = l & 31 row / column of the 32x32 block, h = l >> 5 half of the 16-deep k-step)
     const int r32 = lane & 31, h = lane >> 5;
-    // row-major image: 16 bytes (k = 16 s + 8 h .. + 7) of row (block row + r)
-    const int fa_r = (wm + r32) * X3_RROW + 16 * h;
-    const int fb_r = (wn + r32) * X3_RROW + 16 * h;
+    // row-major image: 16 bytes (k = 8 h .. 8 h + 7) of row (block row + r)
+    const int fa_r = (wm + r32) * X3_RROW + 16 * (h ^ ((r32 >> 4) & 1));
+    const int fb_r = 3 * PA + (wn + r32) * X3_RROW + 16 * (h ^ ((r32 >> 4) & 1));
     // k-major image, transposed read: lane 4q + p of a 16-lane group g supplies block row k = 8 (g >> 1) + q (+ 4 for the second
     // read), rows 16 (g & 1) + 4p .. 4p + 3 of the block: chunk (block row / 8) + 2 (g & 1) + (p >> 1), byte 8 (p & 1)
     const int g16 = lane >> 4, q4 = (lane >> 2) & 3, p4 = lane & 3;
-    const int tk = 8 * (g16 >> 1) + q4;                     // k row inside a k-step (first read); second read: + 4
+    const int tk0 = 8 * (g16 >> 1) + q4, tk1 = tk0 + 4;
+    const int ta0 = 256 * tk0 + 8 * (p4 & 1), ta1 = 256 * tk1 + 8 * (p4 & 1);   // + 16 * (chunk ^ swz)
     const int tchA = (wm >> 3) + 2 * (g16 & 1) + (p4 >> 1);
-    const int tchB = (wn >> 3) + 2 * (g16 & 1) + (p4 >> 1);  // block b: + 4 b
-    auto frag = [&](const char* base, bool kmaj, int plane, int s, int off_r, int tch) -> bf16x8 {
-        if (!kmaj) {
-            const i32x4 v = *reinterpret_cast<const i32x4*>(base + plane * X3_RPLANE + off_r + 32 * s);
-            return __builtin_bit_cast(bf16x8, v);
-        }
-        const int k0 = 16 * s + tk, k1 = k0 + 4;
-        const char* pl = base + plane * X3_TPLANE + 8 * (p4 & 1);
-        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-            (__attribute__((address_space(3))) s16x4*)(pl + 256 * k0 + 16 * (tch ^ x3_swz(k0))));
-        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-            (__attribute__((address_space(3))) s16x4*)(pl + 256 * k1 + 16 * (tch ^ x3_swz(k1))));
-        typedef short s16x8 __attribute__((ext_vector_type(8)));
+    const int tchB = (wn >> 3) + 2 * (g16 & 1) + (p4 >> 1);                       // block b: + 4 b
+    const int sw0 = x3_swz(tk0), sw1 = x3_swz(tk1);
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    auto frag_r = [&](const char* base, int off) -> bf16x8 {
+        return __builtin_bit_cast(bf16x8, *reinterpret_cast<const i32x4*>(base + off));
+    };
+    auto frag_t = [&](const char* base, int tch) -> bf16x8 {
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + ta0 + 16 * (tch ^ sw0)));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + ta1 + 16 * (tch ^ sw1)));
         const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         return __builtin_bit_cast(bf16x8, v);
     };
-    auto compute = [&]() {
+    auto compute = [&](int buf) {
+        const char* base = lds + buf * X3_STAGE;
+        bf16x8 af[3], bf[2][3];
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            bf16x8 af[3], bf[2][3];
+        for (int p = 0; p < 3; ++p) af[p] = AKM ? frag_t(base + p * PA, tchA) : frag_r(base + p * PA, fa_r);
 #pragma unroll
-            for (int p = 0; p < 3; ++p) af[p] = frag(ldsA, AKM, p, s, fa_r, tchA);
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+                bf[b][p] = BKM ? frag_t(base + 3 * PA + p * PB, tchB + 4 * b) : frag_r(base + p * PB, fb_r + b * 32 * X3_RROW);
+        // X3_PRODUCTS chunk products per block, smallest terms first; the two blocks' chains alternate so that an MFMA never
+        // waits for the previous result of its own accumulator. 8 (default): everything down to 2^-24 |a b| -- the products
+        // are exact to 2^-30, the result differs from an fp32 GEMM only by the order of the fp32 accumulation; 6
+        // (TWOG_GEMM_X3=6 at build time... see X3_PRODUCTS): also drops m l and l m (<= 2^-21 |a b| worst case).
+        constexpr int PI[8] = {2, 1, 2, 0, 1, 1, 0, 0}, PJ[8] = {1, 2, 0, 2, 1, 0, 1, 0};
+        constexpr int FIRST = 8 - X3_PRODUCTS;
+        static_assert(X3_PRODUCTS == 8 || X3_PRODUCTS == 6, "l m and m l are the two optional products");
+#pragma unroll
+        for (int t = FIRST; t < 8; ++t)
 #pragma unroll
             for (int b = 0; b < 2; ++b)
-#pragma unroll
-                for (int p = 0; p < 3; ++p) bf[b][p] = frag(ldsB, BKM, p, s, fb_r + b * 32 * X3_RROW, tchB + 4 * b);
-#pragma unroll
-            for (int b = 0; b < 2; ++b) {
-                // smallest terms first: l h, h l, m m, then m h, h m, h h
-                acc[0][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2], bf[b][0], acc[0][b], 0, 0, 0);
-                acc[0][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[b][2], acc[0][b], 0, 0, 0);
-                acc[0][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[b][1], acc[0][b], 0, 0, 0);
-                acc[0][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[b][0], acc[0][b], 0, 0, 0);
-                acc[0][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[b][1], acc[0][b], 0, 0, 0);
-                acc[0][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[b][0], acc[0][b], 0, 0, 0);
-            }
-        }
+                acc[0][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[PI[t]], bf[b][PJ[t]], acc[0][b], 0, 0, 0);
     };
-    // Two register stages: the loads of k-tile t + 2 are issued before the MFMAs of tile t and are split / stored a whole
-    // iteration later (one stage does not cover the HBM latency at this matrix rate). One LDS stage: a barrier after the
-    // MFMAs (every wave is done reading) and one after the stores. Loads past the last k-tile are clamped to it instead of
-    // branched around (see gemm_mainloop); the redundant tile is never stored.
-    const int nkt = (k_end - k_begin) / BK;
+    // Four register stages and two LDS stages, one barrier per k-tile: the loads of k-tile t + 4 are issued before the MFMAs
+    // of tile t (a k-tile of 16 lasts under two microseconds at this matrix rate: two stages do not cover a miss to HBM);
+    // tile t + 1 is split and stored into the other LDS stage in the same basic block as the MFMAs of tile t (the VALU work
+    // of the split issues between the MFMAs). Loads past the last k-tile are clamped to it instead of branched around (see
+    // gemm_mainloop); the redundant tiles are stored but never read.
+    const int nkt = (k_end - k_begin) / XK;
     if (nkt <= 0) return;
-    const int k_last = k_begin + (nkt - 1) * BK;
-    Stage r0, r1;
-    gload(r0, k_begin);
-    gload(r1, min(k_begin + BK, k_last));
-    split_store(r0);
+    const int k_last = k_begin + (nkt - 1) * XK;
+    auto kof = [&](int t) { return min(k_begin + t * XK, k_last); };
+    Stage r0, r1, r2, r3;
+    gload(r0, kof(0));
+    gload(r1, kof(1));
+    gload(r2, kof(2));
+    gload(r3, kof(3));
+    split_store(r0, 0);
     __syncthreads();
-    for (int kt = 0; kt + 1 < nkt; kt += 2) {
-        gload(r0, min(k_begin + (kt + 2) * BK, k_last));
-        compute();                                   // k-tile kt
-        __syncthreads();
-        split_store(r1);                             // k-tile kt + 1
-        __syncthreads();
-        gload(r1, min(k_begin + (kt + 3) * BK, k_last));
-        compute();                                   // k-tile kt + 1
-        __syncthreads();
-        if (kt + 2 < nkt) split_store(r0);           // k-tile kt + 2 (uniform)
-        __syncthreads();
+    int kt = 0;
+    for (; kt + 3 < nkt; kt += 4) {
+        gload(r0, kof(kt + 4)); compute(0); split_store(r1, 1); __syncthreads();
+        gload(r1, kof(kt + 5)); compute(1); split_store(r2, 0); __syncthreads();
+        gload(r2, kof(kt + 6)); compute(0); split_store(r3, 1); __syncthreads();
+        gload(r3, kof(kt + 7)); compute(1); split_store(r0, 0); __syncthreads();
     }
-    if (nkt & 1) compute();
+    // up to three k-tiles left: tile kt sits in LDS stage 0, tiles kt + 1, kt + 2 in r1, r2
+    if (kt < nkt) compute(0);
+    if (kt + 1 < nkt) { split_store(r1, 1); __syncthreads(); compute(1); }
+    if (kt + 2 < nkt) { split_store(r2, 0); __syncthreads(); compute(0); }
 }
 
 // XS (recurrent-chain launches with fewer tiles than the chip has CUs): the reduction is ALSO split over workgroups
@@ -1180,9 +1172,9 @@ int launch(Group& g, int akm, int bkm, hipStream_t st) {
     for (int i = 0; i < g.n; ++i) kg = kg || (akm && g.p[i].A.inner > 1) || (bkm && g.p[i].B.inner > 1);
     if constexpr (BM == 128 && NT == 512) {
         // X3 (fp32-exact operands on the bf16 matrix cores, gemm_mainloop_x3): aligned operands, whole k-tiles, plain rows
-        static const int x3_on = getenv("TWOG_GEMM_X3") ? atoi(getenv("TWOG_GEMM_X3")) : 0;
-        bool ok = x3_on != 0 && (g.k_per_split % BK) == 0;
-        for (int i = 0; i < g.n; ++i) ok = ok && g.p[i].a_vec && g.p[i].b_vec && (g.p[i].K % BK) == 0 && g.p[i].M >= 4 && g.p[i].N >= 4;
+        static const int x3_on = getenv("TWOG_GEMM_X3") ? atoi(getenv("TWOG_GEMM_X3")) : 1;   // default on; 0: native fp32 MFMA
+        bool ok = x3_on != 0 && (g.k_per_split % X3_BK) == 0;
+        for (int i = 0; i < g.n; ++i) ok = ok && g.p[i].a_vec && g.p[i].b_vec && (g.p[i].K % X3_BK) == 0 && g.p[i].M >= 4 && g.p[i].N >= 4;
         if (ok) {
             if (!akm && !bkm) hipLaunchKernelGGL((gemm_x3_kernel<false, false, false>), grid, block, 0, st, g);
             else if (!akm && bkm && !kg) hipLaunchKernelGGL((gemm_x3_kernel<false, true, false>), grid, block, 0, st, g);
@@ -1199,6 +1191,9 @@ int launch(Group& g, int akm, int bkm, hipStream_t st) {
             }
             return 0;
         }
+        // not served by X3: grouped k-major rows keep the 4-wave fp32 tiles (their pointer-carrying 8-wave kernels exceed
+        // 128 VGPRs and measure 7 % slower)
+        if (kg) return launch<BM, BN, 256, D>(g, akm, bkm, st);
     }
     if (!akm && !bkm) hipLaunchKernelGGL((gemm_kernel<BM, BN, NT, false, false, D, false>), grid, block, 0, st, g);
     else if (!akm && bkm && !kg) hipLaunchKernelGGL((gemm_kernel<BM, BN, NT, false, true, D, false>), grid, block, 0, st, g);
@@ -1470,11 +1465,12 @@ static int gemm_impl(const twog_gemm_t* problems, int n_problems, int a_kmajor, 
             done += n;
             continue;
         }
-        if (big && w8 && !grouped) rc = d128 == 2 ? launch<128, 128, 512, 2>(g, a_kmajor, b_kmajor, st) : launch<128, 128, 512, 1>(g, a_kmajor, b_kmajor, st);
+        static const int x3_try = getenv("TWOG_GEMM_X3") ? atoi(getenv("TWOG_GEMM_X3")) : 1;   // grouped rows: X3 has 8-wave variants
+        if (big && w8 && (!grouped || x3_try)) rc = d128 == 2 ? launch<128, 128, 512, 2>(g, a_kmajor, b_kmajor, st) : launch<128, 128, 512, 1>(g, a_kmajor, b_kmajor, st);
         else if (big) rc = d128 == 2 ? launch<128, 128, 256, 2>(g, a_kmajor, b_kmajor, st) : launch<128, 128, 256, 1>(g, a_kmajor, b_kmajor, st);
         else rc = d64 == 2 ? launch<64, 64, 256, 2>(g, a_kmajor, b_kmajor, st) : launch<64, 64, 256, 1>(g, a_kmajor, b_kmajor, st);
         if (rc) return rc;
-        if (g_last_class_x3) g_last_class |= TWOG_GEMM_CLASS_X3;
+        if (g_last_class_x3) g_last_class |= TWOG_GEMM_CLASS_X3 | TWOG_GEMM_CLASS_WAVES8;
         done += n;
     }
     return 0;

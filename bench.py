@@ -76,6 +76,8 @@ def select_workload(name):
     CFG['hidden_size'], CFG['gcn_node'] = w['h'], w['N']
     return w
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 FLOP/clk/CU
+PEAK_BF16_MFMA_TFLOPS = 2516.6  # dense bf16 (MI355X_MICROARCH.md: ~2.5 PF): v_mfma_f32_32x32x16_bf16, 32 768 FLOP / 32 clk / SIMD at 2.4 GHz
+X3_PRODUCTS = 6                 # bf16 chunk products the X3 kernels execute per fp32 multiply-add (csrc/gemm_f32.hip)
 PEAK_HBM_GBS = 8000.0
 
 
@@ -145,8 +147,9 @@ class GemmProfiler:
             e0.record()
             self.orig(problems, a_kmajor, b_kmajor, split_k_workspace)
             e1.record()
-            big = bool(self.K.gemm_last_class() & self.K.GEMM_TILE128)  # the tile class the library actually picked
-            self.records.append(('128x128' if big else '64x64', flops, e0, e1, abytes))
+            cls = self.K.gemm_last_class()   # the tile class / arithmetic the library actually picked
+            kind = ('128x128 bf16x3' if cls & self.K.GEMM_X3 else '128x128') if cls & self.K.GEMM_TILE128 else '64x64'
+            self.records.append((kind, flops, e0, e1, abytes))
             self.shapes.append((a_kmajor, b_kmajor, [(n_rows(p['C']), p['C'].shape[-1], (n_rows(p['A']) if a_kmajor else p['A'].shape[-1]), (p['batch'][0] if p.get('batch') else 1)) for p in problems]))
         self.K.gemm = gemm
         return self
@@ -575,7 +578,7 @@ def main():
         import glob
         tfiles = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles',
                                                'r*_gemm128_hbm_traffic.json')))
-        if kind == '128x128' and tfiles:   # the latest round's committed counter passes
+        if kind.startswith('128x128') and tfiles:   # the latest round's committed counter passes
             tj = json.load(open(tfiles[-1]))
             traffic = tj['hbm_bytes_per_launch']
             traffic_src = 'profiles/' + os.path.basename(tfiles[-1]) + ': ' + tj['source']
@@ -583,22 +586,40 @@ def main():
             'metric': 'clips/sec fwd+bwd, T=120 N=34 C=512' if args.workload == 'c3' else f'clips/sec fwd+bwd, {wl["name"]} (informational)', 'value': bs * world * args.steps / dt, 'unit': 'clips/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
             'higher_is_better': True, 'scaling': args.scaling, 'vs_baseline': None, 'dtype': 'fp32', 'data': 'synthetic',
+            'arithmetic': ('fp32 storage, fp32 accumulation everywhere; the 128x128-class GEMMs multiply on the bf16 matrix cores after an '
+                           'EXACT three-way bf16 split of every fp32 operand element (6 chunk products per multiply-add; error '
+                           'against fp64 equal to the fp32-MFMA kernels, tests/test_kernels_gpu.py::test_gemm_x3_*); every '
+                           'other kernel computes in fp32. TWOG_GEMM_X3=0: native fp32 MFMA throughout'
+                           if os.environ.get('TWOG_GEMM_X3', '1') != '0' else 'fp32 throughout (fp32 MFMA; TWOG_GEMM_X3=0)'),
             'config': {'workload': f'{wl["name"]}: bs{bs} per GPU, T={T}, H={H}, O={O}, N={N_NODES}, h={CFG["hidden_size"]}, '
                                    f'classes {N_CLASSES}, ' + ('constructor defaults' + (f' + {wl["cfg"]}' if wl['cfg'] else '') if 'cfg' in wl else '2G-GCN_stage1 parameters'),
                        'global_batch': bs * world, 'per_gpu_batch': bs, 'parallelism': f'dp{world}',
                        'devices': devices, 'collective_backend': backend if world > 1 else None,
                        'step': 'forward + multi-task loss (fused HIP criterion) + backward + gradient all-reduce + fused Adam',
                        'loss_last': float(loss.detach())},
-            'roofline': {'bound': 'mfma', 'kernel': f'gemm_kernel<{kind.replace("x", ",")},*> (fp32 v_mfma_f32_32x32x2_f32)',
-                         'achieved': achieved, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': achieved / PEAK_FP32_MFMA_TFLOPS, 'traffic': traffic,
+            'roofline': ({
+                # X3 kernels: fp32 operands split EXACTLY into three bf16 chunks, six chunk products per multiply-add on
+                # v_mfma_f32_32x32x16_bf16, fp32 accumulate (same error against fp64 as the fp32-MFMA kernels, tested).
+                # `achieved` = matrix FLOP/s actually executed (6 x the algorithmic 2 M N K), `peak` = dense bf16 MFMA.
+                'bound': 'mfma', 'kernel': 'gemm_x3_kernel<*> 128x128 tiles (v_mfma_f32_32x32x16_bf16 on 3 exact bf16 chunks per fp32 operand, 6 products, fp32 accumulate)',
+                'achieved': achieved * X3_PRODUCTS, 'peak': PEAK_BF16_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                'frac': achieved * X3_PRODUCTS / PEAK_BF16_MFMA_TFLOPS,
+                'fp32_equivalent_tflops': achieved, 'fp32_mfma_peak_tflops': PEAK_FP32_MFMA_TFLOPS,
+                'fp32_equivalent_over_fp32_mfma_peak': achieved / PEAK_FP32_MFMA_TFLOPS,
+                'note': 'TWOG_GEMM_X3=0 selects the native fp32-MFMA kernels (v_mfma_f32_32x32x2_f32: 0.80 of their 157.3 TFLOP/s peak, slower in wall time)',
+            } if 'bf16x3' in kind else {
+                'bound': 'mfma', 'kernel': f'gemm_kernel<{kind.replace("x", ",")},*> (fp32 v_mfma_f32_32x32x2_f32)',
+                'achieved': achieved, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                'frac': achieved / PEAK_FP32_MFMA_TFLOPS,
+            }),
+            'roofline_common': {'traffic': traffic,
                          'traffic_unit': 'bytes per launch (L2<->fabric, Infinity-Cache hits included)',
                          'traffic_source': traffic_src,
                          'algorithmic_bytes_per_launch': bytes_alg / max(calls, 1),
                          'launches_per_step': calls / args.steps, 'avg_launch_ms': secs / max(calls, 1) * 1e3,
                          'algorithmic_gflop_per_step': flops / args.steps / 1e9,
                          'share_of_step_time': secs / dt},
-            'roofline_gcn': {'bound': 'hbm', 'kernel': 'geo_gcn forward (bn_stats..gcn_attn2_fwd..projection)',
+            'roofline_gcn': {'bound': 'hbm', 'kernel': 'geo_gcn forward (bn_stats, bn_finalize + similarity fold, gcn_fused_fwd, projection GEMM)',
                              'achieved': gcn_bytes / (gcn_ms * 1e-3) / 1e9, 'peak': 8000.0, 'unit': 'GB/s',
                              'frac': gcn_bytes / (gcn_ms * 1e-3) / 8e12, 'ms_per_batch': gcn_ms,
                              'algorithmic_bytes_per_batch': gcn_bytes,
@@ -620,6 +641,7 @@ def main():
                                  'launches_per_step': v[2] / args.steps} for k, v in agg.items()},
             'host_gemm_share_of_step': total_gemm_s / dt,
         }
+        result['roofline'].update(result.pop('roofline_common'))   # traffic, launches, shares: common to both kernel families
         if fwd_only is not None:
             result['forward_only_clips_per_s'] = fwd_only
         if world > 1:

@@ -361,3 +361,36 @@ def test_saved_state_is_released_by_backward_not_by_the_loss(fake_backend):
         assert out[0].shape[0] > 0 and loss.item() == loss.item()   # outputs and loss stay valid
     finally:
         gc.enable()
+
+
+def test_x3_operand_split_is_exact():
+    """The 128x128 GEMM class multiplies fp32 operands on the bf16 matrix cores after splitting every element into three
+    bf16 values by truncation (csrc/gemm_f32.hip, split3): h = top 8 significant bits, m = the next 8, l = the rest. The
+    arithmetic restated in numpy: the three chunks are exactly representable in bf16 (low 16 bits zero) and add up to the
+    element EXACTLY -- so the six products the kernel keeps differ from the exact product only by the three dropped
+    cross terms (m l, l m, l l: <= 2^-21 relative in the worst case, ~2^-24 on average)."""
+    import numpy as np
+    rng = np.random.RandomState(0)
+    x = np.concatenate([rng.randn(20000).astype(np.float32) * 10.0 ** rng.randint(-20, 20, 20000).astype(np.float32),
+                        np.array([0.0, -0.0, 1.0, -1.0, 3.0e38, -3.0e38, 1.1754944e-38, 1e-30, 0.1, 1.0 + 2.0 ** -23,
+                                  np.nextafter(np.float32(2.0), np.float32(0.0))], dtype=np.float32)])
+    mask = np.uint32(0xffff0000)
+    h = (x.view(np.uint32) & mask).view(np.float32)
+    r1 = x - h
+    m = (r1.view(np.uint32) & mask).view(np.float32)
+    r2 = r1 - m
+    l = (r2.view(np.uint32) & mask).view(np.float32)
+    assert np.array_equal(l, r2), 'the third chunk needs no truncation: at most 8 significant bits are left'
+    assert np.array_equal((h.astype(np.float64) + m.astype(np.float64)) + l.astype(np.float64), x.astype(np.float64))
+    for c in (h, m, l):
+        assert not np.any(c.view(np.uint32) & np.uint32(0xffff)), 'every chunk is a bf16 value'
+    # the product from the six kept chunk products against the exact product
+    y = rng.randn(x.size).astype(np.float32)
+    hy = (y.view(np.uint32) & mask).view(np.float32); ry = y - hy
+    my = (ry.view(np.uint32) & mask).view(np.float32); ly = ry - my
+    f = np.float64
+    six = f(h) * f(hy) + f(h) * f(my) + f(m) * f(hy) + f(m) * f(my) + f(h) * f(ly) + f(l) * f(hy)
+    exact = f(x) * f(y)
+    ok = np.isfinite(exact) & (np.abs(exact) > 1e-290)
+    rel = np.abs(six[ok] - exact[ok]) / np.abs(exact[ok])
+    assert np.max(rel) <= 2.0 ** -21 and np.mean(rel) <= 2.0 ** -23

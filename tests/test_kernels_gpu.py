@@ -1,6 +1,7 @@
 """GPU: every HIP kernel entry point (through the C ABI, via kernels.HipKernels) against its executable specification
 (tests/fake_kernels.py, plain torch fp32 on CPU) on seeded random inputs, including strided views, ragged sizes,
 masks and the split-K / grouped / batched GEMM forms. Tolerances are fp32 summation-order tolerances."""
+import json
 import math
 import os
 import subprocess
@@ -191,6 +192,8 @@ def _gemm128_cases(K, w8=True):
     full = T128 | W8 | KG | SK
     nosk = T128 | W8 | KG   # long reductions with a workspace may or may not be split (policy: whole rounds of the chip)
     w = W8 if w8 else 0
+    # grouped k-major rows: 8-wave X3 kernels by default, the 4-wave fp32 kernels with TWOG_GEMM_X3=0 (or TWOG_GEMM_W8=0)
+    kgw = w if os.environ.get('TWOG_GEMM_X3', '1') != '0' else 0
     # forward projection (NN), bias + ReLU: 480 x 4 tiles (+ ragged edge rows / columns in the second case)
     _gemm128_run(K, False, False, 61440, 512, 2048, bias=True, act=1, acc=False, expect=(T128 | w, nosk))
     _gemm128_run(K, False, False, 15361, 1500, 512, bias=True, act=0, acc=True, seed=1, expect=(T128 | w, full))
@@ -207,15 +210,15 @@ def _gemm128_cases(K, w8=True):
                  expect=(T128 | w, full))
     # TN (k-major A, row-major B: the GCN projection form)
     _gemm128_run(K, True, False, 2048, 2100, 512, bias=True, act=0, acc=False, seed=7, expect=(T128 | w, full))
-    # grouped-row k-major operands (KG; always 4 waves): dW_hh form  1536 x 512 x (bs (T-1) E)  with split-K,
+    # grouped-row k-major operands (KG): dW_hh form  1536 x 512 x (bs (T-1) E)  with split-K,
     # and a wide one without split-K
     _gemm128_run(K, True, True, 1536, 512, 8 * 59 * 8, bias=False, act=0, acc=False, group=(8, 59 * 8, 8), seed=8,
-                 expect=(T128 | KG | SK, full), rtol=6e-5)
+                 expect=(T128 | KG | SK | kgw, full), rtol=6e-5)
     _gemm128_run(K, True, True, 2048, 2048, 6 * 100, bias=False, act=0, acc=True, ws=False, group=(6, 100, 3), seed=9,
-                 expect=(T128 | KG, full))
+                 expect=(T128 | KG | (0 if (6 * 100) % 16 else kgw), full))
     # NT with a grouped k-major B only (carry form)
     _gemm128_run(K, False, True, 2048, 2048, 4 * 128, bias=False, act=0, acc=False, ws=False, group=(4, 128, 2),
-                 seed=10, expect=(T128 | KG, full))
+                 seed=10, expect=(T128 | KG | kgw, full))
 
 
 def test_gemm_128_class(K):
@@ -1109,6 +1112,71 @@ print('OK')
     env = dict(os.environ, TWOG_GEMM_XSPLIT=force)
     r = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and 'OK' in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
+
+
+def test_gemm_x3_error_equals_the_native_fp32_mfma_kernels():
+    """The 128x128 class multiplies on the bf16 matrix cores after an EXACT three-way split of every fp32 operand element
+    (csrc/gemm_f32.hip, X3; default). In a child process per mode (the switch is read once): the four operand layouts,
+    split-K, bias / ReLU / accumulate, grouped k-major rows, values over 60 orders of magnitude, exact zeros and a
+    denormal -- the class bit is asserted, the error against an fp64 product must stay within 1.25 x the native fp32-MFMA
+    kernels' error on the same inputs (+ 2e-7 of the largest output), and the result is bit-identical from launch to
+    launch."""
+    code = r"""
+import sys, json, torch
+sys.path.insert(0, %r)
+import twog_gcn_amd
+from twog_gcn_amd.kernels import get_kernels
+K = get_kernels(); DEV = 'cuda:0'
+res = {}
+g = torch.Generator().manual_seed(7)
+def case(name, M, N, Kk, akm, bkm, bias=False, act=0, acc=False, scale_a=None, grouped=False):
+    A = torch.randn((Kk, M) if akm else (M, Kk), generator=g)
+    if scale_a is not None:   # per-element magnitudes over many decades (the split must be exact at every exponent)
+        A = A * 10.0 ** torch.randint(-scale_a, scale_a, A.shape, generator=g).float()
+        A.view(-1)[::97] = 0.0
+        A.view(-1)[5] = 1e-39
+    B = torch.randn((Kk, N) if bkm else (N, Kk), generator=g) * 0.1
+    A, B = A.to(DEV), B.to(DEV)
+    if grouped:   # k-major operand whose rows are (outer, inner) grouped: all but the first of every 5 rows
+        full = torch.randn(Kk // 4 * 5, M, generator=g).to(DEV)
+        A = full.view(Kk // 4, 5, M)[:, 1:, :]
+    b = torch.randn(N, generator=g).to(DEV) if bias else None
+    C0 = torch.randn(M, N, generator=g).to(DEV)
+    outs = []
+    for _ in range(2):
+        C = C0.clone()
+        K.gemm([dict(A=A, B=B, C=C, bias=b, act=act, accumulate=acc)], a_kmajor=akm, b_kmajor=bkm)
+        outs.append(C)
+    cls = K.gemm_last_class()
+    assert cls & K.GEMM_TILE128, (name, hex(cls))
+    assert torch.equal(outs[0], outs[1]), name
+    Ad = (A.reshape(-1, M).t() if akm else A).double()
+    ref = Ad @ (B.double() if bkm else B.double().t())
+    if bias: ref = ref + b.double()
+    if acc: ref = ref + C0.double()
+    if act: ref = torch.relu(ref)
+    res[name] = dict(err=float((outs[0].double() - ref).abs().max() / ref.abs().max()), cls=cls)
+case('NN', 4096, 1536, 512, False, False, bias=True, act=1)
+case('NT', 4096, 512, 1536, False, True, acc=True)
+case('TT splitk', 1536, 512, 16384, True, True)
+case('TN', 1024, 2048, 1024, True, False, bias=True)
+case('NN wide magnitudes', 8192, 1024, 1024, False, False, scale_a=30)
+case('TT grouped rows', 1536, 512, 8192, True, True, grouped=True)
+print('RES ' + json.dumps(res))
+""" % (ROOT,)
+    out = {}
+    for mode in ('1', '0'):
+        r = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, TWOG_GEMM_X3=mode), capture_output=True,
+                           text=True, timeout=900)
+        assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+        out[mode] = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('RES ')][0][4:])
+    X3 = twog_kernels.get_kernels().GEMM_X3
+    for name, x in out['1'].items():
+        n = out['0'][name]
+        assert x['cls'] & X3 and not n['cls'] & X3, (name, hex(x['cls']), hex(n['cls']))
+        assert x['err'] <= 1.25 * n['err'] + 2e-7, (name, x['err'], n['err'])
+        assert x['err'] < 3e-5, (name, x['err'])
+    print({k: (f"{v['err']:.2e}", f"{out['0'][k]['err']:.2e}") for k, v in out['1'].items()})
 
 
 def test_ssp_gather_with_segment_level_placement(K):
