@@ -602,6 +602,183 @@ __device__ __forceinline__ void gemm_mainloop_x3(const twog_rows_t A, const twog
     if (kt + 2 < nkt) { split_store(r2, 0); __syncthreads(); compute(0); }
 }
 
+// X3 for the 64-row tile class (the recurrent chains at a real batch: 160 ... 960 tiles of K = 512 ... 1 536, MFMA-bound
+// in fp32: DESIGN.md section 8): the same exact three-way bf16 split and six chunk products as gemm_mainloop_x3, for
+//   64 x 64 tiles with 4 waves (KS = 1, k-tiles of 16) or 8 waves = two k-groups (KS = 2, k-tiles of 32: group g multiplies
+//   k-step g), and the fused GRU forward step's 64 x 192 gate-aware tiles (G3, three accumulators per wave).
+// A is always row-major here (previous states / gradients of a chain step); B is row-major ([N][K] weights: forward) or
+// k-major ([K][N]: the backward chains multiply by W, not W^T). Images: row-major operands [row][XK k] with 32- or 64-byte
+// rows whose 16-byte chunks are XOR-swizzled by the row (conflict-free ds_read_b128 for the hardware's lane groups and
+// conflict-free ds_write_b64); the k-major operand [k][64 rows] in 128-byte rows, chunks swizzled by the k row, read
+// through ds_read_b64_tr_b16.
+#ifndef TWOG_X3S_RS
+#define TWOG_X3S_RS 4
+#endif
+template <int BM, int BN, int NT, bool BKM, int KS, int TN, bool G3, int RS = 4>
+__device__ __forceinline__ void gemm_mainloop_x3s(const twog_rows_t A, const twog_rows_t B, int M, int N, int m0, int n0,
+                                                  int k_begin, int k_end, float* smem, f32x16 (&acc)[1][TN]) {
+    constexpr int XK = 16 * KS, NTG = NT / KS, RB = 2 * XK;       // k-tile depth, threads per k-group, bytes per image row
+    constexpr int WM = BM / (NTG / 128), WN = BN / 2;
+    static_assert(WM == 32 && WN == 32 * TN && (!BKM || (BN == 64 && !G3)), "one 32-row block per wave, TN column blocks");
+    constexpr int PA = BM * RB, PB = BN * RB, STAGE = 3 * PA + 3 * PB;
+    constexpr int FA = BM * XK / 4, FB = BN * XK / 4;             // 16-byte loads per k-tile
+    constexpr int NPA = (FA + NT - 1) / NT, NPB = (FB + NT - 1) / NT;
+    static_assert(FA % NT == 0 || FA < NT, "whole passes");
+    char* lds = reinterpret_cast<char*>(smem);
+    const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) % (NTG / 64), kgrp = (tid >> 6) / (NTG / 64);
+    const int wm = (wave >> 1) * WM, wn = (wave & 1) * WN;
+    auto swz_r = [](int row, int chunk) { return XK == 32 ? (chunk ^ ((row >> 2) & 3)) : (chunk ^ ((row >> 4) & 1)); };
+    auto swz_t = [](int k, int chunk) { return chunk ^ (((k >> 1) & 1) << 2); };
+    uint32_t oa[NPA], ob[NPB];
+    int sa_off[NPA], sb_off[NPB];
+    bool a_on[NPA], b_on[NPB];
+    const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(A.ptr, 0, 0xffffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc(B.ptr, 0, 0xffffffff, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < NPA; ++i) {
+        const int f = tid + i * NT;
+        a_on[i] = f < FA;
+        const int rr = (f % FA) / (XK / 4), cq = f % (XK / 4);
+        oa[i] = 4u * (uint32_t)(twog_row_off(A, min(m0 + rr, M - 1)) + cq * 4);
+        sa_off[i] = rr * RB + 16 * swz_r(rr, cq >> 1) + 8 * (cq & 1);
+    }
+#pragma unroll
+    for (int i = 0; i < NPB; ++i) {
+        const int f = tid + i * NT;
+        b_on[i] = f < FB;
+        if constexpr (BKM) {
+            const int kk = (f % FB) / (BN / 4), cq = f % (BN / 4);   // k row of the tile, quad of tile columns
+            ob[i] = 4u * (uint32_t)((int64_t)kk * B.ld_outer + min(n0 + cq * 4, N - 4));
+            sb_off[i] = 3 * PA + kk * 2 * BN + 16 * swz_t(kk, cq >> 1) + 8 * (cq & 1);
+        } else {
+            const int rr = (f % FB) / (XK / 4), cq = f % (XK / 4);
+            int brow;
+            if constexpr (G3) {   // tile row rr -> gate (rr % 96) / 32 of unit n0 + 32 (rr / 96) + rr % 32 (see gemm_mainloop)
+                const int gate = (rr % 96) / 32, unit = n0 + 32 * (rr / 96) + (rr & 31);
+                brow = gate * N + min(unit, N - 1);
+            } else {
+                brow = min(n0 + rr, N - 1);
+            }
+            ob[i] = 4u * (uint32_t)(twog_row_off(B, brow) + cq * 4);
+            sb_off[i] = 3 * PA + rr * RB + 16 * swz_r(rr, cq >> 1) + 8 * (cq & 1);
+        }
+    }
+    struct Stage { f32x4 a[NPA], b[NPB]; };
+    auto gload = [&](Stage& r, int k0) {
+        const int sa = (int)((uint32_t)k0 * 4u);
+        const int sb = (int)(BKM ? (uint32_t)k0 * (uint32_t)B.ld_outer * 4u : (uint32_t)k0 * 4u);
+#pragma unroll
+        for (int i = 0; i < NPA; ++i) r.a[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, (int)oa[i], sa, 0));
+#pragma unroll
+        for (int i = 0; i < NPB; ++i) r.b[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_b, (int)ob[i], sb, 0));
+    };
+    auto split_store = [&](const Stage& r, int buf) {
+        char* base = lds + buf * STAGE;
+        i32x2 ph, pm, pl;
+#pragma unroll
+        for (int i = 0; i < NPA; ++i) {
+            if (NPA * NT == FA || a_on[i]) {
+                split3(r.a[i], ph, pm, pl);
+                *reinterpret_cast<i32x2*>(base + sa_off[i]) = ph;
+                *reinterpret_cast<i32x2*>(base + sa_off[i] + PA) = pm;
+                *reinterpret_cast<i32x2*>(base + sa_off[i] + 2 * PA) = pl;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NPB; ++i) {
+            if (NPB * NT == FB || b_on[i]) {
+                split3(r.b[i], ph, pm, pl);
+                *reinterpret_cast<i32x2*>(base + sb_off[i]) = ph;
+                *reinterpret_cast<i32x2*>(base + sb_off[i] + PB) = pm;
+                *reinterpret_cast<i32x2*>(base + sb_off[i] + 2 * PB) = pl;
+            }
+        }
+    };
+    const int r32 = lane & 31, h = lane >> 5;
+    const int chunk = (XK == 32 ? 2 * kgrp : 0) + h;                 // this lane's 16 bytes (8 k) of its k-group's k-step
+    const int fa_r = (wm + r32) * RB + 16 * swz_r(wm + r32, chunk);
+    int fb_r[TN];
+#pragma unroll
+    for (int b = 0; b < TN; ++b) fb_r[b] = 3 * PA + (wn + 32 * b + r32) * RB + 16 * swz_r(wn + 32 * b + r32, chunk);
+    const int g16 = lane >> 4, q4 = (lane >> 2) & 3, p4 = lane & 3;
+    const int tk0 = 16 * kgrp + 8 * (g16 >> 1) + q4, tk1 = tk0 + 4;
+    const int tch = (wn >> 3) + 2 * (g16 & 1) + (p4 >> 1);
+    const int ft0 = 3 * PA + tk0 * 2 * BN + 16 * swz_t(tk0, tch) + 8 * (p4 & 1);
+    const int ft1 = 3 * PA + tk1 * 2 * BN + 16 * swz_t(tk1, tch) + 8 * (p4 & 1);
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    f32x16 lo[TN];
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) lo[b][i] = 0.0f;
+    auto compute = [&](int buf) {
+        const char* base = lds + buf * STAGE;
+        bf16x8 af[3], bf[TN][3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) af[p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const i32x4*>(base + p * PA + fa_r));
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                if constexpr (BKM) {
+                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + p * PB + ft0));
+                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + p * PB + ft1));
+                    const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    bf[b][p] = __builtin_bit_cast(bf16x8, v);
+                } else {
+                    bf[b][p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const i32x4*>(base + p * PB + fb_r[b]));
+                }
+            }
+        // h h goes to the main accumulator, the five small products (2^-8 ... 2^-16 of it) to a second one that is added
+        // once after the loop: the main accumulator is rounded once per 16 k instead of six times, and the roundings
+        // of the small one are 2^-8 of an ulp of the result.
+        constexpr int PI[5] = {2, 0, 1, 1, 0}, PJ[5] = {0, 2, 1, 0, 1};   // l h, h l, m m, m h, h m
+#pragma unroll
+        for (int t = 0; t < 5; ++t)
+#pragma unroll
+            for (int b = 0; b < TN; ++b)
+                lo[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[PI[t]], bf[b][PJ[t]], lo[b], 0, 0, 0);
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+            acc[0][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[b][0], acc[0][b], 0, 0, 0);
+    };
+    const int nkt = (k_end - k_begin) / XK;
+    if (nkt <= 0) return;
+    const int k_last = k_begin + (nkt - 1) * XK;
+    auto kof = [&](int t) { return min(k_begin + t * XK, k_last); };
+    // RS register stages in a ring (loads of k-tile t + RS are issued before the MFMAs of tile t), two LDS stages, one
+    // barrier per k-tile. The ring is unrolled so that every stage keeps a static name. RS = 2 for the kernels whose
+    // epilogue operands already fill the register file; 4 by default; 8 where a lone tile per CU is bound by how many
+    // bytes it keeps in flight (chain launches: ~30 GB/s per CU with 4 stages).
+    Stage r[RS];
+#pragma unroll
+    for (int i = 0; i < RS; ++i) gload(r[i], kof(i));
+    split_store(r[0], 0);
+    __syncthreads();
+    int kt = 0;
+    for (; kt + RS - 1 < nkt; kt += RS) {
+#pragma unroll
+        for (int i = 0; i < RS; ++i) {
+            gload(r[i], kof(kt + RS + i));
+            compute(i & 1);
+            split_store(r[(i + 1) % RS], (i + 1) & 1);
+            __syncthreads();
+        }
+    }
+    // up to RS - 1 k-tiles left: tile kt sits in LDS stage 0, tiles kt + j in r[j]
+#pragma unroll
+    for (int j = 0; j < RS - 1; ++j) {
+        if (kt + j < nkt) {
+            compute(j & 1);
+            if (kt + j + 1 < nkt) { split_store(r[j + 1], (j + 1) & 1); __syncthreads(); }
+        }
+    }
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[0][b][i] += lo[b][i];
+}
+
 // XS (recurrent-chain launches with fewer tiles than the chip has CUs): the reduction is ALSO split over workgroups
 // (blockIdx.y = k-slice) and combined inside the launch, without a grid barrier and without waiting: every workgroup
 // writes its partial tile write-through (16-byte sc1 stores, so no release fence), drains them, and one lane draws an
@@ -620,7 +797,9 @@ __device__ __forceinline__ void gemm_tile(const Group& g, const GateArgs* ga) {
     constexpr int LDB = BKM ? (BN + 4) : (BK + 4);
     constexpr int A_ELEMS = AKM ? BK * LDA : BM * LDA;
     constexpr int B_ELEMS = BKM ? BK * LDB : BN * LDB;
-    __shared__ __attribute__((aligned(16))) float smem[2 * (A_ELEMS + B_ELEMS)];
+    // (X3 on the 64-row class: two stages of three bf16 planes per operand, 2 x 6 x 64 rows x 2 XK bytes, XK = 16 KS)
+    constexpr int SMEM_FLOATS = (X3 && BM == 64 && 12 * 64 * 8 * KS > 2 * (A_ELEMS + B_ELEMS)) ? 12 * 64 * 8 * KS : 2 * (A_ELEMS + B_ELEMS);
+    __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS];
 
     // XCD-aware, bijective block -> (problem, tile) map. Blocks are dealt round-robin over the 8 XCDs (speed only:
     // correctness never depends on it), so XCD x = blockIdx & 7 owns the blocks with local index l = blockIdx >> 3.
@@ -750,8 +929,14 @@ __device__ __forceinline__ void gemm_tile(const Group& g, const GateArgs* ga) {
     // uniform per workgroup: aligned operands and a reduction range made of whole k-tiles -> branch-free staging
     const bool fast = a_vec && b_vec && ((k_end - k_begin) % BK == 0);
     if constexpr (X3) {
-        static_assert(!X3 || (BM == 128 && BN == 128 && NT == 512 && !GATE && KS == 1 && !XS), "X3: the 8-wave 128x128 class");
-        gemm_mainloop_x3<AKM, BKM, KG>(A, B, M, N, m0, n0, k_begin, k_end, smem, acc);   // (the host launches it for aligned operands and whole k-tiles only)
+        // (the host launches X3 kernels for aligned operands and whole k-tiles only)
+        if constexpr (BM == 128) {
+            static_assert(!X3 || BM != 128 || (BN == 128 && NT == 512 && !GATE && KS == 1 && !XS), "X3: the 8-wave 128x128 class");
+            gemm_mainloop_x3<AKM, BKM, KG>(A, B, M, N, m0, n0, k_begin, k_end, smem, acc);
+        } else {
+            static_assert(!X3 || BM == 128 || (BM == 64 && BN == 64 && !AKM && !KG && !XS), "X3: 64x64 tiles, row-major A");
+            gemm_mainloop_x3s<BM, BN, NT, BKM, KS, 1, false, (GATE ? 2 : TWOG_X3S_RS)>(A, B, M, N, m0, n0, k_begin, k_end, smem, acc);
+        }
     } else if (fast)
         gemm_mainloop<BM, BN, NT, AKM, BKM, true, TM, TN, D, KG, KS>(A, B, M, N, a_vec, b_vec, m0, n0, k_begin, k_end, smem, acc);
     else
@@ -929,6 +1114,16 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(const Group g) {
 template <bool AKM, bool BKM, bool KG>
 __global__ __launch_bounds__(512, 4) void gemm_x3_kernel(const Group g) {   // 4 waves per SIMD = two workgroups per CU: <= 128 VGPRs
     gemm_tile<128, 128, 512, AKM, BKM, 2, KG, false, 1, false, true>(g, nullptr);
+}
+
+// X3 on the 64x64 class (gemm_mainloop_x3s): 4 waves, or 8 waves = two k-groups; plain and gate-fused epilogues
+template <bool BKM, int KS>
+__global__ __launch_bounds__(256 * KS, 2) void gemm_x3s_kernel(const Group g) {
+    gemm_tile<64, 64, 256 * KS, false, BKM, 2, false, false, KS, false, true>(g, nullptr);
+}
+template <int KS>
+__global__ __launch_bounds__(256 * KS, 2) void gemm_gate_bwd_x3s_kernel(const Group g, const GateArgs ga) {
+    gemm_tile<64, 64, 256 * KS, false, true, 2, false, true, KS, false, true>(g, &ga);
 }
 
 // 64x64 class, A row-major, B k-major (dX = dY W): the only form the recurrent backward chains use
@@ -1322,6 +1517,20 @@ static void prepare_group(const twog_gemm_t* pr, int n, int a_kmajor, int b_kmaj
     }
 }
 
+// X3 on the 64-row tile class pays where the launch is bound by its MFMAs: a real batch (many tiles), reductions of at least
+// 256. TWOG_GEMM_X3=0 (everything native fp32) and TWOG_GEMM_X3S=0 (only this class) turn it off.
+static bool x3s_ok(const Group& g, int a_kmajor, int xk, int min_tiles = 96) {
+    static const int on = (getenv("TWOG_GEMM_X3") ? atoi(getenv("TWOG_GEMM_X3")) : 1) && (getenv("TWOG_GEMM_X3S") ? atoi(getenv("TWOG_GEMM_X3S")) : 1);
+    if (!on || a_kmajor || g.splitk != 1 || g.total_tiles < min_tiles) return false;
+    int kmax = 0;
+    for (int i = 0; i < g.n; ++i) {
+        const Prob& P = g.p[i];
+        if (!P.a_vec || !P.b_vec || P.K % xk || P.batch > 1 || P.B.inner > 1 || P.M < 1 || P.N < 4) return false;
+        kmax = P.K > kmax ? P.K : kmax;
+    }
+    return kmax >= 256;
+}
+
 // Split of the reduction over workgroups for a chain launch (XS kernels). Model: a k-tile of one tile costs `unit` us of
 // fp32 MFMA on a CU (64x64: 16 x 64-cycle MFMAs per SIMD = 0.49 us at the ~2.1 GHz the part sustains; 32x64: half), the
 // workgroups of a launch are dealt over 256 CUs, a CU works its workgroups off one after the other, and a launch with
@@ -1459,7 +1668,11 @@ static int gemm_impl(const twog_gemm_t* problems, int n_problems, int a_kmajor, 
                 continue;
             }
             dim3 grid(g.total_tiles, 1), block(512);
-            if (b_kmajor) hipLaunchKernelGGL((gemm_ks_kernel<true, 2>), grid, block, 0, st, g);
+            if (x3s_ok(g, a_kmajor, 32)) {
+                g_last_class |= TWOG_GEMM_CLASS_X3;
+                if (b_kmajor) hipLaunchKernelGGL((gemm_x3s_kernel<true, 2>), grid, block, 0, st, g);
+                else hipLaunchKernelGGL((gemm_x3s_kernel<false, 2>), grid, block, 0, st, g);
+            } else if (b_kmajor) hipLaunchKernelGGL((gemm_ks_kernel<true, 2>), grid, block, 0, st, g);
             else hipLaunchKernelGGL((gemm_ks_kernel<false, 2>), grid, block, 0, st, g);
             TWOG_CHECK_LAUNCH();
             done += n;
@@ -1468,6 +1681,14 @@ static int gemm_impl(const twog_gemm_t* problems, int n_problems, int a_kmajor, 
         static const int x3_try = getenv("TWOG_GEMM_X3") ? atoi(getenv("TWOG_GEMM_X3")) : 1;   // grouped rows: X3 has 8-wave variants
         if (big && w8 && (!grouped || x3_try)) rc = d128 == 2 ? launch<128, 128, 512, 2>(g, a_kmajor, b_kmajor, st) : launch<128, 128, 512, 1>(g, a_kmajor, b_kmajor, st);
         else if (big) rc = d128 == 2 ? launch<128, 128, 256, 2>(g, a_kmajor, b_kmajor, st) : launch<128, 128, 256, 1>(g, a_kmajor, b_kmajor, st);
+        else if (!big && x3s_ok(g, a_kmajor, 16)) {
+            g_last_class |= TWOG_GEMM_CLASS_X3;
+            dim3 grid(g.total_tiles, 1), block(256);
+            if (b_kmajor) hipLaunchKernelGGL((gemm_x3s_kernel<true, 1>), grid, block, 0, st, g);
+            else hipLaunchKernelGGL((gemm_x3s_kernel<false, 1>), grid, block, 0, st, g);
+            TWOG_CHECK_LAUNCH();
+            rc = 0;
+        }
         else rc = d64 == 2 ? launch<64, 64, 256, 2>(g, a_kmajor, b_kmajor, st) : launch<64, 64, 256, 1>(g, a_kmajor, b_kmajor, st);
         if (rc) return rc;
         if (g_last_class_x3) g_last_class |= TWOG_GEMM_CLASS_X3 | TWOG_GEMM_CLASS_WAVES8;
@@ -1551,11 +1772,18 @@ int twog_internal_gemm_gate_bwd(const twog_gemm_t* pr, int n, const twog_gru_ste
             TWOG_CHECK_LAUNCH();
             return 0;
         }
+        if (x3s_ok(g, 0, 32)) {
+            g_last_class |= TWOG_GEMM_CLASS_X3;
+            hipLaunchKernelGGL(gemm_gate_bwd_x3s_kernel<2>, grid, dim3(512), 0, (hipStream_t)stream, g, ga);
+        } else
         hipLaunchKernelGGL(gemm_gate_bwd_ks_kernel<2>, grid, dim3(512), 0, (hipStream_t)stream, g, ga);
         TWOG_CHECK_LAUNCH();
         return 0;
     }
-    if (d64 == 2) hipLaunchKernelGGL(gemm_gate_bwd_kernel<2>, grid, block, 0, (hipStream_t)stream, g, ga);
+    if (x3s_ok(g, 0, 16)) {
+        g_last_class |= TWOG_GEMM_CLASS_X3;
+        hipLaunchKernelGGL(gemm_gate_bwd_x3s_kernel<1>, grid, block, 0, (hipStream_t)stream, g, ga);
+    } else if (d64 == 2) hipLaunchKernelGGL(gemm_gate_bwd_kernel<2>, grid, block, 0, (hipStream_t)stream, g, ga);
     else hipLaunchKernelGGL(gemm_gate_bwd_kernel<1>, grid, block, 0, (hipStream_t)stream, g, ga);
     TWOG_CHECK_LAUNCH();
     return 0;

@@ -68,7 +68,7 @@ int twog_gemm_f32(const twog_gemm_t* problems, int n_problems, int a_kmajor, int
 #define TWOG_GEMM_CLASS_GRUFWD  64 /* 64 x (64 units x 3 gates) tiles, GRU forward step in the epilogue */
 #define TWOG_GEMM_CLASS_ROWS32  128 /* 32 x 64 tiles (chain launches of small batches)           */
 #define TWOG_GEMM_CLASS_XSPLIT  256 /* reduction split over workgroups, combined inside the launch (last arriver) */
-#define TWOG_GEMM_CLASS_X3      512 /* 128x128 class on the bf16 matrix cores: operands split exactly into 3 bf16, 6 products */
+#define TWOG_GEMM_CLASS_X3      512 /* on the bf16 matrix cores: fp32 operands split exactly into 3 bf16, 6 products (128x128 class; 64x64 class when K >= 256) */
 int twog_gemm_last_class(void);
 
 /* The dependent launches of the recurrent chains (vhoi/models.py:983-1002 frame-level BiGRUs, :785-880 segment loop:

@@ -1115,8 +1115,8 @@ print('OK')
 
 
 def test_gemm_x3_error_equals_the_native_fp32_mfma_kernels():
-    """The 128x128 class multiplies on the bf16 matrix cores after an EXACT three-way split of every fp32 operand element
-    (csrc/gemm_f32.hip, X3; default). In a child process per mode (the switch is read once): the four operand layouts,
+    """The 128x128 class -- and the 64x64 class of the recurrent-chain launches with K >= 256 -- multiply on the bf16 matrix
+    cores after an EXACT three-way split of every fp32 operand element (csrc/gemm_f32.hip, X3; default). In a child process per mode (the switch is read once): the four operand layouts,
     split-K, bias / ReLU / accumulate, grouped k-major rows, values over 60 orders of magnitude, exact zeros and a
     denormal -- the class bit is asserted, the error against an fp64 product must stay within 1.25 x the native fp32-MFMA
     kernels' error on the same inputs (+ 2e-7 of the largest output), and the result is bit-identical from launch to
@@ -1129,7 +1129,7 @@ from twog_gcn_amd.kernels import get_kernels
 K = get_kernels(); DEV = 'cuda:0'
 res = {}
 g = torch.Generator().manual_seed(7)
-def case(name, M, N, Kk, akm, bkm, bias=False, act=0, acc=False, scale_a=None, grouped=False):
+def case(name, M, N, Kk, akm, bkm, bias=False, act=0, acc=False, scale_a=None, grouped=False, chain=False):
     A = torch.randn((Kk, M) if akm else (M, Kk), generator=g)
     if scale_a is not None:   # per-element magnitudes over many decades (the split must be exact at every exponent)
         A = A * 10.0 ** torch.randint(-scale_a, scale_a, A.shape, generator=g).float()
@@ -1145,10 +1145,11 @@ def case(name, M, N, Kk, akm, bkm, bias=False, act=0, acc=False, scale_a=None, g
     outs = []
     for _ in range(2):
         C = C0.clone()
-        K.gemm([dict(A=A, B=B, C=C, bias=b, act=act, accumulate=acc)], a_kmajor=akm, b_kmajor=bkm)
+        K.gemm([dict(A=A, B=B, C=C, bias=b, act=act, accumulate=acc)], a_kmajor=akm, b_kmajor=bkm, chain=chain,
+               split_k_workspace=not chain)
         outs.append(C)
     cls = K.gemm_last_class()
-    assert cls & K.GEMM_TILE128, (name, hex(cls))
+    assert bool(cls & K.GEMM_TILE128) != chain, (name, hex(cls))
     assert torch.equal(outs[0], outs[1]), name
     Ad = (A.reshape(-1, M).t() if akm else A).double()
     ref = Ad @ (B.double() if bkm else B.double().t())
@@ -1162,12 +1163,16 @@ case('TT splitk', 1536, 512, 16384, True, True)
 case('TN', 1024, 2048, 1024, True, False, bias=True)
 case('NN wide magnitudes', 8192, 1024, 1024, False, False, scale_a=30)
 case('TT grouped rows', 1536, 512, 8192, True, True, grouped=True)
+# the 64x64 class of the recurrent chains (row-major A; 8 waves with the k-split inside the workgroup, and 4 waves)
+case('chain NT carry', 1408, 512, 1536, False, True, acc=True, chain=True)
+case('chain NN sender MLPs', 1280, 1024, 512, False, False, bias=True, act=1, chain=True)
+case('chain NT wide magnitudes', 1280, 1024, 1536, False, True, scale_a=30, chain=True)
 print('RES ' + json.dumps(res))
 """ % (ROOT,)
     out = {}
     for mode in ('1', '0'):
-        r = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, TWOG_GEMM_X3=mode), capture_output=True,
-                           text=True, timeout=900)
+        r = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, TWOG_GEMM_X3=mode, TWOG_GEMM_XSPLIT='1'),
+                           capture_output=True, text=True, timeout=900)   # XSPLIT=1: no split over workgroups (fp32 kernels)
         assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
         out[mode] = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('RES ')][0][4:])
     X3 = twog_kernels.get_kernels().GEMM_X3
