@@ -36,6 +36,11 @@ def load(d):
     return out, cnt
 
 
+def is_128(k):
+    """the 128x128 tile class: gemm_x3_kernel (bf16 x 3 split, default) and gemm_kernel<128, 128, ...> (native fp32)"""
+    return k.startswith('gemm_kernel<128, 128') or k.startswith('gemm_x3_kernel')
+
+
 def by_launch(root, dst):
     """128x128-class launches grouped by (kernel variant, grid size): grid = tiles x split-K x workgroup size identifies the
     shape; read / write bytes per dispatch at the L2<->fabric boundary (join with TWOG_BENCH_GEMM_DETAIL=1 of bench.py)."""
@@ -44,7 +49,7 @@ def by_launch(root, dst):
         for f in glob.glob(root + '/' + sub + '/*/*_counter_collection.csv'):
             for r in csv.DictReader(open(f)):
                 k = short(r['Kernel_Name'])
-                if not k.startswith('gemm_kernel<128, 128') or r['Counter_Name'] not in ('FETCH_SIZE', 'WRITE_SIZE'):
+                if not is_128(k) or r['Counter_Name'] not in ('FETCH_SIZE', 'WRITE_SIZE'):
                     continue
                 a = agg[(k, int(r['Grid_Size']), int(r['Workgroup_Size']))]
                 if sub == 'f':
@@ -82,12 +87,12 @@ def main():
         wri = csv.DictWriter(fo, fieldnames=list(rows[0].keys()))
         wri.writeheader()
         wri.writerows(rows)
-    big = [r for r in rows if r['kernel'].startswith('gemm_kernel<128, 128')]
+    big = [r for r in rows if is_128(r['kernel'])]
     if big and len(sys.argv) > 3:
         import json
         nd = sum(r['dispatches'] for r in big)
         by = sum(r['hbm_read_bytes'] + r['hbm_write_bytes'] for r in big)
-        json.dump(dict(kernel='gemm_kernel<128,128,*>', dispatches=nd, hbm_bytes_total=by, hbm_bytes_per_launch=by / nd,
+        json.dump(dict(kernel='128x128 tile class: gemm_x3_kernel<*> + gemm_kernel<128,128,*>', dispatches=nd, hbm_bytes_total=by, hbm_bytes_per_launch=by / nd,
                        source='rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline`'
                               ' (tools/bench_pmc.sh); read bytes = 2 * FETCH_SIZE KiB (gfx950 correction)'),
                   open(sys.argv[3], 'w'), indent=1)

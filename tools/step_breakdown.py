@@ -21,8 +21,14 @@ def cls(r):
     g = int(r['Grid_Size_X']) // max(int(r['Workgroup_Size_X']), 1)
     if 'gemm_gate_bwd_xs' in n:
         return 'recurrence: GEMM NT + fused gate backward, reduction split over workgroups'
+    if 'gemm_gate_bwd_x3s' in n:
+        return 'recurrence: 64x64 GEMM NT + fused gate backward (bf16 x 3)'
     if 'gemm_gate_bwd' in n:
         return 'recurrence: 64x64 GEMM NT + fused gate backward'
+    if 'gemm_x3s_kernel' in n:
+        return 'recurrence: 64x64 GEMM (bf16 x 3) ' + ('8 waves, k-split' if ', 2>' in n else '4 waves') + (' NT' if '<true' in n else ' NN')
+    if 'gemm_x3_kernel' in n:
+        return 'big GEMM 128x128 (bf16 x 3) ' + ('NN (forward)' if '<false, false' in n else 'NT (dX)' if '<false, true' in n else 'TT (dW)' if '<true, true' in n else 'TN')
     if 'gemm_gru_fwd' in n:
         return 'recurrence: frame-level GRU step (W_hh product + gates, one launch)'
     if 'gemm_xs' in n:
