@@ -1429,7 +1429,8 @@ static void prepare_group(const twog_gemm_t* pr, int n, int a_kmajor, int b_kmaj
     static const int force_tile = getenv("TWOG_GEMM_TILE") ? atoi(getenv("TWOG_GEMM_TILE")) : 0;
     static const int force_split = getenv("TWOG_GEMM_SPLITK") ? atoi(getenv("TWOG_GEMM_SPLITK")) : 0;
     const int64_t reach128 = tiles128 * (workspace ? (kmax >= 1024 ? kmax / 512 : 1) : 1);
-    big = wide && (tiles128 >= 256 || reach128 >= 256);
+    static const int big_min = getenv("TWOG_GEMM_BIG_MIN") ? atoi(getenv("TWOG_GEMM_BIG_MIN")) : 256;   // tuning knob
+    big = wide && (tiles128 >= big_min || reach128 >= 256);
     if (force_tile == 128) big = true;
     if (force_tile == 64) big = false;
     const int BMN = big ? 128 : 64;

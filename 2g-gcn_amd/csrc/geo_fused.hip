@@ -18,8 +18,8 @@
 //      adjacency rows -> global and -> scratch, Z = S X_f with X_f read in place as the k-major operand (2- to 4-way
 //      bank-conflicted reads: 2 + 8 LDS cycles against the MFMA's 32), Z -> global. No workgroup barrier inside B:
 //      a wave only writes its own scratch. Two barriers per GROUP of frames instead of five per frame.
-// Weights (W2, M = Wq^T Wk folded by the caller, biases) live in LDS for the whole kernel; grid = one workgroup per CU,
-// looping over groups. The backward pass recomputes e1 from the geometry input (embed1_fwd, bit-identical arithmetic).
+// W1, M = Wq^T Wk (folded by bn_finalize), d and the biases live in LDS for the whole kernel; the W2 operand fragments
+// are read straight from global memory (16 KB, L1-resident); grid = one workgroup per CU, looping over groups. The backward pass recomputes e1 from the geometry input (embed1_fwd, bit-identical arithmetic).
 #include "twog_common.h"
 
 typedef float f32x4g __attribute__((ext_vector_type(4)));

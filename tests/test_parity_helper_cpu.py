@@ -54,3 +54,17 @@ def test_conditioning_moves_a_case_off_the_relu_boundary():
     rounds, nudged = relu_boundary.condition_case(m, fwd)
     assert rounds >= 1 and nudged.get('object_embedding_mlp.0', 0) >= 1
     assert not relu_boundary.boundary_layers(m, fwd(), width=8.0)
+
+
+def test_a_planted_one_percent_gradient_error_fails_the_gate(monkeypatch):
+    """The gate must catch what the old escape clause let through: a 1 % error in ONE kernel's backward (here the ReLU
+    backward of the test double scaled by 1.01) moves the gradients upstream of it by about a percent -- far beyond
+    5e-4, with no boundary unit to blame -- and the comparison has to fail."""
+    orig = FakeKernels.relu_bwd
+
+    def off_by_one_percent(self, dy, y, dx=None):
+        return orig(self, dy * 1.01, y, dx)
+
+    monkeypatch.setattr(FakeKernels, 'relu_bwd', off_by_one_percent)
+    with pytest.raises(AssertionError, match='gradients beyond 5e-4|beyond the fp64 yardstick'):
+        tp._oracle_vs_hip(bs=2, T=5, H=2, O=4, N=26, h=32, backward=True, seed=5)
