@@ -614,7 +614,7 @@ __device__ __forceinline__ void gemm_mainloop_x3(const twog_rows_t A, const twog
 #ifndef TWOG_X3S_RS
 #define TWOG_X3S_RS 4
 #endif
-template <int BM, int BN, int NT, bool BKM, int KS, int TN, bool G3, int RS = 4>
+template <int BM, int BN, int NT, bool BKM, int KS, int TN, bool G3, int RS = 4, bool LO2 = (TN == 1)>
 __device__ __forceinline__ void gemm_mainloop_x3s(const twog_rows_t A, const twog_rows_t B, int M, int N, int m0, int n0,
                                                   int k_begin, int k_end, float* smem, f32x16 (&acc)[1][TN]) {
     constexpr int XK = 16 * KS, NTG = NT / KS, RB = 2 * XK;       // k-tile depth, threads per k-group, bytes per image row
@@ -706,9 +706,9 @@ __device__ __forceinline__ void gemm_mainloop_x3s(const twog_rows_t A, const two
     const int ft0 = 3 * PA + tk0 * 2 * BN + 16 * swz_t(tk0, tch) + 8 * (p4 & 1);
     const int ft1 = 3 * PA + tk1 * 2 * BN + 16 * swz_t(tk1, tch) + 8 * (p4 & 1);
     typedef short s16x8 __attribute__((ext_vector_type(8)));
-    f32x16 lo[TN];
+    f32x16 lo[LO2 ? TN : 1];
 #pragma unroll
-    for (int b = 0; b < TN; ++b)
+    for (int b = 0; b < (LO2 ? TN : 1); ++b)
 #pragma unroll
         for (int i = 0; i < 16; ++i) lo[b][i] = 0.0f;
     auto compute = [&](int buf) {
@@ -732,12 +732,16 @@ __device__ __forceinline__ void gemm_mainloop_x3s(const twog_rows_t A, const two
         // h h goes to the main accumulator, the five small products (2^-8 ... 2^-16 of it) to a second one that is added
         // once after the loop: the main accumulator is rounded once per 16 k instead of six times, and the roundings
         // of the small one are 2^-8 of an ulp of the result.
+        // (LO2 = false -- the three-accumulator GRU tile, whose register file is full: all six into the main accumulator,
+        // small products first, as the 128x128 class does)
         constexpr int PI[5] = {2, 0, 1, 1, 0}, PJ[5] = {0, 2, 1, 0, 1};   // l h, h l, m m, m h, h m
 #pragma unroll
         for (int t = 0; t < 5; ++t)
 #pragma unroll
-            for (int b = 0; b < TN; ++b)
-                lo[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[PI[t]], bf[b][PJ[t]], lo[b], 0, 0, 0);
+            for (int b = 0; b < TN; ++b) {
+                if constexpr (LO2) lo[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[PI[t]], bf[b][PJ[t]], lo[b], 0, 0, 0);
+                else acc[0][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[PI[t]], bf[b][PJ[t]], acc[0][b], 0, 0, 0);
+            }
 #pragma unroll
         for (int b = 0; b < TN; ++b)
             acc[0][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[b][0], acc[0][b], 0, 0, 0);
@@ -773,10 +777,12 @@ __device__ __forceinline__ void gemm_mainloop_x3s(const twog_rows_t A, const two
             if (kt + j + 1 < nkt) { split_store(r[j + 1], (j + 1) & 1); __syncthreads(); }
         }
     }
+    if constexpr (LO2) {
 #pragma unroll
-    for (int b = 0; b < TN; ++b)
+        for (int b = 0; b < TN; ++b)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) acc[0][b][i] += lo[b][i];
+            for (int i = 0; i < 16; ++i) acc[0][b][i] += lo[b][i];
+    }
 }
 
 // XS (recurrent-chain launches with fewer tiles than the chip has CUs): the reduction is ALSO split over workgroups
@@ -1164,10 +1170,11 @@ struct GruFwdGroup {
     int n, tiles_n, hidden;
 };
 
-template <int D, int KS>
+template <int D, int KS, bool X3 = false>
 __global__ __launch_bounds__(256 * KS, 1) void gemm_gru_fwd_kernel(const GruFwdGroup g) {
     constexpr int BM = 64, BN = 192, NT = 256 * KS, TM = 1, TN = 3;
-    __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * (BK + 4)];
+    // X3 (bf16 x 3 on the bf16 matrix cores, see gemm_mainloop_x3s): two stages of three bf16 planes of both operand tiles
+    __shared__ __attribute__((aligned(16))) float smem[X3 ? 2 * 3 * (BM + BN) * (16 * KS) * 2 / 4 : 2 * (BM + BN) * (BK + 4)];
     const int ut = blockIdx.x % g.tiles_n, rt = blockIdx.x / g.tiles_n;
     int pi = 0;
 #pragma unroll 1
@@ -1210,13 +1217,15 @@ __global__ __launch_bounds__(256 * KS, 1) void gemm_gru_fwd_kernel(const GruFwdG
         }
     }
 
-    gemm_mainloop<BM, BN, NT, false, false, true, TM, TN, D, false, KS, true>(P.A, P.B, M, H, 1, 1, m0, n0, 0, H, smem, acc);
+    if constexpr (X3) gemm_mainloop_x3s<BM, BN, NT, false, KS, TN, true, 2, false>(P.A, P.B, M, H, m0, n0, 0, H, smem, acc);
+    else gemm_mainloop<BM, BN, NT, false, false, true, TM, TN, D, false, KS, true>(P.A, P.B, M, H, 1, 1, m0, n0, 0, H, smem, acc);
     f32x16 hn = acc[0][2];
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[0][2][r] = 0.f;
     if (P.K2 > 0) {   // uniform per workgroup: the message columns of W_ih; their n block stays on the input side of the gate
         __syncthreads();   // every wave is done with the operand tiles of the first product
-        gemm_mainloop<BM, BN, NT, false, false, true, TM, TN, D, false, KS, true>(P.A2, P.B2, M, H, 1, 1, m0, n0, 0, P.K2, smem, acc);
+        if constexpr (X3) gemm_mainloop_x3s<BM, BN, NT, false, KS, TN, true, 2, false>(P.A2, P.B2, M, H, m0, n0, 0, P.K2, smem, acc);
+        else gemm_mainloop<BM, BN, NT, false, false, true, TM, TN, D, false, KS, true>(P.A2, P.B2, M, H, 1, 1, m0, n0, 0, P.K2, smem, acc);
     }
     if constexpr (KS == 2) {
         // add the two k-groups' partial tiles (fixed order: group 0 + group 1) through LDS; group 0 runs the epilogue
@@ -1869,7 +1878,14 @@ int twog_internal_gemm_gru_fwd(const twog_gemm_t* gh, const twog_gemm_t* gim, co
     if (dry_run) return 0;
     for (int i = n; i < MAXP; ++i) { g.p[i] = g.p[0]; g.p[i].rt_start = 0x7fffffff; }
     g_last_class = TWOG_GEMM_CLASS_GRUFWD;
-    if (ksplit == 2) hipLaunchKernelGGL((gemm_gru_fwd_kernel<2, 2>), dim3(rt * g.tiles_n), dim3(512), 0, (hipStream_t)stream, g);
+    static const int x3_on = (getenv("TWOG_GEMM_X3") ? atoi(getenv("TWOG_GEMM_X3")) : 1) && (getenv("TWOG_GEMM_X3S") ? atoi(getenv("TWOG_GEMM_X3S")) : 1) &&
+                             (getenv("TWOG_GEMM_X3G") ? atoi(getenv("TWOG_GEMM_X3G")) : 1);
+    bool x3 = x3_on && ksplit == 2 && h >= 256 && h % 32 == 0;   // whole 32-deep k-tiles of both products
+    for (int i = 0; i < n; ++i) x3 = x3 && g.p[i].K2 % 32 == 0;
+    if (x3) {
+        g_last_class |= TWOG_GEMM_CLASS_X3;
+        hipLaunchKernelGGL((gemm_gru_fwd_kernel<2, 2, true>), dim3(rt * g.tiles_n), dim3(512), 0, (hipStream_t)stream, g);
+    } else if (ksplit == 2) hipLaunchKernelGGL((gemm_gru_fwd_kernel<2, 2>), dim3(rt * g.tiles_n), dim3(512), 0, (hipStream_t)stream, g);
     else hipLaunchKernelGGL((gemm_gru_fwd_kernel<2, 1>), dim3(rt * g.tiles_n), dim3(256), 0, (hipStream_t)stream, g);
     TWOG_CHECK_LAUNCH();
     return 0;

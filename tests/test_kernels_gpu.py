@@ -341,7 +341,9 @@ def test_bigru(K, h, bs, T, fusion, monkeypatch):
     res_g = K.bigru_fwd(types_g, bs, T, h)
     # the variant that ran (the forward chain's last launch): the fused step where forced and served, else the gate kernel's
     # GEMM partner
-    assert (K.gemm_last_class() == K.GEMM_GRUFWD) == (fusion == '7' and h % 32 == 0), hex(K.gemm_last_class())
+    cls, fused = K.gemm_last_class(), fusion == '7' and h % 32 == 0
+    assert ((cls & ~K.GEMM_X3) == K.GEMM_GRUFWD) == fused, hex(cls)
+    assert not fused or bool(cls & K.GEMM_X3) == (h >= 256), hex(cls)   # wide reductions multiply on the bf16 matrix cores (X3)
     for (oc, sc), (og, sg) in zip(res_c, res_g):
         close(og, oc, rtol=1e-4, atol=1e-5, what='bigru out')
         close(sg, sc, rtol=1e-4, atol=1e-5, what='bigru save')
@@ -461,7 +463,9 @@ def test_segment_recurrence(K, bs, T, H, O, h, rels, msg, fusion, monkeypatch):
     pg = _seg_params(DEV, bs, T, H, O, h, rels, msg)
     bc = F.segrnn_fwd(pc)
     bg = K.segrnn_fwd(pg)
-    assert (K.gemm_last_class() == K.GEMM_GRUFWD) == (fusion == '7' and h % 32 == 0), hex(K.gemm_last_class())
+    cls, fused = K.gemm_last_class(), fusion == '7' and h % 32 == 0
+    assert ((cls & ~K.GEMM_X3) == K.GEMM_GRUFWD) == fused, hex(cls)
+    assert not fused or bool(cls & K.GEMM_X3) == (h >= 256), hex(cls)   # wide reductions multiply on the bf16 matrix cores (X3)
     keys = ['hs_h', 'hs_o', 'save_h', 'save_o'] + (['msrc_h', 'msrc_o', 'mg_h', 'mg_o', 'att'] if msg else [])
     for k in keys:
         close(bg[k], bc[k], rtol=2e-4, atol=2e-5, what='segrnn fwd ' + k)
