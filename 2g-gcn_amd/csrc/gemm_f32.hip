@@ -436,6 +436,9 @@ __device__ __forceinline__ void split3(const f32x4 v, i32x2& ph, i32x2& pm, i32x
 #ifndef TWOG_X3_PRODUCTS
 #define TWOG_X3_PRODUCTS 6
 #endif
+#ifndef TWOG_X3_ABLATE
+#define TWOG_X3_ABLATE 0   // 1..4: measurement builds of the 128x128 X3 main loop (tools/x3_ablate.sh), wrong results
+#endif
 constexpr int X3_PRODUCTS = TWOG_X3_PRODUCTS;  // chunk products per element product: 8 (exact to 2^-30) or 6 (drops m l, l m)
 constexpr int X3_BK = 16;                    // one v_mfma_f32_32x32x16_bf16 k-step per k-tile
 constexpr int X3_RROW = 32;                  // bytes per row of a [row][16 k] image; its two 16-byte chunks are swapped on rows
@@ -482,6 +485,9 @@ __device__ __forceinline__ void gemm_mainloop_x3(const twog_rows_t A, const twog
         }
     }
     struct Stage { f32x4 a, b; };
+#if TWOG_X3_ABLATE >= 2
+    bool x3_ablate_skip = false;
+#endif
     // KG: a k-major operand whose rows (= k) are (outer, inner) grouped, e.g. "all but the first time step of every clip":
     // the (outer, inner) position of this thread's row is carried from k-tile to k-tile (k only moves forward; the clamped
     // tail repeats the last tile), no division in the loop. Offsets stay below 2^32 bytes (vec_ok).
@@ -516,8 +522,27 @@ __device__ __forceinline__ void gemm_mainloop_x3(const twog_rows_t A, const twog
         }
     };
     auto split_store = [&](const Stage& r, int buf) {
+#if TWOG_X3_ABLATE >= 2   // measurement builds (tools/x3_ablate.sh): no plane stores after the first k-tile
+        if (buf >= 0 && x3_ablate_skip) {
+#if TWOG_X3_ABLATE == 4      // ... but the loaded registers are waited for and consumed
+            asm volatile("" ::"v"(r.a), "v"(r.b));
+#endif
+            return;
+        }
+#endif
         char* base = lds + buf * X3_STAGE;
         i32x2 ph, pm, pl;
+#if TWOG_X3_ABLATE == 1   // measurement build: planes without the split arithmetic (wrong results, same stores)
+        ph = pm = pl = i32x2{(int)pack_hi16(__float_as_uint(r.a[0]), __float_as_uint(r.a[1])), (int)pack_hi16(__float_as_uint(r.a[2]), __float_as_uint(r.a[3]))};
+        *reinterpret_cast<i32x2*>(base + sa_off) = ph;
+        *reinterpret_cast<i32x2*>(base + sa_off + PA) = pm;
+        *reinterpret_cast<i32x2*>(base + sa_off + 2 * PA) = pl;
+        ph = pm = pl = i32x2{(int)pack_hi16(__float_as_uint(r.b[0]), __float_as_uint(r.b[1])), (int)pack_hi16(__float_as_uint(r.b[2]), __float_as_uint(r.b[3]))};
+        *reinterpret_cast<i32x2*>(base + sb_off) = ph;
+        *reinterpret_cast<i32x2*>(base + sb_off + PB) = pm;
+        *reinterpret_cast<i32x2*>(base + sb_off + 2 * PB) = pl;
+        return;
+#endif
         split3(r.a, ph, pm, pl);
         *reinterpret_cast<i32x2*>(base + sa_off) = ph;
         *reinterpret_cast<i32x2*>(base + sa_off + PA) = pm;
@@ -550,9 +575,18 @@ __device__ __forceinline__ void gemm_mainloop_x3(const twog_rows_t A, const twog
         const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         return __builtin_bit_cast(bf16x8, v);
     };
+#if TWOG_X3_ABLATE == 3
+    bf16x8 af[3], bf[2][3];   // measurement build: fragments read once, before the loop
+    bool x3_frag_done = false;
+#endif
     auto compute = [&](int buf) {
         const char* base = lds + buf * X3_STAGE;
+#if TWOG_X3_ABLATE == 3
+        if (!x3_frag_done) {
+#else
         bf16x8 af[3], bf[2][3];
+        {
+#endif
 #pragma unroll
         for (int p = 0; p < 3; ++p) af[p] = AKM ? frag_t(base + p * PA, tchA) : frag_r(base + p * PA, fa_r);
 #pragma unroll
@@ -560,6 +594,10 @@ __device__ __forceinline__ void gemm_mainloop_x3(const twog_rows_t A, const twog
 #pragma unroll
             for (int p = 0; p < 3; ++p)
                 bf[b][p] = BKM ? frag_t(base + 3 * PA + p * PB, tchB + 4 * b) : frag_r(base + p * PB, fb_r + b * 32 * X3_RROW);
+        }
+#if TWOG_X3_ABLATE == 3
+        x3_frag_done = true;
+#endif
         // X3_PRODUCTS chunk products per block, smallest terms first; the two blocks' chains alternate so that an MFMA never
         // waits for the previous result of its own accumulator. 8 (default): everything down to 2^-24 |a b| -- the products
         // are exact to 2^-30, the result differs from an fp32 GEMM only by the order of the fp32 accumulation; 6
@@ -589,6 +627,9 @@ __device__ __forceinline__ void gemm_mainloop_x3(const twog_rows_t A, const twog
     gload(r3, kof(3));
     split_store(r0, 0);
     __syncthreads();
+#if TWOG_X3_ABLATE >= 2
+    x3_ablate_skip = true;
+#endif
     int kt = 0;
     for (; kt + 3 < nkt; kt += 4) {
         gload(r0, kof(kt + 4)); compute(0); split_store(r1, 1); __syncthreads();
