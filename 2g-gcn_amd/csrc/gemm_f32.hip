@@ -47,6 +47,7 @@ struct Group {
     int splitk;      // >= 1
     int k_per_split; // multiple of BK
     int group;       // tile order inside a problem: groups of `group` panels of the major dimension (tile_coords)
+    int xcd_split;   // split-K launches with splitk % 8 == 0: XCD x works the k-splits x, x + 8, ... of ALL tiles (see gemm_tile)
     float* slabs;    // split-K partials: [problem-tile-major] see below
     unsigned* xcnt;  // XS kernels (split-K over workgroups, combined in the launch): arrival ticket per tile, zero between launches
     int xs_early;    // XS: every slice requests the epilogue operands before its reduction loop (small launches: the
@@ -856,7 +857,19 @@ __device__ __forceinline__ void gemm_tile(const Group& g, const GateArgs* ga) {
     // heterogeneous groups stay balanced. Chunk sizes differ by at most one tile; the classes' remainders are dealt
     // around the XCD ring one after the other (cls_rot), which makes the per-XCD totals match the hardware's deal.
     int bid = 0;  // logical tile id
-    {
+    int split = blockIdx.y;
+    if (!XS && g.xcd_split) {
+        // Tall reductions (dW = dY^T X: few tiles, many k-splits): deal whole K-SPLITS to XCDs instead of tile chunks. The
+        // tiles of one split read the same k-range of both operands; on one XCD, started together, they walk that range
+        // in step and its L2 serves every row / column panel chunk once -- dealt by tile chunks every XCD needs (almost)
+        // every chunk panel of every split (measured: 2.1 x the operand bytes at the L2<->fabric boundary). Workgroups
+        // are dispatched round-robin over the XCDs in linear order, so XCD x = L & 7 owns the local indices j = L >> 3;
+        // job j of XCD x is tile j % tiles of split x + 8 (j / tiles). Bijective because splitk % 8 == 0 (host).
+        const int L = blockIdx.y * gridDim.x + blockIdx.x, x = L & 7, j = L >> 3, tiles = gridDim.x;
+        const int sj = j / tiles;
+        split = x + 8 * sj;
+        bid = j - sj * tiles;
+    } else {
         const int x = blockIdx.x & 7;
         int l = blockIdx.x >> 3;
 #pragma unroll 1
@@ -887,7 +900,6 @@ __device__ __forceinline__ void gemm_tile(const Group& g, const GateArgs* ga) {
     int tm_idx, tn_idx;
     tile_coords(G, tile, g.group, tm_idx, tn_idx);
     const int m0 = tm_idx * BM, n0 = tn_idx * BN;
-    const int split = blockIdx.y;
     const int k_begin = split * g.k_per_split;
     const int k_end = min(K, k_begin + g.k_per_split);
     // XS: slices of THIS problem (a grouped launch mixes reduction lengths; the grid has the longest one's count)
@@ -1543,6 +1555,7 @@ static void prepare_group(const twog_gemm_t* pr, int n, int a_kmajor, int b_kmaj
     g.slabs = nullptr;
     g.xcnt = nullptr;
     g.xs_early = 0;
+    g.xcd_split = 0;
     // deterministic split-K when the grid would leave CUs idle and the reduction is long
     if (t < 4096 && kmax >= 1024 && workspace) {
         // pick the split that fills whole "rounds" of resident workgroups (2 per CU for 128-tiles, 4 for 64-tiles)
@@ -1558,12 +1571,31 @@ static void prepare_group(const twog_gemm_t* pr, int n, int a_kmajor, int b_kmaj
             if (eff > best + 0.03) { best = eff; want = sft; }
         }
         if (force_split > 0) want = force_split;
+        // 128x128 class with few tiles (the tall dW reductions): a multiple of 8 splits, whole splits dealt to XCDs
+        // (g.xcd_split, see gemm_tile). An XCD holds 64 such workgroups (32 CUs x 2): take the smallest multiple of 8 whose
+        // t * s / 8 workgroups per XCD fill whole rounds of 64 to 95 % (48 tiles -> 32 splits = 3 rounds; 32 -> 16; 64 -> 8),
+        // else the best one -- unless the plain choice quantises clearly better. TWOG_GEMM_XCD_SPLIT=0: tile chunks.
+        static const int xcd_on = getenv("TWOG_GEMM_XCD_SPLIT") ? atoi(getenv("TWOG_GEMM_XCD_SPLIT")) : 1;
+        int want8 = 0;
+        if (xcd_on && big && want > 1 && force_split <= 0 && t <= 512) {
+            double best8 = 0.0;
+            for (int s8 = 8; s8 <= 64 && s8 <= max_by_k; s8 += 8) {
+                if ((size_t)s8 * t * BMN * BMN * sizeof(float) > workspace_bytes) break;
+                const int64_t per_xcd = (int64_t)t * s8 / 8;
+                const double e8 = (double)per_xcd / (double)(((per_xcd + 63) / 64) * 64);
+                if (e8 > best8 + 1e-9) { best8 = e8; want8 = s8; }
+                if (e8 >= 0.95) break;
+            }
+            if (want8 && best8 + 0.08 < best) want8 = 0;
+        }
+        if (want8) want = want8;
         const size_t need = (size_t)want * t * BMN * BMN * sizeof(float);
         if (want > 1 && need <= workspace_bytes) {
             int kps = (kmax + want - 1) / want;
             g.k_per_split = ((kps + BK - 1) / BK) * BK;
             g.splitk = (kmax + g.k_per_split - 1) / g.k_per_split;
             g.slabs = reinterpret_cast<float*>(workspace);
+            g.xcd_split = (want8 && g.splitk % 8 == 0) ? 1 : 0;
         }
     }
 }
