@@ -416,6 +416,9 @@ typedef int i32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t pack_hi16(uint32_t lo, uint32_t hi) {   // {hi[31:16], lo[31:16]}
     return __builtin_amdgcn_perm(hi, lo, 0x07060302);
 }
+// (Non-finite operands: NaN stays NaN; an operand of +-Inf gives NaN where an fp32 multiply would give +-Inf, because the
+// split subtracts Inf - Inf. The path's GEMM operands are activations, weights and gradients -- finite in any run that is
+// not already broken; the masked softmax's -inf lives inside the attention kernels, never in a GEMM operand.)
 // four consecutive fp32 values -> their three bf16 planes (4 x 2 bytes each), by truncation: h = the top 8 significant bits,
 // m = the top 8 of x - h, l = x - h - m. Exact (both subtractions are, and at most 8 significant bits are left for l), never
 // overflows (a rounding split -- v_cvt_pk_bf16_f32 -- measured 5-8 % slower with the same end-to-end error).

@@ -252,6 +252,22 @@ def test_gemm_128_class_four_wave_tiles():
     assert r.returncode == 0 and 'four-wave OK' in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
+def test_gemm_128_class_split_k_dealt_by_tile_chunks():
+    """Split-K launches of the 128x128 class deal whole k-splits to XCDs by default (a multiple of 8 splits, remapped in
+    the kernel from the workgroup's linear index); TWOG_GEMM_XCD_SPLIT=0 (read once per process) keeps the tile-chunk deal
+    with the round-filling split count. The same cases (incl. the 61 440-row reductions and the grouped-row variants) in a
+    child process with that switch."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ('import tests.test_kernels_gpu as t; from twog_gcn_amd import kernels as k; '
+            't._gemm128_cases(k.get_kernels(), w8=True); print("tile-chunk deal OK")')
+    r = subprocess.run([sys.executable, '-c', code], cwd=root, env=dict(os.environ, TWOG_GEMM_XCD_SPLIT='0'),
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and 'tile-chunk deal OK' in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def test_gemm_64_class_is_reported(K):
     A, B, C = rnd(300, 64).to(DEV), rnd(200, 64, seed=1).to(DEV), torch.empty(300, 200, device=DEV)
     K.gemm([dict(A=A, B=B, C=C)])
