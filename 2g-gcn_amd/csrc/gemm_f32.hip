@@ -1968,5 +1968,5 @@ int twog_internal_gemm_gru_fwd(const twog_gemm_t* gh, const twog_gemm_t* gim, co
 }
 
 extern "C" const char* twog_version(void) {
-    return "lib2ggcn_hip gfx950 fp32-MFMA(32x32x2) gemm tiles 128x128x32/64x64x32";
+    return "lib2ggcn_hip gfx950 fp32 gemm on bf16x3 MFMA(32x32x16) / fp32 MFMA(32x32x2), tiles 128x128 / 64x64 / 32x64";
 }
