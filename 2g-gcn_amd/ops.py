@@ -703,22 +703,23 @@ def segment_recurrence_general_fwd(K, p, P, gi, u, objects_mask):
             tp = t - 1 if d == 0 else t + 1
             L = _seg_step_level(p, bufs, d, t, tp, first, zeros)
             saved[(s_, d)] = relations_general_fwd(K, p, P, L, objects_mask, rels)
-            steps = []
+            steps, projections = [], []   # the projections of both kinds in ONE grouped launch
             for kind, E in E_of.items():
                 if E == 0:
                     continue
                 c = _SEG_CELLS[(kind, d)]
                 fw = p.fw_h if kind == 'h' else p.fw_o
                 gh = e(bs * E, 3 * h)
-                K.gemm([dict(A=L.feats[kind], B=P[c + '.weight_hh'], C=gh, bias=P[c + '.bias_hh'])])
+                projections.append(dict(A=L.feats[kind], B=P[c + '.weight_hh'], C=gh, bias=P[c + '.bias_hh']))
                 gim = None
                 if nm[kind]:
                     gim = e(bs * E, 3 * h)
-                    K.gemm([dict(A=bufs['mg_' + kind][d, :, t], B=P[c + '.weight_ih'][:, fw:], C=gim)])
+                    projections.append(dict(A=bufs['mg_' + kind][d, :, t], B=P[c + '.weight_ih'][:, fw:], C=gim))
                 steps.append(dict(gi=gi[kind][:, t, :, d * 3 * h:(d + 1) * 3 * h], gi2=gim, gh=gh,
                                   h_prev=None if first else L.feats[kind],
                                   h_out=bufs['hs_' + kind][:, t, :, d * h:(d + 1) * h], save=bufs['save_' + kind][d, :, t],
                                   u=u[kind][:, t], rows=bs * E, hidden=h))
+            K.gemm(projections)
             K.gru_step_fwd(steps)
     bufs['general'] = saved
     return bufs
@@ -759,18 +760,20 @@ def segment_recurrence_general_bwd(K, p, P, G, bufs, gi_unused, u, objects_mask,
                                   dgh=out['d_gh_' + kind][:, t, :, d * 3 * h:(d + 1) * 3 * h], dh_prev=carry[d][kind],
                                   u=u[kind][:, t], du=out['d_u_' + kind][:, t], rows=bs * E, hidden=h))
             K.gru_step_bwd(steps)
+            through = []   # both kinds' products with W_hh / W_ih[:, messages] in ONE grouped launch
             for kind, E in E_of.items():
                 if E == 0:
                     continue
                 c = _SEG_CELLS[(kind, d)]
                 fw = p.fw_h if kind == 'h' else p.fw_o
                 if not first:   # carried state gradient through W_hh
-                    K.gemm([dict(A=out['d_gh_' + kind][:, t, :, d * 3 * h:(d + 1) * 3 * h], B=P[c + '.weight_hh'],
-                                 C=carry[d][kind], accumulate=True)], b_kmajor=True)
+                    through.append(dict(A=out['d_gh_' + kind][:, t, :, d * 3 * h:(d + 1) * 3 * h], B=P[c + '.weight_hh'],
+                                        C=carry[d][kind], accumulate=True))
                 if nm[kind]:
                     d_mg[kind] = e(bs * E, nm[kind] * h)
-                    K.gemm([dict(A=out['d_gi_' + kind][:, t, :, d * 3 * h:(d + 1) * 3 * h], B=P[c + '.weight_ih'][:, fw:],
-                                 C=d_mg[kind])], b_kmajor=True)
+                    through.append(dict(A=out['d_gi_' + kind][:, t, :, d * 3 * h:(d + 1) * 3 * h],
+                                        B=P[c + '.weight_ih'][:, fw:], C=d_mg[kind]))
+            K.gemm(through, b_kmajor=True)
             if d_mg:
                 L = _seg_step_level(p, bufs, d, t, tp, first, zeros, carry=trash if first else carry[d], d_mg=d_mg)
                 relations_general_bwd(K, p, P, G, L, bufs['general'][(s_, d)])
