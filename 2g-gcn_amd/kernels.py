@@ -92,8 +92,10 @@ class HipKernels:
         return torch.zeros(*shape, dtype=dtype, device=like.device)
 
     def workspace(self, nbytes, device, key='ws'):
-        """A persistent scratch buffer per (device, key); grown on demand, contents undefined between calls."""
-        k = (str(device), key)
+        """A persistent scratch buffer per (device, key, current stream); grown on demand, contents undefined between
+        calls. Per stream because launches on different streams may run concurrently (split-K slabs, reduction partials);
+        launches that share a buffer are ordered by their stream."""
+        k = (str(device), key, int(self._stream() or 0))
         buf = self._ws.get(k)
         if buf is None or buf.numel() * 4 < nbytes:
             buf = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=device)

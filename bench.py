@@ -130,7 +130,7 @@ class GemmProfiler:
             return call
         self.K.attn_fwd, self.K.attn_bwd = timed('fwd', self.orig_attn[0]), timed('bwd', self.orig_attn[1])
 
-        def gemm(problems, a_kmajor=False, b_kmajor=False, split_k_workspace=True):
+        def gemm(problems, a_kmajor=False, b_kmajor=False, split_k_workspace=True, **kw):
             from twog_gcn_amd.kernels import n_rows
             flops, abytes, tiles128, kmax, wide = 0.0, 0.0, 0, 0, True
             for p in problems:
@@ -145,7 +145,7 @@ class GemmProfiler:
                 wide = wide and M >= 96 and Nn >= 96
             e0, e1 = self.event(), self.event()
             e0.record()
-            self.orig(problems, a_kmajor, b_kmajor, split_k_workspace)
+            self.orig(problems, a_kmajor, b_kmajor, split_k_workspace, **kw)
             e1.record()
             cls = self.K.gemm_last_class()   # the tile class / arithmetic the library actually picked
             kind = ('128x128 bf16x3' if cls & self.K.GEMM_X3 else '128x128') if cls & self.K.GEMM_TILE128 else '64x64'
