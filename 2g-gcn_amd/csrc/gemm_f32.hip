@@ -632,6 +632,8 @@ __device__ __forceinline__ void gemm_mainloop_x3(const twog_rows_t A, const twog
     split_store(r0, 0);
     __syncthreads();
 #if TWOG_X3_ABLATE >= 2
+    split_store(r1, 1);   // BOTH stages hold real planes: the MFMAs' speed depends on their operands (NaN / garbage bit
+    __syncthreads();      // patterns run measurably faster -- less switching, higher clock), so the variants must not differ there
     x3_ablate_skip = true;
 #endif
     int kt = 0;
