@@ -44,7 +44,9 @@ def is_128(k):
 def by_launch(root, dst):
     """128x128-class launches grouped by (kernel variant, grid size): grid = tiles x split-K x workgroup size identifies the
     shape; read / write bytes per dispatch at the L2<->fabric boundary (join with TWOG_BENCH_GEMM_DETAIL=1 of bench.py)."""
-    agg = collections.defaultdict(lambda: [set(), 0.0, 0.0])
+    # (the two passes are separate runs of the bench and may execute different numbers of settling steps: each counter is
+    # divided by the dispatches of ITS pass)
+    agg = collections.defaultdict(lambda: [set(), 0.0, 0.0, set()])
     for sub, col, mul in (('f', 1, 2.0 * 1024), ('w', 2, 1024.0)):
         for f in glob.glob(root + '/' + sub + '/*/*_counter_collection.csv'):
             for r in csv.DictReader(open(f)):
@@ -52,15 +54,14 @@ def by_launch(root, dst):
                 if not is_128(k) or r['Counter_Name'] not in ('FETCH_SIZE', 'WRITE_SIZE'):
                     continue
                 a = agg[(k, int(r['Grid_Size']), int(r['Workgroup_Size']))]
-                if sub == 'f':
-                    a[0].add(r['Dispatch_Id'])
+                a[0 if sub == 'f' else 3].add(r['Dispatch_Id'])
                 a[col] += float(r['Counter_Value']) * mul
     with open(dst, 'w', newline='') as fo:
         wri = csv.writer(fo)
         wri.writerow(['kernel', 'workgroups', 'dispatches', 'read_MB_per_dispatch', 'write_MB_per_dispatch'])
-        for (k, grid, wg), (ids, rd, wr) in sorted(agg.items(), key=lambda kv: -(kv[1][1] + kv[1][2])):
-            n = max(len(ids), 1)
-            wri.writerow([k, grid // max(wg, 1), n, round(rd / n / 1e6, 1), round(wr / n / 1e6, 1)])
+        for (k, grid, wg), (ids, rd, wr, idw) in sorted(agg.items(), key=lambda kv: -(kv[1][1] + kv[1][2])):
+            n, nw = max(len(ids), 1), max(len(idw), 1)
+            wri.writerow([k, grid // max(wg, 1), n, round(rd / n / 1e6, 1), round(wr / nw / 1e6, 1)])
 
 
 def main():
@@ -68,7 +69,7 @@ def main():
     if len(sys.argv) > 4:
         by_launch(root, sys.argv[4])
     f, nf = load(root + '/f')
-    w, _ = load(root + '/w')
+    w, nw = load(root + '/w')
     s, _ = load(root + '/s')
     rows = []
     for k in nf:
@@ -78,7 +79,7 @@ def main():
         gui = sq.get('GRBM_GUI_ACTIVE', 0.0)
         mfma = sq.get('SQ_VALU_MFMA_BUSY_CYCLES', 0.0)
         rows.append(dict(kernel=k, dispatches=nf[k], hbm_read_bytes=int(rd), hbm_write_bytes=int(wr),
-                         hbm_bytes_per_dispatch=int((rd + wr) / max(nf[k], 1)),
+                         hbm_bytes_per_dispatch=int(rd / max(nf[k], 1) + wr / max(nw.get(k, 0), 1)),
                          mfma_util_pct=round(100.0 * mfma / (gui / 8 * 256 * 4), 2) if gui else 0.0,
                          sq_wait_any_frac=round(sq.get('SQ_WAIT_ANY', 0.0) / sq['SQ_WAVE_CYCLES'], 3) if sq.get('SQ_WAVE_CYCLES') else 0.0,
                          sq_wait_inst_frac=round(sq.get('SQ_WAIT_INST_ANY', 0.0) / sq['SQ_WAVE_CYCLES'], 3) if sq.get('SQ_WAVE_CYCLES') else 0.0))
@@ -91,8 +92,11 @@ def main():
     if big and len(sys.argv) > 3:
         import json
         nd = sum(r['dispatches'] for r in big)
+        ndw = max(sum(nw.get(r['kernel'], 0) for r in big), 1)
         by = sum(r['hbm_read_bytes'] + r['hbm_write_bytes'] for r in big)
-        json.dump(dict(kernel='128x128 tile class: gemm_x3_kernel<*> + gemm_kernel<128,128,*>', dispatches=nd, hbm_bytes_total=by, hbm_bytes_per_launch=by / nd,
+        per_launch = sum(r['hbm_read_bytes'] for r in big) / nd + sum(r['hbm_write_bytes'] for r in big) / ndw
+        json.dump(dict(kernel='128x128 tile class: gemm_x3_kernel<*> + gemm_kernel<128,128,*>', dispatches=nd, dispatches_write_pass=ndw,
+                       hbm_bytes_total=by, hbm_bytes_per_launch=per_launch,
                        source='rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline`'
                               ' (tools/bench_pmc.sh); read bytes = 2 * FETCH_SIZE KiB (gfx950 correction)'),
                   open(sys.argv[3], 'w'), indent=1)
