@@ -403,7 +403,7 @@ __device__ __forceinline__ void gemm_mainloop(const twog_rows_t A, const twog_ro
 //
 // Structure: 128x128 tile, 8 waves of 32x64, k-tiles of 16 (one bf16 MFMA k-step), the same branch-free 16-byte global
 // loads into registers (two stages); the split happens once per element on the way into LDS (5.5 VALU operations per
-// element), LDS holds three bf16 planes per operand in two stages (2 x 36 KB: two workgroups per CU), one barrier per
+// element), LDS holds three bf16 planes per operand in two stages (2 x 24 KB; two workgroups per CU by registers), one barrier per
 // k-tile. Row-major operands ([row][k], k contiguous) are stored as [row][16 k] rows of 32 bytes whose two 16-byte chunks
 // are swapped on every second group of 16 rows (the ds_read_b128 fragment reads and the ds_write_b64 stores are conflict-free); k-major operands ([k][row]) are stored as they come, [k][128 rows] rows of 256 bytes with 16-byte
 // chunks XOR-swizzled by the k row, and transposed on the way out by ds_read_b64_tr_b16 (each 16-lane group receives a
@@ -449,7 +449,7 @@ constexpr int X3_RROW = 32;                  // bytes per row of a [row][16 k] i
                                              // 16..31 (mod 32): conflict-free ds_read_b128 (lane groups of the guide) and ds_write_b64
 constexpr int X3_RPLANE = 128 * X3_RROW;     // 4 096
 constexpr int X3_TPLANE = X3_BK * 256;       // [16 k][128 rows] image: 4 096
-constexpr int X3_STAGE = 6 * X3_RPLANE;      // one LDS stage (both operands, worst case): 36 864 bytes; two stages = the tile's 73 728
+constexpr int X3_STAGE = 6 * X3_RPLANE;      // one LDS stage (three planes of both operands): 24 576 bytes; two stages = 49 152
 __device__ __forceinline__ int x3_swz(int k) { return ((k & 3) << 2) | ((k >> 2) & 3); }
 
 template <bool AKM, bool BKM, bool KG>
@@ -851,7 +851,8 @@ __device__ __forceinline__ void gemm_tile(const Group& g, const GateArgs* ga) {
     constexpr int A_ELEMS = AKM ? BK * LDA : BM * LDA;
     constexpr int B_ELEMS = BKM ? BK * LDB : BN * LDB;
     // (X3 on the 64-row class: two stages of three bf16 planes per operand, 2 x 6 x 64 rows x 2 XK bytes, XK = 16 KS)
-    constexpr int SMEM_FLOATS = (X3 && BM == 64 && 12 * 64 * 8 * KS > 2 * (A_ELEMS + B_ELEMS)) ? 12 * 64 * 8 * KS : 2 * (A_ELEMS + B_ELEMS);
+    constexpr int SMEM_FLOATS = (X3 && BM == 128) ? 2 * X3_STAGE / 4
+                                : (X3 && BM == 64 && 12 * 64 * 8 * KS > 2 * (A_ELEMS + B_ELEMS)) ? 12 * 64 * 8 * KS : 2 * (A_ELEMS + B_ELEMS);
     __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS];
 
     // XCD-aware, bijective block -> (problem, tile) map. Blocks are dealt round-robin over the 8 XCDs (speed only:
