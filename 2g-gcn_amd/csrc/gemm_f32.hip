@@ -1497,7 +1497,9 @@ static void prepare_group(const twog_gemm_t* pr, int n, int a_kmajor, int b_kmaj
     static const int force_tile = getenv("TWOG_GEMM_TILE") ? atoi(getenv("TWOG_GEMM_TILE")) : 0;
     static const int force_split = getenv("TWOG_GEMM_SPLITK") ? atoi(getenv("TWOG_GEMM_SPLITK")) : 0;
     const int64_t reach128 = tiles128 * (workspace ? (kmax >= 1024 ? kmax / 512 : 1) : 1);
-    static const int big_min = getenv("TWOG_GEMM_BIG_MIN") ? atoi(getenv("TWOG_GEMM_BIG_MIN")) : 256;   // tuning knob
+    // (200 since the class multiplies on the bf16 pipes: its tiles run at twice the 64x64 class's rate, so a launch that
+    // leaves a fifth of the CUs without a 128-tile still wins -- bs64 step 67.10 -> 66.71 ms; 224: 66.78, 176: 67.15)
+    static const int big_min = getenv("TWOG_GEMM_BIG_MIN") ? atoi(getenv("TWOG_GEMM_BIG_MIN")) : 200;
     big = wide && (tiles128 >= big_min || reach128 >= 256);
     if (force_tile == 128) big = true;
     if (force_tile == 64) big = false;
