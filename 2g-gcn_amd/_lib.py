@@ -7,7 +7,9 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'lib2ggcn_hip.so')
+# TWOG_LIB_PATH: another build of the same library (measurement builds of tools/x3_ablate.sh); never a fallback -- a path
+# that does not load raises exactly like a missing default library
+LIB_PATH = os.environ.get('TWOG_LIB_PATH') or os.path.join(_HERE, 'lib2ggcn_hip.so')
 
 c_float_p = C.POINTER(C.c_float)
 c_double_p = C.POINTER(C.c_double)

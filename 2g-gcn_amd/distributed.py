@@ -12,10 +12,25 @@ per rank. Dead parameters (constructed by the reference but never used, SURVEY.m
 The three cross-sample couplings of SURVEY 8e have an exact-equivalence switch each: sync_bn (a), count_weighted_loss
 (b), global_noise_seed (c).
 """
+import weakref
+
 import torch
 import torch.distributed as dist
 
 from .kernels import get_kernels
+
+
+def _drop_extras(model_ref, wrapper_ref):
+    """weakref.finalize callback of a collected DataParallel: removes what it left beside a model that is still alive."""
+    model = model_ref()
+    if model is None:
+        return
+    from . import ops
+    hook = ops.get_model_extra(model, 'stage_hook')
+    if isinstance(hook, weakref.WeakMethod) and hook() is None:
+        ops.set_grad_stage_hook(model, None)
+    for key in ('bn_stats_reduce', 'noise_shard'):
+        ops.set_model_extra(model, key, None)
 
 
 class FlatParameters:
@@ -104,22 +119,30 @@ class DataParallel:
         self._works, self._launched = [], set()
         self.collective_calls = 0   # collectives issued so far (tests assert the path really ran)
         from . import ops
+        # Everything this wrapper hangs beside the model (ops.set_model_extra: a weak-KEYED table) refers back to the wrapper
+        # only WEAKLY -- the wrapper holds the model, so a strong reference from a table value would keep the weak key, the
+        # model and the flat parameter / gradient buffers alive for the life of the process (a discarded wrapper in a sweep
+        # loop, an EMA re-wrap). A dead wrapper's callables are no-ops.
+        me_ref = weakref.ref(self)
         if sync_bn:
-            def reduce_stats(sums, n_frames, world=self.world, group=process_group, on=self.collective, me=self):
+            def reduce_stats(sums, n_frames, world=self.world, group=process_group, on=self.collective, me_ref=me_ref):
                 if on:
                     dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
-                    me.collective_calls += 1
+                    me = me_ref()
+                    if me is not None:
+                        me.collective_calls += 1
                 return sums, n_frames * world
             ops.set_model_extra(model, 'bn_stats_reduce', reduce_stats)
+        self._count_reducer = None
         if count_weighted_loss:
-            def reduce_counts(counts, world=self.world, group=process_group, on=self.collective, me=self):
+            def reduce_counts(counts, world=self.world, group=process_group, on=self.collective, me_ref=me_ref):
                 """counts: fp64 [terms] valid targets of this rank -> global count / W (the rank losses are averaged)."""
                 if on:
                     dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=group)
-                    me.collective_calls += 1
+                    me = me_ref()
+                    if me is not None:
+                        me.collective_calls += 1
                 return counts / world
-            from . import losses
-            losses.set_count_reducer(reduce_counts)
             self._count_reducer = reduce_counts
         if global_noise_seed is not None:
             ops.set_model_extra(model, 'noise_shard',
@@ -129,7 +152,9 @@ class DataParallel:
         self.flat = FlatParameters(model, stage_of=ops.grad_ready_stage if overlap else None)
         self.bucket = max(1, bucket_mb) * (1 << 20) // 4
         if overlap and self.collective:
-            ops.set_grad_stage_hook(model, self._stage_ready)   # scoped to this model; close() removes it
+            # scoped to this model; close() removes it. A WeakMethod: the table must not own the wrapper (see above)
+            ops.set_grad_stage_hook(model, weakref.WeakMethod(self._stage_ready))
+        weakref.finalize(self, _drop_extras, weakref.ref(model), me_ref)
         if self.collective and broadcast:
             dist.broadcast(self.flat.flat, src=0, group=self.group)
             for b in model.buffers():
@@ -138,13 +163,24 @@ class DataParallel:
 
     def close(self):
         """Detaches this wrapper from the model (stage hook, sync-BN / noise-shard / loss-count settings)."""
-        from . import ops, losses
-        if ops.get_model_extra(self.model, 'stage_hook') == self._stage_ready:
+        from . import ops
+        hook = ops.get_model_extra(self.model, 'stage_hook')
+        if isinstance(hook, weakref.WeakMethod) and hook() == self._stage_ready:
             ops.set_grad_stage_hook(self.model, None)
         for key in ('bn_stats_reduce', 'noise_shard'):
             ops.set_model_extra(self.model, key, None)
-        if getattr(self, '_count_reducer', None) is not None and losses.get_count_reducer() is self._count_reducer:
-            losses.set_count_reducer(None)
+        self._count_reducer = None
+
+    def loss_scope(self):
+        """Context manager for the criterion call(s) of ONE training step: inside it, with count_weighted_loss=True, every
+        term of losses.multi_task_loss is normalised by the GLOBAL number of valid targets (one all-reduce of the per-term
+        counts per criterion call). The reduction is a collective: every rank must enter the scope and call the criterion
+        the same number of times inside it. Outside the scope -- validation on one rank, a second model, no_grad
+        evaluation -- the criterion is the reference's single-process arithmetic and issues no collective.
+            with dp.loss_scope():
+                loss = sum(criterion(out, targets))"""
+        from . import losses
+        return losses.count_reducer_scope(self._count_reducer)
 
     @property
     def grad_scale(self):

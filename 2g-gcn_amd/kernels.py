@@ -99,8 +99,30 @@ class HipKernels:
         buf = self._ws.get(k)
         if buf is None or buf.numel() * 4 < nbytes:
             buf = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=device)
-            self._ws[k] = buf
+            self._ws_put(k, buf)
+        else:
+            self._ws_touch(k)
         return buf
+
+    MAX_STREAMS_PER_WORKSPACE = 4
+
+    def _ws_touch(self, k):
+        self._ws[k] = self._ws.pop(k)   # most recently used last (dict order)
+
+    def _ws_put(self, k, buf):
+        """Workspaces are per (device, kind, stream): at most MAX_STREAMS_PER_WORKSPACE streams keep one of each kind, the
+        least recently used entry goes first (a 320 MB split-K buffer + a 48 MB chain workspace per stream that ever
+        issued a GEMM would otherwise stay for the life of the process). Dropping an entry only drops torch's reference:
+        the caching allocator keeps the memory valid for work already enqueued on the stream that used it."""
+        self._ws.pop(k, None)
+        self._ws[k] = buf
+        same = [q for q in self._ws if q[0] == k[0] and q[1] == k[1]]
+        for q in same[:-self.MAX_STREAMS_PER_WORKSPACE]:
+            del self._ws[q]
+
+    def release_workspaces(self):
+        """Drops every cached workspace (they are re-created on demand)."""
+        self._ws.clear()
 
     def chain_workspace(self, device):
         """(pointer, bytes) of the chain workspace of the CURRENT stream on `device` (include/twog_gcn.h,
@@ -111,7 +133,7 @@ class HipKernels:
         buf = self._ws.get(k)
         if buf is None:
             buf = torch.zeros(int(self.lib.twog_chain_workspace_bytes()) // 4, dtype=torch.float32, device=device)
-            self._ws[k] = buf
+            self._ws_put(k, buf)
         return buf.data_ptr(), buf.numel() * 4
 
     def version(self):

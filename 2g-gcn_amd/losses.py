@@ -42,12 +42,30 @@ _KIND = {nll_loss: _NLL, F.nll_loss: _NLL, binary_cross_entropy_loss: _BCE, budg
 # (distributed.DataParallel(count_weighted_loss=True)) maps this rank's per-term counts [terms] (fp64, on the device) to
 # (global count) / W: the term becomes sum_rank / (count_global / W), whose average over the W ranks -- and so the
 # averaged gradient -- is the global-batch value. No reducer: the reference's single-process arithmetic.
+#
+# The reducer is a COLLECTIVE, so it is never installed process-wide: it is active only inside
+# `with dp.loss_scope():` (count_reducer_scope below), which the training step enters around its criterion call, and only
+# while autograd is recording -- a validation pass on one rank, a second model's criterion or a no_grad evaluation issue
+# no collective and cannot pair with another rank's all-reduce. Every rank must make the same number of criterion calls
+# inside the scope.
 _count_reducer = None
 
 
-def set_count_reducer(fn):
-    global _count_reducer
-    _count_reducer = fn
+class count_reducer_scope:
+    """Context manager: `fn` (or None) reduces the per-term counts of every criterion call made inside the scope."""
+
+    def __init__(self, fn):
+        self.fn, self.prev = fn, None
+
+    def __enter__(self):
+        global _count_reducer
+        self.prev, _count_reducer = _count_reducer, self.fn
+        return self
+
+    def __exit__(self, *exc):
+        global _count_reducer
+        _count_reducer = self.prev
+        return False
 
 
 def get_count_reducer():
@@ -57,7 +75,7 @@ def get_count_reducer():
 class _MultiTaskLoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, spec, *inputs):
-        kinds, targets, weights, ignore = spec
+        kinds, targets, weights, ignore, reducer = spec
         K = get_kernels()
         terms = []
         for x, y, k, w in zip(inputs, targets, kinds, weights):
@@ -65,15 +83,17 @@ class _MultiTaskLoss(torch.autograd.Function):
             y = (y.to(torch.int64) if k == _NLL else y.to(torch.float32)).contiguous()
             terms.append(dict(kind=k, input=x, target=y, weight=w, ignore=ignore))
         losses, stats = K.multitask_loss_fwd(terms)
-        if _count_reducer is not None:
+        if reducer is not None:
             # six to twelve scalars: sum_rank / (count_global / W) per term, 0 / 0 -> NaN for NLL like torch's mean over an
-            # empty selection, 0 for the BCE / budget terms (pyrutils/torch/losses.py:15-16, :32-33)
-            eff = _count_reducer(stats[:, 1].clone())
+            # empty selection, 0 for the BCE / budget terms (pyrutils/torch/losses.py:15-16, :32-33). Same arithmetic as
+            # loss_final_kernel (csrc/loss.hip): the fp64 quotient rounded to fp32, then the fp32 product with the weight
+            # -- with a reducer that returns the counts unchanged (one rank) the losses are bit-identical to the plain path.
+            eff = reducer(stats[:, 1].clone())
             val = stats[:, 0] / eff
             soft = torch.tensor([k != _NLL for k in kinds], device=val.device)
             val = torch.where(soft & (eff <= 0), torch.zeros_like(val), val)
-            w = torch.tensor([float(x) for x in weights], dtype=torch.float64, device=val.device)
-            losses = (w * val).to(torch.float32)
+            w = torch.tensor([float(x) for x in weights], dtype=torch.float32, device=val.device)
+            losses = w * val.to(torch.float32)
             stats = torch.stack([stats[:, 0], eff], 1).contiguous()
         ctx.terms, ctx.stats = terms, stats
         return losses
@@ -90,7 +110,9 @@ class _MultiTaskLoss(torch.autograd.Function):
 def _run(inputs, targets, kinds, weights, ignore_value, reduction):
     if reduction != 'mean':
         raise NotImplementedError("only reduction='mean' (the reference's setting) is implemented")
-    losses = _MultiTaskLoss.apply((list(kinds), list(targets), [float(w) for w in weights], ignore_value), *inputs)
+    # the scope's reducer, and only while autograd records (read here: grad mode is off inside Function.forward)
+    reducer = _count_reducer if torch.is_grad_enabled() else None
+    losses = _MultiTaskLoss.apply((list(kinds), list(targets), [float(w) for w in weights], ignore_value, reducer), *inputs)
     return list(losses.unbind(0))
 
 

@@ -317,6 +317,8 @@ def enable_grad_sinks(params, on: bool = True):
 
 def _stage_done(plan, stage):
     hook = getattr(plan, 'stage_hook', None)
+    if isinstance(hook, weakref.WeakMethod):   # the data-parallel wrapper registers itself weakly (distributed.py)
+        hook = hook()
     if hook is not None:
         hook(stage)
 

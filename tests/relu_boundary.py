@@ -93,6 +93,11 @@ def boundary_layers(model, out, width=4.0):
     return found
 
 
+# what the last condition_case() looked at: ReLU units (layer outputs) and activations (units x rows) of the covered layers
+# and the (unit, row) activations found inside the rounding band over all rounds
+LAST_TOTALS = dict(units=0, activations=0, boundary_activations=0)
+
+
 def condition_case(model, forward, width=8.0, max_rounds=8):
     """Moves a test case OFF the ReLU rounding boundaries instead of excusing what they do to a gradient comparison:
     runs `forward()` (the HIP path, train mode) and, while some ReLU unit has a row whose pre-activation lies within
@@ -105,12 +110,18 @@ def condition_case(model, forward, width=8.0, max_rounds=8):
     for rnd in range(max_rounds):
         out = forward()
         todo = []
+        LAST_TOTALS.update(units=0, activations=0)
+        if rnd == 0:
+            LAST_TOTALS['boundary_activations'] = 0
         with torch.no_grad():
             for layer, x, w, b, factor in _layers(model, out):
+                LAST_TOTALS['units'] += int(w.shape[0])
+                LAST_TOTALS['activations'] += int(w.shape[0]) * int(x.shape[0])
                 count, band = _boundary_units(x, w, b, width * factor, with_band=True)
                 idx = count.nonzero().flatten()
                 if len(idx):
                     todo.append((layer, idx, band[idx]))
+                    LAST_TOTALS['boundary_activations'] += int(count.sum())
         del out
         if not todo:
             return rnd, nudged

@@ -196,7 +196,17 @@ def _worker_counts(rank, world, port, ret, weighted):
     noise = _noise_all(4)
     sl = slice(rank * 2, rank * 2 + 2)
     dp.zero_grad()
-    loss = _criterion_loss(model, xh[sl], xo[sl], mask[sl], cls[sl], seg[sl], noise[:, sl])
+    with dp.loss_scope():   # the count reduction is a collective: active only inside the step's scope
+        loss = _criterion_loss(model, xh[sl], xo[sl], mask[sl], cls[sl], seg[sl], noise[:, sl])
+    calls_in_scope = dp.collective_calls
+    # a criterion call OUTSIDE the scope (rank-0-only validation, a second model) or under no_grad issues no collective
+    from twog_gcn_amd import losses as _losses
+    assert _losses.get_count_reducer() is None
+    if rank == 0:
+        _criterion_loss(model, xh[sl], xo[sl], mask[sl], cls[sl], seg[sl], noise[:, sl])
+    with dp.loss_scope(), torch.no_grad():
+        _criterion_loss(model, xh[sl], xo[sl], mask[sl], cls[sl], seg[sl], noise[:, sl])
+    assert dp.collective_calls == calls_in_scope
     loss.backward()
     dp.all_reduce_gradients()
     ret[rank] = (dp.flat.grad.clone() * dp.grad_scale, float(loss.detach()), dp.collective_calls)
@@ -269,3 +279,52 @@ def test_model_deepcopy_does_not_drag_the_wrapper_along():
         assert ops.get_model_extra(model, 'bn_stats_reduce') is None and ops.get_model_extra(model, 'noise_shard') is None
     finally:
         kernels._set_backend_for_tests(None)
+
+
+def _wrap_and_drop_worker(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import gc
+    import weakref
+    import twog_gcn_amd  # noqa: F401
+    from twog_gcn_amd import kernels, ops
+    from twog_gcn_amd.distributed import DataParallel
+    from tests.fake_kernels import FakeKernels
+    kernels._set_backend_for_tests(FakeKernels())
+    torch.set_num_threads(2)
+    # (a) wrapper AND model dropped without close(): both go, the side table forgets the model
+    model = _tiny_model(seed=0)
+    dp = DataParallel(model, sync_bn=True, global_noise_seed=5, count_weighted_loss=True, force_collectives=True)
+    assert ops.get_model_extra(model, 'stage_hook') is not None
+    refs = (weakref.ref(model), weakref.ref(dp), weakref.ref(dp.flat.flat))
+    n_before = len(ops._MODEL_EXTRAS)
+    del dp, model
+    gc.collect()
+    a = [r() is None for r in refs] + [len(ops._MODEL_EXTRAS) == n_before - 1]
+    # (b) only the wrapper dropped (re-wrap of a live model): its hooks and reducers leave the table
+    model = _tiny_model(seed=0)
+    dp = DataParallel(model, sync_bn=True, global_noise_seed=5, force_collectives=True)
+    r = weakref.ref(dp)
+    del dp
+    gc.collect()
+    b = [r() is None, ops.get_model_extra(model, 'stage_hook') is None, ops.get_model_extra(model, 'bn_stats_reduce') is None,
+         ops.get_model_extra(model, 'noise_shard') is None]
+    # the model still runs (no dangling hook fires in its backward pass)
+    xh, xo, mask, tgt, noise = _batch(2)
+    model._gumbel_noise_override = noise
+    out = model(xh, xo, mask, human_segmentation=torch.ones(xh.shape[:3]))
+    torch.nn.functional.nll_loss(out[4], tgt).backward()
+    ret['a'], ret['b'] = a, b
+    dist.destroy_process_group()
+
+
+def test_discarded_wrapper_and_model_are_collected_without_close():
+    """the side table's values must not own the wrapper -- a wrapper (and its model, and the flat
+    parameter / gradient buffers) dropped WITHOUT close() is collected; a dropped wrapper of a live model takes its stage
+    hook, BatchNorm reducer and noise shard with it."""
+    port = 37500 + os.getpid() % 2000
+    ret = mp.Manager().dict()
+    mp.spawn(_wrap_and_drop_worker, args=(1, port, ret), nprocs=1, join=True)
+    assert all(ret['a']), ret['a']
+    assert all(ret['b']), ret['b']

@@ -86,7 +86,9 @@ def _nccl_worker(rank, world, port, ret):
         for _ in range(3):
             dp.zero_grad()
             out = model(xh, xo, mask, human_segmentation=torch.ones(xh.shape[:3], device=DEV))
-            sum(crit(out, [seg_t, seg_t, tgt, tgt, tgt, tgt])).backward()
+            with dp.loss_scope():
+                loss = sum(crit(out, [seg_t, seg_t, tgt, tgt, tgt, tgt]))
+            loss.backward()
             dp.all_reduce_gradients()
             grads.append(dp.flat.grad.clone().cpu())
             opt.step(dp.grad_scale)

@@ -1204,6 +1204,50 @@ print('RES ' + json.dumps(res))
     print({k: (f"{v['err']:.2e}", f"{out['0'][k]['err']:.2e}") for k, v in out['1'].items()})
 
 
+def test_gemm_x3_same_sign_and_wide_exponent_operands():
+    """The X3 split truncates, so the three dropped chunk products carry the sign of a b: on same-sign operands their sum is
+    a BIAS (towards zero), not noise. tools/x3_bias_probe.py builds the cases against the scheme -- post-ReLU activations x
+    non-negative values with K up to 61 440 (the dW reductions), post-ReLU x signed weights, a 2^40 exponent spread inside
+    every dot product -- in both tile classes; required: the class bit (X3 ran), |mean signed error| <= 1e-7 of the
+    output on the same-sign cases (i.e. below two fp32 ulps of systematic drift over 61 440 terms), and mean / max error
+    within 1e-7 / 2e-6 of sum |a b| everywhere."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'x3_bias_probe.py'), '--json'],
+                       env=dict(os.environ, TWOG_GEMM_XSPLIT='1'), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    rows = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('ROWS ')][0][5:])
+    assert len(rows) >= 9
+    for row in rows:
+        assert row['x3'], row
+        assert abs(row['mean_err_over_sum_abs']) <= 1e-7, row
+        assert row['max'] <= 2e-6, row
+        if 'mean_rel_err_same_sign' in row:
+            assert abs(row['mean_rel_err_same_sign']) <= 1e-7, row
+    print({r_['case']: (f"{r_['mean_err_over_sum_abs']:+.1e}", f"{r_['max']:.1e}") for r_ in rows})
+
+
+def test_gemm_x3_nonfinite_operands_stay_nonfinite(K):
+    """Documented difference of the X3 kernels (csrc/gemm_f32.hip, split3): an operand of +-Inf gives NaN where an fp32
+    multiply gives +-Inf (the split subtracts Inf - Inf); a NaN stays a NaN. Either way the affected outputs are NOT finite
+    -- a broken run cannot look healthy -- and every other output is untouched."""
+    g = torch.Generator().manual_seed(3)
+    M, N, Kk = 2048, 2048, 512   # 256 tiles of 128 x 128: the X3 class
+    A = torch.randn(M, Kk, generator=g)
+    B = torch.randn(N, Kk, generator=g) * 0.1
+    A[5, 17] = float('inf')
+    A[9, 400] = float('nan')
+    B[33, 3] = float('-inf')
+    C = torch.zeros(M, N, device=DEV)
+    K.gemm([dict(A=A.to(DEV), B=B.to(DEV), C=C, bias=None, act=0, accumulate=False)])
+    assert K.gemm_last_class() & K.GEMM_X3
+    bad = torch.zeros(M, N, dtype=torch.bool)
+    bad[5, :] = True; bad[9, :] = True; bad[:, 33] = True
+    Cc = C.cpu()
+    assert not torch.isfinite(Cc[bad]).any(), 'an output fed by Inf / NaN came out finite'
+    assert torch.isfinite(Cc[~bad]).all()
+    ref = (torch.nan_to_num(A, nan=0.0, posinf=0.0, neginf=0.0).double() @ torch.nan_to_num(B, nan=0.0, posinf=0.0, neginf=0.0).double().t())
+    assert (Cc[~bad].double() - ref[~bad]).abs().max() <= 3e-5 * ref[~bad].abs().max()
+
+
 def test_ssp_gather_with_segment_level_placement(K):
     """Weights stored [time][clip][natt] and the gradient rows a column block of wider rows (the segment level's layout)."""
     bs, T, H, O, cols = 3, 5, 2, 8, 48
