@@ -65,3 +65,48 @@ def rel_err(a, b):
     a = np.asarray(a, dtype=np.float64)
     b = np.asarray(b, dtype=np.float64)
     return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-12))
+
+
+# ---- G12 (training trajectory): inputs, targets and initial weights are closed-form (oracle/detgen.py); the fixture holds
+# only what the reference produced. tools/make_golden.py generates the fixture from these same two functions.
+def synth_inputs(name, H, O, N, bs, T, seed):
+    """x_human (bs,T,H,2048+4N), x_objects (bs,T,O,2048), objects_mask (bs,O) -- the generator of the G4 / G12 inputs."""
+    vis = np.maximum(detgen.normal(name + '.xh', (bs, T, H, 2048), seed=seed), 0.0)
+    pos = detgen.uniform(name + '.pos', (bs, T, N, 2), 0.0, 1.0, seed=seed)
+    vel = detgen.normal(name + '.vel', (bs, T, N, 2), std=0.5, seed=seed)
+    geo = np.concatenate([pos, vel], axis=-1).reshape(bs, T, 1, 4 * N)
+    geo = np.repeat(geo, H, axis=2)
+    x_human = np.concatenate([vis, geo], axis=-1).astype(np.float32)
+    x_objects = np.maximum(detgen.normal(name + '.xo', (bs, T, O, 2048), seed=seed), 0.0).astype(np.float32)
+    mask = np.ones((bs, O), dtype=np.float32)
+    mask[0, O - 1] = 0.0
+    if bs > 1 and O > 2:
+        mask[1, O - 2:] = 0.0
+    x_objects = x_objects * mask[:, None, :, None]
+    return x_human, x_objects, mask
+
+
+def g12_targets(meta, step):
+    """Targets of training step `step`: class labels with a ragged tail (ignore_index -1), gate targets."""
+    bs, T, H, seed, n_cls = meta['bs'], meta['T'], meta['H'], meta['seed'], meta['classes'][0]
+    cls = [(detgen.uniform01(f'g12.s{step}.cls{i}', (bs, T, H), seed=seed) * n_cls).astype(np.int64) for i in range(2)]
+    seg = (detgen.uniform01(f'g12.s{step}.seg', (bs, T, H), seed=seed) > 0.55).astype(np.float32)
+    for a in cls:
+        a[1, T - 2:] = -1
+    seg[1, T - 2:] = -1.0
+    return cls, seg
+
+
+def load_g12():
+    z = np.load(os.path.join(GOLDEN, 'g12_training_trajectory.npz'), allow_pickle=False)
+    return z, json.loads(str(z['meta_json']))
+
+
+def g12_step_batch(meta, step):
+    """(model kwargs, criterion targets) of training step `step` as torch tensors."""
+    xh, xo, mask = synth_inputs(f'g12.s{step}', meta['H'], meta['O'], meta['N'], meta['bs'], meta['T'], meta['seed'])
+    cls, seg = g12_targets(meta, step)
+    kw = dict(x_human=torch.from_numpy(xh), x_objects=torch.from_numpy(xo), objects_mask=torch.from_numpy(mask),
+              steps_per_example=torch.full((meta['bs'],), float(meta['T'])))
+    target = [torch.from_numpy(seg), torch.from_numpy(seg)] + [torch.from_numpy(cls[i % 2]) for i in range(4)]
+    return kw, target

@@ -512,11 +512,83 @@ def g11_segmentation_helpers():
     print('g11:', len(out), 'arrays')
 
 
+G12_PARAMS = ['human_recognition_mlp.0.weight', 'objects_to_human_message_mlp.0.weight', 'human_segment_rnn_fcell.weight_hh',
+              'object_bd_rnn.weight_ih_l0', 'geometry_embedding_gcn.weight', 'update_human_segment_mlp.0.weight',
+              'objects_to_object_segment_message_mlp.0.bias', 'geometry_embedding_mlp.2.weight']
+G12_MISC = dict(anticipation_loss_weight=1.0, budget_loss=dict(add=True, human_weight=0.5, object_weight=0.25),
+                first_level_loss_weight=0.3, segmentation_loss=dict(add=True, pretrain=False, weight=0.7))
+G12 = dict(name='g12', H=2, O=4, N=26, hid=16, bs=3, T=8, classes=(13, None), seed=51, gain=1.6, steps=5, lr=1e-4)
+
+
+def g12_training_trajectory():
+    """G12: the reference's TRAINING STEP composed five times -- reference TGGCN (MPHOI layout, every gate learned, train
+    mode) + vhoi.losses.select_loss (every term weighted) + torch.optim.Adam(lr=1e-4), in the order of
+    pyrutils/torch/train_utils.py:143-154 (zero_grad, forward, criterion(reduction='mean'), sum, backward, step); train.py:38-46
+    builds exactly this optimizer and criterion. A fresh batch and fresh Gumbel noise per step (drawn from the default CPU
+    generator, recorded). Stored: the noise, per-step loss lists, BatchNorm running statistics and eight parameters after
+    step 5 (inputs, targets and initial weights are closed-form: oracle/detgen.py)."""
+    class Cfg(dict):
+        def get(self, k, default_value=None, **kw):
+            return dict.get(self, k, default_value if default_value is not None else kw.get('default'))
+
+    c = G12
+    cfg = dict(STAGE1)
+    cfg.update(hidden_size=c['hid'], gcn_node=c['N'])
+    model = TGGCN(input_size=(2048 + 4 * c['N'], 2048), num_classes=c['classes'], **cfg)
+    load_det(model, seed=c['seed'], gain=c['gain'])
+    model.train()
+    crit, names = select_loss('2G-GCN', 'multiple', 'mphoi', Cfg(misc=G12_MISC))
+    opt = torch.optim.Adam(model.parameters(), lr=c['lr'])
+    save = {}
+    init = {n: p.detach().clone() for n, p in model.named_parameters()}
+    torch.manual_seed(42)
+    losses_all, hard_all = [], []
+    for step in range(c['steps']):
+        # inputs and targets: the closed-form generators the tests use (tests/helpers.py), so the fixture need not hold them
+        from tests.helpers import g12_step_batch
+        kw, target = g12_step_batch(dict(c, classes=list(c['classes'])), step)
+        chk = make_inputs(f'g12.s{step}', c['H'], c['O'], c['N'], c['bs'], c['T'], c['seed'])
+        assert np.array_equal(chk[0], kw['x_human'].numpy()) and np.array_equal(chk[1], kw['x_objects'].numpy())
+        with GumbelRecorder() as rec:
+            opt.zero_grad()
+            out = model(**kw)
+            losses = crit(out, target, reduction='mean')
+            loss = sum(losses)
+            loss.backward()
+            opt.step()
+        save[f'noise{step}'] = torch.stack(rec.drawn, 0).numpy()
+        losses_all.append([float(v) for v in losses])
+        hard_all.append(out[0].detach().numpy().copy())
+        soft = out[1].detach()
+        print(f'g12 step {step}: loss {float(loss):.6f}  terms {[round(float(v), 5) for v in losses]}  min|soft-0.5| '
+              f'{float((soft - 0.5).abs().min()):.4f}')
+    save['losses'] = np.array(losses_all, dtype=np.float64)
+    save['hard_gates'] = np.stack(hard_all, 0)
+    save['loss_names'] = np.array(names)
+    bn = model.geometry_embedding_gcn.joint_embed.cnn[0].bn
+    save['bn_running_mean'], save['bn_running_var'] = bn.running_mean.numpy().copy(), bn.running_var.numpy().copy()
+    save['bn_num_batches_tracked'] = np.array(int(bn.num_batches_tracked))
+    P = dict(model.named_parameters())
+    for n in G12_PARAMS:
+        save['final_' + n] = sample_grad(P[n])
+        save['delta_' + n] = sample_grad(P[n].detach() - init[n])
+    # every parameter's largest move and whether it moved at all (dead parameters must stay put)
+    save['moved'] = np.array([n for n, p in P.items() if float((p.detach() - init[n]).abs().max()) > 0])
+    meta = dict(cfg=cfg, misc=G12_MISC, params=G12_PARAMS, **{k: (list(v) if isinstance(v, tuple) else v) for k, v in c.items()},
+                state_dict_shapes={k: list(v.shape) for k, v in model.state_dict().items()})
+    save['meta_json'] = np.array(__import__('json').dumps(meta))
+    np.savez_compressed(os.path.join(OUT, 'g12_training_trajectory.npz'), **save)
+    print('g12:', len(save), 'arrays')
+
+
 if __name__ == '__main__':
     torch.set_num_threads(8)
     os.makedirs(OUT, exist_ok=True)
     if len(sys.argv) > 1 and sys.argv[1] == 'g11':
         g11_segmentation_helpers()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'g12':
+        g12_training_trajectory()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'g4':   # python tools/make_golden.py g4 [case ...]
         g4_full(only=set(sys.argv[2:]) or None)
@@ -529,3 +601,4 @@ if __name__ == '__main__':
     g6_batching()
     g8_postprocess()
     g11_segmentation_helpers()
+    g12_training_trajectory()
