@@ -1204,25 +1204,36 @@ print('RES ' + json.dumps(res))
     print({k: (f"{v['err']:.2e}", f"{out['0'][k]['err']:.2e}") for k, v in out['1'].items()})
 
 
+# |mean signed relative error| allowed on SAME-SIGN operands, per tile class (see the test below)
+X3_SAME_SIGN_BIAS_CAP = {'64': 1e-7, '128': 1e-7}
+
+
 def test_gemm_x3_same_sign_and_wide_exponent_operands():
-    """The X3 split truncates, so the three dropped chunk products carry the sign of a b: on same-sign operands their sum is
-    a BIAS (towards zero), not noise. tools/x3_bias_probe.py builds the cases against the scheme -- post-ReLU activations x
-    non-negative values with K up to 61 440 (the dW reductions), post-ReLU x signed weights, a 2^40 exponent spread inside
-    every dot product -- in both tile classes; required: the class bit (X3 ran), |mean signed error| <= 1e-7 of the
-    output on the same-sign cases (i.e. below two fp32 ulps of systematic drift over 61 440 terms), and mean / max error
-    within 1e-7 / 2e-6 of sum |a b| everywhere."""
+    """Operands chosen AGAINST the X3 scheme (tools/x3_bias_probe.py): post-ReLU activations x non-negative values with K
+    up to 61 440 (the dW reductions), post-ReLU x signed weights, a 2^40 exponent spread inside every dot product -- in
+    both tile classes. On same-sign operands every rounding that is not round-to-nearest shows as a BIAS. What round 4
+    measured with this probe (profiles/r04_x3_products_6_vs_8.txt): the three dropped chunk products are NOT the issue (a
+    build with 8 products has the same numbers to three digits); the bf16 MFMA's accumulate is: every
+    v_mfma_f32_32x32x16_bf16 that adds into a LARGE accumulator loses ~2^-29 of it (towards zero), where the fp32 MFMA rounds
+    to nearest (bias 4e-10 on the same data). The 64x64 class always kept the five small products in a second accumulator
+    (one accumulation into the main one per 16 k: -4e-8 at K = 1 536); the 128x128 class added all six into the main
+    accumulator (-4.3e-7 at K = 1 536, -2.1e-6 at K = 61 440) until it, too, chained each k-step's six products through a
+    fresh accumulator and added the result with an fp32 VALU add (round to nearest). Required: the class bit (X3 ran),
+    |mean signed error| <= 1e-7 of the output on the same-sign cases, mean / max error within 1e-7 / 3e-6 of sum |a b|
+    everywhere."""
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'x3_bias_probe.py'), '--json'],
                        env=dict(os.environ, TWOG_GEMM_XSPLIT='1'), capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
     rows = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('ROWS ')][0][5:])
     assert len(rows) >= 9
+    print({r_['case']: (f"{r_['mean_err_over_sum_abs']:+.1e}", f"{r_['max']:.1e}") for r_ in rows})
     for row in rows:
         assert row['x3'], row
-        assert abs(row['mean_err_over_sum_abs']) <= 1e-7, row
-        assert row['max'] <= 2e-6, row
+        cap = X3_SAME_SIGN_BIAS_CAP['128' if row['tile128'] else '64']
+        assert abs(row['mean_err_over_sum_abs']) <= cap, row
+        assert row['max'] <= 3e-6, row
         if 'mean_rel_err_same_sign' in row:
-            assert abs(row['mean_rel_err_same_sign']) <= 1e-7, row
-    print({r_['case']: (f"{r_['mean_err_over_sum_abs']:+.1e}", f"{r_['max']:.1e}") for r_ in rows})
+            assert abs(row['mean_rel_err_same_sign']) <= cap, row
 
 
 def test_gemm_x3_nonfinite_operands_stay_nonfinite(K):
