@@ -87,6 +87,8 @@ class FusedAdam:
 
     def step(self, grad_scale=1.0):
         self.step_count += 1
+        from . import ops
+        ops.bump_weights_epoch()   # the kernel writes the parameters behind torch's version counters (ops.WeightCache)
         get_kernels().adam_step(self.flat.flat, self.flat.grad, self.exp_avg, self.exp_avg_sq, self.lr, self.betas[0],
                                 self.betas[1], self.eps, self.wd, self.step_count, grad_scale)
 
@@ -155,6 +157,7 @@ class DataParallel:
             # scoped to this model; close() removes it. A WeakMethod: the table must not own the wrapper (see above)
             ops.set_grad_stage_hook(model, weakref.WeakMethod(self._stage_ready))
         weakref.finalize(self, _drop_extras, weakref.ref(model), me_ref)
+        ops.bump_weights_epoch()   # the parameters moved into the flat buffer (and may be overwritten by the broadcast)
         if self.collective and broadcast:
             dist.broadcast(self.flat.flat, src=0, group=self.group)
             for b in model.buffers():

@@ -105,6 +105,8 @@ class GemmProfiler:
         self.K, self.orig, self.records, self.shapes = K, K.gemm, [], []
         self.orig_attn = (K.attn_fwd, K.attn_bwd)
         self.attn = {'fwd': [], 'bwd': []}   # HIP events around the frame-level attention launches
+        self.orig_chain = {n: getattr(K, n) for n in ('bigru_fwd', 'bigru_bwd', 'segrnn_fwd', 'segrnn_bwd')}
+        self.chain = {n: [] for n in self.orig_chain}   # HIP events around the four time loops (they run inside the library)
         self.pool, self.used = pool if pool is not None else [], 0
 
     def event(self):
@@ -130,6 +132,18 @@ class GemmProfiler:
             return call
         self.K.attn_fwd, self.K.attn_bwd = timed('fwd', self.orig_attn[0]), timed('bwd', self.orig_attn[1])
 
+        def chain_timed(name, fn):
+            def call(*a, **kw):
+                e0, e1 = self.event(), self.event()
+                e0.record()
+                r = fn(*a, **kw)
+                e1.record()
+                self.chain[name].append((e0, e1))
+                return r
+            return call
+        for name, fn in self.orig_chain.items():
+            setattr(self.K, name, chain_timed(name, fn))
+
         def gemm(problems, a_kmajor=False, b_kmajor=False, split_k_workspace=True, **kw):
             from twog_gcn_amd.kernels import n_rows
             flops, abytes, tiles128, kmax, wide = 0.0, 0.0, 0, 0, True
@@ -148,7 +162,7 @@ class GemmProfiler:
             self.orig(problems, a_kmajor, b_kmajor, split_k_workspace, **kw)
             e1.record()
             cls = self.K.gemm_last_class()   # the tile class / arithmetic the library actually picked
-            kind = ('128x128 bf16x3' if cls & self.K.GEMM_X3 else '128x128') if cls & self.K.GEMM_TILE128 else '64x64'
+            kind = (('128x128' if cls & self.K.GEMM_TILE128 else '64x64') + (' bf16x3' if cls & self.K.GEMM_X3 else ''))
             self.records.append((kind, flops, e0, e1, abytes))
             self.shapes.append((a_kmajor, b_kmajor, [(n_rows(p['C']), p['C'].shape[-1], (n_rows(p['A']) if a_kmajor else p['A'].shape[-1]), (p['batch'][0] if p.get('batch') else 1)) for p in problems]))
         self.K.gemm = gemm
@@ -157,6 +171,13 @@ class GemmProfiler:
     def __exit__(self, *a):
         self.K.gemm = self.orig
         self.K.attn_fwd, self.K.attn_bwd = self.orig_attn
+        for name, fn in self.orig_chain.items():
+            setattr(self.K, name, fn)
+
+    def chain_ms(self):
+        """Average HIP-event time of one call of each time loop (ms)."""
+        torch.cuda.synchronize()
+        return {n: (sum(a.elapsed_time(b) for a, b in ev) / len(ev) if ev else None) for n, ev in self.chain.items()}
 
     def attn_ms(self, kind):
         torch.cuda.synchronize()
@@ -189,6 +210,44 @@ class GemmProfiler:
             a[2] += 1
             a[3] += abytes
         return agg
+
+
+def chain_model(bs, h):
+    """The four time loops of the shipped configuration (csrc/gru.hip, csrc/segrnn.hip) as the library issues them at a real
+    batch: per loop the GEMM launches per call, their algorithmic FLOPs and which kernel family serves them. Counts follow
+    the loops' code: frame-level BiGRU forward = one fused launch per step (W_hh product + gates); backward = one carry GEMM
+    with the next step's gate backward in its epilogue per step; segment level forward = sender MLPs + [W_hh | W_ih[:, msg]]
+    projections per step (+ attention and gate kernels); backward = projections' dX, sender-MLP dX with the fused gates."""
+    E = {'h': H, 'o': O, 's': 1}
+    rows_f = bs * (H + O + 1)
+    nsh, nso = 2, 2   # sender MLPs on human states (hh | ho), on object states (oh | oo)
+    nmh, nmo = 2, 2   # message blocks received by a human (hh | oh), by an object (ho | oo)
+    f = {}
+    f['bigru_fwd'] = dict(gemm_launches=T, flops=2.0 * 2 * rows_f * 3 * h * h * T,
+                          kernel='gemm_gru_fwd_kernel<2, 2, true> (64 rows x 64 units x 3 gates, bf16x3)')
+    f['bigru_bwd'] = dict(gemm_launches=T - 1, flops=2.0 * 2 * rows_f * h * 3 * h * (T - 1),
+                          kernel='gemm_gate_bwd_x3s* (64x64, bf16x3, gate backward in the epilogue)')
+    send = 2.0 * 2 * (bs * H * nsh * h * h + bs * O * nso * h * h)
+    proj = 2.0 * 2 * (bs * H * 3 * h * (h + nmh * h) + bs * O * 3 * h * (h + nmo * h))
+    f['segrnn_fwd'] = dict(gemm_launches=2 * T, flops=(send + proj) * T,
+                           kernel='gemm_x3s* (sender MLPs, 64x64) + gemm_x3_kernel (projections, 128x128), bf16x3')
+    f['segrnn_bwd'] = dict(gemm_launches=2 * T - 1, flops=(send + proj) * T,
+                           kernel='gemm_x3s* (projections dX, 64x64) + gemm_gate_bwd_x3s* (sender-MLP dX + gates), bf16x3')
+    return f
+
+
+def latest_pmc_rows(substrs):
+    """MFMA-busy of the chain kernels from the latest committed counter pass (profiles/r*_bench_bs64_pmc_summary.csv)."""
+    import csv
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_bench_bs64_pmc_summary.csv')))
+    if not files:
+        return None, {}
+    out = {}
+    for r in csv.DictReader(open(files[-1])):
+        if any(s_ in r['kernel'] for s_ in substrs):
+            out[r['kernel']] = dict(dispatches=int(r['dispatches']), mfma_util_pct=float(r['mfma_util_pct']))
+    return 'profiles/' + os.path.basename(files[-1]), out
 
 
 def _cpu_model():
@@ -569,6 +628,49 @@ def main():
     att_fwd_bytes_all = bs * (att_feat + att_out + att_msg)
     att_bwd_bytes = bs * (att_out + att_feat + att_msg + att_msg + 2 * att_feat)
     att_fwd_ms, att_bwd_ms = prof.attn_ms('fwd'), prof.attn_ms('bwd')
+    chain_ms = prof.chain_ms()
+
+    # ---- N > 1: what the step's collectives cost, and whether the group really spans N devices
+    dist_diag = None
+    if world > 1:
+        ones = torch.ones(1, device=device)
+        dist.all_reduce(ones)
+        buf = torch.empty_like(dp.flat.grad)
+        for _ in range(2):
+            dist.all_reduce(buf)
+        torch.cuda.synchronize()
+        barrier()
+        ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ea.record()
+        for _ in range(10):
+            dist.all_reduce(buf)
+        eb.record()
+        torch.cuda.synchronize()
+        ar_ms = ea.elapsed_time(eb) / 10
+        del buf
+        # the same step with every collective switched off (each rank trains alone on its shard)
+        was = dp.collective
+        dp.collective = False
+        from twog_gcn_amd import ops as _ops2
+        saved_hook = _ops2.get_model_extra(model, 'stage_hook')
+        _ops2.set_grad_stage_hook(model, None)
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+        barrier()
+        tn = time.perf_counter()
+        for _ in range(max(3, args.steps // 2)):
+            step()
+        torch.cuda.synchronize()
+        t_nc = (time.perf_counter() - tn) / max(3, args.steps // 2) * 1e3
+        dp.collective = was
+        _ops2.set_grad_stage_hook(model, saved_hook)
+        tt = torch.tensor([ar_ms, t_nc], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dist_diag = dict(ranks_seen=int(round(float(ones.item()))), allreduce_ms_isolated=float(tt[0]),
+                         allreduce_bytes=int(dp.flat.grad.numel() * 4), allreduce_repeats=10,
+                         step_ms_without_collectives=float(tt[1]),
+                         note='max over ranks; the gradient all-reduce of the timed step is bucketed and overlaps the backward pass')
 
     fwd_only = None
     if True:  # forward-only clips/s is part of every line (north star: ">= 50x the reference CPU forward")
@@ -601,10 +703,18 @@ def main():
             'metric': 'clips/sec fwd+bwd, T=120 N=34 C=512' if args.workload == 'c3' else f'clips/sec fwd+bwd, {wl["name"]} (informational)', 'value': bs * world * args.steps / dt, 'unit': 'clips/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
             'higher_is_better': True, 'scaling': args.scaling, 'vs_baseline': None, 'dtype': 'fp32', 'data': 'synthetic',
-            'arithmetic': ('fp32 storage, fp32 accumulation everywhere; the 128x128-class GEMMs multiply on the bf16 matrix cores after an '
-                           'EXACT three-way bf16 split of every fp32 operand element (6 chunk products per multiply-add; error '
-                           'against fp64 equal to the fp32-MFMA kernels, tests/test_kernels_gpu.py::test_gemm_x3_*); every '
-                           'other kernel computes in fp32. TWOG_GEMM_X3=0: native fp32 MFMA throughout'
+            'arithmetic': ('fp32 storage, fp32 accumulation everywhere. THREE GEMM kernel families multiply on the bf16 matrix cores '
+                           'after an EXACT three-way bf16 split of every fp32 operand element (6 of the 9 chunk products per '
+                           'multiply-add): (1) the 128x128 class gemm_x3_kernel (forward, dX and dW projections, and the segment '
+                           'level\'s per-step projections inside the library); (2) the 64x64 chain class gemm_x3s* / '
+                           'gemm_gate_bwd_x3s* (launches with >= 96 tiles and K >= 256: sender MLPs, backward carries with the fused '
+                           'gate backward); (3) the fused frame-level GRU step gemm_gru_fwd_kernel<2, 2, true>. Error against fp64 '
+                           'within 1.25x the fp32-MFMA kernels on random operands; on SAME-SIGN operands the bf16 MFMA\'s '
+                           'accumulate adds a relative bias (towards zero) of up to 4e-8 (chain class) / 4e-7 at K = 1 536 and '
+                           '2e-6 at K = 61 440 (128x128 class) where the fp32 MFMA has 4e-10 '
+                           '(tests/test_kernels_gpu.py::test_gemm_x3_*, profiles/r04_x3_products_6_vs_8*.txt). Every other kernel '
+                           '(attention, gates, GCN, BatchNorm, loss, Adam, GEMMs of other shapes) computes in fp32. '
+                           'TWOG_GEMM_X3=0: native fp32 MFMA throughout'
                            if os.environ.get('TWOG_GEMM_X3', '1') != '0' else 'fp32 throughout (fp32 MFMA; TWOG_GEMM_X3=0)'),
             'config': {'workload': f'{wl["name"]}: bs{bs} per GPU, T={T}, H={H}, O={O}, N={N_NODES}, h={CFG["hidden_size"]}, '
                                    f'classes {N_CLASSES}, ' + ('constructor defaults' + (f' + {wl["cfg"]}' if wl['cfg'] else '') if 'cfg' in wl else '2G-GCN_stage1 parameters'),
@@ -622,7 +732,7 @@ def main():
                 'fp32_equivalent_tflops': achieved, 'fp32_mfma_peak_tflops': PEAK_FP32_MFMA_TFLOPS,
                 'fp32_equivalent_over_fp32_mfma_peak': achieved / PEAK_FP32_MFMA_TFLOPS,
                 'note': 'TWOG_GEMM_X3=0 selects the native fp32-MFMA kernels (v_mfma_f32_32x32x2_f32: 0.80 of their 157.3 TFLOP/s peak, slower in wall time)',
-            } if 'bf16x3' in kind else {
+            } if kind == '128x128 bf16x3' else {
                 'bound': 'mfma', 'kernel': f'gemm_kernel<{kind.replace("x", ",")},*> (fp32 v_mfma_f32_32x32x2_f32)',
                 'achieved': achieved, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                 'frac': achieved / PEAK_FP32_MFMA_TFLOPS,
@@ -657,6 +767,27 @@ def main():
             'host_gemm_share_of_step': total_gemm_s / prof_steps / (dt / args.steps),
         }
         result['roofline'].update(result.pop('roofline_common'))   # traffic, launches, shares: common to both kernel families
+        # ---- the recurrent chains (they run inside the library: timed per loop call, launch counts from the loops' code)
+        cm = chain_model(bs, CFG['hidden_size'])
+        x3_on = os.environ.get('TWOG_GEMM_X3', '1') != '0' and CFG['hidden_size'] >= 256 and bs * (H + O + 1) >= 6 * 64
+        src, pmc = latest_pmc_rows(('gemm_gate_bwd_x3s', 'gemm_x3s', 'gemm_gru_fwd', 'gemm_x3d', 'gemm_gate_bwd_x3d'))
+        chain_total_ms = sum(v for v in chain_ms.values() if v)
+        result['roofline_chain'] = {
+            'bound': 'latency (240 dependent time steps) + mfma',
+            'loops': {n: {'ms_per_call': chain_ms.get(n), 'gemm_launches_per_call': cm[n]['gemm_launches'],
+                          'us_per_time_step': (chain_ms[n] * 1e3 / T if chain_ms.get(n) else None),
+                          'algorithmic_gflop': cm[n]['flops'] / 1e9,
+                          'fp32_equivalent_tflops': (cm[n]['flops'] / (chain_ms[n] * 1e-3) / 1e12 if chain_ms.get(n) else None),
+                          'kernels': cm[n]['kernel']} for n in cm},
+            'ms_per_step': chain_total_ms, 'share_of_step_time': chain_total_ms / (dt / args.steps * 1e3),
+            'mfma_busy_pct_from_counters': pmc, 'counters_source': src,
+            'note': 'per-loop HIP events on the launch stream; each loop call issues its launches inside lib2ggcn_hip.so'}
+        host_x3 = sum(v[0] for k, v in agg.items() if 'bf16x3' in k)
+        host_all = sum(v[0] for v in agg.values())
+        lib = sum(c['flops'] for c in cm.values()) * prof_steps
+        result['x3_share_of_gemm_flops'] = ((host_x3 + (lib if x3_on else 0.0)) / (host_all + lib)) if host_all + lib > 0 else None
+        if dist_diag is not None:
+            result['distributed_diagnostics'] = dist_diag
         if fwd_only is not None:
             result['forward_only_clips_per_s'] = fwd_only
         if world > 1:
