@@ -29,14 +29,14 @@ class Gemm(C.Structure):  # twog_gemm_t
 
 class WPlanes(C.Structure):  # twog_wplanes_t
     _fields_ = [('w', C.c_void_p), ('rows', C.c_int32), ('cols', C.c_int32), ('ld', C.c_int64), ('rm', C.c_void_p),
-                ('km', C.c_void_p)]
+                ('km', C.c_void_p), ('kf', C.c_void_p)]
 
 
 class WPlanesDir(C.Structure):  # twog_wplanes_dir_t
     _fields_ = [('e', C.POINTER(WPlanes)), ('n', C.c_int32), ('pad_', C.c_int32)]
 
 
-PLANES_RM, PLANES_KM = 1, 2   # TWOG_PLANES_*
+PLANES_RM, PLANES_KM, PLANES_KF = 1, 2, 3   # TWOG_PLANES_*
 
 
 class GruStep(C.Structure):  # twog_gru_step_t
@@ -195,6 +195,7 @@ SIGNATURES = {
     'twog_logsoftmax_permute_bwd': [_P, _P, _P, _I, _I, _I, _I, _P],
     'twog_relu_bwd': [Rows, Rows, Rows, _I, _I, _P],
     'twog_add_rows': [Rows, Rows, _I, _I, _P],
+    'twog_fill_zero': [_P, C.c_size_t, _P],
     'twog_adam_step': [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _F, _P],
     'twog_multitask_loss_fwd': [C.POINTER(Loss), _I, _P, _P, _P, _P],
     'twog_multitask_loss_bwd': [C.POINTER(Loss), _I, _P, _P, _P],

@@ -447,8 +447,9 @@ __device__ __forceinline__ void split3(const f32x4 v, i32x2& ph, i32x2& pm, i32x
 #define TWOG_X3_PRODUCTS 6
 #endif
 #ifndef TWOG_X3_TMPACC
-#define TWOG_X3_TMPACC 1   // 128x128 class: each k-step's products through a fresh accumulator, added by fp32 VALU adds (see compute())
-#endif
+#define TWOG_X3_TMPACC 0   // 1: 128x128 class with each k-step's products through a fresh accumulator, added by fp32 VALU adds (see
+#endif                     // compute()): removes the accumulate bias, but at 128 VGPRs (two workgroups per CU) the temporary spills
+
 constexpr int X3_PRODUCTS = TWOG_X3_PRODUCTS;  // chunk products per element product: 8 (exact to 2^-30) or 6 (drops m l, l m)
 constexpr int X3_BK = 16;                    // one v_mfma_f32_32x32x16_bf16 k-step per k-tile
 constexpr int X3_RROW = 32;                  // bytes per row of a [row][16 k] image; its two 16-byte chunks are swapped on rows
@@ -570,11 +571,13 @@ __device__ __forceinline__ void gemm_mainloop_x3(const twog_rows_t A, const twog
         // WHERE the products are added matters more than how many there are: the bf16 MFMA's accumulate is not a
         // round-to-nearest fp32 add -- every v_mfma_f32_32x32x16_bf16 into a LARGE accumulator loses ~2^-29 of it towards
         // zero (tools/x3_bias_probe.py: on same-sign operands six accumulations per 16 k into the running sum gave a
-        // relative bias of -4.3e-7 at K = 1 536 and -2.1e-6 at K = 61 440, where the fp32 MFMA has 4e-10). TMPACC (default):
+        // relative bias of -4.3e-7 at K = 1 536 and -2.1e-6 at K = 61 440, where the fp32 MFMA has 4e-10). TMPACC (build-time
+        // option TWOG_X3_TMPACC=1; NOT the default: with four register stages the kernel sits at its 128-VGPR budget and the
+        // 16-register temporary spills 360-570 bytes per lane into scratch -- DESIGN.md section 8):
         // the products of one k-step are chained through a FRESH accumulator (C = 0: its roundings are relative to one
         // k-step's partial sum) and that partial sum is added to the running sum by 16 fp32 VALU adds per block (round to
         // nearest even, unbiased); the B fragments of a block are read right before its chain, so the temporary takes the
-        // registers the second block's fragments held. TWOG_X3_TMPACC=0 at build time: the round-3 form.
+        // registers the second block's fragments held. Default (0): all products into the running sum (round 3's form).
         constexpr int PI[8] = {2, 1, 2, 0, 1, 1, 0, 0}, PJ[8] = {1, 2, 0, 2, 1, 0, 1, 0};
         constexpr int FIRST = 8 - X3_PRODUCTS;
         static_assert(X3_PRODUCTS == 8 || X3_PRODUCTS == 6, "l m and m l are the two optional products");
@@ -650,6 +653,18 @@ __device__ __forceinline__ void gemm_mainloop_x3(const twog_rows_t A, const twog
 #ifndef TWOG_X3S_RS
 #define TWOG_X3S_RS 4
 #endif
+// Diagnostic build only (-DTWOG_STAMPS, tools/stamps_probe.sh): cycle stamps at the phase boundaries of the X3 chain loop,
+// summed per wave of workgroup 0 and written to a buffer of their own at the end (cdna_hip_programming.md, In-kernel stamps).
+#ifdef TWOG_STAMPS
+__device__ unsigned long long twog_stamp_buf[16 * 8];
+#define TWOG_STAMP_DECL unsigned long long st_acc[6] = {0, 0, 0, 0, 0, 0}, st_last = 0; { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); st_last = t_; }
+#define TWOG_STAMP(i) { __builtin_amdgcn_sched_barrier(0); unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); st_acc[i] += t_ - st_last; st_last = t_; __builtin_amdgcn_sched_barrier(0); }
+#define TWOG_STAMP_FLUSH if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) { for (int i_ = 0; i_ < 6; ++i_) twog_stamp_buf[(threadIdx.x >> 6) * 8 + i_] = st_acc[i_]; }
+#else
+#define TWOG_STAMP_DECL
+#define TWOG_STAMP(i)
+#define TWOG_STAMP_FLUSH
+#endif
 template <int BM, int BN, int NT, bool BKM, int KS, int TN, bool G3, int RS = 4, bool LO2 = (TN == 1), int KU = 1>
 __device__ __forceinline__ void gemm_mainloop_x3s(const twog_rows_t A, const twog_rows_t B, int M, int N, int m0, int n0,
                                                   int k_begin, int k_end, float* smem, f32x16 (&acc)[1][TN]) {
@@ -661,6 +676,7 @@ __device__ __forceinline__ void gemm_mainloop_x3s(const twog_rows_t A, const two
     constexpr int NPA = (FA + NT - 1) / NT, NPB = (FB + NT - 1) / NT;
     static_assert(FA % NT == 0 || FA < NT, "whole passes");
     char* lds = reinterpret_cast<char*>(smem);
+    TWOG_STAMP_DECL
     const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) % (NTG / 64), kgrp = (tid >> 6) / (NTG / 64);
     const int wm = (wave >> 1) * WM, wn = (wave & 1) * WN;
     auto swz_r = [](int row, int chunk) { return XK == 32 ? (chunk ^ ((row >> 2) & 3)) : (chunk ^ ((row >> 4) & 1)); };
@@ -777,6 +793,10 @@ __device__ __forceinline__ void gemm_mainloop_x3s(const twog_rows_t A, const two
                     bf[b][p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const i32x4*>(base + p * PB + fb_r[b]));
                 }
             }
+#ifdef TWOG_STAMPS
+        asm volatile("" :: "v"(af[0]), "v"(af[1]), "v"(af[2]), "v"(bf[0][0]), "v"(bf[0][1]), "v"(bf[0][2]));
+        TWOG_STAMP(4)
+#endif
         // h h goes to the main accumulator, the five small products (2^-8 ... 2^-16 of it) to a second one that is added
         // once after the loop: the main accumulator is rounded once per 16 k instead of six times, and the roundings
         // of the small one are 2^-8 of an ulp of the result.
@@ -813,11 +833,16 @@ __device__ __forceinline__ void gemm_mainloop_x3s(const twog_rows_t A, const two
 #pragma unroll
         for (int i = 0; i < RS; ++i) {
             gload(r[i], kof(kt + RS + i));
+            TWOG_STAMP(0)
             compute(i & 1);
+            TWOG_STAMP(1)
             split_store(r[(i + 1) % RS], (i + 1) & 1);
+            TWOG_STAMP(2)
             __syncthreads();
+            TWOG_STAMP(3)
         }
     }
+    TWOG_STAMP_FLUSH
     // up to RS - 1 k-tiles left: tile kt sits in LDS stage 0, tiles kt + j in r[j]
 #pragma unroll
     for (int j = 0; j < RS - 1; ++j) {
@@ -1046,6 +1071,109 @@ __device__ __forceinline__ void gemm_mainloop_x3d(const twog_rows_t A, const cha
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// X3F: the 64 x 64 X3 chain classes with the WEIGHT's fragments loaded straight from its pre-split planes into registers.
+//
+// What bounds a chain launch (one workgroup per CU, every wave in step between the barriers) is the CU's LDS: per k-tile of
+// 32 the register-staged kernel writes 24 KB of planes (ds_write_b64: ~85 B/clk per CU) and its eight waves read 48 KB of
+// fragments back (256 B/clk) -- ~480 LDS cycles where the MFMAs need 384 per SIMD -- after splitting both operands (88
+// VALU operations per thread). Half of all that is the WEIGHT, identical for all 120 steps of a chain. Here a wave reads
+// its B fragments -- three planes x 16 bytes per lane and k-step, 1 KB contiguous per wave and plane -- directly from the
+// weight's planes in global memory (twog_weight_planes_build: the RM image for row-major weights is already in
+// fragment order per 32-row block; k-major weights have the KF image), two waves of a tile sharing each fragment through the
+// CU's vector L1. B never enters LDS and is never split in the kernel: LDS traffic, split arithmetic and staging registers
+// halve; the fragments of the next barrier interval are requested before the MFMAs of the current one (double buffer).
+// A is staged and split as in gemm_mainloop_x3s; same MFMA sequence into the same accumulators: bit-identical results.
+template <int NT, bool BKM, int KS, int KU>
+__device__ __forceinline__ void gemm_mainloop_x3f(const twog_rows_t A, const char* bp, uint32_t bp_ps, uint32_t bp_ld, int M,
+                                                  int N, int m0, int n0, int k_begin, int k_end, float* smem,
+                                                  f32x16 (&acc)[1][1]) {
+    constexpr int BM = 64, XK = 16 * KS, NTG = NT / KS, RB = 2 * XK, PA = BM * RB, STAGE = 3 * PA;
+    constexpr int FA = BM * XK / 4;
+    static_assert(FA == NT, "one 16-byte load of A per thread and k-tile");
+    char* lds = reinterpret_cast<char*>(smem);
+    const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) % (NTG / 64), kgrp = (tid >> 6) / (NTG / 64);
+    const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
+    auto swz_r = [](int row, int chunk) { return XK == 32 ? (chunk ^ ((row >> 2) & 3)) : (chunk ^ ((row >> 4) & 1)); };
+    const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(A.ptr, 0, 0xffffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(bp), 0, 0xffffffff, 0x00020000);
+    const int a_rr = tid / (XK / 4), a_cq = tid % (XK / 4);
+    const uint32_t oa = 4u * (uint32_t)(twog_row_off(A, min(m0 + a_rr, M - 1)) + a_cq * 4);
+    const int sa_off = a_rr * RB + 16 * swz_r(a_rr, a_cq >> 1) + 8 * (a_cq & 1);
+    const int r32 = lane & 31, h = lane >> 5;
+    const int chunk = (XK == 32 ? 2 * kgrp : 0) + h;
+    const int fa_r = (wm + r32) * RB + 16 * swz_r(wm + r32, chunk);
+    // B fragment of this lane inside a (plane, k-step) slice of the image: RM -- rows of 32 bytes, the lane's half h;
+    // KF -- the lane's 16 bytes of its 32-column block
+    const uint32_t vb = BKM ? (uint32_t)((n0 + wn) / 32) * 1024u + (uint32_t)lane * 16u
+                            : (uint32_t)(n0 + wn + r32) * 32u + (uint32_t)h * 16u;
+    struct AStage { f32x4 a[KU]; };
+    struct BFrag { bf16x8 b[KU][3]; };
+    auto gload = [&](AStage& r, int k0) {
+#pragma unroll
+        for (int u = 0; u < KU; ++u)
+            r.a[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, (int)oa, (int)((uint32_t)(k0 + u * XK) * 4u), 0));
+    };
+    auto bload = [&](BFrag& f, int k0) {   // k-step of this wave's k-group inside sub-tile u: (k0 + u XK) / 16 + kgrp
+#pragma unroll
+        for (int u = 0; u < KU; ++u) {
+            const uint32_t ks = (uint32_t)((k0 + u * XK) / 16 + kgrp);
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+                f.b[u][p] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc_b, (int)vb, (int)(ks * bp_ld + (uint32_t)p * bp_ps), 0));
+        }
+    };
+    auto split_store = [&](const AStage& r, int buf) {
+        i32x2 ph, pm, pl;
+#pragma unroll
+        for (int u = 0; u < KU; ++u) {
+            char* base = lds + (buf * KU + u) * STAGE + sa_off;
+            split3(r.a[u], ph, pm, pl);
+            *reinterpret_cast<i32x2*>(base) = ph;
+            *reinterpret_cast<i32x2*>(base + PA) = pm;
+            *reinterpret_cast<i32x2*>(base + 2 * PA) = pl;
+        }
+    };
+    f32x16 lo;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) lo[i] = 0.0f;
+    auto compute = [&](int buf, const BFrag& f) {
+#pragma unroll
+        for (int u = 0; u < KU; ++u) {
+            const char* base = lds + (buf * KU + u) * STAGE;
+            bf16x8 af[3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) af[p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const i32x4*>(base + p * PA + fa_r));
+            constexpr int PI[5] = {2, 0, 1, 1, 0}, PJ[5] = {0, 2, 1, 0, 1};   // l h, h l, m m, m h, h m (gemm_mainloop_x3s)
+#pragma unroll
+            for (int t = 0; t < 5; ++t) lo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[PI[t]], f.b[u][PJ[t]], lo, 0, 0, 0);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], f.b[u][0], acc[0][0], 0, 0, 0);
+        }
+    };
+    constexpr int STEP = XK * KU;
+    const int nkt = (k_end - k_begin) / STEP;
+    if (nkt <= 0) return;
+    const int k_last = k_begin + (nkt - 1) * STEP;
+    auto kof = [&](int t) { return min(k_begin + t * STEP, k_last); };
+    // two register stages of A, two fragment sets of B (loads past the last interval are clamped to it, never branched
+    // around: see gemm_mainloop); the loop is unrolled by two so that every stage keeps a static name
+    AStage r0, r1;
+    BFrag f0, f1;
+    gload(r0, kof(0));
+    gload(r1, kof(1));
+    bload(f0, kof(0));
+    split_store(r0, 0);
+    __syncthreads();
+    int kt = 0;
+    for (; kt + 1 < nkt; kt += 2) {
+        gload(r0, kof(kt + 2)); bload(f1, kof(kt + 1)); compute(0, f0); split_store(r1, 1); __syncthreads();
+        gload(r1, kof(kt + 3)); bload(f0, kof(kt + 2)); compute(1, f1); split_store(r0, 0); __syncthreads();
+    }
+    if (kt < nkt) compute(0, f0);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[0][0][i] += lo[i];
+}
+
 // XS (recurrent-chain launches with fewer tiles than the chip has CUs): the reduction is ALSO split over workgroups
 // (blockIdx.y = k-slice) and combined inside the launch, without a grid barrier and without waiting: every workgroup
 // writes its partial tile write-through (16-byte sc1 stores, so no release fence), drains them, and one lane draws an
@@ -1055,7 +1183,7 @@ __device__ __forceinline__ void gemm_mainloop_x3d(const twog_rows_t A, const cha
 // counters are zero again at the launch boundary (graph replays need no memset node). The hand-off form is the
 // guide's split-K recipe (cdna_hip_programming.md section 5 item 2 / MI355X_MICROARCH.md "Valid forms": sc1 payload,
 // every storing wave drained, workgroup barrier, one relaxed agent atomic; the last arriver's loads all sc1).
-template <int BM, int BN, int NT, bool AKM, bool BKM, int D, bool KG, bool GATE, int KS = 1, bool XS = false, bool X3 = false, bool BP = false, int NS = 4, int KU = 1>
+template <int BM, int BN, int NT, bool AKM, bool BKM, int D, bool KG, bool GATE, int KS = 1, bool XS = false, bool X3 = false, bool BP = false, int NS = 4, int KU = 1, bool BF = false>
 __device__ __forceinline__ void gemm_tile(const Group& g, const GateArgs* ga) {
     constexpr int NTG = NT / KS;
     constexpr int WM = BM / (NTG / 128), WN = BN / 2;  // per-wave tile; the waves of a k-group in a (NTG/128) x 2 grid
@@ -1066,7 +1194,9 @@ __device__ __forceinline__ void gemm_tile(const Group& g, const GateArgs* ga) {
     constexpr int B_ELEMS = BKM ? BK * LDB : BN * LDB;
     // (X3 on the 64-row class: two stages of three bf16 planes per operand, 2 x 6 x 64 rows x 2 XK bytes, XK = 16 KS)
     // (BP on the 64-row class: the all-DMA loop's A plane stages + ring of NS slots, gemm_mainloop_x3d)
-    constexpr int SMEM_FLOATS = (X3 && BP && BM == 64) ? x3d_bytes<(X3 && BP && BM == 64), NT, BKM, KS, NS>() / 4
+    // (BF: only the A planes live in LDS -- two stages of KU sub-tiles; at least the k-group exchange area)
+    constexpr int SMEM_FLOATS = (X3 && BF && BM == 64) ? (2 * KU * 3 * 64 * 32 * KS / 4 > 4608 ? 2 * KU * 3 * 64 * 32 * KS / 4 : 4608)
+                                : (X3 && BP && BM == 64) ? x3d_bytes<(X3 && BP && BM == 64), NT, BKM, KS, NS>() / 4
                                 : (X3 && BM == 128) ? 2 * X3_STAGE / 4
                                 : (X3 && BM == 64 && 12 * 64 * 8 * KS * KU > 2 * (A_ELEMS + B_ELEMS)) ? 12 * 64 * 8 * KS * KU : 2 * (A_ELEMS + B_ELEMS);
     __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS];
@@ -1214,6 +1344,9 @@ __device__ __forceinline__ void gemm_tile(const Group& g, const GateArgs* ga) {
         if constexpr (BM == 128) {
             static_assert(!X3 || BM != 128 || (BN == 128 && NT == 512 && !GATE && KS == 1 && !XS), "X3: the 8-wave 128x128 class");
             gemm_mainloop_x3<AKM, BKM, KG>(A, B, M, N, m0, n0, k_begin, k_end, smem, acc);
+        } else if constexpr (BF) {
+            static_assert(!BF || (X3 && BM == 64 && BN == 64 && !AKM && !KG && !XS), "planes: the 64x64 X3 classes");
+            gemm_mainloop_x3f<NT, BKM, KS, KU>(A, G.bp, G.bp_ps, G.bp_ld, M, N, m0, n0, k_begin, k_end, smem, acc);
         } else if constexpr (BP) {
             static_assert(!BP || (X3 && BM == 64 && BN == 64 && !AKM && !KG && !XS), "planes: the 64x64 X3 classes");
             // (operands of batch 0 only: the host offers planes to unbatched problems)
@@ -1419,6 +1552,16 @@ __global__ __launch_bounds__(256 * KS, KS == 2 ? 1 : 2) void gemm_x3su_kernel(co
 template <int KS, int KU>
 __global__ __launch_bounds__(256 * KS, 1) void gemm_gate_bwd_x3su_kernel(const Group g, const GateArgs ga) {
     gemm_tile<64, 64, 256 * KS, false, true, 2, false, true, KS, false, true, false, 4, KU>(g, &ga);
+}
+
+// B fragments straight from the weight's pre-split planes (gemm_mainloop_x3f)
+template <bool BKM, int KS, int KU>
+__global__ __launch_bounds__(256 * KS, (KS == 2 && KU == 2) ? 1 : 2) void gemm_x3f_kernel(const Group g) {
+    gemm_tile<64, 64, 256 * KS, false, BKM, 2, false, false, KS, false, true, false, 4, KU, true>(g, nullptr);
+}
+template <int KS, int KU>
+__global__ __launch_bounds__(256 * KS, 1) void gemm_gate_bwd_x3f_kernel(const Group g, const GateArgs ga) {
+    gemm_tile<64, 64, 256 * KS, false, true, 2, false, true, KS, false, true, false, 4, KU, true>(g, &ga);
 }
 
 // the same with B pre-split (planes) and both operands by LDS-DMA (gemm_mainloop_x3d)
@@ -1735,7 +1878,7 @@ static inline int pad128i(int v) { return (v + 127) / 128 * 128; }
 static bool resolve_planes(const twog_wplanes_dir_t* dir, const twog_rows_t& B, int N, int K, int b_kmajor, int batch, Prob& P) {
     P.bp = nullptr;
     P.bp_ps = P.bp_ld = 0;
-    static const int on = getenv("TWOG_GEMM_BPLANES") ? atoi(getenv("TWOG_GEMM_BPLANES")) : 0;   // measured slower: opt-in
+    static const int on = getenv("TWOG_GEMM_BPLANES") ? atoi(getenv("TWOG_GEMM_BPLANES")) : 1;
     if (!on || !dir || !dir->e || dir->n <= 0 || B.inner > 1 || batch > 1 || (K % 16)) return false;
     const int vrows = b_kmajor ? K : N, vcols = b_kmajor ? N : K;
     for (int i = 0; i < dir->n; ++i) {
@@ -1753,13 +1896,13 @@ static bool resolve_planes(const twog_wplanes_dir_t* dir, const twog_rows_t& B, 
             P.bp = reinterpret_cast<const char*>(e.rm) + ((c0 / 16) * rp + r0) * 32;
             P.bp_ps = (uint32_t)(nkt * rp * 32);
             P.bp_ld = (uint32_t)(rp * 32);
-        } else {
-            const int64_t cp = pad128i(e.cols);
-            if (!e.km || (e.rows % 16) || (c0 % 8) || c0 + over > cp) return false;
+        } else {   // KF: [3][rows / 16][cols_pad / 32][64 lanes][16 bytes]
+            const int64_t cp = pad128i(e.cols), nb = cp / 32;
+            if (!e.kf || (e.rows % 16) || (r0 % 16) || (c0 % 32) || c0 + over > cp) return false;
             if ((uint64_t)3 * e.rows * cp * 2 >= (uint64_t(1) << 32)) return false;
-            P.bp = reinterpret_cast<const char*>(e.km) + (r0 * cp + c0) * 2;
-            P.bp_ps = (uint32_t)((int64_t)e.rows * cp * 2);
-            P.bp_ld = (uint32_t)(cp * 2);
+            P.bp = reinterpret_cast<const char*>(e.kf) + ((r0 / 16) * nb + c0 / 32) * 1024;
+            P.bp_ps = (uint32_t)((int64_t)(e.rows / 16) * nb * 1024);
+            P.bp_ld = (uint32_t)(nb * 1024);
         }
         return true;
     }
@@ -2079,16 +2222,13 @@ static int gemm_impl(const twog_gemm_t* problems, int n_problems, int a_kmajor, 
                 continue;
             }
             dim3 grid(g.total_tiles, 1), block(512);
-            if (x3s_ok(g, a_kmajor, 32) && all_planes(g)) {   // B from the weights' planes, both operands by LDS-DMA
+            if (x3s_ok(g, a_kmajor, 32) && all_planes(g)) {   // B fragments from the weights' planes (gemm_mainloop_x3f)
                 g_last_class |= TWOG_GEMM_CLASS_X3 | TWOG_GEMM_CLASS_BPLANES;
-                if (g.total_tiles <= x3d_ks2_max()) {
-                    if (b_kmajor) hipLaunchKernelGGL((gemm_x3d_kernel<true, 2>), grid, block, 0, st, g);
-                    else hipLaunchKernelGGL((gemm_x3d_kernel<false, 2>), grid, block, 0, st, g);
-                } else {
-                    g_last_class &= ~TWOG_GEMM_CLASS_KSPLIT;
-                    if (b_kmajor) hipLaunchKernelGGL((gemm_x3d_kernel<true, 1>), grid, dim3(256), 0, st, g);
-                    else hipLaunchKernelGGL((gemm_x3d_kernel<false, 1>), grid, dim3(256), 0, st, g);
-                }
+                if (x3s_ku(g, 64) == 2) {
+                    if (b_kmajor) hipLaunchKernelGGL((gemm_x3f_kernel<true, 2, 2>), grid, block, 0, st, g);
+                    else hipLaunchKernelGGL((gemm_x3f_kernel<false, 2, 2>), grid, block, 0, st, g);
+                } else if (b_kmajor) hipLaunchKernelGGL((gemm_x3f_kernel<true, 2, 1>), grid, block, 0, st, g);
+                else hipLaunchKernelGGL((gemm_x3f_kernel<false, 2, 1>), grid, block, 0, st, g);
             } else if (x3s_ok(g, a_kmajor, 32)) {
                 g_last_class |= TWOG_GEMM_CLASS_X3;
                 if (g.total_tiles <= 256 && x3s_ku(g, 64) == 2) {
@@ -2110,8 +2250,11 @@ static int gemm_impl(const twog_gemm_t* problems, int n_problems, int a_kmajor, 
             dim3 grid(g.total_tiles, 1), block(256);
             if (all_planes(g)) {
                 g_last_class |= TWOG_GEMM_CLASS_BPLANES;
-                if (b_kmajor) hipLaunchKernelGGL((gemm_x3d_kernel<true, 1>), grid, block, 0, st, g);
-                else hipLaunchKernelGGL((gemm_x3d_kernel<false, 1>), grid, block, 0, st, g);
+                if (x3s_ku(g, 32) == 2) {
+                    if (b_kmajor) hipLaunchKernelGGL((gemm_x3f_kernel<true, 1, 2>), grid, block, 0, st, g);
+                    else hipLaunchKernelGGL((gemm_x3f_kernel<false, 1, 2>), grid, block, 0, st, g);
+                } else if (b_kmajor) hipLaunchKernelGGL((gemm_x3f_kernel<true, 1, 1>), grid, block, 0, st, g);
+                else hipLaunchKernelGGL((gemm_x3f_kernel<false, 1, 1>), grid, block, 0, st, g);
             } else if (x3s_ku(g, 32) == 2) {
                 if (b_kmajor) hipLaunchKernelGGL((gemm_x3su_kernel<true, 1, 2>), grid, block, 0, st, g);
                 else hipLaunchKernelGGL((gemm_x3su_kernel<false, 1, 2>), grid, block, 0, st, g);
@@ -2205,11 +2348,8 @@ int twog_internal_gemm_gate_bwd(const twog_gemm_t* pr, int n, const twog_gru_ste
         }
         if (x3s_ok(g, 0, 32) && all_planes(g)) {
             g_last_class |= TWOG_GEMM_CLASS_X3 | TWOG_GEMM_CLASS_BPLANES;
-            if (g.total_tiles <= x3d_ks2_max()) hipLaunchKernelGGL(gemm_gate_bwd_x3d_kernel<2>, grid, dim3(512), 0, (hipStream_t)stream, g, ga);
-            else {
-                g_last_class &= ~TWOG_GEMM_CLASS_KSPLIT;
-                hipLaunchKernelGGL(gemm_gate_bwd_x3d_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, g, ga);
-            }
+            if (x3s_ku(g, 64) == 2) hipLaunchKernelGGL((gemm_gate_bwd_x3f_kernel<2, 2>), grid, dim3(512), 0, (hipStream_t)stream, g, ga);
+            else hipLaunchKernelGGL((gemm_gate_bwd_x3f_kernel<2, 1>), grid, dim3(512), 0, (hipStream_t)stream, g, ga);
         } else if (x3s_ok(g, 0, 32)) {
             g_last_class |= TWOG_GEMM_CLASS_X3;
             if (g.total_tiles <= 256 && x3s_ku(g, 64) == 2) hipLaunchKernelGGL((gemm_gate_bwd_x3su_kernel<2, 2>), grid, dim3(512), 0, (hipStream_t)stream, g, ga);
@@ -2221,7 +2361,7 @@ int twog_internal_gemm_gate_bwd(const twog_gemm_t* pr, int n, const twog_gru_ste
     }
     if (x3s_ok(g, 0, 16) && all_planes(g)) {
         g_last_class |= TWOG_GEMM_CLASS_X3 | TWOG_GEMM_CLASS_BPLANES;
-        hipLaunchKernelGGL(gemm_gate_bwd_x3d_kernel<1>, grid, block, 0, (hipStream_t)stream, g, ga);
+        hipLaunchKernelGGL((gemm_gate_bwd_x3f_kernel<1, 1>), grid, block, 0, (hipStream_t)stream, g, ga);
     } else if (x3s_ok(g, 0, 16)) {
         g_last_class |= TWOG_GEMM_CLASS_X3;
         hipLaunchKernelGGL(gemm_gate_bwd_x3s_kernel<1>, grid, block, 0, (hipStream_t)stream, g, ga);
@@ -2337,6 +2477,12 @@ int twog_internal_gemm_gru_fwd(const twog_gemm_t* gh, const twog_gemm_t* gim, co
     TWOG_CHECK_LAUNCH();
     return 0;
 }
+
+#ifdef TWOG_STAMPS
+extern "C" int twog_debug_stamps(unsigned long long* out) {   // diagnostic builds only: [wave][8] cycle sums of workgroup 0
+    return -(int)hipMemcpyFromSymbol(out, HIP_SYMBOL(twog_stamp_buf), sizeof(unsigned long long) * 16 * 8);
+}
+#endif
 
 extern "C" const char* twog_version(void) {
     return "lib2ggcn_hip gfx950 fp32 gemm on bf16x3 MFMA(32x32x16) / fp32 MFMA(32x32x2), tiles 128x128 / 64x64 / 32x64";

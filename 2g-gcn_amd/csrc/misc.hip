@@ -232,6 +232,34 @@ extern "C" int twog_filter_fwd(const float* soft, float* hard, float* grad_mask,
     return 0;
 }
 
+// Zero fill of caller-owned device memory (16-byte stores; head / tail bytes one by one): what torch.zeros / Tensor.zero_()
+// did on the step's path until round 4 -- 19 ATen fill launches per step; the host now clears each group of buffers it
+// allocates (one torch.empty for the group) with ONE launch of this kernel.
+__global__ __launch_bounds__(256) void fill_zero_kernel(char* p, size_t nbytes) {
+    const size_t head = (16 - (reinterpret_cast<uintptr_t>(p) & 15)) & 15;
+    const size_t h = head < nbytes ? head : nbytes;
+    const size_t body = (nbytes - h) / 16;
+    uint4* q = reinterpret_cast<uint4*>(p + h);
+    const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < body; i += (size_t)gridDim.x * 256) q[i] = z;
+    if (blockIdx.x == 0) {
+        for (size_t i = threadIdx.x; i < h; i += 256) p[i] = 0;
+        const size_t t0 = h + body * 16;
+        for (size_t i = t0 + threadIdx.x; i < nbytes; i += 256) p[i] = 0;
+    }
+}
+
+extern "C" int twog_fill_zero(void* p, size_t nbytes, void* stream) {
+    if (nbytes == 0) return 0;
+    if (!p) return -2;
+    const size_t body = nbytes / 16;
+    const size_t want = (body + 255) / 256;
+    const unsigned blocks = (unsigned)(want < 1 ? 1 : (want > 4096 ? 4096 : want));
+    hipLaunchKernelGGL(fill_zero_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<char*>(p), nbytes);
+    TWOG_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int twog_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
                               float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale,
                               void* stream) {

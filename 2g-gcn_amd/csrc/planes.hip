@@ -78,6 +78,31 @@ __global__ __launch_bounds__(256) void planes_km_kernel(const float* __restrict_
     }
 }
 
+// KF: the matrix read as a k-major B operand ([K = rows][N = cols]) in MFMA FRAGMENT order: [3][rows / 16][cols_pad / 32][64 lanes][8]
+// bf16 -- lane l = n + 32 h of the (k-step ks, column block nb) piece holds W[16 ks + 8 h + j][32 nb + n], j = 0..7: the B
+// fragment of v_mfma_f32_32x32x16_bf16, so a wave loads its fragment with ONE 16-byte load per lane, 1 KB contiguous.
+__global__ __launch_bounds__(256) void planes_kf_kernel(const float* __restrict__ w, int rows, int cols, int64_t ld,
+                                                        int cols_pad, char* __restrict__ out) {
+    const int64_t nb = cols_pad / 32, nks = rows / 16;
+    const int64_t total = nks * nb * 64;
+    const int64_t plane = nks * nb * 1024;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int lane = (int)(i & 63), n = lane & 31, h = lane >> 5;
+        const int64_t piece = i >> 6, b = piece % nb, ks = piece / nb;
+        const int c = (int)(b * 32 + n);
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = c < cols ? w[(ks * 16 + 8 * h + j) * ld + c] : 0.f;
+        uint2 ph0, pm0, pl0, ph1, pm1, pl1;
+        split3(f32x4{v[0], v[1], v[2], v[3]}, ph0, pm0, pl0);
+        split3(f32x4{v[4], v[5], v[6], v[7]}, ph1, pm1, pl1);
+        char* o = out + i * 16;
+        *reinterpret_cast<uint4*>(o) = make_uint4(ph0.x, ph0.y, ph1.x, ph1.y);
+        *reinterpret_cast<uint4*>(o + plane) = make_uint4(pm0.x, pm0.y, pm1.x, pm1.y);
+        *reinterpret_cast<uint4*>(o + 2 * plane) = make_uint4(pl0.x, pl0.y, pl1.x, pl1.y);
+    }
+}
+
 inline int pad128(int v) { return (v + 127) / 128 * 128; }
 
 }  // namespace
@@ -85,7 +110,7 @@ inline int pad128(int v) { return (v + 127) / 128 * 128; }
 extern "C" size_t twog_weight_planes_bytes(int rows, int cols, int kind) {
     if (rows <= 0 || cols <= 0) return 0;
     if (kind == TWOG_PLANES_RM) return (cols % 16) ? 0 : (size_t)3 * (cols / 16) * pad128(rows) * 32;
-    if (kind == TWOG_PLANES_KM) return (rows % 16) ? 0 : (size_t)3 * rows * pad128(cols) * 2;
+    if (kind == TWOG_PLANES_KM || kind == TWOG_PLANES_KF) return (rows % 16) ? 0 : (size_t)3 * rows * pad128(cols) * 2;
     return 0;
 }
 
@@ -100,6 +125,11 @@ extern "C" int twog_weight_planes_build(const float* w, int rows, int cols, int6
         const int64_t total = (int64_t)(cols / 16) * rp * 4;
         const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
         hipLaunchKernelGGL(planes_rm_kernel, dim3(blocks), dim3(256), 0, st, w, rows, cols, ld, rp, reinterpret_cast<char*>(planes));
+    } else if (kind == TWOG_PLANES_KF) {
+        const int cp = pad128(cols);
+        const int64_t total = (int64_t)(rows / 16) * (cp / 32) * 64;
+        const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+        hipLaunchKernelGGL(planes_kf_kernel, dim3(blocks), dim3(256), 0, st, w, rows, cols, ld, cp, reinterpret_cast<char*>(planes));
     } else {
         if ((cols & 3) == 0 && (ld & 3)) return -2;
         const int cp = pad128(cols);

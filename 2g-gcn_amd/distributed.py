@@ -70,7 +70,11 @@ class FlatParameters:
                 off += n
 
     def zero_grad(self):
-        self.grad.zero_()
+        K = get_kernels()
+        if hasattr(K, 'fill_zero') and self.grad.is_cuda:
+            K.fill_zero(self.grad)   # the library's clear (no ATen fill on the step's path)
+        else:
+            self.grad.zero_()
         for p in self.params:  # autograd accumulates in place into these views
             if p.grad is None or p.grad.data_ptr() == 0:
                 raise RuntimeError('parameter lost its flat gradient view')

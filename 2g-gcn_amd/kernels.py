@@ -9,6 +9,7 @@ Row-strided views: a matrix operand may be a 2-D view (rows, cols) or a 3-D view
 stride on cols -- it maps onto twog_rows_t without a copy.
 """
 import ctypes as C
+import math
 
 import torch
 
@@ -65,13 +66,15 @@ class PlanesDir:
     """A twog_wplanes_dir_t for the library: the weights a caller holds pre-split planes for (include/twog_gcn.h)."""
 
     def __init__(self, entries):
-        self.entries = [e for e in entries if e[1] is not None or e[2] is not None]
+        # entries: (w, rm, km[, kf]) -- images of twog_weight_planes_build, None where absent
+        self.entries = [tuple(e) + (None,) * (4 - len(e)) for e in entries]
+        self.entries = [e for e in self.entries if any(x is not None for x in e[1:])]
         n = len(self.entries)
         self._arr = (L.WPlanes * max(n, 1))()
-        for a, (w, rm, km) in zip(self._arr, self.entries):
+        for a, (w, rm, km, kf) in zip(self._arr, self.entries):
             assert w.dim() == 2 and w.stride(1) == 1
             a.w, a.rows, a.cols, a.ld = w.data_ptr(), w.shape[0], w.shape[1], w.stride(0)
-            a.rm, a.km = _ptr(rm), _ptr(km)
+            a.rm, a.km, a.kf = _ptr(rm), _ptr(km), _ptr(kf)
         self._dir = L.WPlanesDir(self._arr, n, 0)
         self.ptr = C.addressof(self._dir)
 
@@ -106,8 +109,28 @@ class HipKernels:
     def empty(self, *shape, like=None, dtype=torch.float32):
         return torch.empty(*shape, dtype=dtype, device=like.device)
 
-    def zeros(self, *shape, like=None, dtype=torch.float32):
-        return torch.zeros(*shape, dtype=dtype, device=like.device)
+    def zeros(self, *shape, like=None, dtype=torch.float32, device=None):
+        """A zeroed buffer: torch owns the memory, the library clears it (twog_fill_zero) -- no ATen kernel on the path."""
+        t = torch.empty(*shape, dtype=dtype, device=like.device if like is not None else device)
+        return self.fill_zero(t)
+
+    def fill_zero(self, t):
+        """In-place clear of a contiguous tensor (the whole storage range it spans)."""
+        assert t.is_contiguous()
+        if t.numel():
+            self._check(self.lib.twog_fill_zero(t.data_ptr(), t.numel() * t.element_size(), self._stream()), 'twog_fill_zero')
+        return t
+
+    def zeros_many(self, shapes, device, dtype=torch.float32):
+        """Zeroed fp32 buffers of the given shapes carved out of ONE allocation and cleared by ONE launch (each view starts
+        on a 256-byte boundary)."""
+        sizes = [int(math.prod(sh)) for sh in shapes]
+        offs, total = [], 0
+        for n in sizes:
+            offs.append(total)
+            total += (n + 63) // 64 * 64
+        buf = self.zeros(max(total, 1), dtype=dtype, device=device)
+        return [buf[o:o + n].view(*sh) for o, n, sh in zip(offs, sizes, shapes)]
 
     def workspace(self, nbytes, device, key='ws'):
         """A persistent scratch buffer per (device, key, current stream); grown on demand, contents undefined between
@@ -159,7 +182,7 @@ class HipKernels:
 
     # ---------------------------------------------------------------- pre-split weights (planes)
     supports_planes = True
-    PLANES_RM, PLANES_KM = L.PLANES_RM, L.PLANES_KM
+    PLANES_RM, PLANES_KM, PLANES_KF = L.PLANES_RM, L.PLANES_KM, L.PLANES_KF
 
     def weight_planes(self, w, kind, out=None):
         """The three exact bf16 planes of the fp32 matrix `w` (2-D, unit column stride) in the image `kind` (PLANES_RM: for
@@ -362,7 +385,7 @@ class HipKernels:
             out = torch.empty(bs, T, E, 2 * h, dtype=torch.float32, device=dev)
             save = torch.empty(2, bs, T, E, 4 * h, dtype=torch.float32, device=dev)
             tmp = torch.empty(2, bs * E, 3 * h, dtype=torch.float32, device=dev)
-            zeros = torch.zeros(bs * E, h, dtype=torch.float32, device=dev)
+            zeros = self.zeros(bs * E, h, device=dev)
             keep += [tmp, zeros]
             a = arr[i]
             a.gi, a.w_hh_f, a.b_hh_f, a.w_hh_r, a.b_hh_r = (gi.data_ptr(), y['w_hh_f'].data_ptr(),
@@ -504,7 +527,7 @@ class HipKernels:
                     mg_h=e(2, bs, T, H, nmh * h), mg_o=e(2, bs, T, O, nmo * h), att=e(2, T, bs, natt),
                     tmp_gim_h=e(2, bs * H, 3 * h), tmp_gim_o=e(2, bs * O, 3 * h), tmp_gh_h=e(2, bs * H, 3 * h),
                     tmp_gh_o=e(2, bs * O, 3 * h),
-                    zeros=torch.zeros(bs * max(H, O, 1), h, dtype=torch.float32, device=dev))
+                    zeros=self.zeros(bs * max(H, O, 1), h, device=dev))
         s = L.SegRnn()
         self._fill_seg(s, p, bufs)
         self._check(self.lib.twog_segrnn_fwd(C.byref(s), *self.chain_workspace(dev), self._stream()), 'twog_segrnn_fwd')
@@ -518,10 +541,10 @@ class HipKernels:
         def e(*shape):
             return torch.empty(*[max(int(x), 0) for x in shape], dtype=torch.float32, device=dev)
 
+        d_u_h, d_u_o = self.zeros_many([(bs, T, max(H, 0)), (bs, T, max(O, 0))], dev)
         out = dict(d_gi_h=e(bs, T, H, 6 * h), d_gi_o=e(bs, T, O, 6 * h), d_gh_h=e(bs, T, H, 6 * h),
                    d_gh_o=e(bs, T, O, 6 * h),
-                   d_u_h=torch.zeros(bs, T, H, dtype=torch.float32, device=dev),
-                   d_u_o=torch.zeros(bs, T, O, dtype=torch.float32, device=dev),
+                   d_u_h=d_u_h, d_u_o=d_u_o,
                    d_pre_h=e(2, bs, T, H, nsh * h), d_pre_o=e(2, bs, T, O, nso * h))
         scratch = dict(carry_h=e(2, bs * H, h), carry_o=e(2, bs * O, h), tmp_dmg_h=e(2, bs * H, nmh * h),
                        tmp_dmg_o=e(2, bs * O, nmo * h), trash=e(bs * max(H, O, 1), h),

@@ -343,43 +343,34 @@ class WeightCache:
         return out
 
     def planes_dir(self, K, specs):
-        """specs: list of (key, 2-D weight tensor, source tensors whose change invalidates it, want_rm, want_km).
+        """specs: list of (key, 2-D weight tensor, source tensors whose change invalidates it, kinds wanted).
         Returns K.planes_dir(...) over the up-to-date images (None when the backend has no planes)."""
-        if not getattr(K, 'supports_planes', False) or os.environ.get('TWOG_GEMM_BPLANES', '0') == '0':
-            return None   # opt-in: the all-DMA kernels measured slower than the register-staged ones (DESIGN.md section 8)
+        if not getattr(K, 'supports_planes', False) or os.environ.get('TWOG_GEMM_BPLANES', '1') == '0':
+            return None
         verify = bool(os.environ.get('TWOG_VERIFY_DERIVED'))
+        order = (K.PLANES_RM, K.PLANES_KM, K.PLANES_KF)
         entries, sig = [], []
-        for key, w, src, want_rm, want_km in specs:
+        for key, w, src, kinds in specs:
             if w is None:
                 continue
             w = w.detach()
             st = self._stamp(src) + (w.data_ptr(),)
             e = self.planes.get(key)
-            if e is None or e['stamp'] != st:
-                e = e or dict(rm=None, km=None)
-                if want_rm or e['rm'] is not None:
-                    e['rm'] = K.weight_planes(w, K.PLANES_RM, out=e['rm'])
-                    self.builds += e['rm'] is not None
-                if want_km or e['km'] is not None:
-                    e['km'] = K.weight_planes(w, K.PLANES_KM, out=e['km'])
-                    self.builds += e['km'] is not None
-                e['stamp'] = st
-                self.planes[key] = e
-            else:
-                if want_rm and e['rm'] is None:
-                    e['rm'] = K.weight_planes(w, K.PLANES_RM)
-                    self.builds += e['rm'] is not None
-                if want_km and e['km'] is None:
-                    e['km'] = K.weight_planes(w, K.PLANES_KM)
-                    self.builds += e['km'] is not None
-                if verify:
-                    for kind, img in ((K.PLANES_RM, e['rm']), (K.PLANES_KM, e['km'])):
-                        if img is not None and not torch.equal(img, K.weight_planes(w, kind)):
-                            raise RuntimeError(f'stale planes of {key}: a parameter was written behind torch '
-                                               f'(ops.bump_weights_epoch)')
-            entries.append((w, e['rm'], e['km']))
-            sig.append((w.data_ptr(), tuple(w.shape), w.stride(0), 0 if e['rm'] is None else e['rm'].data_ptr(),
-                        0 if e['km'] is None else e['km'].data_ptr()))
+            if e is None:
+                e = self.planes[key] = dict(stamp=None, img={})
+            fresh = e['stamp'] != st
+            for kind in order:
+                if kind not in kinds and kind not in e['img']:
+                    continue
+                if fresh or kind not in e['img']:
+                    e['img'][kind] = K.weight_planes(w, kind, out=e['img'].get(kind))
+                    self.builds += e['img'][kind] is not None
+                elif verify and e['img'][kind] is not None and not torch.equal(e['img'][kind], K.weight_planes(w, kind)):
+                    raise RuntimeError(f'stale planes of {key}: a parameter was written behind torch (ops.bump_weights_epoch)')
+            e['stamp'] = st
+            imgs = tuple(e['img'].get(kind) for kind in order)
+            entries.append((w,) + imgs)
+            sig.append((w.data_ptr(), tuple(w.shape), w.stride(0)) + tuple(0 if i is None else i.data_ptr() for i in imgs))
         sig = tuple(sig)
         if self.dir is None or self.dir_sig != sig:
             self.dir, self.dir_sig = K.planes_dir(entries), sig
@@ -403,10 +394,11 @@ def chain_planes(K, p, P):
     if wc is None or p.h < 256 or p.h % 64:
         return None
     specs = []
+    kinds = (K.PLANES_RM, K.PLANES_KF) if getattr(K, 'supports_planes', False) else ()
     for n in ('human', 'object', 'geometry'):
         for sfx in ('', '_reverse'):
             w = P[f'{n}_bd_rnn.weight_hh_l0{sfx}']
-            specs.append((f'{n}_bd_rnn.weight_hh_l0{sfx}', w, [w], True, True))
+            specs.append((f'{n}_bd_rnn.weight_hh_l0{sfx}', w, [w], kinds))
     if not p.general_segment():
         cells = {(k, d): f'{kk}_segment_rnn_{"fb"[d]}cell' for k, kk in (('h', 'human'), ('o', 'object')) for d in range(2)}
         for (k, d), cell in cells.items():
@@ -414,13 +406,13 @@ def chain_planes(K, p, P):
                 continue
             for nm in ('.weight_hh', '.weight_ih'):
                 w = P[cell + nm]
-                specs.append((cell + nm, w, [w], True, True))
+                specs.append((cell + nm, w, [w], kinds))
         if p.msg_segment:
             for key, rels in (('w_smsg_h', [r for r in ('hh', 'ho') if getattr(p, 'rel_' + r)]),
                               ('w_smsg_o', [r for r in ('oh', 'oo') if getattr(p, 'rel_' + r)])):
                 if rels:
                     src = [P[_SEG_MLP[r] + '.0.weight'] for r in rels]
-                    specs.append((key, wc.pack(key, src), src, True, True))
+                    specs.append((key, wc.pack(key, src), src, kinds))
     return wc.planes_dir(K, specs)
 
 
@@ -1222,8 +1214,11 @@ def tggcn_backward(K, plan: Plan, P, S, x_human, x_objects, objects_mask, d_outp
     def empty(*shape):
         return torch.empty(*shape, dtype=torch.float32, device=dev)
 
-    def zeros(*shape):
-        return torch.zeros(*shape, dtype=torch.float32, device=dev)
+    def zeros(*shape):   # cleared by the library (twog_fill_zero), not by an ATen fill; the test double has no such entry point
+        return K.zeros(*shape, device=dev) if hasattr(K, 'fill_zero') else torch.zeros(*shape, dtype=torch.float32, device=dev)
+
+    def zeros_many(shapes):   # one allocation, one clear
+        return K.zeros_many(shapes, dev) if hasattr(K, 'zeros_many') else [zeros(*sh) for sh in shapes]
 
     outs = S['outputs']
     if p.n_aff is None:
@@ -1300,7 +1295,7 @@ def tggcn_backward(K, plan: Plan, P, S, x_human, x_objects, objects_mask, d_outp
         so = K.segrnn_bwd(seg_p, sb, dHS_h, dHS_o)
     HUM, OBJ, GEO = S['HUM'], S['OBJ'], S['GEO']
     HUMv, OBJv, GEOv = _v2(HUM), _v2(OBJ), _v2(GEO)
-    dHUM, dOBJ, dGEO = zeros(bs, T, H, p.Wh), zeros(bs, T, O, p.Wo), zeros(bs, T, 1, p.Ws)
+    dHUM, dOBJ, dGEO = zeros_many([(bs, T, H, p.Wh), (bs, T, O, p.Wo), (bs, T, 1, p.Ws)])
     dHUMv, dOBJv, dGEOv = _v2(dHUM), _v2(dOBJ), _v2(dGEO)
     cells = {('h', 0): 'human_segment_rnn_fcell', ('h', 1): 'human_segment_rnn_bcell',
              ('o', 0): 'object_segment_rnn_fcell', ('o', 1): 'object_segment_rnn_bcell'}

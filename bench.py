@@ -565,6 +565,48 @@ def main():
     log(f'timed region done: {dt / args.steps * 1e3:.1f} ms/step; per step (device): '
         + ' '.join(f'{step_ev[i].elapsed_time(step_ev[i + 1]):.0f}' for i in range(args.steps)))
 
+    # ---- N > 1: what the step's collectives cost, and whether the group really spans N devices
+    dist_diag = None
+    if world > 1:
+        ones = torch.ones(1, device=device)
+        dist.all_reduce(ones)
+        buf = torch.empty_like(dp.flat.grad)
+        for _ in range(2):
+            dist.all_reduce(buf)
+        torch.cuda.synchronize()
+        barrier()
+        ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ea.record()
+        for _ in range(10):
+            dist.all_reduce(buf)
+        eb.record()
+        torch.cuda.synchronize()
+        ar_ms = ea.elapsed_time(eb) / 10
+        del buf
+        # the same step with every collective switched off (each rank trains alone on its shard)
+        was = dp.collective
+        dp.collective = False
+        from twog_gcn_amd import ops as _ops2
+        saved_hook = _ops2.get_model_extra(model, 'stage_hook')
+        _ops2.set_grad_stage_hook(model, None)
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+        barrier()
+        tn = time.perf_counter()
+        for _ in range(max(3, args.steps // 2)):
+            step()
+        torch.cuda.synchronize()
+        t_nc = (time.perf_counter() - tn) / max(3, args.steps // 2) * 1e3
+        dp.collective = was
+        _ops2.set_grad_stage_hook(model, saved_hook)
+        tt = torch.tensor([ar_ms, t_nc], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dist_diag = dict(ranks_seen=int(round(float(ones.item()))), allreduce_ms_isolated=float(tt[0]),
+                         allreduce_bytes=int(dp.flat.grad.numel() * 4), allreduce_repeats=10,
+                         step_ms_without_collectives=float(tt[1]),
+                         note='max over ranks; the gradient all-reduce of the timed step is bucketed and overlaps the backward pass')
+
     # ---- N > 1: the OTHER scaling mode in the same line (SURVEY 8e asks for both). `value` is the mode --scaling names
     # (default weak: the workload's 64 clips on every GPU); the secondary run keeps everything else and changes only the
     # clips per GPU: strong = BASELINE configs[3]'s fixed GLOBAL batch of 64 (64 / N per GPU), weak = 64 per GPU.
@@ -630,47 +672,6 @@ def main():
     att_fwd_ms, att_bwd_ms = prof.attn_ms('fwd'), prof.attn_ms('bwd')
     chain_ms = prof.chain_ms()
 
-    # ---- N > 1: what the step's collectives cost, and whether the group really spans N devices
-    dist_diag = None
-    if world > 1:
-        ones = torch.ones(1, device=device)
-        dist.all_reduce(ones)
-        buf = torch.empty_like(dp.flat.grad)
-        for _ in range(2):
-            dist.all_reduce(buf)
-        torch.cuda.synchronize()
-        barrier()
-        ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        ea.record()
-        for _ in range(10):
-            dist.all_reduce(buf)
-        eb.record()
-        torch.cuda.synchronize()
-        ar_ms = ea.elapsed_time(eb) / 10
-        del buf
-        # the same step with every collective switched off (each rank trains alone on its shard)
-        was = dp.collective
-        dp.collective = False
-        from twog_gcn_amd import ops as _ops2
-        saved_hook = _ops2.get_model_extra(model, 'stage_hook')
-        _ops2.set_grad_stage_hook(model, None)
-        for _ in range(3):
-            step()
-        torch.cuda.synchronize()
-        barrier()
-        tn = time.perf_counter()
-        for _ in range(max(3, args.steps // 2)):
-            step()
-        torch.cuda.synchronize()
-        t_nc = (time.perf_counter() - tn) / max(3, args.steps // 2) * 1e3
-        dp.collective = was
-        _ops2.set_grad_stage_hook(model, saved_hook)
-        tt = torch.tensor([ar_ms, t_nc], device=device, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dist_diag = dict(ranks_seen=int(round(float(ones.item()))), allreduce_ms_isolated=float(tt[0]),
-                         allreduce_bytes=int(dp.flat.grad.numel() * 4), allreduce_repeats=10,
-                         step_ms_without_collectives=float(tt[1]),
-                         note='max over ranks; the gradient all-reduce of the timed step is bucketed and overlaps the backward pass')
 
     fwd_only = None
     if True:  # forward-only clips/s is part of every line (north star: ">= 50x the reference CPU forward")

@@ -78,12 +78,14 @@ int twog_gemm_f32(const twog_gemm_t* problems, int n_problems, int a_kmajor, int
  * --------------------------------------------------------------------------------------------------------------- */
 #define TWOG_PLANES_RM 1
 #define TWOG_PLANES_KM 2
+#define TWOG_PLANES_KF 3   /* k-major reading, MFMA fragment order: bf16 [3][rows / 16][cols_pad / 32][64 lanes][8] (see csrc/planes.hip) */
 typedef struct {
     const float* w;   /* the fp32 matrix the planes were built from: [rows][cols], row stride ld (elements) */
     int32_t rows, cols;
     int64_t ld;
     const void* rm;   /* TWOG_PLANES_RM image or NULL */
     const void* km;   /* TWOG_PLANES_KM image or NULL */
+    const void* kf;   /* TWOG_PLANES_KF image or NULL */
 } twog_wplanes_t;
 typedef struct {
     const twog_wplanes_t* e;
@@ -508,6 +510,9 @@ int twog_add_rows(twog_rows_t src, twog_rows_t dst, int rows, int cols, void* st
 
 /* Fused Adam on one flat fp32 parameter buffer (torch.optim.Adam semantics; reference train.py:39). The gradient is
  * multiplied by grad_scale first (1/world_size after a sum all-reduce). */
+/* Zero fill of `nbytes` bytes at `p` (any alignment) on `stream`: the step's workspace / gradient clears (torch.zeros and
+ * Tensor.zero_() on the reference's path, e.g. optimizer.zero_grad(), pyrutils/torch/train_utils.py:146). */
+int twog_fill_zero(void* p, size_t nbytes, void* stream);
 int twog_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
                    float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale, void* stream);
 

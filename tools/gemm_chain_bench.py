@@ -32,8 +32,8 @@ for M, N, Kk, bkm, note in SHAPES:
     C = torch.empty(M, N, device=dev)
     pl = None
     if PLANES:
-        img = K.weight_planes(B, K.PLANES_KM if bkm else K.PLANES_RM)
-        pl = K.planes_dir([(B, None, img) if bkm else (B, img, None)])
+        img = K.weight_planes(B, K.PLANES_KF if bkm else K.PLANES_RM)
+        pl = K.planes_dir([(B, None, None, img) if bkm else (B, img, None, None)])
     for i in range(20):
         K.gemm([dict(A=As[i % 16], B=B, C=C)], b_kmajor=bkm, split_k_workspace=False, chain=CHAIN, planes=pl)
     torch.cuda.synchronize()
