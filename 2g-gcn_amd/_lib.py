@@ -27,18 +27,6 @@ class Gemm(C.Structure):  # twog_gemm_t
                 ('a_batch_stride', C.c_int64), ('b_batch_stride', C.c_int64), ('c_batch_stride', C.c_int64)]
 
 
-class WPlanes(C.Structure):  # twog_wplanes_t
-    _fields_ = [('w', C.c_void_p), ('rows', C.c_int32), ('cols', C.c_int32), ('ld', C.c_int64), ('rm', C.c_void_p),
-                ('km', C.c_void_p), ('kf', C.c_void_p)]
-
-
-class WPlanesDir(C.Structure):  # twog_wplanes_dir_t
-    _fields_ = [('e', C.POINTER(WPlanes)), ('n', C.c_int32), ('pad_', C.c_int32)]
-
-
-PLANES_RM, PLANES_KM, PLANES_KF = 1, 2, 3   # TWOG_PLANES_*
-
-
 class GruStep(C.Structure):  # twog_gru_step_t
     _fields_ = [('gi', Rows), ('gi2', Rows), ('gh', Rows), ('h_prev', Rows), ('h_out', Rows), ('save', Rows),
                 ('u', C.c_void_p), ('u_ld_outer', C.c_int64), ('u_ld_inner', C.c_int64), ('u_inner', C.c_int32),
@@ -55,13 +43,13 @@ class GruStepBwd(C.Structure):  # twog_gru_step_bwd_t
 class BiGru(C.Structure):  # twog_bigru_t
     _fields_ = [('gi', C.c_void_p), ('w_hh_f', C.c_void_p), ('b_hh_f', C.c_void_p), ('w_hh_r', C.c_void_p),
                 ('b_hh_r', C.c_void_p), ('out', C.c_void_p), ('save', C.c_void_p), ('tmp_gh', C.c_void_p),
-                ('zeros', C.c_void_p), ('E', C.c_int32), ('pad_', C.c_int32), ('planes', C.c_void_p)]
+                ('zeros', C.c_void_p), ('E', C.c_int32), ('pad_', C.c_int32)]
 
 
 class BiGruBwd(C.Structure):  # twog_bigru_bwd_t
     _fields_ = [('d_out', C.c_void_p), ('save', C.c_void_p), ('out', C.c_void_p), ('w_hh_f', C.c_void_p),
                 ('w_hh_r', C.c_void_p), ('d_gi', C.c_void_p), ('d_gh', C.c_void_p), ('carry', C.c_void_p),
-                ('E', C.c_int32), ('pad_', C.c_int32), ('planes', C.c_void_p)]
+                ('E', C.c_int32), ('pad_', C.c_int32)]
 
 
 class Attn(C.Structure):  # twog_attn_t
@@ -93,7 +81,7 @@ class SegRnn(C.Structure):  # twog_segrnn_t
                 ('hs_h', C.c_void_p), ('hs_o', C.c_void_p), ('save_h', C.c_void_p), ('save_o', C.c_void_p),
                 ('msrc_h', C.c_void_p), ('msrc_o', C.c_void_p), ('mg_h', C.c_void_p), ('mg_o', C.c_void_p),
                 ('att', C.c_void_p), ('tmp_gim_h', C.c_void_p), ('tmp_gim_o', C.c_void_p), ('tmp_gh_h', C.c_void_p),
-                ('tmp_gh_o', C.c_void_p), ('zeros', C.c_void_p), ('planes', C.c_void_p)]
+                ('tmp_gh_o', C.c_void_p), ('zeros', C.c_void_p)]
 
 
 class SegRnnBwd(C.Structure):  # twog_segrnn_bwd_t
@@ -144,10 +132,6 @@ LOSS_MAX_TERMS, LOSS_BLOCKS = 16, 64  # TWOG_LOSS_MAX_TERMS, TWOG_LOSS_BLOCKS
 _I, _L, _F, _P = C.c_int, C.c_int64, C.c_float, C.c_void_p
 SIGNATURES = {
     'twog_gemm_f32': [C.POINTER(Gemm), _I, _I, _I, _P, C.c_size_t, _P],
-    'twog_gemm_f32_p': [C.POINTER(Gemm), _I, _I, _I, _P, C.c_size_t, _P, _P],
-    'twog_gemm_f32_chain_p': [C.POINTER(Gemm), _I, _I, _I, _P, C.c_size_t, _P, _P],
-    'twog_weight_planes_bytes': [_I, _I, _I],
-    'twog_weight_planes_build': [_P, _I, _I, _L, _I, _P, _P],
     'twog_gemm_last_class': [],
     'twog_chain_workspace_bytes': [],
     'twog_gemm_f32_chain': [C.POINTER(Gemm), _I, _I, _I, _P, C.c_size_t, _P],
@@ -220,7 +204,6 @@ def load():
         fn.argtypes = argtypes
         fn.restype = C.c_int
     lib.twog_chain_workspace_bytes.restype = C.c_size_t
-    lib.twog_weight_planes_bytes.restype = C.c_size_t
     lib.twog_version.restype = C.c_char_p
     lib.twog_version.argtypes = []
     _lib = lib

@@ -36,10 +36,6 @@ struct Prob {
     int n_major;       // logical tile order: consecutive tiles share the B column panel (weights larger than activations)
     int batch;         // independent problems sharing shapes; operand b of batch i = ptr + i * *_bs
     int64_t a_bs, b_bs, c_bs;
-    // B pre-split into bf16 planes (twog_weight_planes_build), resolved from the caller's planes directory: base of this
-    // operand's view inside the image, bytes between planes, bytes between k-tiles of 16 (RM) / between k rows (KM)
-    const char* bp;
-    uint32_t bp_ps, bp_ld;
 };
 
 struct Group {
@@ -859,321 +855,6 @@ __device__ __forceinline__ void gemm_mainloop_x3s(const twog_rows_t A, const two
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// X3D: the 64-row X3 tile classes with BOTH operands arriving by LDS-DMA (buffer_load ... lds), B from PRE-SPLIT planes.
-//
-// The chain launches (one 64 x 64 or 64 x 192 tile per CU, K = 512 ... 1 536, 240 dependent launches per step) were
-// bound by how fast a lone workgroup can pull its operands through registers: two to four register stages of 16 bytes per
-// thread are all the bytes it keeps in flight, and half of them are the WEIGHT, split into bf16 planes again by every
-// launch of every step. Here
-//   * B comes from the weight's planes (twog_weight_planes_build: written once per optimizer step) by LDS-DMA pieces of
-//     1 KB (64 lanes x 16 bytes, per-lane source address = the image's swizzle applied on the SOURCE side, linear LDS
-//     destination) straight into a ring of NS slots: no VGPR staging, no split arithmetic, no ds_write for B;
-//   * A (previous states / gradients of a chain step: fp32, written by the previous launch) comes by the same DMA as RAW
-//     fp32 rows into the slot; every wave copies exactly the bytes its OWN lanes split afterwards (ds_read_b128 of the
-//     lane's own 16 bytes -> split3 -> three ds_write_b64 into the plane image the MFMA fragments read), so that the raw
-//     tile needs no barrier of its own -- the issuing wave's vmcnt wait is enough (MI355X_MICROARCH.md, LDS-DMA ordering);
-//   * nothing in the loop is a compiler-visible vector-memory operation: every DMA is inline asm, every wait a counted
-//     s_waitcnt vmcnt(n) of our own (n = pieces this wave issued for the k-tiles that may stay in flight), one barrier
-//     per k-tile as before. The ring keeps NS - 1 k-tiles (20 ... 44 KB each) in flight per workgroup.
-// Arithmetic, plane images of A, fragment reads, MFMA order and accumulators are those of gemm_mainloop_x3s: the results
-// are bit-identical to the register-staged kernels (tests/test_kernels_gpu.py::test_gemm_planes_*).
-__device__ __forceinline__ void x3d_dma16(uint32_t lds_addr, int voff, __amdgpu_buffer_rsrc_t rs, int soff) {
-    // M0 carries the LDS base of the piece; written in the statement that uses it (the compiler does not preserve it)
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds_addr), "v"(voff), "s"(rs), "s"(soff) : "memory");
-}
-__device__ __forceinline__ void x3d_vmwait(int n) {   // s_waitcnt takes an immediate: wave-uniform switch
-    switch (n) {
-#define TWOG_W(i) case i: asm volatile("s_waitcnt vmcnt(" #i ")" ::: "memory"); break;
-        TWOG_W(0) TWOG_W(1) TWOG_W(2) TWOG_W(3) TWOG_W(4) TWOG_W(5) TWOG_W(6) TWOG_W(7) TWOG_W(8) TWOG_W(9) TWOG_W(10) TWOG_W(11)
-        TWOG_W(12) TWOG_W(13) TWOG_W(14) TWOG_W(15) TWOG_W(16) TWOG_W(17) TWOG_W(18) TWOG_W(19) TWOG_W(20) TWOG_W(21) TWOG_W(22)
-        TWOG_W(23) TWOG_W(24) TWOG_W(25) TWOG_W(26) TWOG_W(27) TWOG_W(28)
-#undef TWOG_W
-        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-    }
-}
-
-template <int BN, int NT, bool BKM, int KS, int TN, bool G3, int NS, bool LO2 = (TN == 1)>
-struct X3D {
-    static constexpr int BM = 64, XK = 16 * KS, NTG = NT / KS, NW = NT / 64, RB = 2 * XK;
-    static constexpr int PA = BM * RB;                      // one A plane of a k-tile
-    static constexpr int ASTAGE = 3 * PA;                   // A planes: two stages
-    static constexpr int ARAW = BM * XK * 4;                // raw fp32 rows of a k-tile: NW pieces of 1 KB, one per wave
-    static constexpr int PB = XK * BN * 2;                  // one B plane of a k-tile (both images)
-    static constexpr int BSLOT = 3 * PB;
-    static constexpr int SLOT = ARAW + BSLOT;
-    static constexpr int BYTES = 2 * ASTAGE + NS * SLOT;
-    static constexpr int NPB = BSLOT / 1024;                // B pieces per k-tile
-    static constexpr int CNT_LO = 1 + NPB / NW, CNT_HI = 1 + (NPB + NW - 1) / NW;   // DMAs per wave and k-tile
-    static_assert(ARAW == NW * 1024, "one raw A piece per wave");
-    static_assert(BSLOT % 1024 == 0 && (NS - 1) * CNT_HI <= 28, "piece size / wait range");
-    static_assert(!BKM || (BN == 64 && !G3), "k-major B: 64-column tiles");
-};
-
-template <bool ON, int NT, bool BKM, int KS, int NS>
-constexpr int x3d_bytes() {   // LDS bytes of the 64 x 64 class (only instantiated for kernels that use the loop)
-    if constexpr (ON) return X3D<64, NT, BKM, KS, 1, false, NS>::BYTES;
-    else return 0;
-}
-
-template <bool ON, int KS, int NS>
-constexpr int x3d_g3_bytes() {   // the fused GRU forward tile (64 rows x 192 gate columns)
-    if constexpr (ON) return X3D<192, 256 * KS, false, KS, 3, true, NS, false>::BYTES;
-    else return 0;
-}
-
-template <int BN, int NT, bool BKM, int KS, int TN, bool G3, int NS, bool LO2 = (TN == 1)>
-__device__ __forceinline__ void gemm_mainloop_x3d(const twog_rows_t A, const char* bp, uint32_t bp_ps, uint32_t bp_ld, int M,
-                                                  int N, int m0, int n0, int k_begin, int k_end, float* smem,
-                                                  f32x16 (&acc)[1][TN]) {
-    using L = X3D<BN, NT, BKM, KS, TN, G3, NS, LO2>;
-    constexpr int XK = L::XK, NTG = L::NTG, NW = L::NW, RB = L::RB, PA = L::PA, D = NS - 1;
-    constexpr int WN = BN / 2;
-    static_assert(WN == 32 * TN, "TN column blocks per wave");
-    char* lds = reinterpret_cast<char*>(smem);
-    const uint32_t lds0 = (uint32_t)(uintptr_t)lds;           // LDS byte address of the array (low 32 bits of the flat address)
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave of the workgroup, provably uniform
-    const int wave = wv % (NTG / 64), kgrp = wv / (NTG / 64);
-    const int wm = (wave >> 1) * 32, wn = (wave & 1) * WN;
-    auto swz_r = [](int row, int chunk) { return XK == 32 ? (chunk ^ ((row >> 2) & 3)) : (chunk ^ ((row >> 4) & 1)); };
-    const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(A.ptr, 0, 0xffffffff, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(bp), 0, 0xffffffff, 0x00020000);
-    // ---- A: this wave's raw piece = tile rows [wv * RPP, (wv + 1) * RPP), lane -> (row, quad of k); the same thread splits it
-    const int a_rr = tid / (XK / 4), a_cq = tid % (XK / 4);
-    const int va = (int)(4u * (uint32_t)(twog_row_off(A, min(m0 + a_rr, M - 1)) + a_cq * 4));
-    const int sa_off = a_rr * RB + 16 * swz_r(a_rr, a_cq >> 1) + 8 * (a_cq & 1);     // plane image position of its 4 values
-    const int raw_off = 2 * L::ASTAGE + wv * 1024 + lane * 16;                       // + slot * SLOT
-    // ---- B pieces of this wave: q = wv + i * NW. Source offsets (bytes from bp, without the k-tile's scalar offset):
-    constexpr int NPW = (L::NPB + NW - 1) / NW;
-    int vb[NPW];
-    const bool hi = wv < (L::NPB % NW);        // this wave issues one piece more than the others
-    const int my_cnt = (L::NPB % NW) ? (hi ? L::CNT_HI : L::CNT_LO) : L::CNT_LO;
-#pragma unroll
-    for (int i = 0; i < NPW; ++i) {
-        const int q = min(wv + i * NW, L::NPB - 1);
-        if constexpr (BKM) {
-            constexpr int PPP = L::PB / 1024;                 // pieces per plane
-            const int p = q / PPP, c = q - p * PPP;
-            const int pos = c * 1024 + lane * 16, k = pos / (2 * BN), cp = (pos % (2 * BN)) / 16;
-            const int sw = ((k >> 1) & 1) << 2;               // swz_t of gemm_mainloop_x3s
-            vb[i] = (int)((uint32_t)p * bp_ps + (uint32_t)k * bp_ld + (uint32_t)n0 * 2u + 16u * (uint32_t)(cp ^ sw));
-        } else {
-            constexpr int PPJ = BN / 32;                      // pieces per (plane, 16-deep sub-tile): 32 rows each
-            const int pj = q / PPJ, c = q - pj * PPJ, p = pj / KS, j = pj - p * KS;
-            int row0;
-            if constexpr (G3) row0 = (c % 3) * N + n0 + 32 * (c / 3);   // gate block c % 3 of the units n0 + 32 (c / 3) ...
-            else row0 = n0 + 32 * c;
-            const int r = lane >> 1;
-            vb[i] = (int)((uint32_t)p * bp_ps + (uint32_t)j * bp_ld + (uint32_t)(row0 + r) * 32u + 16u * (uint32_t)((lane & 1) ^ ((r >> 4) & 1)));
-        }
-    }
-    const int nkt = (k_end - k_begin) / XK;
-    if (nkt <= 0) return;
-    // scalar offsets of k-tile t
-    auto soff_a = [&](int t) { return (int)((uint32_t)(k_begin + t * XK) * 4u); };
-    auto soff_b = [&](int t) { return BKM ? (int)((uint32_t)(k_begin + t * XK) * bp_ld) : (int)((uint32_t)(k_begin / 16 + t * KS) * bp_ld); };
-    auto issue = [&](int t, int slot) {
-        const uint32_t base = lds0 + 2 * L::ASTAGE + (uint32_t)slot * L::SLOT;
-        x3d_dma16(base + (uint32_t)wv * 1024u, va, rsrc_a, soff_a(t));
-        const int sb = soff_b(t);
-#pragma unroll
-        for (int i = 0; i < NPW; ++i)
-            if (i + 1 < NPW || (L::NPB % NW) == 0 || hi)
-                x3d_dma16(base + L::ARAW + (uint32_t)(wv + i * NW) * 1024u, vb[i], rsrc_b, sb);
-    };
-    auto split_store = [&](int slot, int stage) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(lds + raw_off + slot * L::SLOT);
-        i32x2 ph, pm, pl;
-        split3(v, ph, pm, pl);
-        char* base = lds + stage * L::ASTAGE + sa_off;
-        *reinterpret_cast<i32x2*>(base) = ph;
-        *reinterpret_cast<i32x2*>(base + PA) = pm;
-        *reinterpret_cast<i32x2*>(base + 2 * PA) = pl;
-    };
-    // ---- fragments (gemm_mainloop_x3s's, with B in 16-deep sub-images [plane][j][row][32 bytes] when row-major)
-    const int r32 = lane & 31, h = lane >> 5;
-    const int chunk = (XK == 32 ? 2 * kgrp : 0) + h;
-    const int fa_r = (wm + r32) * RB + 16 * swz_r(wm + r32, chunk);
-    int fb_r[TN];
-#pragma unroll
-    for (int b = 0; b < TN; ++b) fb_r[b] = kgrp * (BN * 32) + (wn + 32 * b + r32) * 32 + 16 * (h ^ (((wn + 32 * b + r32) >> 4) & 1));
-    const int g16 = lane >> 4, q4 = (lane >> 2) & 3, p4 = lane & 3;
-    const int tk0 = 16 * kgrp + 8 * (g16 >> 1) + q4, tk1 = tk0 + 4;
-    const int tch = (wn >> 3) + 2 * (g16 & 1) + (p4 >> 1);
-    auto swz_t = [](int k, int ch) { return ch ^ (((k >> 1) & 1) << 2); };
-    const int ft0 = tk0 * 2 * BN + 16 * swz_t(tk0, tch) + 8 * (p4 & 1);
-    const int ft1 = tk1 * 2 * BN + 16 * swz_t(tk1, tch) + 8 * (p4 & 1);
-    typedef short s16x8 __attribute__((ext_vector_type(8)));
-    f32x16 lo[LO2 ? TN : 1];
-#pragma unroll
-    for (int b = 0; b < (LO2 ? TN : 1); ++b)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) lo[b][i] = 0.0f;
-    auto compute = [&](int slot, int stage) {
-        const char* abase = lds + stage * L::ASTAGE;
-        const char* bbase = lds + 2 * L::ASTAGE + slot * L::SLOT + L::ARAW;
-        bf16x8 af[3], bf[TN][3];
-#pragma unroll
-        for (int p = 0; p < 3; ++p) af[p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const i32x4*>(abase + p * PA + fa_r));
-#pragma unroll
-        for (int b = 0; b < TN; ++b)
-#pragma unroll
-            for (int p = 0; p < 3; ++p) {
-                if constexpr (BKM) {
-                    const s16x4 l4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(bbase + p * L::PB + ft0));
-                    const s16x4 h4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(bbase + p * L::PB + ft1));
-                    const s16x8 v = {l4[0], l4[1], l4[2], l4[3], h4[0], h4[1], h4[2], h4[3]};
-                    bf[b][p] = __builtin_bit_cast(bf16x8, v);
-                } else {
-                    bf[b][p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const i32x4*>(bbase + p * L::PB + fb_r[b]));
-                }
-            }
-        constexpr int PI[5] = {2, 0, 1, 1, 0}, PJ[5] = {0, 2, 1, 0, 1};   // l h, h l, m m, m h, h m  (as gemm_mainloop_x3s)
-#pragma unroll
-        for (int t = 0; t < 5; ++t)
-#pragma unroll
-            for (int b = 0; b < TN; ++b) {
-                if constexpr (LO2) lo[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[PI[t]], bf[b][PJ[t]], lo[b], 0, 0, 0);
-                else acc[0][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[PI[t]], bf[b][PJ[t]], acc[0][b], 0, 0, 0);
-            }
-#pragma unroll
-        for (int b = 0; b < TN; ++b)
-            acc[0][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[b][0], acc[0][b], 0, 0, 0);
-    };
-    // ---- pipeline: k-tile t lives in slot t % NS; D = NS - 1 tiles in flight. Only existing tiles are requested, so the
-    // waits count exactly: before the split of tile t + 1 this wave may leave the DMAs of min(D - 1, nkt - 2 - t) younger
-    // tiles outstanding (my_cnt each).
-#pragma unroll
-    for (int i = 0; i < D; ++i)
-        if (i < nkt) issue(i, i);
-    x3d_vmwait(min(D - 1, nkt - 1) * my_cnt);
-    split_store(0, 0);
-    __syncthreads();
-    int slot = 0, nslot = D % NS;   // slot of tile t, slot that tile t + D goes to
-    for (int t = 0; t < nkt; ++t) {
-        if (t + D < nkt) issue(t + D, nslot);
-        compute(slot, t & 1);
-        const int s1 = slot + 1 == NS ? 0 : slot + 1;
-        if (t + 1 < nkt) {
-            x3d_vmwait(min(D - 1, nkt - 2 - t) * my_cnt);
-            split_store(s1, (t + 1) & 1);
-        }
-        __syncthreads();
-        slot = s1;
-        nslot = nslot + 1 == NS ? 0 : nslot + 1;
-    }
-    if constexpr (LO2) {
-#pragma unroll
-        for (int b = 0; b < TN; ++b)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[0][b][i] += lo[b][i];
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// X3F: the 64 x 64 X3 chain classes with the WEIGHT's fragments loaded straight from its pre-split planes into registers.
-//
-// What bounds a chain launch (one workgroup per CU, every wave in step between the barriers) is the CU's LDS: per k-tile of
-// 32 the register-staged kernel writes 24 KB of planes (ds_write_b64: ~85 B/clk per CU) and its eight waves read 48 KB of
-// fragments back (256 B/clk) -- ~480 LDS cycles where the MFMAs need 384 per SIMD -- after splitting both operands (88
-// VALU operations per thread). Half of all that is the WEIGHT, identical for all 120 steps of a chain. Here a wave reads
-// its B fragments -- three planes x 16 bytes per lane and k-step, 1 KB contiguous per wave and plane -- directly from the
-// weight's planes in global memory (twog_weight_planes_build: the RM image for row-major weights is already in
-// fragment order per 32-row block; k-major weights have the KF image), two waves of a tile sharing each fragment through the
-// CU's vector L1. B never enters LDS and is never split in the kernel: LDS traffic, split arithmetic and staging registers
-// halve; the fragments of the next barrier interval are requested before the MFMAs of the current one (double buffer).
-// A is staged and split as in gemm_mainloop_x3s; same MFMA sequence into the same accumulators: bit-identical results.
-template <int NT, bool BKM, int KS, int KU>
-__device__ __forceinline__ void gemm_mainloop_x3f(const twog_rows_t A, const char* bp, uint32_t bp_ps, uint32_t bp_ld, int M,
-                                                  int N, int m0, int n0, int k_begin, int k_end, float* smem,
-                                                  f32x16 (&acc)[1][1]) {
-    constexpr int BM = 64, XK = 16 * KS, NTG = NT / KS, RB = 2 * XK, PA = BM * RB, STAGE = 3 * PA;
-    constexpr int FA = BM * XK / 4;
-    static_assert(FA == NT, "one 16-byte load of A per thread and k-tile");
-    char* lds = reinterpret_cast<char*>(smem);
-    const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) % (NTG / 64), kgrp = (tid >> 6) / (NTG / 64);
-    const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
-    auto swz_r = [](int row, int chunk) { return XK == 32 ? (chunk ^ ((row >> 2) & 3)) : (chunk ^ ((row >> 4) & 1)); };
-    const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(A.ptr, 0, 0xffffffff, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(bp), 0, 0xffffffff, 0x00020000);
-    const int a_rr = tid / (XK / 4), a_cq = tid % (XK / 4);
-    const uint32_t oa = 4u * (uint32_t)(twog_row_off(A, min(m0 + a_rr, M - 1)) + a_cq * 4);
-    const int sa_off = a_rr * RB + 16 * swz_r(a_rr, a_cq >> 1) + 8 * (a_cq & 1);
-    const int r32 = lane & 31, h = lane >> 5;
-    const int chunk = (XK == 32 ? 2 * kgrp : 0) + h;
-    const int fa_r = (wm + r32) * RB + 16 * swz_r(wm + r32, chunk);
-    // B fragment of this lane inside a (plane, k-step) slice of the image: RM -- rows of 32 bytes, the lane's half h;
-    // KF -- the lane's 16 bytes of its 32-column block
-    const uint32_t vb = BKM ? (uint32_t)((n0 + wn) / 32) * 1024u + (uint32_t)lane * 16u
-                            : (uint32_t)(n0 + wn + r32) * 32u + (uint32_t)h * 16u;
-    struct AStage { f32x4 a[KU]; };
-    struct BFrag { bf16x8 b[KU][3]; };
-    auto gload = [&](AStage& r, int k0) {
-#pragma unroll
-        for (int u = 0; u < KU; ++u)
-            r.a[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, (int)oa, (int)((uint32_t)(k0 + u * XK) * 4u), 0));
-    };
-    auto bload = [&](BFrag& f, int k0) {   // k-step of this wave's k-group inside sub-tile u: (k0 + u XK) / 16 + kgrp
-#pragma unroll
-        for (int u = 0; u < KU; ++u) {
-            const uint32_t ks = (uint32_t)((k0 + u * XK) / 16 + kgrp);
-#pragma unroll
-            for (int p = 0; p < 3; ++p)
-                f.b[u][p] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc_b, (int)vb, (int)(ks * bp_ld + (uint32_t)p * bp_ps), 0));
-        }
-    };
-    auto split_store = [&](const AStage& r, int buf) {
-        i32x2 ph, pm, pl;
-#pragma unroll
-        for (int u = 0; u < KU; ++u) {
-            char* base = lds + (buf * KU + u) * STAGE + sa_off;
-            split3(r.a[u], ph, pm, pl);
-            *reinterpret_cast<i32x2*>(base) = ph;
-            *reinterpret_cast<i32x2*>(base + PA) = pm;
-            *reinterpret_cast<i32x2*>(base + 2 * PA) = pl;
-        }
-    };
-    f32x16 lo;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) lo[i] = 0.0f;
-    auto compute = [&](int buf, const BFrag& f) {
-#pragma unroll
-        for (int u = 0; u < KU; ++u) {
-            const char* base = lds + (buf * KU + u) * STAGE;
-            bf16x8 af[3];
-#pragma unroll
-            for (int p = 0; p < 3; ++p) af[p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const i32x4*>(base + p * PA + fa_r));
-            constexpr int PI[5] = {2, 0, 1, 1, 0}, PJ[5] = {0, 2, 1, 0, 1};   // l h, h l, m m, m h, h m (gemm_mainloop_x3s)
-#pragma unroll
-            for (int t = 0; t < 5; ++t) lo = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[PI[t]], f.b[u][PJ[t]], lo, 0, 0, 0);
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], f.b[u][0], acc[0][0], 0, 0, 0);
-        }
-    };
-    constexpr int STEP = XK * KU;
-    const int nkt = (k_end - k_begin) / STEP;
-    if (nkt <= 0) return;
-    const int k_last = k_begin + (nkt - 1) * STEP;
-    auto kof = [&](int t) { return min(k_begin + t * STEP, k_last); };
-    // two register stages of A, two fragment sets of B (loads past the last interval are clamped to it, never branched
-    // around: see gemm_mainloop); the loop is unrolled by two so that every stage keeps a static name
-    AStage r0, r1;
-    BFrag f0, f1;
-    gload(r0, kof(0));
-    gload(r1, kof(1));
-    bload(f0, kof(0));
-    split_store(r0, 0);
-    __syncthreads();
-    int kt = 0;
-    for (; kt + 1 < nkt; kt += 2) {
-        gload(r0, kof(kt + 2)); bload(f1, kof(kt + 1)); compute(0, f0); split_store(r1, 1); __syncthreads();
-        gload(r1, kof(kt + 3)); bload(f0, kof(kt + 2)); compute(1, f1); split_store(r0, 0); __syncthreads();
-    }
-    if (kt < nkt) compute(0, f0);
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[0][0][i] += lo[i];
-}
-
 // XS (recurrent-chain launches with fewer tiles than the chip has CUs): the reduction is ALSO split over workgroups
 // (blockIdx.y = k-slice) and combined inside the launch, without a grid barrier and without waiting: every workgroup
 // writes its partial tile write-through (16-byte sc1 stores, so no release fence), drains them, and one lane draws an
@@ -1183,7 +864,7 @@ __device__ __forceinline__ void gemm_mainloop_x3f(const twog_rows_t A, const cha
 // counters are zero again at the launch boundary (graph replays need no memset node). The hand-off form is the
 // guide's split-K recipe (cdna_hip_programming.md section 5 item 2 / MI355X_MICROARCH.md "Valid forms": sc1 payload,
 // every storing wave drained, workgroup barrier, one relaxed agent atomic; the last arriver's loads all sc1).
-template <int BM, int BN, int NT, bool AKM, bool BKM, int D, bool KG, bool GATE, int KS = 1, bool XS = false, bool X3 = false, bool BP = false, int NS = 4, int KU = 1, bool BF = false>
+template <int BM, int BN, int NT, bool AKM, bool BKM, int D, bool KG, bool GATE, int KS = 1, bool XS = false, bool X3 = false, int KU = 1>
 __device__ __forceinline__ void gemm_tile(const Group& g, const GateArgs* ga) {
     constexpr int NTG = NT / KS;
     constexpr int WM = BM / (NTG / 128), WN = BN / 2;  // per-wave tile; the waves of a k-group in a (NTG/128) x 2 grid
@@ -1193,11 +874,7 @@ __device__ __forceinline__ void gemm_tile(const Group& g, const GateArgs* ga) {
     constexpr int A_ELEMS = AKM ? BK * LDA : BM * LDA;
     constexpr int B_ELEMS = BKM ? BK * LDB : BN * LDB;
     // (X3 on the 64-row class: two stages of three bf16 planes per operand, 2 x 6 x 64 rows x 2 XK bytes, XK = 16 KS)
-    // (BP on the 64-row class: the all-DMA loop's A plane stages + ring of NS slots, gemm_mainloop_x3d)
-    // (BF: only the A planes live in LDS -- two stages of KU sub-tiles; at least the k-group exchange area)
-    constexpr int SMEM_FLOATS = (X3 && BF && BM == 64) ? (2 * KU * 3 * 64 * 32 * KS / 4 > 4608 ? 2 * KU * 3 * 64 * 32 * KS / 4 : 4608)
-                                : (X3 && BP && BM == 64) ? x3d_bytes<(X3 && BP && BM == 64), NT, BKM, KS, NS>() / 4
-                                : (X3 && BM == 128) ? 2 * X3_STAGE / 4
+    constexpr int SMEM_FLOATS = (X3 && BM == 128) ? 2 * X3_STAGE / 4
                                 : (X3 && BM == 64 && 12 * 64 * 8 * KS * KU > 2 * (A_ELEMS + B_ELEMS)) ? 12 * 64 * 8 * KS * KU : 2 * (A_ELEMS + B_ELEMS);
     __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS];
 
@@ -1344,13 +1021,6 @@ __device__ __forceinline__ void gemm_tile(const Group& g, const GateArgs* ga) {
         if constexpr (BM == 128) {
             static_assert(!X3 || BM != 128 || (BN == 128 && NT == 512 && !GATE && KS == 1 && !XS), "X3: the 8-wave 128x128 class");
             gemm_mainloop_x3<AKM, BKM, KG>(A, B, M, N, m0, n0, k_begin, k_end, smem, acc);
-        } else if constexpr (BF) {
-            static_assert(!BF || (X3 && BM == 64 && BN == 64 && !AKM && !KG && !XS), "planes: the 64x64 X3 classes");
-            gemm_mainloop_x3f<NT, BKM, KS, KU>(A, G.bp, G.bp_ps, G.bp_ld, M, N, m0, n0, k_begin, k_end, smem, acc);
-        } else if constexpr (BP) {
-            static_assert(!BP || (X3 && BM == 64 && BN == 64 && !AKM && !KG && !XS), "planes: the 64x64 X3 classes");
-            // (operands of batch 0 only: the host offers planes to unbatched problems)
-            gemm_mainloop_x3d<64, NT, BKM, KS, 1, false, NS>(A, G.bp, G.bp_ps, G.bp_ld, M, N, m0, n0, k_begin, k_end, smem, acc);
         } else {
             static_assert(!X3 || BM == 128 || (BM == 64 && BN == 64 && !AKM && !KG && !XS), "X3: 64x64 tiles, row-major A");
             gemm_mainloop_x3s<BM, BN, NT, BKM, KS, 1, false, (GATE || KU > 1 ? 2 : TWOG_X3S_RS), true, KU>(A, B, M, N, m0, n0, k_begin, k_end, smem, acc);
@@ -1547,31 +1217,11 @@ __global__ __launch_bounds__(256 * KS, 2) void gemm_gate_bwd_x3s_kernel(const Gr
 // KU k-tiles per barrier interval (launches that run one workgroup per CU: at most 256 tiles)
 template <bool BKM, int KS, int KU>
 __global__ __launch_bounds__(256 * KS, KS == 2 ? 1 : 2) void gemm_x3su_kernel(const Group g) {
-    gemm_tile<64, 64, 256 * KS, false, BKM, 2, false, false, KS, false, true, false, 4, KU>(g, nullptr);
+    gemm_tile<64, 64, 256 * KS, false, BKM, 2, false, false, KS, false, true, KU>(g, nullptr);
 }
 template <int KS, int KU>
 __global__ __launch_bounds__(256 * KS, 1) void gemm_gate_bwd_x3su_kernel(const Group g, const GateArgs ga) {
-    gemm_tile<64, 64, 256 * KS, false, true, 2, false, true, KS, false, true, false, 4, KU>(g, &ga);
-}
-
-// B fragments straight from the weight's pre-split planes (gemm_mainloop_x3f)
-template <bool BKM, int KS, int KU>
-__global__ __launch_bounds__(256 * KS, (KS == 2 && KU == 2) ? 1 : 2) void gemm_x3f_kernel(const Group g) {
-    gemm_tile<64, 64, 256 * KS, false, BKM, 2, false, false, KS, false, true, false, 4, KU, true>(g, nullptr);
-}
-template <int KS, int KU>
-__global__ __launch_bounds__(256 * KS, 1) void gemm_gate_bwd_x3f_kernel(const Group g, const GateArgs ga) {
-    gemm_tile<64, 64, 256 * KS, false, true, 2, false, true, KS, false, true, false, 4, KU, true>(g, &ga);
-}
-
-// the same with B pre-split (planes) and both operands by LDS-DMA (gemm_mainloop_x3d)
-template <bool BKM, int KS>
-__global__ __launch_bounds__(256 * KS, KS == 2 ? 2 : 2) void gemm_x3d_kernel(const Group g) {
-    gemm_tile<64, 64, 256 * KS, false, BKM, 2, false, false, KS, false, true, true>(g, nullptr);
-}
-template <int KS>
-__global__ __launch_bounds__(256 * KS, 2) void gemm_gate_bwd_x3d_kernel(const Group g, const GateArgs ga) {
-    gemm_tile<64, 64, 256 * KS, false, true, 2, false, true, KS, false, true, true>(g, &ga);
+    gemm_tile<64, 64, 256 * KS, false, true, 2, false, true, KS, false, true, KU>(g, &ga);
 }
 
 // 64x64 class, A row-major, B k-major (dX = dY W): the only form the recurrent backward chains use
@@ -1606,22 +1256,17 @@ struct GruFwdProb {
     const float* u;               // segment gate per row or nullptr
     int u_ld_outer, u_ld_inner;
     int K2, rows, has_prev, rt_start, inner;
-    const char* bp; const char* bp2;   // planes (RM image) of B and B2, or nullptr (see Prob)
-    uint32_t bp_ps, bp_ld, bp2_ps, bp2_ld;
 };
 struct GruFwdGroup {
     GruFwdProb p[MAXP];
     int n, tiles_n, hidden;
 };
 
-template <int D, int KS, bool X3 = false, bool BP = false>
+template <int D, int KS, bool X3 = false>
 __global__ __launch_bounds__(256 * KS, 1) void gemm_gru_fwd_kernel(const GruFwdGroup g) {
     constexpr int BM = 64, BN = 192, NT = 256 * KS, TM = 1, TN = 3;
-    constexpr int NS = 3;   // BP: ring slots of the all-DMA loop (gemm_mainloop_x3d): 24 KB of A planes + 3 x 44 KB = 156 KB
     // X3 (bf16 x 3 on the bf16 matrix cores, see gemm_mainloop_x3s): two stages of three bf16 planes of both operand tiles
-    constexpr int BP_BYTES = x3d_g3_bytes<BP, KS, NS>();
-    __shared__ __attribute__((aligned(16))) float smem[BP ? BP_BYTES / 4
-                                                       : X3 ? 2 * 3 * (BM + BN) * (16 * KS) * 2 / 4 : 2 * (BM + BN) * (BK + 4)];
+    __shared__ __attribute__((aligned(16))) float smem[X3 ? 2 * 3 * (BM + BN) * (16 * KS) * 2 / 4 : 2 * (BM + BN) * (BK + 4)];
     const int ut = blockIdx.x % g.tiles_n, rt = blockIdx.x / g.tiles_n;
     int pi = 0;
 #pragma unroll 1
@@ -1664,16 +1309,14 @@ __global__ __launch_bounds__(256 * KS, 1) void gemm_gru_fwd_kernel(const GruFwdG
         }
     }
 
-    if constexpr (BP) gemm_mainloop_x3d<BN, NT, false, KS, TN, true, NS, false>(P.A, P.bp, P.bp_ps, P.bp_ld, M, H, m0, n0, 0, H, smem, acc);
-    else if constexpr (X3) gemm_mainloop_x3s<BM, BN, NT, false, KS, TN, true, 2, false>(P.A, P.B, M, H, m0, n0, 0, H, smem, acc);
+    if constexpr (X3) gemm_mainloop_x3s<BM, BN, NT, false, KS, TN, true, 2, false>(P.A, P.B, M, H, m0, n0, 0, H, smem, acc);
     else gemm_mainloop<BM, BN, NT, false, false, true, TM, TN, D, false, KS, true>(P.A, P.B, M, H, 1, 1, m0, n0, 0, H, smem, acc);
     f32x16 hn = acc[0][2];
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[0][2][r] = 0.f;
     if (P.K2 > 0) {   // uniform per workgroup: the message columns of W_ih; their n block stays on the input side of the gate
         __syncthreads();   // every wave is done with the operand tiles of the first product
-        if constexpr (BP) gemm_mainloop_x3d<BN, NT, false, KS, TN, true, NS, false>(P.A2, P.bp2, P.bp2_ps, P.bp2_ld, M, H, m0, n0, 0, P.K2, smem, acc);
-        else if constexpr (X3) gemm_mainloop_x3s<BM, BN, NT, false, KS, TN, true, 2, false>(P.A2, P.B2, M, H, m0, n0, 0, P.K2, smem, acc);
+        if constexpr (X3) gemm_mainloop_x3s<BM, BN, NT, false, KS, TN, true, 2, false>(P.A2, P.B2, M, H, m0, n0, 0, P.K2, smem, acc);
         else gemm_mainloop<BM, BN, NT, false, false, true, TM, TN, D, false, KS, true>(P.A2, P.B2, M, H, 1, 1, m0, n0, 0, P.K2, smem, acc);
     }
     if constexpr (KS == 2) {
@@ -1871,47 +1514,8 @@ extern "C" int twog_gemm_last_class(void) { return g_last_class; }
 
 // Builds the launch descriptor of one chunk (<= MAXP problems): tile class, class-sorted problem list (order[i] = index of
 // the caller's problem that became sorted problem i), XCD map, split-K. Shared by the plain and the gate-fused launch.
-static inline int pad128i(int v) { return (v + 127) / 128 * 128; }
-
-// Looks the B operand of a problem up in the caller's planes directory (include/twog_gcn.h, twog_weight_planes_build): B may
-// be a listed weight or a row / column block of one. Fills the operand's view of the image; false = split B in the kernel.
-static bool resolve_planes(const twog_wplanes_dir_t* dir, const twog_rows_t& B, int N, int K, int b_kmajor, int batch, Prob& P) {
-    P.bp = nullptr;
-    P.bp_ps = P.bp_ld = 0;
-    static const int on = getenv("TWOG_GEMM_BPLANES") ? atoi(getenv("TWOG_GEMM_BPLANES")) : 1;
-    if (!on || !dir || !dir->e || dir->n <= 0 || B.inner > 1 || batch > 1 || (K % 16)) return false;
-    const int vrows = b_kmajor ? K : N, vcols = b_kmajor ? N : K;
-    for (int i = 0; i < dir->n; ++i) {
-        const twog_wplanes_t& e = dir->e[i];
-        if (!e.w || B.ptr < e.w || e.ld != B.ld_outer) continue;
-        const int64_t off = B.ptr - e.w;
-        if (off >= (int64_t)e.rows * e.ld) continue;
-        const int64_t r0 = off / e.ld, c0 = off % e.ld;
-        if (r0 + vrows > e.rows || c0 + vcols > e.cols) continue;
-        const int over = (N + 63) / 64 * 64;   // columns a 64-wide tile may touch
-        if (!b_kmajor) {
-            const int64_t rp = pad128i(e.rows), nkt = e.cols / 16;
-            if (!e.rm || (e.cols % 16) || (c0 % 16) || (r0 % 32) || r0 + over > rp) return false;
-            if ((uint64_t)3 * nkt * rp * 32 >= (uint64_t(1) << 32)) return false;
-            P.bp = reinterpret_cast<const char*>(e.rm) + ((c0 / 16) * rp + r0) * 32;
-            P.bp_ps = (uint32_t)(nkt * rp * 32);
-            P.bp_ld = (uint32_t)(rp * 32);
-        } else {   // KF: [3][rows / 16][cols_pad / 32][64 lanes][16 bytes]
-            const int64_t cp = pad128i(e.cols), nb = cp / 32;
-            if (!e.kf || (e.rows % 16) || (r0 % 16) || (c0 % 32) || c0 + over > cp) return false;
-            if ((uint64_t)3 * e.rows * cp * 2 >= (uint64_t(1) << 32)) return false;
-            P.bp = reinterpret_cast<const char*>(e.kf) + ((r0 / 16) * nb + c0 / 32) * 1024;
-            P.bp_ps = (uint32_t)((int64_t)(e.rows / 16) * nb * 1024);
-            P.bp_ld = (uint32_t)(nb * 1024);
-        }
-        return true;
-    }
-    return false;
-}
-
 static void prepare_group(const twog_gemm_t* pr, int n, int a_kmajor, int b_kmajor, void* workspace,
-                          size_t workspace_bytes, Group& g, int* order, bool& big, int& bm,
-                          const twog_wplanes_dir_t* planes = nullptr) {
+                          size_t workspace_bytes, Group& g, int* order, bool& big, int& bm) {
     // tile choice: 128x128 tiles (4 MFMA tiles per wave, half the LDS traffic per FLOP) whenever the problems are
     // at least one tile wide and -- possibly with split-K -- still fill the chip; 64x64 for the skinny ones.
     int64_t tiles128 = 0;
@@ -1977,7 +1581,6 @@ static void prepare_group(const twog_gemm_t* pr, int n, int a_kmajor, int b_kmaj
         t += ntiles;
         P.a_vec = vec_ok(P.A, q.a_batch_stride, a_kmajor ? P.M : P.K, a_kmajor ? P.K : P.M);
         P.b_vec = vec_ok(P.B, q.b_batch_stride, b_kmajor ? P.N : P.K, b_kmajor ? P.K : P.N);
-        resolve_planes(planes, P.B, P.N, P.K, b_kmajor, P.batch, P);
     }
     for (int c = 0, rot = 0; c < g.n_cls; ++c) {
         g.cls_rot[c] = rot & 7;
@@ -2064,19 +1667,6 @@ static int x3s_ku(const Group& g, int depth) {
     return ku;
 }
 
-// every problem of the launch has its B planes: the all-DMA kernels (gemm_mainloop_x3d) can serve it
-static bool all_planes(const Group& g) {
-    for (int i = 0; i < g.n; ++i)
-        if (!g.p[i].bp) return false;
-    return g.n > 0;
-}
-// x3d tiles: 8 waves with the k-split inside the workgroup (104 KB of LDS: one workgroup per CU) while every tile gets a CU of
-// its own, 4-wave tiles (52 KB) beyond that
-static int x3d_ks2_max() {
-    static const int v = getenv("TWOG_X3D_KS2_MAX") ? atoi(getenv("TWOG_X3D_KS2_MAX")) : 384;   // = the k-split class of the register-staged kernels: same arithmetic order
-    return v;
-}
-
 // Split of the reduction over workgroups for a chain launch (XS kernels). Model: a k-tile of one tile costs `unit` us of
 // fp32 MFMA on a CU (64x64: 16 x 64-cycle MFMAs per SIMD = 0.49 us at the ~2.1 GHz the part sustains; 32x64: half), the
 // workgroups of a launch are dealt over 256 CUs, a CU works its workgroups off one after the other, and a launch with
@@ -2136,19 +1726,11 @@ static bool try_xsplit(Group& g, int bm, int kmax, void* chain_ws, size_t chain_
 }
 
 static int gemm_impl(const twog_gemm_t* problems, int n_problems, int a_kmajor, int b_kmajor, void* workspace,
-                     size_t workspace_bytes, void* chain_ws, size_t chain_ws_bytes, const twog_wplanes_dir_t* planes, void* stream);
+                     size_t workspace_bytes, void* chain_ws, size_t chain_ws_bytes, void* stream);
 
 extern "C" int twog_gemm_f32(const twog_gemm_t* problems, int n_problems, int a_kmajor, int b_kmajor, void* workspace,
                              size_t workspace_bytes, void* stream) {
-    return gemm_impl(problems, n_problems, a_kmajor, b_kmajor, workspace, workspace_bytes, nullptr, 0, nullptr, stream);
-}
-extern "C" int twog_gemm_f32_p(const twog_gemm_t* problems, int n_problems, int a_kmajor, int b_kmajor, void* workspace,
-                               size_t workspace_bytes, const twog_wplanes_dir_t* planes, void* stream) {
-    return gemm_impl(problems, n_problems, a_kmajor, b_kmajor, workspace, workspace_bytes, nullptr, 0, planes, stream);
-}
-extern "C" int twog_gemm_f32_chain_p(const twog_gemm_t* problems, int n_problems, int a_kmajor, int b_kmajor, void* chain_ws,
-                                     size_t chain_ws_bytes, const twog_wplanes_dir_t* planes, void* stream) {
-    return gemm_impl(problems, n_problems, a_kmajor, b_kmajor, nullptr, 0, chain_ws, chain_ws_bytes, planes, stream);
+    return gemm_impl(problems, n_problems, a_kmajor, b_kmajor, workspace, workspace_bytes, nullptr, 0, stream);
 }
 
 // The launches of a recurrent chain (few tiles, K = h ... 3h, each dependent on the previous one): `chain_ws` (>= 16 KB
@@ -2156,7 +1738,7 @@ extern "C" int twog_gemm_f32_chain_p(const twog_gemm_t* problems, int n_problems
 // twog_chain_workspace_bytes) lets the library split the reduction over workgroups and combine it inside the launch.
 extern "C" int twog_gemm_f32_chain(const twog_gemm_t* problems, int n_problems, int a_kmajor, int b_kmajor, void* chain_ws,
                                    size_t chain_ws_bytes, void* stream) {
-    return gemm_impl(problems, n_problems, a_kmajor, b_kmajor, nullptr, 0, chain_ws, chain_ws_bytes, nullptr, stream);
+    return gemm_impl(problems, n_problems, a_kmajor, b_kmajor, nullptr, 0, chain_ws, chain_ws_bytes, stream);
 }
 
 extern "C" size_t twog_chain_workspace_bytes(void) {
@@ -2164,7 +1746,7 @@ extern "C" size_t twog_chain_workspace_bytes(void) {
 }
 
 static int gemm_impl(const twog_gemm_t* problems, int n_problems, int a_kmajor, int b_kmajor, void* workspace,
-                     size_t workspace_bytes, void* chain_ws, size_t chain_ws_bytes, const twog_wplanes_dir_t* planes, void* stream) {
+                     size_t workspace_bytes, void* chain_ws, size_t chain_ws_bytes, void* stream) {
     if (n_problems <= 0) return 0;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     int done = 0;
@@ -2175,7 +1757,7 @@ static int gemm_impl(const twog_gemm_t* problems, int n_problems, int a_kmajor, 
         int order[MAXP];
         bool big;
         int bm;
-        prepare_group(pr, n, a_kmajor, b_kmajor, workspace, workspace_bytes, g, order, big, bm, planes);
+        prepare_group(pr, n, a_kmajor, b_kmajor, workspace, workspace_bytes, g, order, big, bm);
         static const int depth = getenv("TWOG_GEMM_DEPTH") ? atoi(getenv("TWOG_GEMM_DEPTH")) : 0;  // tuning knob
         const int d128 = depth ? (depth & 3) : 2, d64 = depth ? ((depth >> 2) & 3) : 2;
         int rc;
@@ -2222,14 +1804,7 @@ static int gemm_impl(const twog_gemm_t* problems, int n_problems, int a_kmajor, 
                 continue;
             }
             dim3 grid(g.total_tiles, 1), block(512);
-            if (x3s_ok(g, a_kmajor, 32) && all_planes(g)) {   // B fragments from the weights' planes (gemm_mainloop_x3f)
-                g_last_class |= TWOG_GEMM_CLASS_X3 | TWOG_GEMM_CLASS_BPLANES;
-                if (x3s_ku(g, 64) == 2) {
-                    if (b_kmajor) hipLaunchKernelGGL((gemm_x3f_kernel<true, 2, 2>), grid, block, 0, st, g);
-                    else hipLaunchKernelGGL((gemm_x3f_kernel<false, 2, 2>), grid, block, 0, st, g);
-                } else if (b_kmajor) hipLaunchKernelGGL((gemm_x3f_kernel<true, 2, 1>), grid, block, 0, st, g);
-                else hipLaunchKernelGGL((gemm_x3f_kernel<false, 2, 1>), grid, block, 0, st, g);
-            } else if (x3s_ok(g, a_kmajor, 32)) {
+            if (x3s_ok(g, a_kmajor, 32)) {
                 g_last_class |= TWOG_GEMM_CLASS_X3;
                 if (g.total_tiles <= 256 && x3s_ku(g, 64) == 2) {
                     if (b_kmajor) hipLaunchKernelGGL((gemm_x3su_kernel<true, 2, 2>), grid, block, 0, st, g);
@@ -2248,14 +1823,7 @@ static int gemm_impl(const twog_gemm_t* problems, int n_problems, int a_kmajor, 
         else if (!big && x3s_ok(g, a_kmajor, 16)) {
             g_last_class |= TWOG_GEMM_CLASS_X3;
             dim3 grid(g.total_tiles, 1), block(256);
-            if (all_planes(g)) {
-                g_last_class |= TWOG_GEMM_CLASS_BPLANES;
-                if (x3s_ku(g, 32) == 2) {
-                    if (b_kmajor) hipLaunchKernelGGL((gemm_x3f_kernel<true, 1, 2>), grid, block, 0, st, g);
-                    else hipLaunchKernelGGL((gemm_x3f_kernel<false, 1, 2>), grid, block, 0, st, g);
-                } else if (b_kmajor) hipLaunchKernelGGL((gemm_x3f_kernel<true, 1, 1>), grid, block, 0, st, g);
-                else hipLaunchKernelGGL((gemm_x3f_kernel<false, 1, 1>), grid, block, 0, st, g);
-            } else if (x3s_ku(g, 32) == 2) {
+            if (x3s_ku(g, 32) == 2) {
                 if (b_kmajor) hipLaunchKernelGGL((gemm_x3su_kernel<true, 1, 2>), grid, block, 0, st, g);
                 else hipLaunchKernelGGL((gemm_x3su_kernel<false, 1, 2>), grid, block, 0, st, g);
             } else if (b_kmajor) hipLaunchKernelGGL((gemm_x3s_kernel<true, 1>), grid, block, 0, st, g);
@@ -2277,13 +1845,13 @@ static int gemm_impl(const twog_gemm_t* problems, int n_problems, int a_kmajor, 
 // buffer; the gate's dh2 is taken from the accumulators, not from memory). Returns 1 without launching when this chunk
 // is not served by the fused kernel (tile class, grouped rows, too many partial slots) -- dry_run only asks that.
 int twog_internal_gemm_gate_bwd(const twog_gemm_t* pr, int n, const twog_gru_step_bwd_t* gates, float* const* du_part,
-                                int dry_run, void* chain_ws, size_t chain_ws_bytes, void* stream, const twog_wplanes_dir_t* planes) {
+                                int dry_run, void* chain_ws, size_t chain_ws_bytes, void* stream) {
     if (n <= 0 || n > MAXP) return 1;
     Group g;
     int order[MAXP];
     bool big;
     int bm;
-    prepare_group(pr, n, 0, 1, nullptr, 0, g, order, big, bm, planes);
+    prepare_group(pr, n, 0, 1, nullptr, 0, g, order, big, bm);
     if (big || g.splitk != 1) return 1;
     auto span31 = [](const twog_rows_t& m, int rows, int64_t width) {  // largest element offset fits 31 bits
         const int inner = m.inner > 1 ? m.inner : 1;
@@ -2346,11 +1914,7 @@ int twog_internal_gemm_gate_bwd(const twog_gemm_t* pr, int n, const twog_gru_ste
             TWOG_CHECK_LAUNCH();
             return 0;
         }
-        if (x3s_ok(g, 0, 32) && all_planes(g)) {
-            g_last_class |= TWOG_GEMM_CLASS_X3 | TWOG_GEMM_CLASS_BPLANES;
-            if (x3s_ku(g, 64) == 2) hipLaunchKernelGGL((gemm_gate_bwd_x3f_kernel<2, 2>), grid, dim3(512), 0, (hipStream_t)stream, g, ga);
-            else hipLaunchKernelGGL((gemm_gate_bwd_x3f_kernel<2, 1>), grid, dim3(512), 0, (hipStream_t)stream, g, ga);
-        } else if (x3s_ok(g, 0, 32)) {
+        if (x3s_ok(g, 0, 32)) {
             g_last_class |= TWOG_GEMM_CLASS_X3;
             if (g.total_tiles <= 256 && x3s_ku(g, 64) == 2) hipLaunchKernelGGL((gemm_gate_bwd_x3su_kernel<2, 2>), grid, dim3(512), 0, (hipStream_t)stream, g, ga);
             else hipLaunchKernelGGL(gemm_gate_bwd_x3s_kernel<2>, grid, dim3(512), 0, (hipStream_t)stream, g, ga);
@@ -2359,10 +1923,7 @@ int twog_internal_gemm_gate_bwd(const twog_gemm_t* pr, int n, const twog_gru_ste
         TWOG_CHECK_LAUNCH();
         return 0;
     }
-    if (x3s_ok(g, 0, 16) && all_planes(g)) {
-        g_last_class |= TWOG_GEMM_CLASS_X3 | TWOG_GEMM_CLASS_BPLANES;
-        hipLaunchKernelGGL((gemm_gate_bwd_x3f_kernel<1, 1>), grid, block, 0, (hipStream_t)stream, g, ga);
-    } else if (x3s_ok(g, 0, 16)) {
+    if (x3s_ok(g, 0, 16)) {
         g_last_class |= TWOG_GEMM_CLASS_X3;
         hipLaunchKernelGGL(gemm_gate_bwd_x3s_kernel<1>, grid, block, 0, (hipStream_t)stream, g, ga);
     } else if (d64 == 2) hipLaunchKernelGGL(gemm_gate_bwd_kernel<2>, grid, block, 0, (hipStream_t)stream, g, ga);
@@ -2382,7 +1943,7 @@ int twog_internal_gru_fwd_mode(void) {
 }
 
 int twog_internal_gemm_gru_fwd(const twog_gemm_t* gh, const twog_gemm_t* gim, const twog_gru_step_t* st, int n,
-                               int dry_run, void* stream, const twog_wplanes_dir_t* planes) {
+                               int dry_run, void* stream) {
     // TWOG_GRU_FWD_FUSION: bit 0 = chains without message products (frame-level BiGRU), bit 1 = with (segment level),
     // bit 2 = always (skip the cost model below). Default 3: both levels, each launch decided by the model.
     const int mode = twog_internal_gru_fwd_mode();   // read per call: tests switch it inside one process
@@ -2430,16 +1991,6 @@ int twog_internal_gemm_gru_fwd(const twog_gemm_t* gh, const twog_gemm_t* gim, co
         P.u_ld_outer = (int)S.u_ld_outer; P.u_ld_inner = (int)S.u_ld_inner;
         P.rows = S.rows; P.has_prev = S.h_prev.ptr ? 1 : 0; P.rt_start = rt; P.inner = inner;
         rt += (S.rows + 63) / 64;
-        // planes of both weights (the gate-aware tile reads 32-row blocks of the three gate thirds: whole 64-unit tiles only)
-        Prob tmp;
-        P.bp = P.bp2 = nullptr; P.bp_ps = P.bp_ld = P.bp2_ps = P.bp2_ld = 0;
-        if (planes && (h % 64) == 0 && resolve_planes(planes, q.B, 3 * h, h, 0, 1, tmp)) {
-            P.bp = tmp.bp; P.bp_ps = tmp.bp_ps; P.bp_ld = tmp.bp_ld;
-            if (m2) {
-                if (resolve_planes(planes, gim[i].B, 3 * h, gim[i].K, 0, 1, tmp)) { P.bp2 = tmp.bp; P.bp2_ps = tmp.bp_ps; P.bp2_ld = tmp.bp_ld; }
-                else P.bp = nullptr;
-            }
-        }
     }
     if (!(mode & 4)) {
         // Cost model (us of fp32 MFMA work per CU at 614 GFLOP/s, tiles dealt in rounds over 256 CUs; measured at BASELINE
@@ -2464,12 +2015,7 @@ int twog_internal_gemm_gru_fwd(const twog_gemm_t* gh, const twog_gemm_t* gim, co
                              (getenv("TWOG_GEMM_X3G") ? atoi(getenv("TWOG_GEMM_X3G")) : 1);
     bool x3 = x3_on && ksplit == 2 && h >= 256 && h % 32 == 0;   // whole 32-deep k-tiles of both products
     for (int i = 0; i < n; ++i) x3 = x3 && g.p[i].K2 % 32 == 0;
-    bool bpl = x3;
-    for (int i = 0; i < n; ++i) bpl = bpl && g.p[i].bp != nullptr;
-    if (bpl) {
-        g_last_class |= TWOG_GEMM_CLASS_X3 | TWOG_GEMM_CLASS_BPLANES;
-        hipLaunchKernelGGL((gemm_gru_fwd_kernel<2, 2, true, true>), dim3(rt * g.tiles_n), dim3(512), 0, (hipStream_t)stream, g);
-    } else if (x3) {
+    if (x3) {
         g_last_class |= TWOG_GEMM_CLASS_X3;
         hipLaunchKernelGGL((gemm_gru_fwd_kernel<2, 2, true>), dim3(rt * g.tiles_n), dim3(512), 0, (hipStream_t)stream, g);
     } else if (ksplit == 2) hipLaunchKernelGGL((gemm_gru_fwd_kernel<2, 2>), dim3(rt * g.tiles_n), dim3(512), 0, (hipStream_t)stream, g);

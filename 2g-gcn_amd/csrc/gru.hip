@@ -215,11 +215,10 @@ static int bigru_fwd_impl(const twog_bigru_t* types, int n_types, int bs, int T,
         }
         // one launch: the W_hh products on gate-aware tiles with the gate math in the epilogue (gemm_f32.hip); shapes it
         // does not serve (hidden size not a multiple of the k-tile) take the GEMM + gate kernel pair
-        const twog_wplanes_dir_t* planes = n_types > 0 ? types[0].planes : nullptr;
-        int rc = twog_internal_gemm_gru_fwd(gm, nullptr, st, n, 0, stream, planes);
+        int rc = twog_internal_gemm_gru_fwd(gm, nullptr, st, n, 0, stream);
         if (rc < 0) return rc;
         if (rc == 0) continue;
-        rc = twog_gemm_f32_chain_p(gm, n, 0, 0, chain_ws, chain_ws_bytes, planes, stream);
+        rc = twog_gemm_f32_chain(gm, n, 0, 0, chain_ws, chain_ws_bytes, stream);
         if (rc) return rc;
         rc = twog_gru_step_fwd(st, n, stream);
         if (rc) return rc;
@@ -274,7 +273,6 @@ static int bigru_bwd_impl(const twog_bigru_bwd_t* types, int n_types, int bs, in
     // The carry GEMM of step s is the only writer of the carried gradient, so the gate backward of step s-1 runs in its
     // epilogue (gemm_f32.hip, GateArgs) instead of in a launch of its own; the first step has no GEMM before it.
     bool fuse = T > 1 && (h + 63) / 64 <= 8 && getenv("TWOG_NO_GATE_FUSION") == nullptr;
-    const twog_wplanes_dir_t* planes = n_types > 0 ? types[0].planes : nullptr;
     for (int s = T - 1; s >= 0; --s) {
         twog_gemm_t gm[8];
         twog_gru_step_bwd_t st[8], nxt[8];
@@ -288,14 +286,14 @@ static int bigru_bwd_impl(const twog_bigru_bwd_t* types, int n_types, int bs, in
             rc = 1;
             if (fuse) {
                 make_step(s - 1, nxt, nullptr);
-                rc = twog_internal_gemm_gate_bwd(gm, n, nxt, nullptr, 0, chain_ws, chain_ws_bytes, stream, planes);
+                rc = twog_internal_gemm_gate_bwd(gm, n, nxt, nullptr, 0, chain_ws, chain_ws_bytes, stream);
                 if (rc < 0) return rc;
                 if (rc == 1) {  // shape not served by the fused kernel: decided at the first step
                     if (s != T - 1) return -120;
                     fuse = false;
                 }
             }
-            if (rc == 1) rc = twog_gemm_f32_chain_p(gm, n, 0, 1, chain_ws, chain_ws_bytes, planes, stream);
+            if (rc == 1) rc = twog_gemm_f32_chain(gm, n, 0, 1, chain_ws, chain_ws_bytes, stream);
             if (rc) return rc;
         }
     }

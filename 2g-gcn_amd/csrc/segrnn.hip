@@ -111,7 +111,7 @@ static int segrnn_fwd_impl(const twog_segrnn_t* desc, void* chain_ws, size_t cha
                              d.bs * d.O, d.nso * h, h, 1, 0);
                 }
             }
-            rc = twog_gemm_f32_chain_p(gm, n, 0, 0, chain_ws, chain_ws_bytes, S.planes, stream);
+            rc = twog_gemm_f32_chain(gm, n, 0, 0, chain_ws, chain_ws_bytes, stream);
             if (rc) return rc;
             // (2) attention + weighted sums
             twog_attn_t at[2];
@@ -166,10 +166,10 @@ static int segrnn_fwd_impl(const twog_segrnn_t* desc, void* chain_ws, size_t cha
             }
         }
         // both products and the gates in one launch where the shapes allow it (gemm_gru_fwd_kernel, gemm_f32.hip)
-        rc = twog_internal_gemm_gru_fwd(ghp, gimp, st, ns, 0, stream, S.planes);
+        rc = twog_internal_gemm_gru_fwd(ghp, gimp, st, ns, 0, stream);
         if (rc < 0) return rc;
         if (rc == 0) continue;
-        rc = twog_gemm_f32_chain_p(gm, n, 0, 0, chain_ws, chain_ws_bytes, S.planes, stream);
+        rc = twog_gemm_f32_chain(gm, n, 0, 0, chain_ws, chain_ws_bytes, stream);
         if (rc) return rc;
         rc = twog_gru_step_fwd(st, ns, stream);
         if (rc) return rc;
@@ -288,14 +288,14 @@ static int segrnn_bwd_impl(const twog_segrnn_t* desc, const twog_segrnn_bwd_t* b
         if (n) {
             rc = 1;
             if (fuse && fuse_b && !first) {  // problems are exactly the four W_hh GEMMs, in (dir, kind) order
-                rc = twog_internal_gemm_gate_bwd(gm, n, nxt, nxt_part, 0, chain_ws, chain_ws_bytes, stream, S.planes);
+                rc = twog_internal_gemm_gate_bwd(gm, n, nxt, nxt_part, 0, chain_ws, chain_ws_bytes, stream);
                 if (rc < 0) return rc;
                 if (rc == 1) {  // shape not served by the fused kernel: decided at the first step, cannot change later
                     if (s != T - 1) return -120;
                     fuse = false;
                 }
             }
-            if (rc == 1) rc = twog_gemm_f32_chain_p(gm, n, 0, 1, chain_ws, chain_ws_bytes, S.planes, stream);
+            if (rc == 1) rc = twog_gemm_f32_chain(gm, n, 0, 1, chain_ws, chain_ws_bytes, stream);
             if (rc) return rc;
         }
         if (!msg) continue;
@@ -347,14 +347,14 @@ static int segrnn_bwd_impl(const twog_segrnn_t* desc, const twog_segrnn_bwd_t* b
         }
         rc = 1;
         if (fuse && fuse_e) {  // problems are exactly (dir, kind) = the order of make_gates
-            rc = twog_internal_gemm_gate_bwd(gm, n, nxt, nxt_part, 0, chain_ws, chain_ws_bytes, stream, S.planes);
+            rc = twog_internal_gemm_gate_bwd(gm, n, nxt, nxt_part, 0, chain_ws, chain_ws_bytes, stream);
             if (rc < 0) return rc;
             if (rc == 1) {
                 if (s != T - 1) return -122;
                 fuse = false;
             }
         }
-        if (rc == 1) rc = twog_gemm_f32_chain_p(gm, n, 0, 1, chain_ws, chain_ws_bytes, S.planes, stream);
+        if (rc == 1) rc = twog_gemm_f32_chain(gm, n, 0, 1, chain_ws, chain_ws_bytes, stream);
         if (rc) return rc;
     }
     if (fuse) {

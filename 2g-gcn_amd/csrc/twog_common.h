@@ -28,12 +28,11 @@ inline void twog_allow_dynamic_lds(K kernel, int bytes, std::atomic<uint32_t>& d
 // library-internal (gemm_f32.hip): grouped C += A B launch whose epilogue runs the GRU gate backward of the next chain step
 // chain_ws / chain_ws_bytes: the chain workspace of twog_gemm_f32_chain (NULL: the reduction is never split over workgroups)
 int twog_internal_gemm_gate_bwd(const twog_gemm_t* problems, int n, const twog_gru_step_bwd_t* gates,
-                                float* const* du_part, int dry_run, void* chain_ws, size_t chain_ws_bytes, void* stream,
-                                const twog_wplanes_dir_t* planes = nullptr);
+                                float* const* du_part, int dry_run, void* chain_ws, size_t chain_ws_bytes, void* stream);
 
 // library-internal (gemm_f32.hip): one launch for the W_hh (and message) products of a forward chain step AND its gates
 int twog_internal_gemm_gru_fwd(const twog_gemm_t* gh, const twog_gemm_t* gim, const twog_gru_step_t* steps, int n,
-                               int dry_run, void* stream, const twog_wplanes_dir_t* planes = nullptr);
+                               int dry_run, void* stream);
 
 int twog_internal_gru_fwd_mode(void);   // TWOG_GRU_FWD_FUSION (part of the chains' hipGraph keys: it changes what is captured)
 

@@ -62,26 +62,6 @@ def n_rows(t):
     return t.shape[0] if t.dim() == 2 else t.shape[0] * t.shape[1]
 
 
-class PlanesDir:
-    """A twog_wplanes_dir_t for the library: the weights a caller holds pre-split planes for (include/twog_gcn.h)."""
-
-    def __init__(self, entries):
-        # entries: (w, rm, km[, kf]) -- images of twog_weight_planes_build, None where absent
-        self.entries = [tuple(e) + (None,) * (4 - len(e)) for e in entries]
-        self.entries = [e for e in self.entries if any(x is not None for x in e[1:])]
-        n = len(self.entries)
-        self._arr = (L.WPlanes * max(n, 1))()
-        for a, (w, rm, km, kf) in zip(self._arr, self.entries):
-            assert w.dim() == 2 and w.stride(1) == 1
-            a.w, a.rows, a.cols, a.ld = w.data_ptr(), w.shape[0], w.shape[1], w.stride(0)
-            a.rm, a.km, a.kf = _ptr(rm), _ptr(km), _ptr(kf)
-        self._dir = L.WPlanesDir(self._arr, n, 0)
-        self.ptr = C.addressof(self._dir)
-
-    def __len__(self):
-        return len(self.entries)
-
-
 class HipKernels:
     """The product backend. `tests/fake_kernels.py` implements the same methods in plain torch for CPU-side tests of
     the host logic; it is never reachable from this package."""
@@ -180,35 +160,8 @@ class HipKernels:
     def version(self):
         return self.lib.twog_version().decode()
 
-    # ---------------------------------------------------------------- pre-split weights (planes)
-    supports_planes = True
-    PLANES_RM, PLANES_KM, PLANES_KF = L.PLANES_RM, L.PLANES_KM, L.PLANES_KF
-
-    def weight_planes(self, w, kind, out=None):
-        """The three exact bf16 planes of the fp32 matrix `w` (2-D, unit column stride) in the image `kind` (PLANES_RM: for
-        launches that read w as B row-major; PLANES_KM: as B k-major), or None when the shape is not served
-        (include/twog_gcn.h, twog_weight_planes_build). Returns a uint8 tensor owning the image; `out` (a tensor this
-        method returned for the same shape and kind) is rewritten in place."""
-        assert w.dim() == 2 and w.stride(1) == 1 and w.dtype == torch.float32
-        rows, cols, ld = w.shape[0], w.shape[1], w.stride(0)
-        nbytes = int(self.lib.twog_weight_planes_bytes(rows, cols, kind))
-        if nbytes == 0 or w.data_ptr() % 16 or ld % 4:
-            return None
-        if out is None or out.numel() != nbytes or out.device != w.device:
-            out = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
-        rc = self.lib.twog_weight_planes_build(w.data_ptr(), rows, cols, ld, kind, out.data_ptr(), self._stream())
-        if rc == -2:
-            return None
-        self._check(rc, 'twog_weight_planes_build')
-        return out
-
-    def planes_dir(self, entries):
-        """entries: list of (w, rm or None, km or None) -> a PlanesDir whose `.ptr` is what the library takes as
-        `const twog_wplanes_dir_t*` (the object owns the ctypes arrays and keeps the tensors alive)."""
-        return PlanesDir(entries)
-
     # ---------------------------------------------------------------- GEMM
-    def gemm(self, problems, a_kmajor=False, b_kmajor=False, split_k_workspace=True, chain=False, planes=None):
+    def gemm(self, problems, a_kmajor=False, b_kmajor=False, split_k_workspace=True, chain=False):
         """problems: list of dicts with keys A, B, C (row-strided views), bias (1-D or None), act (0/1), accumulate.
         Logical shapes: A (M,K) [or stored (K,M) if a_kmajor], B (N,K) [or (K,N) if b_kmajor], C (M,N).
         Optional 'batch': (n, a_stride, b_stride, c_stride) in elements. chain=True: a launch of a recurrent chain
@@ -246,23 +199,20 @@ class HipKernels:
                 g.batch, g.a_batch_stride, g.b_batch_stride, g.c_batch_stride = 1, 0, 0, 0
             else:
                 g.batch, g.a_batch_stride, g.b_batch_stride, g.c_batch_stride = b
-        pdir = planes.ptr if planes is not None else None
         if chain:
-            rc = self.lib.twog_gemm_f32_chain_p(arr, n, int(a_kmajor), int(b_kmajor), *self.chain_workspace(dev), pdir,
-                                                self._stream())
+            rc = self.lib.twog_gemm_f32_chain(arr, n, int(a_kmajor), int(b_kmajor), *self.chain_workspace(dev), self._stream())
             self._check(rc, 'twog_gemm_f32_chain')
             return
         ws_ptr, ws_bytes = 0, 0
         if split_k_workspace:
             ws = self.workspace(320 << 20, dev, 'splitk')
             ws_ptr, ws_bytes = ws.data_ptr(), ws.numel() * 4
-        rc = self.lib.twog_gemm_f32_p(arr, n, int(a_kmajor), int(b_kmajor), ws_ptr, ws_bytes, pdir, self._stream())
+        rc = self.lib.twog_gemm_f32(arr, n, int(a_kmajor), int(b_kmajor), ws_ptr, ws_bytes, self._stream())
         self._check(rc, 'twog_gemm_f32')
 
     GEMM_TILE128, GEMM_WAVES8, GEMM_KG, GEMM_SPLITK, GEMM_GATE, GEMM_KSPLIT, GEMM_GRUFWD, GEMM_ROWS32 = 1, 2, 4, 8, 16, 32, 64, 128  # TWOG_GEMM_CLASS_*
     GEMM_XSPLIT = 256
     GEMM_X3 = 512
-    GEMM_BPLANES = 1024
 
     def gemm_last_class(self):
         """Bit field (GEMM_*) of the kernel variant the most recent gemm() chunk of this thread selected."""
@@ -371,9 +321,8 @@ class HipKernels:
         return dx, dqk
 
     # ---------------------------------------------------------------- frame-level BiGRU
-    def bigru_fwd(self, types, bs, T, h, planes=None):
-        """types: list of dicts {gi (bs,T,E,6h), w_hh_f, b_hh_f, w_hh_r, b_hh_r}. Returns [(out (bs,T,E,2h), save)].
-        planes: a PlanesDir with the RM images of the W_hh matrices (optional)."""
+    def bigru_fwd(self, types, bs, T, h):
+        """types: list of dicts {gi (bs,T,E,6h), w_hh_f, b_hh_f, w_hh_r, b_hh_r}. Returns [(out (bs,T,E,2h), save)]."""
         n = len(types)
         arr = (L.BiGru * n)()
         outs, keep = [], []
@@ -392,12 +341,11 @@ class HipKernels:
                                                              _ptr(y.get('b_hh_f')), y['w_hh_r'].data_ptr(),
                                                              _ptr(y.get('b_hh_r')))
             a.out, a.save, a.tmp_gh, a.zeros, a.E = out.data_ptr(), save.data_ptr(), tmp.data_ptr(), zeros.data_ptr(), E
-            a.planes = planes.ptr if planes is not None else None
             outs.append((out, save))
         self._check(self.lib.twog_bigru_fwd(arr, n, bs, T, h, *self.chain_workspace(dev), self._stream()), 'twog_bigru_fwd')
         return outs
 
-    def bigru_bwd(self, types, bs, T, h, planes=None):
+    def bigru_bwd(self, types, bs, T, h):
         """types: list of dicts {d_out, save, out, w_hh_f, w_hh_r}. Returns [(d_gi, d_gh)] each (bs,T,E,6h)."""
         n = len(types)
         arr = (L.BiGruBwd * n)()
@@ -415,7 +363,6 @@ class HipKernels:
             a.d_out, a.save, a.out = d_out.data_ptr(), y['save'].data_ptr(), y['out'].data_ptr()
             a.w_hh_f, a.w_hh_r = y['w_hh_f'].data_ptr(), y['w_hh_r'].data_ptr()
             a.d_gi, a.d_gh, a.carry, a.E = d_gi.data_ptr(), d_gh.data_ptr(), carry.data_ptr(), E
-            a.planes = planes.ptr if planes is not None else None
             outs.append((d_gi, d_gh))
         self._check(self.lib.twog_bigru_bwd(arr, n, bs, T, h, *self.chain_workspace(dev), self._stream()), 'twog_bigru_bwd')
         return outs
@@ -509,8 +456,6 @@ class HipKernels:
         for k in ['hs_h', 'hs_o', 'save_h', 'save_o', 'msrc_h', 'msrc_o', 'mg_h', 'mg_o', 'att', 'tmp_gim_h',
                   'tmp_gim_o', 'tmp_gh_h', 'tmp_gh_o', 'zeros']:
             setattr(s, k, _ptr(bufs[k]))
-        pl = p.get('planes')
-        s.planes = pl.ptr if pl is not None else None
 
     def segrnn_fwd(self, p):
         """p: parameter/input dict (see ops.SegmentRecurrence). Allocates and returns the state/saved buffers."""

@@ -295,10 +295,9 @@ def set_grad_stage_hook(model, fn):
     set_model_extra(model, 'stage_hook', fn)
 
 
-# ---- derived forms of the weights: they change only when a weight does, i.e. once per optimizer step -- not once per launch.
-# (1) the packed sender-MLP weights of the segment level (a torch.cat per forward until round 4); (2) the weights' bf16 planes
-# for the X3 GEMM kernels (include/twog_gcn.h, twog_weight_planes_build): every launch that reads a weight as its B operand
-# used to split it into three bf16 chunks again -- 240 chain launches per step for W_hh alone.
+# ---- derived forms of the weights: they change only when a weight does, i.e. once per optimizer step -- not once per forward:
+# the packed sender-MLP weights of the segment level (four torch.cat launches per forward until round 4). (Round 4 also kept
+# the weights' pre-split bf16 planes here for X3 GEMM kernels fed from them; measured slower, removed: DESIGN.md section 8.)
 # Validity: an entry is stamped with (data_ptr, torch's version counter, shape) of its source tensors and a process-wide
 # EPOCH. In-place torch ops on a parameter bump its version counter (torch.optim.*, load_state_dict, .data = ...). Writers
 # that go AROUND torch -- the fused Adam kernel on the flat buffer, a broadcast into the flat buffer -- call
@@ -313,12 +312,12 @@ def bump_weights_epoch():
 
 class WeightCache:
     """Per-model cache of weight-derived device buffers (see above). Buffers are rewritten IN PLACE when their source
-    changes, and the planes directory object is kept while its set of entries is unchanged, so device addresses -- and with
-    them the keys of captured launch graphs (TWOG_GRAPHS=1) -- are stable across steps."""
+    changes, so device addresses -- and with them the keys of captured launch graphs (TWOG_GRAPHS=1) -- are stable across
+    steps."""
 
     def __init__(self):
-        self.packed, self.planes, self.dir, self.dir_sig = {}, {}, None, None
-        self.builds = 0   # plane images written so far (tests / bench)
+        self.packed = {}
+        self.builds = 0   # buffers (re)written so far (tests)
 
     @staticmethod
     def _stamp(tensors):
@@ -340,41 +339,8 @@ class WeightCache:
             else:
                 out = torch.cat([t.detach() for t in tensors], 0)
         self.packed[key] = (st, out)
+        self.builds += 1
         return out
-
-    def planes_dir(self, K, specs):
-        """specs: list of (key, 2-D weight tensor, source tensors whose change invalidates it, kinds wanted).
-        Returns K.planes_dir(...) over the up-to-date images (None when the backend has no planes)."""
-        if not getattr(K, 'supports_planes', False) or os.environ.get('TWOG_GEMM_BPLANES', '1') == '0':
-            return None
-        verify = bool(os.environ.get('TWOG_VERIFY_DERIVED'))
-        order = (K.PLANES_RM, K.PLANES_KM, K.PLANES_KF)
-        entries, sig = [], []
-        for key, w, src, kinds in specs:
-            if w is None:
-                continue
-            w = w.detach()
-            st = self._stamp(src) + (w.data_ptr(),)
-            e = self.planes.get(key)
-            if e is None:
-                e = self.planes[key] = dict(stamp=None, img={})
-            fresh = e['stamp'] != st
-            for kind in order:
-                if kind not in kinds and kind not in e['img']:
-                    continue
-                if fresh or kind not in e['img']:
-                    e['img'][kind] = K.weight_planes(w, kind, out=e['img'].get(kind))
-                    self.builds += e['img'][kind] is not None
-                elif verify and e['img'][kind] is not None and not torch.equal(e['img'][kind], K.weight_planes(w, kind)):
-                    raise RuntimeError(f'stale planes of {key}: a parameter was written behind torch (ops.bump_weights_epoch)')
-            e['stamp'] = st
-            imgs = tuple(e['img'].get(kind) for kind in order)
-            entries.append((w,) + imgs)
-            sig.append((w.data_ptr(), tuple(w.shape), w.stride(0)) + tuple(0 if i is None else i.data_ptr() for i in imgs))
-        sig = tuple(sig)
-        if self.dir is None or self.dir_sig != sig:
-            self.dir, self.dir_sig = K.planes_dir(entries), sig
-        return self.dir if len(self.dir) else None
 
 
 def weight_cache_of(model):
@@ -383,37 +349,6 @@ def weight_cache_of(model):
         c = WeightCache()
         set_model_extra(model, 'weight_cache', c)
     return c
-
-
-def chain_planes(K, p, P):
-    """Planes directory of the weights the recurrent chains read as GEMM B operands: the frame-level BiGRUs' W_hh
-    (vhoi/models.py:267-301), the segment cells' W_hh and W_ih (:294-320) and the packed segment sender MLPs (:336-436).
-    RM images serve the forward launches, KM the backward chains (dX = dY W). None when there is nothing to serve: the X3
-    kernels take reductions of at least 256, i.e. hidden sizes from 256 (csrc/gemm_f32.hip, x3s_ok)."""
-    wc = getattr(p, 'wcache', None)
-    if wc is None or p.h < 256 or p.h % 64:
-        return None
-    specs = []
-    kinds = (K.PLANES_RM, K.PLANES_KF) if getattr(K, 'supports_planes', False) else ()
-    for n in ('human', 'object', 'geometry'):
-        for sfx in ('', '_reverse'):
-            w = P[f'{n}_bd_rnn.weight_hh_l0{sfx}']
-            specs.append((f'{n}_bd_rnn.weight_hh_l0{sfx}', w, [w], kinds))
-    if not p.general_segment():
-        cells = {(k, d): f'{kk}_segment_rnn_{"fb"[d]}cell' for k, kk in (('h', 'human'), ('o', 'object')) for d in range(2)}
-        for (k, d), cell in cells.items():
-            if k == 'o' and p.O == 0:
-                continue
-            for nm in ('.weight_hh', '.weight_ih'):
-                w = P[cell + nm]
-                specs.append((cell + nm, w, [w], kinds))
-        if p.msg_segment:
-            for key, rels in (('w_smsg_h', [r for r in ('hh', 'ho') if getattr(p, 'rel_' + r)]),
-                              ('w_smsg_o', [r for r in ('oh', 'oo') if getattr(p, 'rel_' + r)])):
-                if rels:
-                    src = [P[_SEG_MLP[r] + '.0.weight'] for r in rels]
-                    specs.append((key, wc.pack(key, src), src, kinds))
-    return wc.planes_dir(K, specs)
 
 
 def grad_ready_stage(name: str) -> int:
@@ -442,11 +377,6 @@ def _stage_done(plan, stage):
         hook = hook()
     if hook is not None:
         hook(stage)
-
-
-def _planes_kw(planes):
-    """Keyword for the time-loop entry points: only backends with planes get it (the torch test double has none)."""
-    return {} if planes is None else {'planes': planes}
 
 
 class _Params(dict):
@@ -950,7 +880,7 @@ def tggcn_forward(K, plan: Plan, P, x_human, x_objects, objects_mask, human_seg,
     K.gemm(probs)
     res = K.bigru_fwd([dict(gi=gi, w_hh_f=P[f'{n}_bd_rnn.weight_hh_l0'], b_hh_f=P[f'{n}_bd_rnn.bias_hh_l0'],
                             w_hh_r=P[f'{n}_bd_rnn.weight_hh_l0_reverse'], b_hh_r=P[f'{n}_bd_rnn.bias_hh_l0_reverse'])
-                       for gi, (n, _, _) in zip(gis, ents)], bs, T, h, **_planes_kw(chain_planes(K, p, P)))
+                       for gi, (n, _, _) in zip(gis, ents)], bs, T, h)
     HFR = [r[0] for r in res]
     S['bigru_save'] = [r[1] for r in res]
     K.gemm([dict(A=_v2(hfr), B=P[f'{n}_bd_embedding_mlp.0.weight'], C=Ev[:, h:2 * h],
@@ -1155,7 +1085,6 @@ def tggcn_forward(K, plan: Plan, P, x_human, x_objects, objects_mask, human_seg,
         bias_on = p.has_bias
         seg_p['b_smsg_h'] = wc.pack('b_smsg_h', [P[_SEG_MLP[r] + '.0.bias'] for r in sh_rel]) if (sh_rel and bias_on) else None
         seg_p['b_smsg_o'] = wc.pack('b_smsg_o', [P[_SEG_MLP[r] + '.0.bias'] for r in so_rel]) if (so_rel and bias_on) else None
-        seg_p['planes'] = chain_planes(K, p, P)
         S['seg_rels'] = (sh_rel, so_rel)
     if p.general_segment():
         seg_bufs = segment_recurrence_general_fwd(K, p, P, {'h': gi_h, 'o': gi_o}, {'h': u_h, 'o': u_o}, objects_mask)
@@ -1572,7 +1501,7 @@ def tggcn_backward(K, plan: Plan, P, S, x_human, x_objects, objects_mask, d_outp
         dhfrs.append(dhfr)
         types.append(dict(d_out=dhfr, save=save, out=hfr, w_hh_f=P[name + '_bd_rnn.weight_hh_l0'],
                           w_hh_r=P[name + '_bd_rnn.weight_hh_l0_reverse']))
-    res = K.bigru_bwd(types, bs, T, h, **_planes_kw(chain_planes(K, p, P)))
+    res = K.bigru_bwd(types, bs, T, h)
     for (name, Ev, dEv, E, _), hfr, (dgi, dgh) in zip(ents, HFR, res):
         dgiv, dghv = _v2(dgi), _v2(dgh)
         for d, sfx in enumerate(('', '_reverse')):

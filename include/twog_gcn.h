@@ -58,45 +58,6 @@ typedef struct {
 int twog_gemm_f32(const twog_gemm_t* problems, int n_problems, int a_kmajor, int b_kmajor, void* workspace,
                   size_t workspace_bytes, void* stream);
 
-/* ---------------------------------------------------------------------------------------------------------------
- * Pre-split weights ("planes"). The X3 kernels multiply fp32 operands as three exact bf16 chunks (h, m, l: see
- * TWOG_GEMM_CLASS_X3). A WEIGHT -- the B operand of every forward / dX launch: nn.Linear.weight, GRU weight_ih / weight_hh
- * (pyrutils/torch/models.py:31-36, vhoi/models.py:267-320) -- changes once per optimizer step but is split again by every
- * launch that reads it (240 chain launches per step read W_hh alone). twog_weight_planes_build writes the three bf16 planes
- * of a weight matrix ONCE, in layouts the kernels copy straight into LDS with buffer_load ... lds (no register staging,
- * no split arithmetic, no ds_write for B), bit-identical results (the split is exact and element-wise):
- *   TWOG_PLANES_RM  for launches that read the matrix as B row-major ([N = rows][K = cols], b_kmajor = 0):
- *                   bf16 [3 planes][cols / 16][rows_pad][16], rows_pad = rows rounded up to 128 (zero rows);
- *   TWOG_PLANES_KM  for launches that read it as B k-major ([K = rows][N = cols], b_kmajor = 1: dX = dY W):
- *                   bf16 [3 planes][rows][cols_pad], cols_pad = cols rounded up to 128 (zero columns).
- * cols % 16 == 0 (RM) / rows % 16 == 0 (KM) required, w 16-byte aligned, ld % 4 == 0; otherwise -2 (the caller simply does
- * not offer planes for that weight). A twog_wplanes_dir_t lists the weights a caller has planes for; launches given the
- * directory look their B operands up in it (a B that is a row / column block of a listed weight resolves too, when the
- * block starts on a multiple of 32 rows and 16 columns) and fall back to the in-kernel split for anything else. The
- * caller rebuilds planes whenever it changes a weight; stale planes are the caller's bug (tools: TWOG_VERIFY_PLANES=1
- * makes the Python binding compare before every use).
- * --------------------------------------------------------------------------------------------------------------- */
-#define TWOG_PLANES_RM 1
-#define TWOG_PLANES_KM 2
-#define TWOG_PLANES_KF 3   /* k-major reading, MFMA fragment order: bf16 [3][rows / 16][cols_pad / 32][64 lanes][8] (see csrc/planes.hip) */
-typedef struct {
-    const float* w;   /* the fp32 matrix the planes were built from: [rows][cols], row stride ld (elements) */
-    int32_t rows, cols;
-    int64_t ld;
-    const void* rm;   /* TWOG_PLANES_RM image or NULL */
-    const void* km;   /* TWOG_PLANES_KM image or NULL */
-    const void* kf;   /* TWOG_PLANES_KF image or NULL */
-} twog_wplanes_t;
-typedef struct {
-    const twog_wplanes_t* e;
-    int32_t n;
-    int32_t pad_;
-} twog_wplanes_dir_t;
-size_t twog_weight_planes_bytes(int rows, int cols, int kind);
-int twog_weight_planes_build(const float* w, int rows, int cols, int64_t ld, int kind, void* planes, void* stream);
-/* twog_gemm_f32 / twog_gemm_f32_chain with a planes directory (NULL = none) */
-int twog_gemm_f32_p(const twog_gemm_t* problems, int n_problems, int a_kmajor, int b_kmajor, void* workspace,
-                    size_t workspace_bytes, const twog_wplanes_dir_t* planes, void* stream);
 /* Which kernel variant the calling thread's most recent twog_gemm_f32 chunk (or fused gate launch) selected -- lets a
  * test assert that it exercised the variant it was written for. Bit field: */
 #define TWOG_GEMM_CLASS_TILE128 1  /* 128x128 tiles (else 64x64)                        */
@@ -109,7 +70,6 @@ int twog_gemm_f32_p(const twog_gemm_t* problems, int n_problems, int a_kmajor, i
 #define TWOG_GEMM_CLASS_ROWS32  128 /* 32 x 64 tiles (chain launches of small batches)           */
 #define TWOG_GEMM_CLASS_XSPLIT  256 /* reduction split over workgroups, combined inside the launch (last arriver) */
 #define TWOG_GEMM_CLASS_X3      512 /* on the bf16 matrix cores: fp32 operands split exactly into 3 bf16, 6 products (128x128 class; 64x64 class when K >= 256) */
-#define TWOG_GEMM_CLASS_BPLANES 1024 /* B came pre-split from a planes directory, copied global -> LDS by buffer_load ... lds */
 int twog_gemm_last_class(void);
 
 /* The dependent launches of the recurrent chains (vhoi/models.py:983-1002 frame-level BiGRUs, :785-880 segment loop:
@@ -123,8 +83,6 @@ int twog_gemm_last_class(void);
 size_t twog_chain_workspace_bytes(void);
 int twog_gemm_f32_chain(const twog_gemm_t* problems, int n_problems, int a_kmajor, int b_kmajor, void* chain_ws,
                         size_t chain_ws_bytes, void* stream);
-int twog_gemm_f32_chain_p(const twog_gemm_t* problems, int n_problems, int a_kmajor, int b_kmajor, void* chain_ws,
-                          size_t chain_ws_bytes, const twog_wplanes_dir_t* planes, void* stream);
 
 /* ===============================================================================================================
  * Geometric-level GCN (pyrutils/torch/models_gcn.py:6-100; called at vhoi/models.py:640-645).
@@ -221,7 +179,6 @@ typedef struct {
     float* zeros;        /* [bs*E][h] zeros (initial state)                                              */
     int32_t E;
     int32_t pad_;
-    const twog_wplanes_dir_t* planes; /* pre-split W_hh (RM image) or NULL: see twog_weight_planes_build */
 } twog_bigru_t;
 int twog_bigru_fwd(const twog_bigru_t* types, int n_types, int bs, int T, int hidden, void* chain_ws,
                    size_t chain_ws_bytes, void* stream); /* chain_ws: see twog_gemm_f32_chain (NULL ok) */
@@ -237,7 +194,6 @@ typedef struct {
     float* carry;        /* scratch [2][bs*E][h]                                                         */
     int32_t E;
     int32_t pad_;
-    const twog_wplanes_dir_t* planes; /* pre-split W_hh (KM image) or NULL */
 } twog_bigru_bwd_t;
 int twog_bigru_bwd(const twog_bigru_bwd_t* types, int n_types, int bs, int T, int hidden, void* chain_ws,
                    size_t chain_ws_bytes, void* stream);
@@ -320,7 +276,6 @@ typedef struct {
     float* tmp_gh_h;  /* scratch [2][bs*H][3h] */
     float* tmp_gh_o;  /* scratch [2][bs*O][3h] */
     float* zeros;     /* [bs*max(H,O)][h] zeros */
-    const twog_wplanes_dir_t* planes; /* pre-split W_hh / W_ih / sender-MLP weights (RM forward, KM backward) or NULL */
 } twog_segrnn_t;
 int twog_segrnn_fwd(const twog_segrnn_t* desc, void* chain_ws, size_t chain_ws_bytes, void* stream); /* chain_ws: see twog_gemm_f32_chain */
 

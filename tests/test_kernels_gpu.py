@@ -1312,199 +1312,6 @@ torch.save(outs, sys.argv[1])
         assert torch.equal(a, b), float((a - b).abs().max())
 
 
-# ------------------------------------------------------------------------------------------ pre-split weights (planes)
-def _bf16_planes_to_float(img_u8, shape):
-    return img_u8.view(torch.bfloat16).view(*shape).float()
-
-
-@pytest.mark.parametrize('rows,cols', [(1536, 512), (200, 96), (64, 3072), (130, 48)])
-def test_weight_planes_images_are_the_exact_split(K, rows, cols):
-    """twog_weight_planes_build: the three bf16 planes add back to the fp32 weight bit for bit (h + m + l, exact), the
-    truncation split is the kernels' (h = top 8 significant bits, ...), both images sit where include/twog_gcn.h says, the
-    padding is zero, a row-strided source works, and an in-place rebuild rewrites the same buffer."""
-    w_full = rnd(rows, cols + 8, seed=5) * torch.exp2(torch.randint(-20, 20, (rows, cols + 8), generator=torch.Generator().manual_seed(1)).float())
-    w_full.view(-1)[::53] = 0.0
-    w = w_full.to(DEV)[:, :cols]                  # row stride cols + 8
-    rp, cp = -(-rows // 128) * 128, -(-cols // 128) * 128
-    rm = K.weight_planes(w, K.PLANES_RM)
-    km = K.weight_planes(w, K.PLANES_KM)
-    kf = K.weight_planes(w, K.PLANES_KF)
-    if rows % 16:
-        assert kf is None
-    else:   # fragment order: [plane][k-step][32-column block][lane = n + 32 h][j] = W[16 ks + 8 h + j][32 nb + n]
-        img = _bf16_planes_to_float(kf, (3, rows // 16, cp // 32, 2, 32, 8))        # [p][ks][nb][h][n][j]
-        back = img.permute(0, 1, 3, 5, 2, 4).reshape(3, rows, cp)                    # [p][ks, h, j][nb, n]
-        assert torch.equal(back[:, :, cols:], torch.zeros_like(back[:, :, cols:]))
-        assert torch.equal((back[0, :, :cols].double() + back[1, :, :cols].double() + back[2, :, :cols].double()).float(), w)
-        assert torch.equal(back[0, :, :cols], (w.view(torch.int32) & -65536).view(torch.float32))
-    if cols % 16:
-        assert rm is None
-    else:
-        img = _bf16_planes_to_float(rm, (3, cols // 16, rp, 16))          # [plane][k-tile][row][16 k]
-        back = img.permute(0, 2, 1, 3).reshape(3, rp, cols)
-        assert torch.equal(back[:, rows:], torch.zeros_like(back[:, rows:]))
-        h_, m_, l_ = back[0, :rows], back[1, :rows], back[2, :rows]
-        assert torch.equal((h_.double() + m_.double() + l_.double()).float(), w)   # exact: three 8-bit chunks of the significand
-        assert torch.equal(h_, (w.view(torch.int32) & -65536).view(torch.float32))
-        assert torch.equal(m_, ((w - h_).view(torch.int32) & -65536).view(torch.float32))
-    if rows % 16:
-        assert km is None
-    else:
-        img = _bf16_planes_to_float(km, (3, rows, cp))
-        assert torch.equal(img[:, :, cols:], torch.zeros_like(img[:, :, cols:]))
-        assert torch.equal((img[0, :, :cols].double() + img[1, :, :cols].double() + img[2, :, :cols].double()).float(), w)
-        ptr = km.data_ptr()
-        w.mul_(1.5)
-        km2 = K.weight_planes(w, K.PLANES_KM, out=km)
-        assert km2.data_ptr() == ptr
-        img = _bf16_planes_to_float(km2, (3, rows, cp))
-        assert torch.equal((img[0, :, :cols].double() + img[1, :, :cols].double() + img[2, :, :cols].double()).float(), w)
-
-
-def _gemm_with_and_without_planes(K, probs, bkm, chain, planes):
-    outs = []
-    for pl in (None, planes, planes):
-        ps = [dict(p, C=p['C0'].clone()) for p in probs]
-        K.gemm([{k: v for k, v in p.items() if k != 'C0'} for p in ps], b_kmajor=bkm, chain=chain, split_k_workspace=not chain,
-               planes=pl)
-        outs.append(([p['C'] for p in ps], K.gemm_last_class()))
-    return outs
-
-
-@pytest.fixture()
-def planes_on():
-    """The planes kernels are on by default (TWOG_GEMM_BPLANES=0 turns them off; read once per process)."""
-    if os.environ.get('TWOG_GEMM_BPLANES', '1') == '0':
-        pytest.skip('TWOG_GEMM_BPLANES=0')
-
-
-@pytest.mark.parametrize('bkm', [False, True])
-def test_gemm_planes_are_bit_identical_chain_classes(K, bkm, planes_on):
-    """The X3 chain kernels that read their B fragments straight from the weight's pre-split planes (gemm_mainloop_x3f)
-    against the register-staged X3 kernels that split B themselves: torch.equal, launch after launch -- 64 x 64 tiles with
-    8 waves (k-split, at most 256 tiles) and with 4 waves (more tiles), bias / ReLU / accumulate epilogues, ragged M,
-    a grouped launch mixing reduction lengths, B as a column block of a wider weight (the segment cells' W_ih[:, msg]),
-    short reductions (K = 256: fewer k-tiles than ring slots + 1). The class bits say which kernel ran."""
-    def prob(M, N, K_, bias, act, acc, seed, wide=0):
-        g = torch.Generator().manual_seed(seed)
-        A = torch.randn(M, K_, generator=g).to(DEV)
-        if bkm:
-            Wf = (torch.randn(K_, N + wide, generator=g) * 0.1).to(DEV)
-            B = Wf[:, wide:] if wide else Wf
-        else:
-            Wf = (torch.randn(N, K_ + wide, generator=g) * 0.1).to(DEV)
-            B = Wf[:, wide:] if wide else Wf
-        return dict(A=A, B=B, W=Wf, C0=torch.randn(M, N, generator=g).to(DEV), bias=torch.randn(N, generator=g).to(DEV) if bias else None,
-                    act=act, accumulate=acc)
-    cases = [
-        [prob(1408, 512, 1536, False, 0, True, 1)],                       # BiGRU backward carry at bs64: 176 tiles, 8 waves
-        [prob(1280, 1024, 512, True, 1, False, 2)],                       # segment sender MLPs: 320 tiles, 4 waves
-        [prob(1280, 1024, 1536, False, 0, False, 3, wide=512)],           # d_mg = d_gi W_ih[:, msg]: B a column block
-        [prob(810, 512, 256, True, 0, True, 4)],                          # ragged rows (13 row tiles), K = 256
-        [prob(128, 1536, 512, True, 0, False, 5), prob(128, 1536, 1024, False, 0, False, 6, wide=1536),
-         prob(512, 1536, 512, True, 0, False, 7), prob(512, 1536, 1024, False, 0, True, 8, wide=2048)],   # mixed K, grouped
-    ]
-    for probs in cases:
-        kind = K.PLANES_KF if bkm else K.PLANES_RM
-        entries = []
-        for p in probs:
-            img = K.weight_planes(p['W'], kind)
-            assert img is not None
-            entries.append((p['W'], None, None, img) if bkm else (p['W'], img, None, None))
-        planes = K.planes_dir(entries)
-        run = [{k: v for k, v in p.items() if k != 'W'} for p in probs]
-        (c0, cls0), (c1, cls1), (c2, cls2) = _gemm_with_and_without_planes(K, run, bkm, True, planes)
-        assert cls0 & K.GEMM_X3 and not cls0 & K.GEMM_BPLANES, hex(cls0)
-        assert cls1 & K.GEMM_X3 and cls1 & K.GEMM_BPLANES, hex(cls1)
-        for a, b, c in zip(c0, c1, c2):
-            assert torch.equal(a, b), ('planes vs in-kernel split', [tuple(x.shape) for x in c0], float((a - b).abs().max()))
-            assert torch.equal(b, c), 'launch-to-launch difference'
-        # a weight the directory does not list falls back to the in-kernel split, silently and correctly
-        other = K.planes_dir([(torch.zeros(16, 16, device=DEV), K.weight_planes(torch.zeros(16, 16, device=DEV), K.PLANES_RM), None)])
-        (c3, cls3), _, _ = _gemm_with_and_without_planes(K, run, bkm, True, other)[1:] + [None]
-        assert not cls3 & K.GEMM_BPLANES
-        for a, b in zip(c0, c3):
-            assert torch.equal(a, b)
-
-
-@pytest.mark.parametrize('h,bs,T', [(512, 64, 3), (256, 40, 5)])
-def test_bigru_with_planes_is_bit_identical(K, h, bs, T, planes_on):
-    """Frame-level BiGRU chains, forward (fused step: 64 rows x 64 units x 3 gates, W_hh from RM planes) and backward (carry
-    GEMM with the gate backward in its epilogue, W_hh from KM planes): bit-identical to the same chains without planes."""
-    ws = 0.2 * math.sqrt(64.0 / h)
-    types = []
-    for i, E in enumerate((2, 8, 1)):
-        d = dict(gi=rnd(bs, T, E, 6 * h, seed=i), w_hh_f=rnd(3 * h, h, seed=10 + i, scale=ws), b_hh_f=rnd(3 * h, seed=20 + i),
-                 w_hh_r=rnd(3 * h, h, seed=30 + i, scale=ws), b_hh_r=rnd(3 * h, seed=40 + i))
-        types.append({k: v.to(DEV) for k, v in d.items()})
-    entries = []
-    for d in types:
-        for k in ('w_hh_f', 'w_hh_r'):
-            entries.append((d[k], K.weight_planes(d[k], K.PLANES_RM), None, K.weight_planes(d[k], K.PLANES_KF)))
-    planes = K.planes_dir(entries)
-    res0 = K.bigru_fwd(types, bs, T, h)
-    cls0 = K.gemm_last_class()
-    res1 = K.bigru_fwd(types, bs, T, h, planes=planes)
-    cls1 = K.gemm_last_class()
-    assert cls1 & K.GEMM_BPLANES and not cls0 & K.GEMM_BPLANES, (hex(cls0), hex(cls1))
-    for (o0, s0), (o1, s1) in zip(res0, res1):
-        assert torch.equal(o0, o1) and torch.equal(s0, s1)
-    bt = [dict(d_out=rnd(*o.shape, seed=50 + i).to(DEV), save=sv, out=o, w_hh_f=d['w_hh_f'], w_hh_r=d['w_hh_r'])
-          for i, ((o, sv), d) in enumerate(zip(res0, types))]
-    g0 = K.bigru_bwd(bt, bs, T, h)
-    g1 = K.bigru_bwd(bt, bs, T, h, planes=planes)
-    assert K.gemm_last_class() & K.GEMM_BPLANES
-    for (a0, b0), (a1, b1) in zip(g0, g1):
-        assert torch.equal(a0, a1) and torch.equal(b0, b1)
-
-
-def test_full_model_with_planes_is_bit_identical_and_tracks_weight_updates():
-    """The whole path at the bench's batch (64 clips, T = 3, h = 512) with the weights' planes (default) and without
-    (TWOG_GEMM_BPLANES=0), each in a child process: every output and every parameter gradient torch.equal -- and again after
-    an optimizer step (the planes are rebuilt from the updated weights: stamps + epoch, ops.WeightCache), under
-    TWOG_VERIFY_DERIVED=1 (every cached image is compared with a fresh one at every use)."""
-    code = r"""
-import sys, torch
-sys.path.insert(0, %r)
-import twog_gcn_amd
-from twog_gcn_amd.models import TGGCN
-from twog_gcn_amd import ops
-from twog_gcn_amd.distributed import DataParallel, FusedAdam
-from tests.test_parity_gpu import STAGE1, _synthetic
-DEV = 'cuda:0'
-bs, T, H, O, N, h = 64, 3, 2, 8, 34, 512
-torch.manual_seed(0)
-m = TGGCN(input_size=(2048 + 4 * N, 2048), num_classes=(13, None), hidden_size=h, gcn_node=N, **STAGE1).to(DEV).train()
-dp = DataParallel(m); opt = FusedAdam(dp.flat, lr=1e-3)
-xh, xo, mask = (t.to(DEV) for t in _synthetic(bs, T, H, O, N, 1))
-seg = torch.ones(bs, T, H, device=DEV)
-m._gumbel_noise_override = torch.distributions.gumbel.Gumbel(0.0, 1.0).sample((T * O, bs, 2))
-res = []
-for step in range(2):
-    dp.zero_grad()
-    out = m(xh, xo, mask, human_segmentation=seg)
-    (out[4].sum() + out[5].sum() + out[1].sum()).backward()
-    res.append([o.detach().cpu() for o in out] + [dp.flat.grad.clone().cpu()])
-    opt.step()
-wc = ops.weight_cache_of(m)
-torch.save(dict(res=res, builds=wc.builds, entries=0 if wc.dir is None else len(wc.dir)), sys.argv[1])
-""" % (ROOT,)
-    import tempfile
-    got = {}
-    for mode in ('1', '0'):
-        with tempfile.NamedTemporaryFile(suffix='.pt') as f:
-            r = subprocess.run([sys.executable, '-c', code, f.name], env=dict(os.environ, TWOG_GEMM_BPLANES=mode, TWOG_VERIFY_DERIVED='1', TWOG_X3S_KU='1'),
-                               capture_output=True, text=True, timeout=900)
-            assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
-            got[mode] = torch.load(f.name)
-    assert got['1']['entries'] >= 14 and got['1']['builds'] >= 2 * 2 * got['1']['entries'], (got['1']['entries'], got['1']['builds'])
-    assert got['0']['entries'] == 0
-    for step in range(2):
-        for a, b in zip(got['1']['res'][step], got['0']['res'][step]):
-            assert torch.equal(a, b), ('step', step, float((a - b).abs().max()))
-    assert not torch.equal(got['1']['res'][0][-1], got['1']['res'][1][-1])   # the second step really saw other weights
-
-
 def test_ssp_gather_with_segment_level_placement(K):
     """Weights stored [time][clip][natt] and the gradient rows a column block of wider rows (the segment level's layout)."""
     bs, T, H, O, cols = 3, 5, 2, 8, 48

@@ -12,8 +12,7 @@ import twog_gcn_amd  # noqa
 from twog_gcn_amd.kernels import get_kernels
 K = get_kernels()
 dev = 'cuda'
-CHAIN = 'chain' in sys.argv[1:]
-PLANES = 'planes' in sys.argv[1:]   # B from the weight's pre-split planes (all-DMA kernels, gemm_mainloop_x3d)
+CHAIN = len(sys.argv) > 1 and sys.argv[1] == 'chain'
 SHAPES = [  # M, N, K, b_kmajor, note
     (1408, 512, 1536, True, 'BiGRU backward carry (176 tiles)'),
     (1280, 512, 1536, True, 'segment backward carry (160 tiles)'),
@@ -30,18 +29,14 @@ for M, N, Kk, bkm, note in SHAPES:
     As = [torch.randn(M, Kk, device=dev) for _ in range(16)]
     B = torch.randn((Kk, N) if bkm else (N, Kk), device=dev)
     C = torch.empty(M, N, device=dev)
-    pl = None
-    if PLANES:
-        img = K.weight_planes(B, K.PLANES_KF if bkm else K.PLANES_RM)
-        pl = K.planes_dir([(B, None, None, img) if bkm else (B, img, None, None)])
     for i in range(20):
-        K.gemm([dict(A=As[i % 16], B=B, C=C)], b_kmajor=bkm, split_k_workspace=False, chain=CHAIN, planes=pl)
+        K.gemm([dict(A=As[i % 16], B=B, C=C)], b_kmajor=bkm, split_k_workspace=False, chain=CHAIN)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g):
         for i in range(128):
-            K.gemm([dict(A=As[i % 16], B=B, C=C)], b_kmajor=bkm, split_k_workspace=False, chain=CHAIN, planes=pl)
+            K.gemm([dict(A=As[i % 16], B=B, C=C)], b_kmajor=bkm, split_k_workspace=False, chain=CHAIN)
     g.replay(); torch.cuda.synchronize()
     e0.record()
     for _ in range(4):
