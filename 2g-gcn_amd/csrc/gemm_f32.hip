@@ -617,6 +617,20 @@ __device__ __forceinline__ void gemm_mainloop_x3(const twog_rows_t A, const twog
     if (nkt <= 0) return;
     const int k_last = k_begin + (nkt - 1) * XK;
     auto kof = [&](int t) { return min(k_begin + t * XK, k_last); };
+#if TWOG_X3_TMPACC
+    // (TMPACC: two register stages -- the temporary accumulator takes the registers of the other two)
+    Stage r0, r1;
+    gload(r0, kof(0));
+    gload(r1, kof(1));
+    split_store(r0, 0);
+    __syncthreads();
+    int kt = 0;
+    for (; kt + 1 < nkt; kt += 2) {
+        gload(r0, kof(kt + 2)); compute(0); split_store(r1, 1); __syncthreads();
+        gload(r1, kof(kt + 3)); compute(1); split_store(r0, 0); __syncthreads();
+    }
+    if (kt < nkt) compute(0);
+#else
     Stage r0, r1, r2, r3;
     gload(r0, kof(0));
     gload(r1, kof(1));
@@ -635,6 +649,7 @@ __device__ __forceinline__ void gemm_mainloop_x3(const twog_rows_t A, const twog
     if (kt < nkt) compute(0);
     if (kt + 1 < nkt) { split_store(r1, 1); __syncthreads(); compute(1); }
     if (kt + 2 < nkt) { split_store(r2, 0); __syncthreads(); compute(0); }
+#endif
 }
 
 // X3 for the 64-row tile class (the recurrent chains at a real batch: 160 ... 960 tiles of K = 512 ... 1 536, MFMA-bound
