@@ -664,6 +664,14 @@ __device__ __forceinline__ void gemm_mainloop_x3(const twog_rows_t A, const twog
 #ifndef TWOG_X3S_RS
 #define TWOG_X3S_RS 4
 #endif
+// cache policy of the chain kernels' operand loads (the aux field of buffer_load: 0 default, 2 = nt: streamed, evicted first).
+// A of a chain launch is read once per launch (previous states / gradients), B is the weight every step comes back to.
+#ifndef TWOG_X3S_A_AUX
+#define TWOG_X3S_A_AUX 0
+#endif
+#ifndef TWOG_X3S_B_AUX
+#define TWOG_X3S_B_AUX 0
+#endif
 // Diagnostic build only (-DTWOG_STAMPS, tools/stamps_probe.sh): cycle stamps at the phase boundaries of the X3 chain loop,
 // summed per wave of workgroup 0 and written to a buffer of their own at the end (cdna_hip_programming.md, In-kernel stamps).
 #ifdef TWOG_STAMPS
@@ -737,9 +745,9 @@ __device__ __forceinline__ void gemm_mainloop_x3s(const twog_rows_t A, const two
             const int sa = (int)((uint32_t)(k0 + u * XK) * 4u);
             const int sb = (int)(BKM ? (uint32_t)(k0 + u * XK) * (uint32_t)B.ld_outer * 4u : (uint32_t)(k0 + u * XK) * 4u);
 #pragma unroll
-            for (int i = 0; i < NPA; ++i) r.a[u][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, (int)oa[i], sa, 0));
+            for (int i = 0; i < NPA; ++i) r.a[u][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, (int)oa[i], sa, TWOG_X3S_A_AUX));
 #pragma unroll
-            for (int i = 0; i < NPB; ++i) r.b[u][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_b, (int)ob[i], sb, 0));
+            for (int i = 0; i < NPB; ++i) r.b[u][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_b, (int)ob[i], sb, TWOG_X3S_B_AUX));
         }
     };
     auto split_store = [&](const Stage& r, int buf) {

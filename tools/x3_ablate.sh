@@ -1,3 +1,5 @@
+# NOTE (round 4): the TWOG_X3_ABLATE branches were removed from csrc/gemm_f32.hip; this script applies to the round-3 tree
+# (git 99b4ed3), whose results are committed as profiles/r03_x3_ablation.txt.
 # GPU box: the 128x128 X3 main loop with parts removed (build-time TWOG_X3_ABLATE=1..4; each measurement library is built
 # BESIDE the shipped one -- hipcc -DTWOG_X3_ABLATE=n ... -o gpurun_out/lib_ablate<n>.so, see tools/x3_ablate_build.sh -- and
 # selected through TWOG_LIB_PATH: the shipped lib2ggcn_hip.so is never touched). Results of the ablated builds are WRONG by
