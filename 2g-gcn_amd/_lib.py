@@ -116,6 +116,18 @@ class Relation(C.Structure):  # twog_relation_t
                 ('S', C.c_int32), ('D', C.c_int32), ('hidden', C.c_int32), ('pad_', C.c_int32)]
 
 
+class RowOp(C.Structure):  # twog_rowop_t
+    _fields_ = [('a', Rows), ('b', Rows), ('dst', Rows), ('s', C.c_void_p), ('v', C.c_void_p), ('kind', C.c_int32),
+                ('rows', C.c_int32), ('cols', C.c_int32), ('pad_', C.c_int32)]
+
+
+TAPE_GEMM, TAPE_RELATION_FWD, TAPE_RELATION_BWD, TAPE_GRU_STEP_FWD, TAPE_GRU_STEP_BWD, TAPE_ROWOPS = range(6)   # TWOG_TAPE_*
+
+
+class TapeEntry(C.Structure):  # twog_tape_entry_t
+    _fields_ = [('kind', C.c_int32), ('n', C.c_int32), ('flags', C.c_int32), ('pad_', C.c_int32), ('desc', C.c_void_p)]
+
+
 class RelationBwd(C.Structure):  # twog_relation_bwd_t
     _fields_ = [('f', Relation), ('dout', Rows), ('dmsg', Rows), ('dp_r', Rows), ('dp_s', Rows), ('dq', Rows),
                 ('dk', Rows), ('da_r', C.c_void_p), ('dc_s', C.c_void_p), ('dscore_sum', C.c_void_p),
@@ -165,6 +177,8 @@ SIGNATURES = {
     'twog_relation_limits': [],
     'twog_relation_fwd': [C.POINTER(Relation), _P],
     'twog_relation_bwd': [C.POINTER(RelationBwd), _P],
+    'twog_relation_fwd_n': [C.POINTER(Relation), _I, _P],
+    'twog_relation_bwd_n': [C.POINTER(RelationBwd), _I, _P],
     'twog_ssp_fwd': [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     'twog_ssp_gather': [_P, _L, _P, _L, _L, _I, _P, _I, _I, _I, _I, _I, _P],
     'twog_ssp_bwd': [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
@@ -179,6 +193,8 @@ SIGNATURES = {
     'twog_logsoftmax_permute_bwd': [_P, _P, _P, _I, _I, _I, _I, _P],
     'twog_relu_bwd': [Rows, Rows, Rows, _I, _I, _P],
     'twog_add_rows': [Rows, Rows, _I, _I, _P],
+    'twog_rowops': [C.POINTER(RowOp), _I, _P],
+    'twog_tape_run': [C.POINTER(TapeEntry), C.POINTER(TapeEntry), _I, _I, _I, _P, C.c_size_t, _P],
     'twog_fill_zero': [_P, C.c_size_t, _P],
     'twog_adam_step': [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _F, _P],
     'twog_multitask_loss_fwd': [C.POINTER(Loss), _I, _P, _P, _P, _P],

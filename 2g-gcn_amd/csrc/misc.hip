@@ -39,6 +39,23 @@ __global__ __launch_bounds__(256) void add_rows_kernel(twog_rows_t src, twog_row
     }
 }
 
+// Several small row-wise operations in one launch (blockIdx.y = operation): what the host-composed general segment loop
+// runs between its grouped GEMMs, once per dependency level instead of once per relation and direction.
+constexpr int MAXROWOPS = 16;
+struct RowOpBatch { twog_rowop_t op[MAXROWOPS]; };
+__global__ __launch_bounds__(256) void rowops_kernel(const RowOpBatch G) {
+    const twog_rowop_t& o = G.op[blockIdx.y];
+    const int cols = o.cols;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < (int64_t)o.rows * cols;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int r = (int)(i / cols), c = (int)(i - (int64_t)r * cols);
+        float* d = twog_row_ptr(o.dst, r) + c;
+        if (o.kind == TWOG_ROWOP_RELU_BWD) *d = twog_row_ptr(o.b, r)[c] > 0.f ? twog_row_ptr(o.a, r)[c] : 0.f;
+        else if (o.kind == TWOG_ROWOP_ADD) *d += twog_row_ptr(o.a, r)[c];
+        else *d = fmaf(o.s[r], o.v[c], *d);
+    }
+}
+
 // logits [(b,t,e)][C] -> out [b][C][t][e] = log_softmax over C        (vhoi/models.py:909-917)
 __global__ __launch_bounds__(256) void lsm_permute_fwd_kernel(const float* logits, float* out, int bs, int T, int E,
                                                               int C) {
@@ -173,6 +190,31 @@ extern "C" int twog_relu_bwd(twog_rows_t dy, twog_rows_t y, twog_rows_t dx, int 
         hipLaunchKernelGGL(relu_bwd_scalar_kernel, dim3(grid_for((int64_t)rows * cols)), dim3(256), 0, st, dy, y, dx,
                            rows, cols);
     TWOG_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int twog_rowops(const twog_rowop_t* ops, int n_ops, void* stream) {
+    for (int i = 0; i < n_ops; ++i) {
+        const twog_rowop_t& o = ops[i];
+        if (o.kind < TWOG_ROWOP_RELU_BWD || o.kind > TWOG_ROWOP_RANK1 || o.rows < 0 || o.cols < 0) return -2;
+        if (o.rows == 0 || o.cols == 0) continue;
+        if (!o.dst.ptr || (o.kind == TWOG_ROWOP_RANK1 ? (!o.s || !o.v) : !o.a.ptr) ||
+            (o.kind == TWOG_ROWOP_RELU_BWD && !o.b.ptr))
+            return -2;
+    }
+    for (int done = 0; done < n_ops; done += MAXROWOPS) {
+        RowOpBatch G;
+        const int m = n_ops - done < MAXROWOPS ? n_ops - done : MAXROWOPS;
+        int64_t most = 0;
+        for (int i = 0; i < m; ++i) {
+            G.op[i] = ops[done + i];
+            const int64_t n = (int64_t)G.op[i].rows * G.op[i].cols;
+            if (n > most) most = n;
+        }
+        if (most == 0) continue;
+        hipLaunchKernelGGL(rowops_kernel, dim3(grid_for(most, 256, 1024), m), dim3(256), 0, (hipStream_t)stream, G);
+        TWOG_CHECK_LAUNCH();
+    }
     return 0;
 }
 

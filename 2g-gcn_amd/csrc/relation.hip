@@ -102,8 +102,7 @@ __device__ __forceinline__ float recv_scale(const twog_relation_t& A, int inst, 
     return A.recv_mask[(int64_t)(inst / A.inst_per_clip) * A.R + r];
 }
 
-__global__ __launch_bounds__(256) void relation_fwd_kernel(const twog_relation_t A) {
-    __shared__ float sV[MAXE * MAXE], sS[MAXE * MAXE], sW[MAXE * MAXE];
+__device__ __forceinline__ void relation_fwd_body(const twog_relation_t& A, float* sV, float* sS, float* sW) {
     const int inst = blockIdx.x;
     const int R = A.R, S = A.S, hid = A.hidden;
     const RowSet q = rowset(A.q, inst, R), k = rowset(A.k, inst, S);
@@ -126,8 +125,24 @@ __global__ __launch_bounds__(256) void relation_fwd_kernel(const twog_relation_t
     }
 }
 
-__global__ __launch_bounds__(256) void relation_bwd_kernel(const twog_relation_bwd_t B) {
-    __shared__ float sV[MAXE * MAXE], sS[MAXE * MAXE], sW[MAXE * MAXE], sRaw[MAXE * MAXE], sD[MAXE * MAXE];
+__global__ __launch_bounds__(256) void relation_fwd_kernel(const twog_relation_t A) {
+    __shared__ float sV[MAXE * MAXE], sS[MAXE * MAXE], sW[MAXE * MAXE];
+    relation_fwd_body(A, sV, sS, sW);
+}
+
+// Several relations in one launch (blockIdx.y = descriptor): the host-composed segment loop issues every relation of
+// both directions of a chain step together. Descriptors travel as kernel arguments (8 x 320 B / 6 x 552 B < 4 KB).
+constexpr int MAXREL_F = 8, MAXREL_B = 6;
+struct RelFwdBatch { twog_relation_t d[MAXREL_F]; };
+__global__ __launch_bounds__(256) void relation_fwd_n_kernel(const RelFwdBatch G) {
+    __shared__ float sV[MAXE * MAXE], sS[MAXE * MAXE], sW[MAXE * MAXE];
+    const twog_relation_t& A = G.d[blockIdx.y];
+    if ((int)blockIdx.x >= A.n_inst || A.R == 0) return;
+    relation_fwd_body(A, sV, sS, sW);
+}
+
+__device__ __forceinline__ void relation_bwd_body(const twog_relation_bwd_t& B, float* sV, float* sS, float* sW,
+                                                  float* sRaw, float* sD) {
     const twog_relation_t& A = B.f;
     const int inst = blockIdx.x;
     const int R = A.R, S = A.S, hid = A.hidden, D = A.D;
@@ -250,6 +265,19 @@ __global__ __launch_bounds__(256) void relation_bwd_kernel(const twog_relation_b
         }
 }
 
+__global__ __launch_bounds__(256) void relation_bwd_kernel(const twog_relation_bwd_t B) {
+    __shared__ float sV[MAXE * MAXE], sS[MAXE * MAXE], sW[MAXE * MAXE], sRaw[MAXE * MAXE], sD[MAXE * MAXE];
+    relation_bwd_body(B, sV, sS, sW, sRaw, sD);
+}
+
+struct RelBwdBatch { twog_relation_bwd_t d[MAXREL_B]; };
+__global__ __launch_bounds__(256) void relation_bwd_n_kernel(const RelBwdBatch G) {
+    __shared__ float sV[MAXE * MAXE], sS[MAXE * MAXE], sW[MAXE * MAXE], sRaw[MAXE * MAXE], sD[MAXE * MAXE];
+    const twog_relation_bwd_t& B = G.d[blockIdx.y];
+    if ((int)blockIdx.x >= B.f.n_inst || B.f.R == 0) return;
+    relation_bwd_body(B, sV, sS, sW, sRaw, sD);
+}
+
 inline bool rows_ok(const twog_rows_t& m, int n) { return !m.ptr || m.inner <= 1 || m.inner == n; }
 inline int check(const twog_relation_t& a) {
     if (a.R < 0 || a.S < 0 || a.R > MAXE || a.S > MAXE || a.hidden <= 0 || a.inst_per_clip <= 0) return -2;
@@ -278,7 +306,7 @@ extern "C" int twog_relation_fwd(const twog_relation_t* a, void* stream) {
     return 0;
 }
 
-extern "C" int twog_relation_bwd(const twog_relation_bwd_t* b, void* stream) {
+static int check_bwd(const twog_relation_bwd_t* b) {
     const twog_relation_t& a = b->f;
     if (int rc = check(a)) return rc;
     if (!b->dout.ptr || !rows_ok(b->dout, a.R) || !rows_ok(b->dmsg, a.S) || !rows_ok(b->dp_r, a.R) ||
@@ -286,8 +314,52 @@ extern "C" int twog_relation_bwd(const twog_relation_bwd_t* b, void* stream) {
         return -2;
     if (a.msg_mode == TWOG_REL_MSG_PAIR && (!b->dp_r.ptr || !b->dp_s.ptr)) return -2;
     if (a.score_mode == TWOG_REL_ADDITIVE && (!b->da_r || !b->dc_s)) return -2;
+    return 0;
+}
+
+extern "C" int twog_relation_bwd(const twog_relation_bwd_t* b, void* stream) {
+    const twog_relation_t& a = b->f;
+    if (int rc = check_bwd(b)) return rc;
     if (a.n_inst <= 0 || a.R == 0) return 0;
     hipLaunchKernelGGL(relation_bwd_kernel, dim3(a.n_inst), dim3(256), 0, (hipStream_t)stream, *b);
     TWOG_CHECK_LAUNCH();
+    return 0;
+}
+
+// n relations per call, MAXREL_F / MAXREL_B per launch. The descriptors of one call must not ACCUMULATE into the same
+// rows (dq / dk with *_accumulate): the launches of a chunk run concurrently.
+extern "C" int twog_relation_fwd_n(const twog_relation_t* rels, int n, void* stream) {
+    for (int i = 0; i < n; ++i)
+        if (int rc = check(rels[i])) return rc;
+    for (int done = 0; done < n; done += MAXREL_F) {
+        RelFwdBatch G;
+        const int m = n - done < MAXREL_F ? n - done : MAXREL_F;
+        int max_inst = 0;
+        for (int i = 0; i < m; ++i) {
+            G.d[i] = rels[done + i];
+            if (G.d[i].R > 0 && G.d[i].n_inst > max_inst) max_inst = G.d[i].n_inst;
+        }
+        if (max_inst <= 0) continue;
+        hipLaunchKernelGGL(relation_fwd_n_kernel, dim3(max_inst, m), dim3(256), 0, (hipStream_t)stream, G);
+        TWOG_CHECK_LAUNCH();
+    }
+    return 0;
+}
+
+extern "C" int twog_relation_bwd_n(const twog_relation_bwd_t* rels, int n, void* stream) {
+    for (int i = 0; i < n; ++i)
+        if (int rc = check_bwd(rels + i)) return rc;
+    for (int done = 0; done < n; done += MAXREL_B) {
+        RelBwdBatch G;
+        const int m = n - done < MAXREL_B ? n - done : MAXREL_B;
+        int max_inst = 0;
+        for (int i = 0; i < m; ++i) {
+            G.d[i] = rels[done + i];
+            if (G.d[i].f.R > 0 && G.d[i].f.n_inst > max_inst) max_inst = G.d[i].f.n_inst;
+        }
+        if (max_inst <= 0) continue;
+        hipLaunchKernelGGL(relation_bwd_n_kernel, dim3(max_inst, m), dim3(256), 0, (hipStream_t)stream, G);
+        TWOG_CHECK_LAUNCH();
+    }
     return 0;
 }

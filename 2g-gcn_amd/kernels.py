@@ -71,6 +71,7 @@ class HipKernels:
     def __init__(self):
         self.lib = L.load()
         self._ws = {}
+        self._tape = None
 
     # ---------------------------------------------------------------- utilities
     @staticmethod
@@ -202,6 +203,9 @@ class HipKernels:
         if chain:
             rc = self.lib.twog_gemm_f32_chain(arr, n, int(a_kmajor), int(b_kmajor), *self.chain_workspace(dev), self._stream())
             self._check(rc, 'twog_gemm_f32_chain')
+            return
+        if self._tape is not None:
+            self._tape.append((L.TAPE_GEMM, n, int(a_kmajor) | int(b_kmajor) << 1, arr))
             return
         ws_ptr, ws_bytes = 0, 0
         if split_k_workspace:
@@ -384,6 +388,9 @@ class HipKernels:
                 setattr(g, k, rows_of(d.get(k)))
             self._u_fields(g, d.get('u'))
             g.rows, g.hidden = d['rows'], d['hidden']
+        if self._tape is not None:
+            self._tape.append((L.TAPE_GRU_STEP_FWD, len(steps), 0, arr))
+            return
         self._check(self.lib.twog_gru_step_fwd(arr, len(steps), self._stream()), 'twog_gru_step_fwd')
 
     def gru_step_bwd(self, steps):
@@ -395,6 +402,9 @@ class HipKernels:
             self._u_fields(g, d.get('u'))
             g.du = _ptr(d.get('du'))
             g.rows, g.hidden, g.dh_prev_accumulate = d['rows'], d['hidden'], int(d.get('dh_prev_accumulate', 0))
+        if self._tape is not None:
+            self._tape.append((L.TAPE_GRU_STEP_BWD, len(steps), 0, arr))
+            return
         self._check(self.lib.twog_gru_step_bwd(arr, len(steps), self._stream()), 'twog_gru_step_bwd')
 
     # ---------------------------------------------------------------- entity attention
@@ -665,16 +675,112 @@ class HipKernels:
         self._fill_relation(a, d)
         self._check(self.lib.twog_relation_fwd(C.byref(a), self._stream()), 'twog_relation_fwd')
 
+    def relation_fwd_many(self, ds):
+        """Several relations in one call (a few launches of up to 8 descriptors): the general segment loop's level."""
+        arr = (L.Relation * len(ds))()
+        for a, d in zip(arr, ds):
+            self._fill_relation(a, d)
+        if self._tape is not None:
+            self._tape.append((L.TAPE_RELATION_FWD, len(ds), 0, arr))
+            return
+        self._check(self.lib.twog_relation_fwd_n(arr, len(ds), self._stream()), 'twog_relation_fwd_n')
+
+    def relation_bwd_many(self, ds):
+        """The descriptors must not accumulate (dq / dk) into the same rows: they run concurrently."""
+        arr = (L.RelationBwd * len(ds))()
+        for b, d in zip(arr, ds):
+            self._fill_relation_bwd(b, d)
+        if self._tape is not None:
+            self._tape.append((L.TAPE_RELATION_BWD, len(ds), 0, arr))
+            return
+        self._check(self.lib.twog_relation_bwd_n(arr, len(ds), self._stream()), 'twog_relation_bwd_n')
+
+    _ROWOP = {'relu_bwd': 0, 'add': 1, 'rank1': 2}   # TWOG_ROWOP_*
+
+    def rowops(self, ops):
+        """ops: ('relu_bwd', dy, y, dx) | ('add', src, dst) | ('rank1', dst, s, v), row-strided views; ONE launch per 16
+        operations. No two operations of a call may write the same rows."""
+        if not ops:
+            return
+        arr = (L.RowOp * len(ops))()
+        none = rows_of(None)
+        for o, op in zip(arr, ops):
+            o.kind = self._ROWOP[op[0]]
+            if op[0] == 'relu_bwd':
+                _, dy, y, dst = op
+                o.a, o.b = rows_of(dy), rows_of(y)
+            elif op[0] == 'add':
+                _, src, dst = op
+                o.a, o.b = rows_of(src), none
+            else:
+                _, dst, sv, v = op
+                assert sv.is_contiguous() and v.is_contiguous() and sv.numel() == n_rows(dst) and v.numel() == dst.shape[-1]
+                o.a, o.b, o.s, o.v = none, none, sv.data_ptr(), v.data_ptr()
+            o.dst, o.rows, o.cols = rows_of(dst), n_rows(dst), dst.shape[-1]
+        if self._tape is not None:
+            self._tape.append((L.TAPE_ROWOPS, len(ops), 0, arr))
+            return
+        self._check(self.lib.twog_rowops(arr, len(ops), self._stream()), 'twog_rowops')
+
+    # ---------------------------------------------------------------- recorded steps of an affine loop (twog_tape_run)
+    def tape_begin(self):
+        """From here to tape_end(), gemm / gru_step_* / relation_*_many / rowops calls are RECORDED (descriptor arrays
+        kept, nothing issued). Any other entry point called in between is a programming error the recording cannot see:
+        the general segment loop (ops.segment_recurrence_general_*) uses only these six."""
+        assert self._tape is None
+        self._tape = []
+
+    def tape_end(self):
+        t, self._tape = self._tape, None
+        return t
+
+    @staticmethod
+    def tape_predict(a, b, k):
+        """The descriptor bytes twog_tape_run builds for step a + k: per 64-bit word a + k (b - a). For checking a third
+        composed step against the rule before trusting it with the rest of the loop."""
+        import numpy as np
+        out = []
+        for (ka, na, fa, da), (kb, nb, fb, db) in zip(a, b):
+            wa = np.frombuffer(bytes(da), dtype=np.uint64)
+            wb = np.frombuffer(bytes(db), dtype=np.uint64)
+            out.append((wa + np.uint64(k) * (wb - wa)).tobytes())
+        return out
+
+    @staticmethod
+    def tape_same_program(a, b):
+        return len(a) == len(b) and all(x[:3] == y[:3] for x, y in zip(a, b))
+
+    def tape_matches(self, a, b, c, k):
+        """True if the composed step c is what the replay would run as step a + k."""
+        if not (self.tape_same_program(a, b) and self.tape_same_program(a, c)):
+            return False
+        return all(bytes(e[3]) == w for e, w in zip(c, self.tape_predict(a, b, k)))
+
+    def tape_run(self, a, b, k_begin, k_end, device):
+        """Issues steps a + k, k_begin <= k < k_end, of the loop whose consecutive steps a and b were recorded."""
+        assert self._tape is None and self.tape_same_program(a, b)
+        n = len(a)
+        ea, eb = (L.TapeEntry * n)(), (L.TapeEntry * n)()
+        for arr, tape in ((ea, a), (eb, b)):
+            for e, (kind, cnt, flags, desc) in zip(arr, tape):
+                e.kind, e.n, e.flags, e.desc = kind, cnt, flags, C.addressof(desc)
+        ws = self.workspace(320 << 20, device, 'splitk')
+        self._check(self.lib.twog_tape_run(ea, eb, n, k_begin, k_end, ws.data_ptr(), ws.numel() * 4, self._stream()),
+                    'twog_tape_run')
+
     def relation_bwd(self, d):
         """d: dict(f=<forward descriptor>, dout, dmsg | dp_r, dp_s, dq, dk, da_r, dc_s, dq_accumulate, ...)."""
         b = L.RelationBwd()
+        self._fill_relation_bwd(b, d)
+        self._check(self.lib.twog_relation_bwd(C.byref(b), self._stream()), 'twog_relation_bwd')
+
+    def _fill_relation_bwd(self, b, d):
         self._fill_relation(b.f, d['f'])
         for k in ('dout', 'dmsg', 'dp_r', 'dp_s', 'dq', 'dk'):
             setattr(b, k, rows_of(d.get(k)))
         b.da_r, b.dc_s, b.dscore_sum = _ptr(d.get('da_r')), _ptr(d.get('dc_s')), _ptr(d.get('dscore_sum'))
         b.dq_accumulate, b.dk_accumulate = int(d.get('dq_accumulate', 0)), int(d.get('dk_accumulate', 0))
         b.relu_mask_dmsg = int(d.get('relu_mask_dmsg', 0))
-        self._check(self.lib.twog_relation_bwd(C.byref(b), self._stream()), 'twog_relation_bwd')
 
     # ---------------------------------------------------------------- position features / rare gate strategies
     def pos_embed_fwd(self, out, bs, T, E, hidden, w=None, b=None, periodic=False, s=None, steps=None, divide=False):

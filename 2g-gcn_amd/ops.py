@@ -452,12 +452,7 @@ def _lin_w_grads(K, G, wname, bname, dY, X, cols=None, total=None):
         dW = torch.empty(N, Kin, dtype=torch.float32, device=dY.device)
         K.gemm([dict(A=dY, B=X, C=dW)], a_kmajor=True, b_kmajor=True)
         G.add(wname, dW)
-    if bname is not None and G.has(bname):
-        dstb = G.sink(bname)
-        if dstb is not None:
-            K.colsum(dY, out=dstb.view(-1), accumulate=True)
-        else:
-            G.add(bname, K.colsum(dY))
+    _bias_grad(K, G, bname, dY)
 
 
 def geo_gcn_forward(K, P, x_human, bs, T, N, training, bn_bufs, S, save_x=True):
@@ -531,155 +526,272 @@ class _RelLevel:
         return (not self.segment) and rel in ('ho', 'so')
 
 
-def relations_general_fwd(K, p, P, L, objects_mask, rels):
-    """Messages of the relations `rels` at level L in every form the tuned kernel does not cover (relational,
-    receiver-specific, concat / bilinear / distance-based attention): per relation a couple of GEMMs -- a Linear on
-    cat[receiver, sender] is split into a receiver and a sender projection -- and one launch of the general relation
-    kernel (relation.hip). Writes L.outs[rel]; returns what the backward pass needs."""
+class _Staged:
+    """Launch queue of the general relation code. Producers (generators: one per relation, and per direction at the
+    segment level) enqueue the launches of their current dependency level and yield; run() advances all of them level
+    by level and issues each KIND of launch once per level -- grouped GEMMs (8 problems per launch), the
+    multi-descriptor relation kernel, one batch of row operations -- where the code used to issue one launch per
+    relation, direction and operation. Launches of one level that ADD into the same rows (the feature gradients of
+    relations that share a sender or receiver kind) are dealt into consecutive waves."""
+
+    def __init__(self, K):
+        self.K = K
+        self._gemm, self._rf, self._rb, self._ops = {}, [], [], []
+
+    def gemm(self, problems, **flags):
+        self._gemm.setdefault(tuple(sorted(flags.items())), []).extend(problems)
+
+    def relation_fwd(self, f):
+        self._rf.append(f)
+
+    def relation_bwd(self, b):
+        self._rb.append(b)
+
+    def relu_bwd(self, dy, y, dx):
+        self._ops.append(('relu_bwd', dy, y, dx))
+
+    def rank1_update(self, dst, s_, v):
+        self._ops.append(('rank1', dst, s_, v))
+
+    @staticmethod
+    def _waves(items, targets):
+        waves = []
+        for it in items:
+            t = targets(it)
+            for w_items, w_t in waves:
+                if not (t & w_t):
+                    w_items.append(it)
+                    w_t |= t
+                    break
+            else:
+                waves.append(([it], set(t)))
+        return [w for w, _ in waves]
+
+    @staticmethod
+    def _rb_targets(b):
+        return {b[k].data_ptr() for k, acc in (('dq', 'dq_accumulate'), ('dk', 'dk_accumulate'))
+                if b.get(acc) and b.get(k) is not None}
+
+    def flush(self):
+        K = self.K
+        for flags, probs in self._gemm.items():
+            for wave in self._waves(probs, lambda g: {g['C'].data_ptr()} if g.get('accumulate') else set()):
+                K.gemm(wave, **dict(flags))
+        if self._rf:
+            K.relation_fwd_many(self._rf)
+        for wave in self._waves(self._rb, self._rb_targets):
+            K.relation_bwd_many(wave)
+        for wave in self._waves(self._ops, lambda o: {o[1].data_ptr()} if o[0] == 'rank1' else set()):
+            K.rowops(wave)
+        self._gemm, self._rf, self._rb, self._ops = {}, [], [], []
+
+    def run(self, producers):
+        live = list(producers)
+        done = object()
+        while live:
+            live = [g for g in live if next(g, done) is not done]
+            self.flush()
+
+
+def _bias_grad(K, G, bname, dY):
+    if bname is None or not G.has(bname):
+        return
+    dstb = G.sink(bname)
+    if dstb is not None:
+        K.colsum(dY, out=dstb.view(-1), accumulate=True)
+    else:
+        G.add(bname, K.colsum(dY))
+
+
+class _NowCtx:
+    """Temporaries and parameter gradients of the general relation code in their immediate form: fresh buffers, every
+    weight gradient computed where its operands appear (frame level: all frames in one call)."""
+
+    def __init__(self, K, G, n_inst, dev):
+        self.K, self.G, self.nI, self.dev = K, G, n_inst, dev
+
+    def new(self, key, rows, cols):
+        return torch.empty(self.nI * rows, cols, dtype=torch.float32, device=self.dev)
+
+    def new_flat(self, key, n):
+        return torch.empty(self.nI * n, dtype=torch.float32, device=self.dev)
+
+    def lin(self, wname, bname, dY, X, cols=None, total=None, keys=None):
+        _lin_w_grads(self.K, self.G, wname, bname, dY, X, cols=cols, total=total)
+
+    def additive(self, a_, FR, FS, da_r, dc_s, D):
+        """relu(Linear(cat[query, key]) -> 1): weight = [sum_r da_r FR | sum_s dc_s FS], bias = sum da_r."""
+        K, G = self.K, self.G
+        dw = torch.empty(2 * D, dtype=torch.float32, device=self.dev)
+        K.colsum(FR, rowscale=da_r, out=dw[:D])
+        K.colsum(FS, rowscale=dc_s, out=dw[D:])
+        G.add(a_ + '.weight', dw.view(1, -1))
+        G.add(a_ + '.bias', K.colsum(da_r.view(-1, 1)))
+
+    def bilinear(self, a_, dkp, FS, dscore_sum, D):
+        K, G = self.K, self.G
+        dA = torch.empty(D, D, dtype=torch.float32, device=self.dev)
+        K.gemm([dict(A=dkp, B=FS, C=dA)], a_kmajor=True, b_kmajor=True)
+        G.add(a_ + '.weight', dA.view(1, D, D))
+        G.add(a_ + '.bias', K.colsum(dscore_sum.view(-1, 1)))
+
+
+def _relation_fwd(Q, p, P, L, objects_mask, rel, saved, ctx):
+    """Producer (see _Staged) of relation `rel`'s messages at level L in every form the tuned kernel does not cover
+    (relational, receiver-specific, concat / bilinear / distance-based attention): a couple of GEMMs -- a Linear on
+    cat[receiver, sender] is split into a receiver and a sender projection -- and the general relation kernel
+    (relation.hip). Writes L.outs[rel]; saved[rel] = what the backward pass needs."""
+    K = Q.K
     h, D, nI = p.h, L.D, L.n_inst
-    dev = objects_mask.device
+    rk, sk = _REL_ENDS[rel]
+    R, Sn = L.sizes[rk], L.sizes[sk]
+    if R == 0:
+        return
+    FR, FS, out_block = L.feats[rk], L.feats[sk], L.outs[rel]
+    nm = L.names(rel)
+    f = dict(n_inst=nI, inst_per_clip=L.ipc, R=R, S=Sn, D=D, hidden=h, exclude_self=int(rel in ('hh', 'oo')),
+             send_mask=objects_mask if sk == 'o' else None)
+    rec = dict(rel=rel, f=f)
+    saved[rel] = rec
+    if p.relational:
+        # m = f( sum_s mask_s * g(cat[receiver, sender_s]) )   (models.py:1667-1690)
+        gw = P[nm['g'] + '.weight']
+        p_r, p_s, agg = ctx.new('p_r', R, h), ctx.new('p_s', Sn, h), ctx.new('agg', R, h)
+        Q.gemm([dict(A=FR, B=gw[:, :D], C=p_r), dict(A=FS, B=gw[:, D:], C=p_s, bias=P[nm['g'] + '.bias'])])
+        yield
+        f.update(score_mode=K.REL_SUM, msg_mode=K.REL_MSG_PAIR, p_r=p_r, p_s=p_s, out=agg)
+        Q.relation_fwd(f)
+        yield
+        Q.gemm([dict(A=agg, B=P[nm['f'] + '.weight'], C=out_block, bias=P[nm['f'] + '.bias'], act=1)])
+        rec.update(agg=agg)
+        if L.recv_masked(rel):   # the receiver's mask multiplies the finished message (:720, :729)
+            yield
+            rows_mask = objects_mask.view(p.bs, 1, p.O).expand(p.bs, L.ipc, p.O).contiguous().view(-1)
+            K.scale_rows(out_block, rows_mask)
+        return
+    w = P[nm['msg'] + '.weight']
+    if p.specific:     # message_fn(cat[receiver, sender]) (:1712-1713): receiver part + sender part, ReLU per pair
+        p_r, p_s = ctx.new('p_r', R, h), ctx.new('p_s', Sn, h)
+        Q.gemm([dict(A=FR, B=w[:, :D], C=p_r), dict(A=FS, B=w[:, D:], C=p_s, bias=P[nm['msg'] + '.bias'])])
+        f.update(msg_mode=K.REL_MSG_PAIR, p_r=p_r, p_s=p_s)
+    else:
+        msg = ctx.new('msg', Sn, h)
+        Q.gemm([dict(A=FS, B=w, C=msg, bias=P[nm['msg'] + '.bias'], act=1)])
+        f.update(msg_mode=K.REL_MSG_SENDER, msg=msg)
+    f.update(out=out_block, recv_mask=objects_mask if L.recv_masked(rel) else None)
+    dist = _rel_distance_view(p, L.dists, rel, nI)
+    if sk == 's':
+        f.update(score_mode=K.REL_SUM)        # one sender: its softmax weight is 1 whatever the score (Appendix A4)
+    elif p.mean_pool:
+        f.update(score_mode=K.REL_MEAN)
+    elif dist is not None:
+        f.update(score_mode=K.REL_DISTANCE, dist=dist)
+    elif p.att_style == 'dot':
+        f.update(score_mode=K.REL_DOT, q=FR, k=FS, scale=L.scale)
+    elif p.att_style == 'concat':   # relu(Linear(cat[query, key]) -> 1) (:1739-1741)
+        aw = P[nm['att'] + '.0.weight']
+        a_r, c_s = ctx.new('a_r', R, 1), ctx.new('c_s', Sn, 1)
+        Q.gemm([dict(A=FR, B=aw[:, :D], C=a_r, bias=P[nm['att'] + '.0.bias']), dict(A=FS, B=aw[:, D:], C=c_s)])
+        f.update(score_mode=K.REL_ADDITIVE, a_r=a_r, c_s=c_s)
+    else:                           # relu(Bilinear(query, key)) (:1746): keys transformed once per sender
+        kp = ctx.new('kp', Sn, D)
+        Q.gemm([dict(A=FS, B=P[nm['att'] + '.weight'].view(D, D), C=kp)])
+        f.update(score_mode=K.REL_DOT, q=FR, k=kp, scale=1.0, relu_scores=1, score_bias=P[nm['att'] + '.bias'])
+    if rel == 'oh':
+        f['att'] = ctx.new_flat('att', R * Sn).view(nI, R, Sn)   # inspect_model (:1203-1237)
+    yield
+    Q.relation_fwd(f)
+
+
+def relations_general_fwd(K, p, P, L, objects_mask, rels):
+    """Messages of the relations `rels` at level L (see _relation_fwd), all relations advancing together: one grouped
+    GEMM and one relation launch per dependency level. Returns what the backward pass needs."""
     saved = {}
-
-    def empty(*shape):
-        return torch.empty(*shape, dtype=torch.float32, device=dev)
-
-    for rel in rels:
-        rk, sk = _REL_ENDS[rel]
-        R, Sn = L.sizes[rk], L.sizes[sk]
-        if R == 0:
-            continue
-        FR, FS, out_block = L.feats[rk], L.feats[sk], L.outs[rel]
-        nm = L.names(rel)
-        f = dict(n_inst=nI, inst_per_clip=L.ipc, R=R, S=Sn, D=D, hidden=h, exclude_self=int(rel in ('hh', 'oo')),
-                 send_mask=objects_mask if sk == 'o' else None)
-        rec = dict(rel=rel, f=f)
-        if p.relational:
-            # m = f( sum_s mask_s * g(cat[receiver, sender_s]) )   (models.py:1667-1690)
-            gw = P[nm['g'] + '.weight']
-            p_r, p_s, agg = empty(nI * R, h), empty(nI * Sn, h), empty(nI * R, h)
-            K.gemm([dict(A=FR, B=gw[:, :D], C=p_r), dict(A=FS, B=gw[:, D:], C=p_s, bias=P[nm['g'] + '.bias'])])
-            f.update(score_mode=K.REL_SUM, msg_mode=K.REL_MSG_PAIR, p_r=p_r, p_s=p_s, out=agg)
-            K.relation_fwd(f)
-            K.gemm([dict(A=agg, B=P[nm['f'] + '.weight'], C=out_block, bias=P[nm['f'] + '.bias'], act=1)])
-            if L.recv_masked(rel):   # the receiver's mask multiplies the finished message (:720, :729)
-                rows_mask = objects_mask.view(p.bs, 1, p.O).expand(p.bs, L.ipc, p.O).contiguous().view(-1)
-                K.scale_rows(out_block, rows_mask)
-            rec.update(agg=agg)
-            saved[rel] = rec
-            continue
-        w = P[nm['msg'] + '.weight']
-        if p.specific:     # message_fn(cat[receiver, sender]) (:1712-1713): receiver part + sender part, ReLU per pair
-            p_r, p_s = empty(nI * R, h), empty(nI * Sn, h)
-            K.gemm([dict(A=FR, B=w[:, :D], C=p_r), dict(A=FS, B=w[:, D:], C=p_s, bias=P[nm['msg'] + '.bias'])])
-            f.update(msg_mode=K.REL_MSG_PAIR, p_r=p_r, p_s=p_s)
-        else:
-            msg = empty(nI * Sn, h)
-            K.gemm([dict(A=FS, B=w, C=msg, bias=P[nm['msg'] + '.bias'], act=1)])
-            f.update(msg_mode=K.REL_MSG_SENDER, msg=msg)
-        f.update(out=out_block, recv_mask=objects_mask if L.recv_masked(rel) else None)
-        dist = _rel_distance_view(p, L.dists, rel, nI)
-        if sk == 's':
-            f.update(score_mode=K.REL_SUM)        # one sender: its softmax weight is 1 whatever the score (Appendix A4)
-        elif p.mean_pool:
-            f.update(score_mode=K.REL_MEAN)
-        elif dist is not None:
-            f.update(score_mode=K.REL_DISTANCE, dist=dist)
-        elif p.att_style == 'dot':
-            f.update(score_mode=K.REL_DOT, q=FR, k=FS, scale=L.scale)
-        elif p.att_style == 'concat':   # relu(Linear(cat[query, key]) -> 1) (:1739-1741)
-            aw = P[nm['att'] + '.0.weight']
-            a_r, c_s = empty(nI * R, 1), empty(nI * Sn, 1)
-            K.gemm([dict(A=FR, B=aw[:, :D], C=a_r, bias=P[nm['att'] + '.0.bias']), dict(A=FS, B=aw[:, D:], C=c_s)])
-            f.update(score_mode=K.REL_ADDITIVE, a_r=a_r, c_s=c_s)
-        else:                           # relu(Bilinear(query, key)) (:1746): keys transformed once per sender
-            kp = empty(nI * Sn, D)
-            K.gemm([dict(A=FS, B=P[nm['att'] + '.weight'].view(D, D), C=kp)])
-            f.update(score_mode=K.REL_DOT, q=FR, k=kp, scale=1.0, relu_scores=1, score_bias=P[nm['att'] + '.bias'])
-        if rel == 'oh':
-            f['att'] = empty(nI, R, Sn)   # inspect_model: objects -> human weights (:1203-1237)
-        K.relation_fwd(f)
-        saved[rel] = rec
+    Q = _Staged(K)
+    ctx = _NowCtx(K, None, L.n_inst, objects_mask.device)
+    Q.run([_relation_fwd(Q, p, P, L, objects_mask, rel, saved, ctx) for rel in rels])
     return saved
 
 
-def relations_general_bwd(K, p, P, G, L, saved):
-    """Backward of relations_general_fwd: gradients of the message / relation / attention parameters (added to G), and
-    the feature gradients ADDED into L.dfeats; L.douts[rel] is the gradient wrt the written message block."""
-    h, D, nI = p.h, L.D, L.n_inst
-    dev = next(iter(L.feats.values())).device
+def _relation_bwd(Q, p, P, G, L, rel, rec, ctx):
+    """Producer of the backward pass of _relation_fwd: gradients of the message / relation / attention parameters (through
+    ctx: at once, or after the loop from per-step buffers), the feature gradients ADDED into L.dfeats; L.douts[rel] is
+    the gradient wrt the written message block."""
+    K = Q.K
+    h, D = p.h, L.D
+    rk, sk = _REL_ENDS[rel]
+    R, Sn = L.sizes[rk], L.sizes[sk]
+    FR, FS = L.feats[rk], L.feats[sk]
+    dFR, dFS = L.dfeats[rk], L.dfeats[sk]
+    dout_block = L.douts[rel]
+    nm = L.names(rel)
+    f = rec['f']
 
-    def empty(*shape):
-        return torch.empty(*shape, dtype=torch.float32, device=dev)
-
-    def split_linear_bwd(wname, bname, dp_r, dp_s, FR, FS, dFR, dFS):
+    def split_linear_bwd(wname, bname, dp_r, dp_s):
         """Linear on cat[receiver, sender] whose two halves were applied separately (the bias went with the sender)."""
         w = P[wname]
-        _lin_w_grads(K, G, wname, None, dp_r, FR, cols=(0, D), total=w.shape[1])
-        _lin_w_grads(K, G, wname, bname, dp_s, FS, cols=(D, 2 * D), total=w.shape[1])
-        K.gemm([dict(A=dp_r, B=w[:, :D], C=dFR, accumulate=True)], b_kmajor=True)
-        K.gemm([dict(A=dp_s, B=w[:, D:], C=dFS, accumulate=True)], b_kmajor=True)
+        ctx.lin(wname, None, dp_r, FR, cols=(0, D), total=w.shape[1], keys=('dp_r', rk))
+        ctx.lin(wname, bname, dp_s, FS, cols=(D, 2 * D), total=w.shape[1], keys=('dp_s', sk))
+        Q.gemm([dict(A=dp_r, B=w[:, :D], C=dFR, accumulate=True), dict(A=dp_s, B=w[:, D:], C=dFS, accumulate=True)],
+               b_kmajor=True)
 
-    for rel, rec in saved.items():
-        rk, sk = _REL_ENDS[rel]
-        R, Sn = L.sizes[rk], L.sizes[sk]
-        FR, FS = L.feats[rk], L.feats[sk]
-        dFR, dFS = L.dfeats[rk], L.dfeats[sk]
-        dout_block = L.douts[rel]
-        nm = L.names(rel)
-        f = rec['f']
-        if p.relational:
-            dpre = K.relu_bwd(dout_block, L.outs[rel])      # a masked receiver's block is 0: its gradient too
-            _lin_w_grads(K, G, nm['f'] + '.weight', nm['f'] + '.bias', dpre, rec['agg'])
-            dagg = empty(nI * R, h)
-            K.gemm([dict(A=dpre, B=P[nm['f'] + '.weight'], C=dagg)], b_kmajor=True)
-            dp_r, dp_s = empty(nI * R, h), empty(nI * Sn, h)
-            K.relation_bwd(dict(f=f, dout=dagg, dp_r=dp_r, dp_s=dp_s))
-            split_linear_bwd(nm['g'] + '.weight', nm['g'] + '.bias', dp_r, dp_s, FR, FS, dFR, dFS)
-            continue
-        m_ = nm['msg']
-        if sk == 's' and not p.mean_pool and p.att_style != 'dot':
-            for n_ in ((nm['att'] + '.weight', nm['att'] + '.bias') if p.att_style == 'general' else
-                       (nm['att'] + '.0.weight', nm['att'] + '.0.bias')):
-                if G.has(n_):
-                    G.add(n_, torch.zeros_like(P[n_]))
-        b = dict(f=f, dout=dout_block, relu_mask_dmsg=1)
-        if p.specific:
-            b.update(dp_r=empty(nI * R, h), dp_s=empty(nI * Sn, h))
-        else:
-            b.update(dmsg=empty(nI * Sn, h))
-        mode = f['score_mode']
-        dkp = None
-        if mode == K.REL_DOT and 'score_bias' not in f:
-            b.update(dq=dFR, dk=dFS, dq_accumulate=1, dk_accumulate=1)
-        elif mode == K.REL_DOT:       # bilinear: keys are the transformed ones
-            dkp = empty(nI * Sn, D)
-            b.update(dq=dFR, dq_accumulate=1, dk=dkp, dscore_sum=empty(nI))
-        elif mode == K.REL_ADDITIVE:
-            b.update(da_r=empty(nI * R), dc_s=empty(nI * Sn))
-        K.relation_bwd(b)
-        if p.specific:
-            split_linear_bwd(m_ + '.weight', m_ + '.bias', b['dp_r'], b['dp_s'], FR, FS, dFR, dFS)
-        else:
-            _lin_w_grads(K, G, m_ + '.weight', m_ + '.bias', b['dmsg'], FS)
-            K.gemm([dict(A=b['dmsg'], B=P[m_ + '.weight'], C=dFS, accumulate=True)], b_kmajor=True)
-        if mode == K.REL_ADDITIVE:
-            a_ = nm['att'] + '.0'
-            aw = P[a_ + '.weight'].view(-1)
-            dw = empty(2 * D)
-            K.colsum(FR, rowscale=b['da_r'], out=dw[:D])
-            K.colsum(FS, rowscale=b['dc_s'], out=dw[D:])
-            G.add(a_ + '.weight', dw.view(1, -1))
-            G.add(a_ + '.bias', K.colsum(b['da_r'].view(-1, 1)))
-            K.rank1_update(dFR, b['da_r'], aw[:D])
-            K.rank1_update(dFS, b['dc_s'], aw[D:])
-        elif dkp is not None:
-            a_ = nm['att']
-            A_ = P[a_ + '.weight'].view(D, D)
-            dA = empty(D, D)
-            K.gemm([dict(A=dkp, B=FS, C=dA)], a_kmajor=True, b_kmajor=True)
-            G.add(a_ + '.weight', dA.view(1, D, D))
-            G.add(a_ + '.bias', K.colsum(b['dscore_sum'].view(-1, 1)))
-            K.gemm([dict(A=dkp, B=A_, C=dFS, accumulate=True)], b_kmajor=True)
+    if p.relational:
+        dpre = ctx.new('dpre', R, h)
+        Q.relu_bwd(dout_block, L.outs[rel], dpre)      # a masked receiver's block is 0: its gradient too
+        yield
+        ctx.lin(nm['f'] + '.weight', nm['f'] + '.bias', dpre, rec['agg'], keys=('dpre', 'agg'))
+        dagg = ctx.new('dagg', R, h)
+        Q.gemm([dict(A=dpre, B=P[nm['f'] + '.weight'], C=dagg)], b_kmajor=True)
+        yield
+        dp_r, dp_s = ctx.new('dp_r', R, h), ctx.new('dp_s', Sn, h)
+        Q.relation_bwd(dict(f=f, dout=dagg, dp_r=dp_r, dp_s=dp_s))
+        yield
+        split_linear_bwd(nm['g'] + '.weight', nm['g'] + '.bias', dp_r, dp_s)
+        return
+    m_ = nm['msg']
+    if sk == 's' and not p.mean_pool and p.att_style != 'dot':
+        for n_ in ((nm['att'] + '.weight', nm['att'] + '.bias') if p.att_style == 'general' else
+                   (nm['att'] + '.0.weight', nm['att'] + '.0.bias')):
+            if G.has(n_):
+                G.add(n_, torch.zeros_like(P[n_]))
+    b = dict(f=f, dout=dout_block, relu_mask_dmsg=1)
+    if p.specific:
+        b.update(dp_r=ctx.new('dp_r', R, h), dp_s=ctx.new('dp_s', Sn, h))
+    else:
+        b.update(dmsg=ctx.new('dmsg', Sn, h))
+    mode = f['score_mode']
+    dkp = None
+    if mode == K.REL_DOT and 'score_bias' not in f:
+        b.update(dq=dFR, dk=dFS, dq_accumulate=1, dk_accumulate=1)
+    elif mode == K.REL_DOT:       # bilinear: keys are the transformed ones
+        dkp = ctx.new('dkp', Sn, D)
+        b.update(dq=dFR, dq_accumulate=1, dk=dkp, dscore_sum=ctx.new_flat('dscore_sum', 1))
+    elif mode == K.REL_ADDITIVE:
+        b.update(da_r=ctx.new_flat('da_r', R), dc_s=ctx.new_flat('dc_s', Sn))
+    Q.relation_bwd(b)
+    yield
+    if p.specific:
+        split_linear_bwd(m_ + '.weight', m_ + '.bias', b['dp_r'], b['dp_s'])
+    else:
+        ctx.lin(m_ + '.weight', m_ + '.bias', b['dmsg'], FS, keys=('dmsg', sk))
+        Q.gemm([dict(A=b['dmsg'], B=P[m_ + '.weight'], C=dFS, accumulate=True)], b_kmajor=True)
+    if mode == K.REL_ADDITIVE:
+        a_ = nm['att'] + '.0'
+        aw = P[a_ + '.weight'].view(-1)
+        ctx.additive(a_, FR, FS, b['da_r'], b['dc_s'], D)
+        Q.rank1_update(dFR, b['da_r'], aw[:D])
+        Q.rank1_update(dFS, b['dc_s'], aw[D:])
+    elif dkp is not None:
+        a_ = nm['att']
+        ctx.bilinear(a_, dkp, FS, b['dscore_sum'], D)
+        Q.gemm([dict(A=dkp, B=P[a_ + '.weight'].view(D, D), C=dFS, accumulate=True)], b_kmajor=True)
+
+
+def relations_general_bwd(K, p, P, G, L, saved):
+    """Backward of relations_general_fwd."""
+    Q = _Staged(K)
+    ctx = _NowCtx(K, G, L.n_inst, next(iter(L.feats.values())).device)
+    Q.run([_relation_bwd(Q, p, P, G, L, rel, rec, ctx) for rel, rec in saved.items()])
 
 
 _FRAME_RELS = ('hh', 'oh', 'sh', 'ho', 'so', 'oo')
@@ -734,11 +846,152 @@ def _seg_step_level(p, bufs, d, t, tp, first, zeros, carry=None, d_mg=None):
     return _RelLevel(p, True, p.bs, 1, prev, outs, dists, p.scale_seg, carry, douts or None)
 
 
+class _SegDeferred:
+    """Per-step buffers of the general segment loop whose consumers are parameter gradients. The loop used to add every
+    weight gradient step by step (T x directions x relations small k-major GEMMs and column sums -- most of its
+    launches); now a step writes its operand into slot t of a [bs][T][rows][cols] buffer per (direction, relation) and
+    finish() runs ONE tall GEMM per weight block after the loop, as the tuned path does. Operands that pair with the
+    previous segment states are matched against the state buffer hs in place: slot t of direction 0 with hs[:, t - 1],
+    of direction 1 with hs[:, t + 1]; the chain start multiplies zeros and only feeds the bias sums. Per-instance
+    scalars (additive attention, bilinear bias) are kept time-major, [T][bs * n], contiguous per step as the relation
+    kernel wants them."""
+
+    SLOTTED = ('agg', 'dpre', 'dp_r', 'dp_s', 'dmsg', 'dkp')
+
+    def __init__(self, K, p, dev, slots=None):
+        self.K, self.p, self.dev = K, p, dev
+        self.slots = {} if slots is None else slots   # (d, rel, key) -> buffer
+        self.recipes = {}
+
+    def at(self, d, rel, t):
+        return _SegCtx(self, d, rel, t)
+
+    def _with_prev(self, d, buf):
+        """The slots of the steps that have a previous state, as (bs, (T-1) rows, cols)."""
+        T = self.p.T
+        return (buf[:, 1:T] if d == 0 else buf[:, 0:T - 1]).flatten(1, 2)
+
+    def _prev(self, d, hs):
+        """Those previous states, in place in the state buffer: (bs, (T-1) E, h)."""
+        T, h = self.p.T, self.p.h
+        return (hs[:, 0:T - 1, :, 0:h] if d == 0 else hs[:, 1:T, :, h:2 * h]).flatten(1, 2)
+
+    def _scale_of(self, d, tm, n):
+        """Time-major per-instance scalars [T][bs * n] -> [(b, t, e)] order of the steps that have a previous state."""
+        K, bs, T = self.K, self.p.bs, self.p.T
+        src = (tm[1:T] if d == 0 else tm[0:T - 1]).view(T - 1, bs, n).permute(1, 0, 2)
+        dst = K.zeros(bs * (T - 1), n, like=tm) if hasattr(K, 'zeros') else torch.zeros(bs * (T - 1), n)   # test double
+        K.add_rows(src, dst)
+        return dst.view(-1)
+
+    def finish(self, G, bufs):
+        K, p = self.K, self.p
+        bs, T, h = p.bs, p.T, p.h
+        hs = {'h': bufs['hs_h'], 'o': bufs['hs_o']}
+        for (d, rel, what, wname, cols), r in self.recipes.items():
+            if what == 'lin':
+                bname, (ykey, xkey), total = r
+                dY = self.slots[(d, rel, ykey)]
+                if xkey == 'agg':
+                    X = self.slots[(d, rel, 'agg')]
+                    _lin_w_grads(K, G, wname, bname, dY.flatten(0, 2), X.flatten(0, 2))
+                    continue
+                if T > 1:
+                    _lin_w_grads(K, G, wname, None, self._with_prev(d, dY), self._prev(d, hs[xkey]), cols=cols, total=total)
+                else:   # a chain of one step: the features are the zero state, the weight gradient exists and is zero
+                    _lin_w_grads(K, G, wname, None, dY[:, 0], torch.zeros(bs, dY.shape[2], h, device=self.dev), cols=cols,
+                                 total=total)
+                _bias_grad(K, G, bname, dY.flatten(0, 2))
+            elif what == 'additive':
+                rk, sk, D = r
+                da_r, dc_s = self.slots[(d, rel, 'da_r')], self.slots[(d, rel, 'dc_s')]
+                dw = torch.zeros(2 * D, dtype=torch.float32, device=self.dev)
+                if T > 1:
+                    for kind, tm, half in ((rk, da_r, dw[:D]), (sk, dc_s, dw[D:])):
+                        n = p.H if kind == 'h' else p.O
+                        K.colsum(self._prev(d, hs[kind]), rowscale=self._scale_of(d, tm, n), out=half)
+                G.add(wname + '.weight', dw.view(1, -1))
+                G.add(wname + '.bias', K.colsum(da_r.view(-1, 1)))
+            else:   # bilinear
+                sk, D = r
+                dkp, ds = self.slots[(d, rel, 'dkp')], self.slots[(d, rel, 'dscore_sum')]
+                dA = torch.zeros(D, D, dtype=torch.float32, device=self.dev)
+                if T > 1:
+                    K.gemm([dict(A=self._with_prev(d, dkp), B=self._prev(d, hs[sk]), C=dA)], a_kmajor=True, b_kmajor=True)
+                G.add(wname + '.weight', dA.view(1, D, D))
+                G.add(wname + '.bias', K.colsum(ds.view(-1, 1)))
+
+
+class _SegCtx:
+    """_SegDeferred bound to one (direction, relation, step): same interface as _NowCtx."""
+
+    def __init__(self, owner, d, rel, t):
+        self.o, self.d, self.rel, self.t = owner, d, rel, t
+
+    def new(self, key, rows, cols):
+        """Slot t of the (direction, relation, key) buffer: [bs][T][rows][cols] for the operands of deferred parameter
+        gradients, time-major [T][bs * rows][cols] for everything else -- never a fresh allocation, so that a step's
+        addresses are those of the previous step plus a constant (see twog_tape_run)."""
+        o, p = self.o, self.o.p
+        slotted = key in o.SLOTTED
+        buf = o.slots.get((self.d, self.rel, key))
+        if buf is None:
+            shape = (p.bs, p.T, rows, cols) if slotted else (p.T, p.bs * rows, cols)
+            buf = o.slots[(self.d, self.rel, key)] = torch.empty(*shape, dtype=torch.float32, device=o.dev)
+        return buf[:, self.t] if slotted else buf[self.t]
+
+    def new_flat(self, key, n):
+        o, p = self.o, self.o.p
+        buf = o.slots.get((self.d, self.rel, key))
+        if buf is None:
+            buf = o.slots[(self.d, self.rel, key)] = torch.empty(p.T, p.bs * n, dtype=torch.float32, device=o.dev)
+        return buf[self.t]
+
+    def lin(self, wname, bname, dY, X, cols=None, total=None, keys=None):
+        self.o.recipes.setdefault((self.d, self.rel, 'lin', wname, cols), (bname, keys, total))
+
+    def additive(self, a_, FR, FS, da_r, dc_s, D):
+        rk, sk = _REL_ENDS[self.rel]
+        self.o.recipes.setdefault((self.d, self.rel, 'additive', a_, None), (rk, sk, D))
+
+    def bilinear(self, a_, dkp, FS, dscore_sum, D):
+        self.o.recipes.setdefault((self.d, self.rel, 'bilinear', a_, None), (_REL_ENDS[self.rel][1], D))
+
+
+def _general_tape(K, T):
+    """The general segment loop composes a few steps on the host and hands the rest to twog_tape_run when the backend
+    records (the HIP backend; the CPU test double runs every step) and the chain is long enough to have two template
+    steps between its special first and last ones. TWOG_GENERAL_TAPE=0: every step composed on the host."""
+    return hasattr(K, 'tape_run') and T >= 8 and os.environ.get('TWOG_GENERAL_TAPE', '1') != '0'
+
+
+def _run_affine_steps(K, compose, steps, dev, can_compose_all=True):
+    """steps: consecutive chain steps with the same structure. Records the first three, checks the third against the
+    affine rule and replays the whole range in the library; composes them one by one if the rule does not hold."""
+    tapes = []
+    for s_ in steps[:3]:
+        K.tape_begin()
+        try:
+            compose(s_)
+        finally:
+            tapes.append(K.tape_end())
+    if K.tape_matches(tapes[0], tapes[1], tapes[2], 2):
+        K.tape_run(tapes[0], tapes[1], 0, len(steps), dev)
+        return True
+    if not can_compose_all:
+        raise RuntimeError('general segment loop: the recorded backward steps are not affine in the step index')
+    for s_ in steps:   # not affine (should not happen): the plain loop
+        compose(s_)
+    return False
+
+
 def segment_recurrence_general_fwd(K, p, P, gi, u, objects_mask):
     """Segment-level loop (models.py:785-880) for the message forms the library's captured loop does not run: one chain
-    step after the other composed from the host -- general relation kernels for the messages, GEMMs for the
-    projections, the fused gate kernel for h_t = u GRUCell(x, h) + (1 - u) h. Same buffers as twog_segrnn_fwd. Slow
-    (hundreds of small launches per direction) but complete; none of these forms is in a shipped configuration."""
+    step after the other, BOTH directions of a step together -- per dependency level one grouped GEMM and one
+    multi-descriptor launch of the general relation kernel for all relations (_Staged), one grouped GEMM for the
+    projections, one launch of the fused gate kernel for h_t = u GRUCell(x, h) + (1 - u) h. The host composes the first
+    steps; steps 1 ... T-1 have the same structure with every operand one slot further, and the library replays them
+    (twog_tape_run). Same buffers as twog_segrnn_fwd. None of these forms is in a shipped configuration."""
     bs, T, h = p.bs, p.T, p.h
     dev = objects_mask.device
     E_of = {'h': p.H, 'o': p.O}
@@ -751,42 +1004,64 @@ def segment_recurrence_general_fwd(K, p, P, gi, u, objects_mask):
     for kind, E in E_of.items():
         bufs['hs_' + kind], bufs['save_' + kind] = e(bs, T, E, 2 * h), e(2, bs, T, E, 4 * h)
         bufs['mg_' + kind] = e(2, bs, T, E, nm[kind] * h)
+    gh = {k: e(2, T, bs * E, 3 * h) for k, E in E_of.items()}
+    gim = {k: e(2, T, bs * E, 3 * h) for k, E in E_of.items() if nm[k]}
     zeros = {k: torch.zeros(bs, E, h, dtype=torch.float32, device=dev) for k, E in E_of.items()}
     rels = [r for r in _SEG_RELS if getattr(p, 'rel_' + r)]
     saved = {}
-    for s_ in range(T):
+    Q = _Staged(K)
+    slots = _SegDeferred(K, p, dev)
+
+    def step(s_):
         first = s_ == 0
+        levels, producers = [], []
         for d in range(2):
             t = s_ if d == 0 else T - 1 - s_
             tp = t - 1 if d == 0 else t + 1
             L = _seg_step_level(p, bufs, d, t, tp, first, zeros)
-            saved[(s_, d)] = relations_general_fwd(K, p, P, L, objects_mask, rels)
-            steps, projections = [], []   # the projections of both kinds in ONE grouped launch
+            sv = saved[(s_, d)] = {}
+            producers += [_relation_fwd(Q, p, P, L, objects_mask, rel, sv, slots.at(d, rel, t)) for rel in rels]
+            levels.append((d, t, L))
+        Q.run(producers)
+        steps, projections = [], []   # the projections of both kinds and both directions in ONE grouped launch
+        for d, t, L in levels:
             for kind, E in E_of.items():
                 if E == 0:
                     continue
                 c = _SEG_CELLS[(kind, d)]
                 fw = p.fw_h if kind == 'h' else p.fw_o
-                gh = e(bs * E, 3 * h)
-                projections.append(dict(A=L.feats[kind], B=P[c + '.weight_hh'], C=gh, bias=P[c + '.bias_hh']))
-                gim = None
+                projections.append(dict(A=L.feats[kind], B=P[c + '.weight_hh'], C=gh[kind][d, t], bias=P[c + '.bias_hh']))
                 if nm[kind]:
-                    gim = e(bs * E, 3 * h)
-                    projections.append(dict(A=bufs['mg_' + kind][d, :, t], B=P[c + '.weight_ih'][:, fw:], C=gim))
-                steps.append(dict(gi=gi[kind][:, t, :, d * 3 * h:(d + 1) * 3 * h], gi2=gim, gh=gh,
-                                  h_prev=None if first else L.feats[kind],
+                    projections.append(dict(A=bufs['mg_' + kind][d, :, t], B=P[c + '.weight_ih'][:, fw:], C=gim[kind][d, t]))
+                steps.append(dict(gi=gi[kind][:, t, :, d * 3 * h:(d + 1) * 3 * h], gi2=gim[kind][d, t] if nm[kind] else None,
+                                  gh=gh[kind][d, t], h_prev=None if first else L.feats[kind],
                                   h_out=bufs['hs_' + kind][:, t, :, d * h:(d + 1) * h], save=bufs['save_' + kind][d, :, t],
                                   u=u[kind][:, t], rows=bs * E, hidden=h))
-            K.gemm(projections)
-            K.gru_step_fwd(steps)
+        K.gemm(projections)
+        K.gru_step_fwd(steps)
+
+    if _general_tape(K, T):
+        step(0)
+        _run_affine_steps(K, step, list(range(1, T)), dev)
+        K.tape_begin()   # the descriptors of the last steps, which the backward pass starts from: composed, not issued
+        try:
+            for s_ in (T - 4, T - 3, T - 2, T - 1):
+                step(s_)
+        finally:
+            K.tape_end()
+    else:
+        for s_ in range(T):
+            step(s_)
     bufs['general'] = saved
+    bufs['general_slots'] = slots.slots
     return bufs
 
 
 def segment_recurrence_general_bwd(K, p, P, G, bufs, gi_unused, u, objects_mask, d_hs):
-    """Backward through segment_recurrence_general_fwd. Returns d_gi / d_gh / d_u like twog_segrnn_bwd (the caller turns
-    them into the GRUCell weight gradients with large GEMMs); the message parameters' gradients are added to G here,
-    step by step."""
+    """Backward through segment_recurrence_general_fwd, both directions of a step together; steps T-2 ... 1 replayed by the
+    library from two composed ones. Returns d_gi / d_gh / d_u like twog_segrnn_bwd (the caller turns them into the
+    GRUCell weight gradients with large GEMMs); the message parameters' gradients are added to G after the loop from
+    the per-step buffers (_SegDeferred)."""
     bs, T, h = p.bs, p.T, p.h
     dev = objects_mask.device
     E_of = {'h': p.H, 'o': p.O}
@@ -800,14 +1075,19 @@ def segment_recurrence_general_bwd(K, p, P, G, bufs, gi_unused, u, objects_mask,
         out['d_gi_' + kind], out['d_gh_' + kind] = e(bs, T, E, 6 * h), e(bs, T, E, 6 * h)
         out['d_u_' + kind] = torch.zeros(bs, T, E, dtype=torch.float32, device=dev)
     carry = [{k: e(bs, E, h) for k, E in E_of.items()} for _ in range(2)]
-    trash = {k: e(bs, E, h) for k, E in E_of.items()}
+    trash = [{k: e(bs, E, h) for k, E in E_of.items()} for _ in range(2)]
+    d_mg_all = {k: e(2, T, bs * E, nm[k] * h) for k, E in E_of.items() if nm[k]}
     zeros = {k: torch.zeros(bs, E, h, dtype=torch.float32, device=dev) for k, E in E_of.items()}
-    for s_ in range(T - 1, -1, -1):
+    Q = _Staged(K)
+    slots = _SegDeferred(K, p, dev, bufs['general_slots'])
+
+    def step(s_):
         first, last = s_ == 0, s_ == T - 1
+        steps, through, levels = [], [], []
         for d in range(2):
             t = s_ if d == 0 else T - 1 - s_
             tp = t - 1 if d == 0 else t + 1
-            steps, d_mg = [], {}
+            d_mg = {}
             prev = {k: (None if first else bufs['hs_' + k][:, tp, :, d * h:(d + 1) * h]) for k in E_of}
             for kind, E in E_of.items():
                 if E == 0:
@@ -817,24 +1097,36 @@ def segment_recurrence_general_bwd(K, p, P, G, bufs, gi_unused, u, objects_mask,
                                   dgi=out['d_gi_' + kind][:, t, :, d * 3 * h:(d + 1) * 3 * h],
                                   dgh=out['d_gh_' + kind][:, t, :, d * 3 * h:(d + 1) * 3 * h], dh_prev=carry[d][kind],
                                   u=u[kind][:, t], du=out['d_u_' + kind][:, t], rows=bs * E, hidden=h))
-            K.gru_step_bwd(steps)
-            through = []   # both kinds' products with W_hh / W_ih[:, messages] in ONE grouped launch
-            for kind, E in E_of.items():
-                if E == 0:
-                    continue
                 c = _SEG_CELLS[(kind, d)]
                 fw = p.fw_h if kind == 'h' else p.fw_o
                 if not first:   # carried state gradient through W_hh
                     through.append(dict(A=out['d_gh_' + kind][:, t, :, d * 3 * h:(d + 1) * 3 * h], B=P[c + '.weight_hh'],
                                         C=carry[d][kind], accumulate=True))
                 if nm[kind]:
-                    d_mg[kind] = e(bs * E, nm[kind] * h)
+                    d_mg[kind] = d_mg_all[kind][d, t]
                     through.append(dict(A=out['d_gi_' + kind][:, t, :, d * 3 * h:(d + 1) * 3 * h],
                                         B=P[c + '.weight_ih'][:, fw:], C=d_mg[kind]))
-            K.gemm(through, b_kmajor=True)
-            if d_mg:
-                L = _seg_step_level(p, bufs, d, t, tp, first, zeros, carry=trash if first else carry[d], d_mg=d_mg)
-                relations_general_bwd(K, p, P, G, L, bufs['general'][(s_, d)])
+            levels.append((d, t, tp, d_mg))
+        K.gru_step_bwd(steps)          # both kinds, both directions: one launch
+        K.gemm(through, b_kmajor=True)  # their products with W_hh / W_ih[:, messages]: one grouped launch
+        producers = []
+        for d, t, tp, d_mg in levels:
+            if not d_mg:
+                continue
+            L = _seg_step_level(p, bufs, d, t, tp, first, zeros, carry=trash[d] if first else carry[d], d_mg=d_mg)
+            producers += [_relation_bwd(Q, p, P, G, L, rel, rec, slots.at(d, rel, t))
+                          for rel, rec in bufs['general'][(s_, d)].items()]
+        Q.run(producers)
+
+    if _general_tape(K, T):
+        step(T - 1)
+        # steps T-2 ... 1; composed here: T-2, T-3, T-4 (the forward pass left the descriptors of T-4 ... T-1 and 0 ... 3)
+        _run_affine_steps(K, step, list(range(T - 2, 0, -1)), dev, can_compose_all=False)
+        step(0)
+    else:
+        for s_ in range(T - 1, -1, -1):
+            step(s_)
+    slots.finish(G, bufs)
     return out
 
 

@@ -408,6 +408,11 @@ typedef struct {
     int32_t pad_;
 } twog_relation_bwd_t;
 int twog_relation_bwd(const twog_relation_bwd_t* rel, void* stream);
+/* n relations per call, several descriptors per launch: the general segment-level loop (vhoi/models.py:785-880 with the
+ * message forms above) issues all relations of both directions of a chain step together. The descriptors of one call
+ * must not ACCUMULATE into the same rows (dq / dk with *_accumulate set): they run concurrently. */
+int twog_relation_fwd_n(const twog_relation_t* rels, int n, void* stream);
+int twog_relation_bwd_n(const twog_relation_bwd_t* rels, int n, void* stream);
 
 /* ===============================================================================================================
  * Segment-boundary gates (vhoi/models.py:1477-1533, :1620-1627; pyrutils/torch/distributions.py:4-53) with
@@ -462,6 +467,37 @@ int twog_logsoftmax_permute_bwd(const float* out, const float* dout, float* dlog
 /* Elementwise helpers between GEMMs in the backward pass: dx = dy * (y > 0) (ReLU'), dst += src. */
 int twog_relu_bwd(twog_rows_t dy, twog_rows_t y, twog_rows_t dx, int rows, int cols, void* stream);
 int twog_add_rows(twog_rows_t src, twog_rows_t dst, int rows, int cols, void* stream);
+/* Several of these small row-wise operations in one launch (same callers as twog_relu_bwd / twog_add_rows /
+ * twog_rank1_update, issued once per dependency level by the general segment-level loop). No two operations of one call
+ * may write the same rows. */
+enum { TWOG_ROWOP_RELU_BWD = 0, TWOG_ROWOP_ADD = 1, TWOG_ROWOP_RANK1 = 2 };
+typedef struct {
+    twog_rows_t a, b, dst; /* RELU_BWD: dst = a * (b > 0);  ADD: dst += a;  RANK1: dst[r][c] += s[r] * v[c] */
+    const float* s;        /* RANK1: [rows] */
+    const float* v;        /* RANK1: [cols] */
+    int32_t kind, rows, cols, pad_;
+} twog_rowop_t;
+int twog_rowops(const twog_rowop_t* ops, int n_ops, void* stream);
+
+/* ===============================================================================================================
+ * Replay of a recorded call sequence for the further steps of a loop (the general segment-level loop,
+ * vhoi/models.py:785-880 with the message forms of twog_relation_*): the host composes two consecutive chain steps a, b
+ * as lists of calls (kind, flags, descriptor array in HOST memory) without issuing them; every 64-bit word w of every
+ * descriptor of step a + k is  w(a) + k * (w(b) - w(a))  -- per-step operands live in consecutive slots of per-step
+ * buffers, everything else is equal in a and b. Runs steps k_begin <= k < k_end in order (k = 0 is step a itself);
+ * the calls are exactly the entry points above. workspace: the split-K scratch handed to twog_gemm_f32.
+ * =============================================================================================================== */
+enum { TWOG_TAPE_GEMM = 0, TWOG_TAPE_RELATION_FWD = 1, TWOG_TAPE_RELATION_BWD = 2, TWOG_TAPE_GRU_STEP_FWD = 3,
+       TWOG_TAPE_GRU_STEP_BWD = 4, TWOG_TAPE_ROWOPS = 5 };
+typedef struct {
+    int32_t kind;     /* TWOG_TAPE_* */
+    int32_t n;        /* descriptors in the call */
+    int32_t flags;    /* GEMM: bit 0 a_kmajor, bit 1 b_kmajor */
+    int32_t pad_;
+    const void* desc; /* host array of n descriptors of the kind's type */
+} twog_tape_entry_t;
+int twog_tape_run(const twog_tape_entry_t* step_a, const twog_tape_entry_t* step_b, int n_entries, int k_begin, int k_end,
+                  void* workspace, size_t workspace_bytes, void* stream);
 
 /* Fused Adam on one flat fp32 parameter buffer (torch.optim.Adam semantics; reference train.py:39). The gradient is
  * multiplied by grad_scale first (1/world_size after a sum all-reduce). */

@@ -680,6 +680,19 @@ class FakeKernels:
         if d.get('att') is not None:
             d['att'].copy_(w.reshape(d['att'].shape))
 
+    def relation_fwd_many(self, ds):
+        for d in ds:
+            self.relation_fwd(d)
+
+    def relation_bwd_many(self, bs):
+        for b in bs:
+            self.relation_bwd(b)
+
+    def rowops(self, ops):
+        """ops: ('relu_bwd', dy, y, dx) | ('add', src, dst) | ('rank1', dst, s, v) -- one launch on the device."""
+        for op in ops:
+            getattr(self, {'relu_bwd': 'relu_bwd', 'add': 'add_rows', 'rank1': 'rank1_update'}[op[0]])(*op[1:])
+
     def relation_bwd(self, b):
         d = b['f']
         keys = [k for k in ('q', 'k', 'msg', 'p_r', 'p_s', 'a_r', 'c_s', 'score_bias') if d.get(k) is not None]

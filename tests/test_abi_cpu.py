@@ -41,7 +41,7 @@ def test_struct_layouts_match_the_c_compiler(tmp_path):
                'twog_gru_step_bwd_t': _lib.GruStepBwd, 'twog_bigru_t': _lib.BiGru, 'twog_bigru_bwd_t': _lib.BiGruBwd,
                'twog_attn_t': _lib.Attn, 'twog_attn_bwd_t': _lib.AttnBwd, 'twog_segrnn_t': _lib.SegRnn,
                'twog_segrnn_bwd_t': _lib.SegRnnBwd, 'twog_gate_t': _lib.Gate, 'twog_loss_t': _lib.Loss,
-               'twog_relation_t': _lib.Relation, 'twog_relation_bwd_t': _lib.RelationBwd}
+               'twog_relation_t': _lib.Relation, 'twog_relation_bwd_t': _lib.RelationBwd, 'twog_rowop_t': _lib.RowOp, 'twog_tape_entry_t': _lib.TapeEntry}
     src = tmp_path / 'sz.c'
     body = ''.join(f'printf("{n} %zu\\n", sizeof({n}));' for n in structs)
     src.write_text(f'#include <stdio.h>\n#include "{HEADER}"\nint main(void){{{body}return 0;}}\n')

@@ -512,6 +512,94 @@ def test_randomised_layouts_vs_oracle():
     print(f'30 random cases: worst output {worst_o:.2e}, worst gradient {worst_g:.2e}')
 
 
+GENERAL_FORMS = {
+    'relational': dict(message_type='v1'),
+    'specific': dict(message_granularity='v2'),
+    'concat': dict(attention_style='v1'),
+    'bilinear': dict(attention_style='v4'),
+    'specific_concat': dict(message_granularity='v2', attention_style='v1'),
+    'specific_mean_pool': dict(message_granularity='v2', message_aggregation='mp'),
+    'distance': dict(),
+    'constructor_defaults': None,
+}
+
+
+@pytest.mark.parametrize('form', sorted(GENERAL_FORMS))
+def test_general_segment_loop_replayed_by_the_library_equals_the_composed_loop_and_the_oracle(form, monkeypatch):
+    """The general segment-level loop (relational / receiver-specific messages, concat / bilinear / distance attention)
+    composes its first steps on the host and lets the library replay the rest (twog_tape_run: every descriptor word
+    affine in the step index). At T = 12: (a) the replayed loop's outputs and parameter gradients are BIT-IDENTICAL to
+    the loop composed step by step (TWOG_GENERAL_TAPE=0) -- the same launches with the same arguments; (b) both agree
+    with the oracle (outputs 1e-4, gradients 5e-4 of their scale + 5e-6)."""
+    bs, T, H, O, N, h = 3, 12, 2, 3, 26, 32
+    over = GENERAL_FORMS[form]
+    cfg = dict(message_segment=True) if over is None else dict(STAGE1, **over)
+    torch.manual_seed(77)
+    m = TGGCN(input_size=(2048 + 4 * N, 2048), num_classes=(13, None), hidden_size=h, gcn_node=N, **cfg)
+    assert m_plan_is_general(m, bs, T, H, O, N, form == 'distance')
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    x_human, x_objects, mask = _synthetic(bs, T, H, O, N, seed=5)
+    g = torch.Generator().manual_seed(9)
+    kw = dict(human_segmentation=(torch.rand(bs, T, H, generator=g) < 0.6).float())
+    if form == 'distance':
+        def dd(*shape):
+            d = torch.rand(*shape, generator=g) * 2 + 0.05
+            d[torch.rand(*shape, generator=g) < 0.15] = 0.0
+            return d
+        kw.update(human_human_distances=dd(bs, T, H, H), human_object_distances=dd(bs, T, H, O),
+                  object_object_distances=dd(bs, T, O, O))
+    noise = torch.distributions.gumbel.Gumbel(0.0, 1.0).sample((T * O, bs, 2))
+    osd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and 'running' not in k else v.clone())
+           for k, v in sd.items()}
+    ref = cpu_ref.tggcn_forward(osd, dict(m.cfg), x_human, x_objects, mask, training=True, gumbel_noise=noise, **kw)
+    rs = [torch.randn(o.shape, generator=torch.Generator().manual_seed(i)) for i, o in enumerate(ref)]
+    sum((o * r).sum() for o, r in zip(ref, rs) if o.requires_grad).backward()
+    m = m.to(DEV).train()
+    m._gumbel_noise_override = noise
+    dkw = {k: v.to(DEV) for k, v in kw.items()}
+    K = twog_kernels.get_kernels()
+    runs = {}
+    for mode in ('1', '0'):
+        monkeypatch.setenv('TWOG_GENERAL_TAPE', mode)
+        m.load_state_dict(sd)
+        m.zero_grad(set_to_none=True)
+        replays = []
+        if mode == '1':
+            real = K.tape_run
+            monkeypatch.setattr(K, 'tape_run', lambda *a, **k: (replays.append(a[2:4]), real(*a, **k))[1])
+        out = m(x_human.to(DEV), x_objects.to(DEV), mask.to(DEV), **dkw)
+        sum((o * r.to(DEV)).sum() for o, r in zip(out, rs) if o.requires_grad).backward()
+        if mode == '1':
+            monkeypatch.undo()
+            assert replays == [(0, T - 1), (0, T - 2)], replays   # forward steps 1 ... T-1, backward steps T-2 ... 1
+        runs[mode] = ([o.detach().cpu() for o in out],
+                      {n: (None if p.grad is None else p.grad.detach().cpu().clone()) for n, p in m.named_parameters()})
+    for a, b in zip(runs['1'][0], runs['0'][0]):
+        assert torch.equal(a, b)
+    for n, ga in runs['1'][1].items():
+        gb = runs['0'][1][n]
+        assert (ga is None) == (gb is None) and (ga is None or torch.equal(ga, gb)), n
+    for i, (o, r) in enumerate(zip(runs['1'][0], ref)):
+        err = (o - r.detach()).abs().max().item() / max(1.0, r.detach().abs().max().item())
+        assert err < REL, (form, i, err)
+    for n, ga in runs['1'][1].items():
+        g_ref = osd[n].grad
+        if g_ref is None:
+            assert ga is None or float(ga.abs().max()) == 0.0, n
+            continue
+        scale = max(g_ref.abs().max().item(), 1e-6)
+        err = (ga - g_ref).abs().max().item()
+        assert err < GRAD_REL * scale + GRAD_ABS, (form, n, err / scale)
+
+
+def m_plan_is_general(m, bs, T, H, O, N, dists):
+    from twog_gcn_amd import ops
+    p = ops.Plan(m.cfg, bs, T, H, O, N, 2048, 13, None, True, False)
+    if dists:
+        p.dists = {'hh': 1}
+    return p.general_segment()
+
+
 def test_inspect_model_attention_scores_vs_oracle():
     """predict.py --inspect_model on the HIP path: the three (bs, H, T, O) objects->human attention tensors."""
     z, meta = load_g4('c2_stage1')
