@@ -1,0 +1,378 @@
+// Frame-level bidirectional GRU recurrence as ONE persistent launch with the recurrent weights resident on the chip.
+//
+// Reference: _process_frame_level_rnn (vhoi/models.py:983-1002): nn.GRU(h, h, bidirectional) per entity type, all
+// entities of a type batched as rows; gate order r, z, n. Same inputs, outputs and saved tensors as twog_bigru_fwd
+// (gru.hip), which issues one launch per time step (gemm_gru_fwd_kernel: each of its 176 tiles re-reads a 384 KB slice
+// of W_hh every step).
+//
+// Here the chip is partitioned once: a workgroup (one per CU, 4 waves, one per SIMD) owns, for the whole sequence, a
+// slice of 16 hidden units x 3 gates of ONE (entity type, direction) weight and a chunk of at most 16 of that type's
+// 16-row tiles. The slice's 48 x h weights are split ONCE into their three bf16 planes and kept in LDS as ready MFMA B
+// fragments (lane-linear 1 KB blocks per (k-block, gate, plane): 144 KB at h = 512); every wave owns up to four row
+// tiles and runs the whole reduction for them (exact 3 x bf16 split of the streamed states, 6 of 9 products on
+// v_mfma_f32_16x16x32_bf16, fp32 accumulate, the h.h product and the five small ones in separate accumulators like
+// the 64x64 class), each B fragment it reads serving all its tiles; then the input projection, the gate math, and the
+// tile's 16 columns of h_t. No partial sums cross waves: a row tile's chain lives in one wave.
+//
+// Steps are ordered inside the launch. A row tile of step s needs all h / 16 slices of that tile from step s - 1 --
+// nothing else: the wave w of every workgroup of a (group, chunk) combination works the same tiles, so the hand-off is
+// between same-numbered waves of those workgroups, per the agent-scope rules of gfx950 (per-XCD L2s are not coherent):
+// states stored write-through (16-byte sc1 stores), the storing wave drains them (s_waitcnt vmcnt(0)) and one of its
+// lanes adds to the combination's wave counter (agent scope); the consuming wave polls that counter with sc1 loads and
+// reads the states with sc1 loads only. Every spin is bounded (a trap, not a hang, if the grid is not fully resident).
+// With 8 combinations (the bench shape) the 32 workgroups of a combination share blockIdx mod 8, i.e. an XCD: their
+// exchange stays in that XCD's L2 -- a matter of speed, never of correctness. Bit-reproducible: fixed summation order.
+#include "twog_common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((__vector_size__(4 * sizeof(unsigned))));
+
+#ifndef TWOG_GP_ABLATE
+#define TWOG_GP_ABLATE 0   // measurement builds only (tools/bigru_persist_ablate.sh): 1 no MFMAs, 2 no state loads, 4 no poll,
+#endif                     // 8 no save stores, 16 no gi / h0 loads -- wrong results by design, only the times count
+
+constexpr int MAXG = 8;     // (entity type, direction) groups
+constexpr int MAXC = 32;    // (group, row chunk) combinations, each worked by hidden / 16 workgroups
+constexpr int MAXTW = 4;    // row tiles per wave at most: a chunk has at most 4 * MAXTW tiles
+constexpr int SC1 = 16;     // aux bits of the buffer instructions: sc1 (write-through stores / L2-served loads)
+
+struct PGroup {
+    const float* gi;     // [bs][T][E][6h]
+    const float* w_hh;   // [3h][h] of this direction
+    const float* b_hh;   // [3h] or nullptr
+    float* out;          // [bs][T][E][2h]
+    float* save;         // [2][bs][T][E][4h]
+    int E, dir, rows;    // rows = bs * E
+};
+struct PCombo { int group, rt0, rt1, tw; };   // row tiles [rt0, rt1): wave w owns tiles rt0 + w * tw ... + tw - 1
+struct PArgs {
+    PGroup g[MAXG];
+    PCombo c[MAXC];
+    unsigned* pub;       // [MAXC][4] zero at launch: arrivals (workgroups x steps) of each wave's tiles
+    unsigned* error;     // set to 1 before a trap (spin bound exceeded)
+    int n_combos, bs, T;
+    int spin_limit;
+};
+
+__device__ __forceinline__ uint32_t pack_hi16(uint32_t lo, uint32_t hi) { return __builtin_amdgcn_perm(hi, lo, 0x07060302); }
+
+// eight consecutive fp32 values -> the three bf16 planes of an MFMA fragment (element j = value j), by truncation: exact
+__device__ __forceinline__ void split8(const f32x4 a, const f32x4 b, bf16x8& ph, bf16x8& pm, bf16x8& pl) {
+    uint32_t x[8], r1[8], r2[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const float f0 = i < 4 ? a[i] : b[i - 4];
+        x[i] = __float_as_uint(f0);
+        const float f1 = f0 - __uint_as_float(x[i] & 0xffff0000u);
+        r1[i] = __float_as_uint(f1);
+        r2[i] = __float_as_uint(f1 - __uint_as_float(r1[i] & 0xffff0000u));
+    }
+    ph = __builtin_bit_cast(bf16x8, i32x4{(int)pack_hi16(x[0], x[1]), (int)pack_hi16(x[2], x[3]), (int)pack_hi16(x[4], x[5]), (int)pack_hi16(x[6], x[7])});
+    pm = __builtin_bit_cast(bf16x8, i32x4{(int)pack_hi16(r1[0], r1[1]), (int)pack_hi16(r1[2], r1[3]), (int)pack_hi16(r1[4], r1[5]), (int)pack_hi16(r1[6], r1[7])});
+    pl = __builtin_bit_cast(bf16x8, i32x4{(int)pack_hi16(r2[0], r2[1]), (int)pack_hi16(r2[2], r2[3]), (int)pack_hi16(r2[4], r2[5]), (int)pack_hi16(r2[6], r2[7])});
+}
+
+__device__ __forceinline__ f32x4 mfma(const bf16x8 a, const bf16x8 b, const f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
+// NKB k-blocks of 32: hidden = 32 * NKB. TWC: row tiles per wave at most (of all combinations); D: k-blocks of states in
+// flight per wave beside the one being multiplied -- with one tile per wave (small batches: the step is a latency chain)
+// the whole row of states is requested at once.
+template <int NKB, int TWC>
+__global__ __launch_bounds__(256, 1) void bigru_persist_fwd_kernel(const PArgs P) {
+    constexpr int TW = TWC;
+    constexpr int D = TWC == 1 ? NKB : (TWC == 2 ? (NKB < 8 ? NKB : 8) : (NKB < 3 ? NKB : 3));
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int h = 32 * NKB, n_wg = h / 16;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i16 = lane & 15, g4 = lane >> 4;
+    const int combo = (int)blockIdx.x % P.n_combos, slice = (int)blockIdx.x / P.n_combos;
+    const PCombo& C = P.c[combo];
+    const PGroup& G = P.g[C.group];
+    const int T = P.T, E = G.E, dir = G.dir;
+    const float inv_e = 1.0f / (float)E;
+    unsigned* pub = P.pub + combo * 4 + wave;
+    const int t0 = C.rt0 + wave * C.tw;
+    const int nt = max(0, min(C.tw, C.rt1 - t0));   // this wave's tiles: t0 ... t0 + nt - 1
+    // LDS: the weight slice as B fragments [k-block][gate][plane][64 lanes] x 16 bytes, then a [16][20] float scratch per wave
+    i32x4* wfrag = reinterpret_cast<i32x4*>(smem);
+    float* scratch = reinterpret_cast<float*>(smem + NKB * 9 * 1024) + wave * 16 * 20;
+    // lane l of a fragment holds W[gate c][unit 16 slice + (l & 15)][k = 32 kb + 8 (l >> 4) + j], j = 0..7
+    for (int f = wave; f < NKB * 3; f += 4) {
+        const int kb = f / 3, c = f - kb * 3;
+        const float* w = G.w_hh + (int64_t)(c * h + slice * 16 + i16) * h + kb * 32 + 8 * g4;
+        bf16x8 ph, pm, pl;
+        split8(*reinterpret_cast<const f32x4*>(w), *reinterpret_cast<const f32x4*>(w + 4), ph, pm, pl);
+        wfrag[((kb * 3 + c) * 3 + 0) * 64 + lane] = __builtin_bit_cast(i32x4, ph);
+        wfrag[((kb * 3 + c) * 3 + 1) * 64 + lane] = __builtin_bit_cast(i32x4, pm);
+        wfrag[((kb * 3 + c) * 3 + 2) * 64 + lane] = __builtin_bit_cast(i32x4, pl);
+    }
+    float bias[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) bias[c] = G.b_hh ? G.b_hh[c * h + slice * 16 + i16] : 0.f;
+    __syncthreads();
+    if (nt == 0) return;   // (a wave without tiles neither waits nor is waited for: the counters are per wave)
+    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(G.out, 0, 0xffffffff, 0x00020000);
+    const int col = slice * 16 + i16;
+    // byte offset of (row, column 0 of this direction) at time x in `out`: rows (b, e) of [bs][T][E][2h]
+    auto out_off = [&](int row, int x) -> uint32_t {
+        const int b = (int)(((float)row + 0.5f) * inv_e), e = row - b * E;
+        return 4u * (uint32_t)((((int64_t)b * T + x) * E + e) * (2 * h) + dir * h);
+    };
+
+    for (int s = 0; s < T; ++s) {
+        const int t = dir == 0 ? s : T - 1 - s, tp = dir == 0 ? t - 1 : t + 1;
+        // the input projections of this wave's outputs: independent of the chain, requested before the wait
+        float gi[TW][4][3];
+#pragma unroll
+        for (int i = 0; i < TW; ++i)
+            if (i < nt && !(TWOG_GP_ABLATE & 16)) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = min((t0 + i) * 16 + 4 * g4 + r, G.rows - 1);
+                    const int b = (int)(((float)row + 0.5f) * inv_e), e = row - b * E;
+                    const float* p = G.gi + ((((int64_t)b * T + t) * E + e) * 6 + dir * 3) * h + col;
+                    gi[i][r][0] = p[0]; gi[i][r][1] = p[h]; gi[i][r][2] = p[2 * h];
+                }
+            }
+        f32x4 hi[TW][3], lo[TW][3];
+#pragma unroll
+        for (int i = 0; i < TW; ++i)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { hi[i][c] = f32x4{0.f, 0.f, 0.f, 0.f}; lo[i][c] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        float h0[TW][4];
+#pragma unroll
+        for (int i = 0; i < TW; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) h0[i][r] = 0.f;
+        if (s > 0) {
+            // every slice has published step s - 1 of this wave's tiles
+            if (lane == 0 && !(TWOG_GP_ABLATE & 4)) {
+                const unsigned want = (unsigned)s * (unsigned)n_wg;
+                int spins = 0;
+                while (__hip_atomic_load(pub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > P.spin_limit) {
+                        __hip_atomic_store(P.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __builtin_trap();
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            uint32_t abase[TW];
+#pragma unroll
+            for (int i = 0; i < TW; ++i) {
+                const int row = min((t0 + min(i, nt - 1)) * 16 + i16, G.rows - 1);
+                abase[i] = out_off(row, tp) + 4u * (uint32_t)(8 * g4);
+                if (TWOG_GP_ABLATE & 2) abase[i] = 4u * (uint32_t)(lane * 8);
+            }
+#pragma unroll
+            for (int i = 0; i < TW; ++i)
+                if (i < nt && !(TWOG_GP_ABLATE & 16)) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = min((t0 + i) * 16 + 4 * g4 + r, G.rows - 1);
+                        h0[i][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_out, (int)(out_off(row, tp) + 4u * (uint32_t)col), 0, SC1));
+                    }
+                }
+            auto load_a = [&](int kb, f32x4 (&a)[TW][2]) {
+#pragma unroll
+                for (int i = 0; i < TW; ++i) {
+                    a[i][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_out, (int)(abase[i] + 128u * kb), 0, SC1));
+                    a[i][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_out, (int)(abase[i] + 128u * kb + 16u), 0, SC1));
+                }
+            };
+            auto mac = [&](int kb, const f32x4 (&a)[TW][2]) {
+                if (TWOG_GP_ABLATE & 1) return;
+                bf16x8 ah[TW], am[TW], al[TW];
+#pragma unroll
+                for (int i = 0; i < TW; ++i) split8(a[i][0], a[i][1], ah[i], am[i], al[i]);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const bf16x8 wh = __builtin_bit_cast(bf16x8, wfrag[((kb * 3 + c) * 3 + 0) * 64 + lane]);
+                    const bf16x8 wm = __builtin_bit_cast(bf16x8, wfrag[((kb * 3 + c) * 3 + 1) * 64 + lane]);
+                    const bf16x8 wl = __builtin_bit_cast(bf16x8, wfrag[((kb * 3 + c) * 3 + 2) * 64 + lane]);
+#pragma unroll
+                    for (int i = 0; i < TW; ++i) {
+                        if (i < nt) {
+                            hi[i][c] = mfma(ah[i], wh, hi[i][c]);
+                            lo[i][c] = mfma(ah[i], wm, lo[i][c]);
+                            lo[i][c] = mfma(am[i], wh, lo[i][c]);
+                            lo[i][c] = mfma(am[i], wm, lo[i][c]);
+                            lo[i][c] = mfma(ah[i], wl, lo[i][c]);
+                            lo[i][c] = mfma(al[i], wh, lo[i][c]);
+                        }
+                    }
+                }
+            };
+            // D k-blocks in flight beside the one being multiplied (straight-line code: the compiler counts its waits)
+            f32x4 ring[D][TW][2];
+#pragma unroll
+            for (int kb = 0; kb < D; ++kb) load_a(kb, ring[kb]);
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb) {
+                mac(kb, ring[kb % D]);
+                if (kb + D < NKB) load_a(kb + D, ring[kb % D]);
+            }
+        }
+        // ---- gates; the states first (write-through), then the signal, then what only the backward pass reads
+        float rg[TW][4], zz[TW][4], nn[TW][4], hn4[TW][4];
+#pragma unroll
+        for (int i = 0; i < TW; ++i) {
+            if (i < nt) {
+                const int rt = t0 + i;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float hr = hi[i][0][r] + lo[i][0][r] + bias[0], hz = hi[i][1][r] + lo[i][1][r] + bias[1];
+                    hn4[i][r] = hi[i][2][r] + lo[i][2][r] + bias[2];
+                    rg[i][r] = 1.0f / (1.0f + expf(-(gi[i][r][0] + hr)));
+                    zz[i][r] = 1.0f / (1.0f + expf(-(gi[i][r][1] + hz)));
+                    nn[i][r] = tanhf(gi[i][r][2] + rg[i][r] * hn4[i][r]);
+                    scratch[(4 * g4 + r) * 20 + i16] = (1.0f - zz[i][r]) * nn[i][r] + zz[i][r] * h0[i][r];
+                }
+                // the tile's 16 x 16 states: one 16-byte write-through store per lane (row = lane / 4, 4 units)
+                const int srow = lane >> 2, sc = (lane & 3) * 4;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(scratch + srow * 20 + sc);   // same wave wrote it: in order
+                const int row = rt * 16 + srow;
+                if (row < G.rows)
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs_out,
+                                                           (int)(out_off(row, t) + 4u * (uint32_t)(slice * 16 + sc)), 0, SC1);
+            }
+        }
+        // publish step s of this wave's tiles: the wave drains its stores, then one lane signals
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_fetch_add(pub, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int i = 0; i < TW; ++i) {
+            if (i < nt && !(TWOG_GP_ABLATE & 8)) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = (t0 + i) * 16 + 4 * g4 + r;
+                    if (row < G.rows) {
+                        const int b = (int)(((float)row + 0.5f) * inv_e), e = row - b * E;
+                        float* sv = G.save + ((((int64_t)dir * P.bs + b) * T + t) * E + e) * (4 * h) + col;
+                        sv[0] = rg[i][r]; sv[h] = zz[i][r]; sv[2 * h] = nn[i][r]; sv[3 * h] = hn4[i][r];
+                    }
+                }
+            }
+        }
+    }
+}
+
+}  // namespace
+
+// Plans the partition for (n_types entity counts E, bs, hidden) on n_cus compute units: per (type, direction) group the
+// number of row-tile chunks (every chunk is worked by hidden / 16 workgroups, one per slice of 16 units), growing the
+// group with the longest chunk while the grid still fits. Returns the number of (group, chunk) combinations or -1 when
+// the shape is not served: hidden not 128 / 256 / 512, more combinations x slices than compute units, or a chunk of
+// more than 16 row tiles (four per wave).
+static int plan(const twog_bigru_t* types, int n_types, int bs, int hidden, int n_cus, PCombo* combos) {
+    if (hidden != 128 && hidden != 256 && hidden != 512) return -1;
+    const int slices = hidden / 16, n_groups = 2 * n_types;
+    if (n_groups > MAXG || n_groups * slices > n_cus) return -1;
+    int total = n_groups, rt[MAXG], chunks[MAXG];
+    for (int g = 0; g < n_groups; ++g) {
+        chunks[g] = 1;
+        rt[g] = (bs * types[g / 2].E + 15) / 16;
+        if (rt[g] == 0) return -1;
+    }
+    for (;;) {
+        int best = -1, longest = 1;
+        for (int g = 0; g < n_groups; ++g) {
+            const int len = (rt[g] + chunks[g] - 1) / chunks[g];
+            if (len > longest && chunks[g] < rt[g]) { longest = len; best = g; }
+        }
+        if (best < 0 || (total + 1) * slices > n_cus || total + 1 > MAXC) break;
+        ++chunks[best];
+        ++total;
+    }
+    int n = 0;
+    for (int g = 0; g < n_groups; ++g)
+        for (int c = 0; c < chunks[g]; ++c) {
+            PCombo& C = combos[n++];
+            C.group = g;
+            C.rt0 = c * rt[g] / chunks[g];
+            C.rt1 = (c + 1) * rt[g] / chunks[g];
+            const int tiles = C.rt1 - C.rt0;
+            if (tiles > 4 * MAXTW) return -1;
+            C.tw = (tiles + 3) / 4;
+        }
+    return n;
+}
+
+// 2 if twog_bigru_fwd_persistent serves this shape on the current device AND is the faster path (every wave owns at
+// most one row tile: the small-batch regime, where a step is a latency chain -- 9.2 us per step against 17.4 at 8
+// clips; with more tiles per wave the launch-per-step path wins: 48 against 31 us at 64 clips);
+// 1 if it is served but slower; 0 if it is not served.
+extern "C" int twog_bigru_persistent_supported(const twog_bigru_t* types, int n_types, int bs, int hidden) {
+    int dev = 0, n_cus = 0;
+    if (n_types <= 0 || n_types > MAXG / 2) return 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    if (hipDeviceGetAttribute(&n_cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+    PCombo combos[MAXC];
+    const int n = plan(types, n_types, bs, hidden, n_cus, combos);
+    if (n <= 0) return 0;
+    for (int i = 0; i < n; ++i)
+        if (combos[i].tw > 1) return 1;
+    return 2;
+}
+
+// Same contract as twog_bigru_fwd (tmp_gh and zeros unused). sync: device memory, >= 1024 uint32, ZERO at launch
+// ([0, 128) the waves' arrival counters, [128] the error word).
+extern "C" int twog_bigru_fwd_persistent(const twog_bigru_t* types, int n_types, int bs, int T, int hidden, void* sync,
+                                         void* stream) {
+    if (n_types <= 0 || T <= 0) return 0;
+    if (n_types > MAXG / 2) return -2;
+    int dev = 0, n_cus = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return -(int)e;
+    e = hipDeviceGetAttribute(&n_cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (e != hipSuccess) return -(int)e;
+    PArgs P;
+    const int n_combos = plan(types, n_types, bs, hidden, n_cus, P.c);
+    if (n_combos <= 0 || !sync) return -2;
+    for (int k = 0; k < n_types; ++k)
+        for (int dir = 0; dir < 2; ++dir) {
+            PGroup& G = P.g[2 * k + dir];
+            const twog_bigru_t& Y = types[k];
+            G.gi = Y.gi; G.w_hh = dir == 0 ? Y.w_hh_f : Y.w_hh_r; G.b_hh = dir == 0 ? Y.b_hh_f : Y.b_hh_r;
+            G.out = Y.out; G.save = Y.save; G.E = Y.E; G.dir = dir; G.rows = bs * Y.E;
+        }
+    P.pub = static_cast<unsigned*>(sync);
+    P.error = P.pub + MAXC * 4;
+    P.n_combos = n_combos; P.bs = bs; P.T = T;
+    P.spin_limit = 1 << 24;   // x ~0.1 us: seconds -- a grid that is not fully resident ends in a trap, not a hang
+    const int grid = n_combos * (hidden / 16);
+    const size_t lds = (size_t)(hidden / 32) * 9 * 1024 + 4 * 16 * 20 * 4;
+    int twc = 1;
+    for (int i = 0; i < n_combos; ++i)
+        if (P.c[i].tw > twc) twc = P.c[i].tw;
+    twc = twc > 2 ? 4 : twc;
+    hipStream_t st = (hipStream_t)stream;
+#define TWOG_GP_LAUNCH(NKB_, TWC_)                                                                              \
+    do {                                                                                                        \
+        static std::atomic<uint32_t> done{0};                                                                   \
+        twog_allow_dynamic_lds(bigru_persist_fwd_kernel<NKB_, TWC_>, 160 * 1024, done);                         \
+        hipLaunchKernelGGL((bigru_persist_fwd_kernel<NKB_, TWC_>), dim3(grid), dim3(256), lds, st, P);          \
+    } while (0)
+#define TWOG_GP_LAUNCH_H(NKB_)                                                                                  \
+    do {                                                                                                        \
+        if (twc == 1) TWOG_GP_LAUNCH(NKB_, 1);                                                                  \
+        else if (twc == 2) TWOG_GP_LAUNCH(NKB_, 2);                                                             \
+        else TWOG_GP_LAUNCH(NKB_, 4);                                                                           \
+    } while (0)
+    switch (hidden) {
+        case 128: TWOG_GP_LAUNCH_H(4); break;
+        case 256: TWOG_GP_LAUNCH_H(8); break;
+        default: TWOG_GP_LAUNCH_H(16); break;
+    }
+#undef TWOG_GP_LAUNCH_H
+#undef TWOG_GP_LAUNCH
+    TWOG_CHECK_LAUNCH();
+    return 0;
+}

@@ -10,6 +10,7 @@ stride on cols -- it maps onto twog_rows_t without a copy.
 """
 import ctypes as C
 import math
+import os
 
 import torch
 
@@ -346,8 +347,25 @@ class HipKernels:
                                                              _ptr(y.get('b_hh_r')))
             a.out, a.save, a.tmp_gh, a.zeros, a.E = out.data_ptr(), save.data_ptr(), tmp.data_ptr(), zeros.data_ptr(), E
             outs.append((out, save))
+        self.last_bigru_persistent = self.bigru_persistent(arr, n, bs, h)
+        if self.last_bigru_persistent:
+            # one persistent launch, W_hh slices resident in registers (csrc/gru_persist.hip); sync words zeroed per call
+            sync = self.zeros(1024, device=dev)
+            keep.append(sync)
+            self._check(self.lib.twog_bigru_fwd_persistent(arr, n, bs, T, h, sync.data_ptr(), self._stream()),
+                        'twog_bigru_fwd_persistent')
+            return outs
         self._check(self.lib.twog_bigru_fwd(arr, n, bs, T, h, *self.chain_workspace(dev), self._stream()), 'twog_bigru_fwd')
         return outs
+
+    def bigru_persistent(self, arr, n, bs, h):
+        """True when the frame-level recurrence runs as the persistent launch: where the library serves the shape and
+        rates it the faster path (small batches: at most one 16-row tile per wave). TWOG_BIGRU_PERSIST=1: wherever it is
+        served; =0: never."""
+        mode = os.environ.get('TWOG_BIGRU_PERSIST', 'auto')
+        if mode == '0':
+            return False
+        return int(self.lib.twog_bigru_persistent_supported(arr, n, bs, h)) >= (1 if mode == '1' else 2)
 
     def bigru_bwd(self, types, bs, T, h):
         """types: list of dicts {d_out, save, out, w_hh_f, w_hh_r}. Returns [(d_gi, d_gh)] each (bs,T,E,6h)."""

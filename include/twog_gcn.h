@@ -181,7 +181,17 @@ typedef struct {
     int32_t pad_;
 } twog_bigru_t;
 int twog_bigru_fwd(const twog_bigru_t* types, int n_types, int bs, int T, int hidden, void* chain_ws,
-                   size_t chain_ws_bytes, void* stream); /* chain_ws: see twog_gemm_f32_chain (NULL ok) */
+                   size_t chain_ws_bytes, void* stream);
+/* The same recurrence as ONE persistent launch (csrc/gru_persist.hip): a workgroup per compute unit owns 16 hidden
+ * units x 3 gates of one (type, direction) weight for the whole sequence -- split once into bf16 planes, resident in
+ * LDS as MFMA fragments -- and a chunk of the type's 16-row tiles, up to four per wave; the steps are ordered inside
+ * the launch by agent-scope counters between same-numbered waves. Same inputs, outputs and saved tensors as
+ * twog_bigru_fwd (tmp_gh / zeros unused). sync: device memory, >= 1024 uint32, ZERO when the launch starts.
+ * twog_bigru_persistent_supported: 0 = shape not served (hidden not 128 / 256 / 512, or the (type, direction, chunk) x
+ * hidden / 16 workgroups do not fit the device), 1 = served, 2 = served and the faster path (at most one tile per
+ * wave: small batches). */
+int twog_bigru_persistent_supported(const twog_bigru_t* types, int n_types, int bs, int hidden);
+int twog_bigru_fwd_persistent(const twog_bigru_t* types, int n_types, int bs, int T, int hidden, void* sync, void* stream); /* chain_ws: see twog_gemm_f32_chain (NULL ok) */
 
 typedef struct {
     const float* d_out;  /* [bs][T][E][2h] gradient wrt out                                              */

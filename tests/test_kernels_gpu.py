@@ -346,6 +346,7 @@ def test_gcn_kernels(K, N):
                                     (512, 8, 120)])   # last: BASELINE T and width
 def test_bigru(K, h, bs, T, fusion, monkeypatch):
     monkeypatch.setenv('TWOG_GRU_FWD_FUSION', fusion)   # read per call by the library; part of the chain's graph key
+    monkeypatch.setenv('TWOG_BIGRU_PERSIST', '0')       # this test is about the launch-per-step path and its kernel classes
     types_c, types_g = [], []
     ws = 0.2 if T < 100 else 0.2 * math.sqrt(64.0 / h)   # long chains: keep the hidden pre-activations O(1)
     for i, E in enumerate((2, 3, 1)):
@@ -371,6 +372,46 @@ def test_bigru(K, h, bs, T, fusion, monkeypatch):
     for (gc, hc), (gg, hg) in zip(F.bigru_bwd(bt_c, bs, T, h), K.bigru_bwd(bt_g, bs, T, h)):
         close(gg, gc, rtol=1e-4, atol=1e-5, what='bigru d_gi')
         close(hg, hc, rtol=1e-4, atol=1e-5, what='bigru d_gh')
+
+
+@pytest.mark.parametrize('h,bs,T,Es', [(512, 64, 5, (2, 8, 1)), (512, 8, 7, (2, 4, 1)), (512, 64, 120, (2, 8, 1)),
+                                       (256, 50, 4, (2, 3, 1)), (128, 3, 3, (1, 5, 1)), (512, 37, 6, (2, 9, 2))])
+def test_bigru_persistent_launch_matches_the_stepwise_recurrence(K, h, bs, T, Es, monkeypatch):
+    """The frame-level recurrence as ONE persistent launch (csrc/gru_persist.hip: W_hh slices in registers, steps ordered
+    inside the launch by agent-scope counters) against the specification and against the launch-per-step path: outputs
+    and every saved gate tensor; two runs bit-identical (fixed summation order; the hand-off is either right or the
+    states are garbage)."""
+    types_c, types_g = [], []
+    ws = 0.2 if T < 100 else 0.2 * math.sqrt(64.0 / h)
+    for i, E in enumerate(Es):
+        d = dict(gi=rnd(bs, T, E, 6 * h, seed=i), w_hh_f=rnd(3 * h, h, seed=10 + i, scale=ws), b_hh_f=rnd(3 * h, seed=20 + i),
+                 w_hh_r=rnd(3 * h, h, seed=30 + i, scale=ws), b_hh_r=rnd(3 * h, seed=40 + i))
+        types_c.append(d)
+        types_g.append({k: v.to(DEV) for k, v in d.items()})
+    res_c = F.bigru_fwd(types_c, bs, T, h)
+    monkeypatch.setenv('TWOG_BIGRU_PERSIST', '0')
+    res_s = K.bigru_fwd(types_g, bs, T, h)
+    monkeypatch.setenv('TWOG_BIGRU_PERSIST', '1')
+    called = []
+    real = K.lib.twog_bigru_fwd_persistent
+    monkeypatch.setattr(K.lib, 'twog_bigru_fwd_persistent', lambda *a: (called.append(1), real(*a))[1])
+    res_p = K.bigru_fwd(types_g, bs, T, h)
+    res_q = K.bigru_fwd(types_g, bs, T, h)
+    torch.cuda.synchronize()
+    assert len(called) == 2, 'the persistent launch did not run'
+    for (oc, sc), (os_, ss), (op, sp), (oq, sq) in zip(res_c, res_s, res_p, res_q):
+        assert torch.isfinite(op).all() and torch.isfinite(sp).all()
+        close(op, oc, rtol=1e-4, atol=1e-5, what='persistent bigru out vs spec')
+        close(sp, sc, rtol=1e-4, atol=1e-5, what='persistent bigru save vs spec')
+        close(op, os_, rtol=2e-5, atol=2e-6, what='persistent vs stepwise out')
+        assert torch.equal(op, oq) and torch.equal(sp, sq), 'two runs of the persistent launch differ'
+    # the default policy: the persistent launch where every wave owns at most one row tile (small batches), else per step
+    monkeypatch.delenv('TWOG_BIGRU_PERSIST')
+    called.clear()
+    K.bigru_fwd(types_g, bs, T, h)
+    assert len(called) == int(K.last_bigru_persistent), (bs, Es, called)
+    if h == 512 and bs in (8, 64):
+        assert K.last_bigru_persistent == (bs == 8), (bs, Es)
 
 
 # ---------------------------------------------------------------------------------------------------- entity attention
