@@ -163,6 +163,8 @@ SIGNATURES = {
     'twog_bigru_fwd': [C.POINTER(BiGru), _I, _I, _I, _I, _P, C.c_size_t, _P],
     'twog_bigru_persistent_supported': [C.POINTER(BiGru), _I, _I, _I],
     'twog_bigru_fwd_persistent': [C.POINTER(BiGru), _I, _I, _I, _I, _P, _P],
+    'twog_bigru_bwd_persistent_supported': [C.POINTER(BiGruBwd), _I, _I, _I],
+    'twog_bigru_bwd_persistent': [C.POINTER(BiGruBwd), _I, _I, _I, _I, _P, _P],
     'twog_bigru_bwd': [C.POINTER(BiGruBwd), _I, _I, _I, _I, _P, C.c_size_t, _P],
     'twog_attn_fwd': [C.POINTER(Attn), _I, _P],
     'twog_attn_limits': [C.POINTER(C.c_int), C.POINTER(C.c_int)],

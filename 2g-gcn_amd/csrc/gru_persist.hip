@@ -77,6 +77,20 @@ __device__ __forceinline__ void split8(const f32x4 a, const f32x4 b, bf16x8& ph,
     pl = __builtin_bit_cast(bf16x8, i32x4{(int)pack_hi16(r2[0], r2[1]), (int)pack_hi16(r2[2], r2[3]), (int)pack_hi16(r2[4], r2[5]), (int)pack_hi16(r2[6], r2[7])});
 }
 
+// four floats of the transposition scratch, read AS floats: a load through a vector-typed pointer does not alias the
+// float stores as far as the compiler's type-based analysis goes, and the next block's stores were moved in front of it
+__device__ __forceinline__ f32x4 row4(const float* p) { return f32x4{p[0], p[1], p[2], p[3]}; }
+// The scratch transposes a tile between lanes of ONE wave. At the ISA level a wave's LDS operations run in order; at the
+// language level the lanes are independent threads, and the compiler may thread a lane-dependent branch (the masked
+// store behind the read) through the scratch writes, so that the masked-out lanes write AFTER the others have read
+// (seen: wrong columns exactly where a quad of rows was partly valid). A convergent wave barrier on both sides of the
+// exchange pins writes, reads and the next writes in program order for all lanes.
+__device__ __forceinline__ void lanes_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 __device__ __forceinline__ f32x4 mfma(const bf16x8 a, const bf16x8 b, const f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
@@ -235,13 +249,15 @@ __global__ __launch_bounds__(256, 1) void bigru_persist_fwd_kernel(const PArgs P
                     nn[i][r] = tanhf(gi[i][r][2] + rg[i][r] * hn4[i][r]);
                     scratch[(4 * g4 + r) * 20 + i16] = (1.0f - zz[i][r]) * nn[i][r] + zz[i][r] * h0[i][r];
                 }
+                lanes_sync();
                 // the tile's 16 x 16 states: one 16-byte write-through store per lane (row = lane / 4, 4 units)
                 const int srow = lane >> 2, sc = (lane & 3) * 4;
-                const f32x4 v = *reinterpret_cast<const f32x4*>(scratch + srow * 20 + sc);   // same wave wrote it: in order
+                const f32x4 v = row4(scratch + srow * 20 + sc);   // same wave wrote it: LDS operations of a wave run in order
                 const int row = rt * 16 + srow;
                 if (row < G.rows)
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs_out,
                                                            (int)(out_off(row, t) + 4u * (uint32_t)(slice * 16 + sc)), 0, SC1);
+                lanes_sync();
             }
         }
         // publish step s of this wave's tiles: the wave drains its stores, then one lane signals
@@ -264,6 +280,182 @@ __global__ __launch_bounds__(256, 1) void bigru_persist_fwd_kernel(const PArgs P
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Backward through time, small-batch form (one 16-row tile per wave at most). A workgroup owns 16 hidden units of one
+// (type, direction): the carried gradient of those units lives in registers for the whole sequence, and the 3h x 16
+// slice of W_hh that produces it (d h_prev[:, u] = sum_k d_gh[:, k] W_hh[k][u], k over the 3h gate rows) in LDS as
+// B fragments. Per step: gate backward of the own units (gru.hip's arithmetic) -> d_gi, d_gh columns (d_gh
+// write-through: it is the next product's operand for EVERY slice) -> signal -> wait for all slices -> the complete
+// d_gh rows x the slice -> carried gradient of the next step. Same hand-off rules as the forward kernel.
+// ---------------------------------------------------------------------------------------------------------------
+struct BGroup {
+    const float* d_out;  // [bs][T][E][2h]
+    const float* save;   // [2][bs][T][E][4h]
+    const float* out;    // [bs][T][E][2h]
+    const float* w_hh;   // [3h][h] of this direction
+    float* d_gi;         // [bs][T][E][6h]
+    float* d_gh;         // [bs][T][E][6h]
+    int E, dir, rows;
+};
+struct BArgs {
+    BGroup g[MAXG];
+    PCombo c[MAXC];
+    unsigned* pub;
+    unsigned* error;
+    int n_combos, bs, T;
+    int spin_limit;
+};
+
+template <int NKH>   // hidden = 32 * NKH; the reduction runs over 3h = 96 * NKH, i.e. 3 * NKH k-blocks
+__global__ __launch_bounds__(256, 1) void bigru_persist_bwd_kernel(const BArgs P) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int h = 32 * NKH, n_wg = h / 16, NKB = 3 * NKH;
+    constexpr int D = NKB < 24 ? NKB : 24;   // k-blocks of d_gh in flight
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i16 = lane & 15, g4 = lane >> 4;
+    const int combo = (int)blockIdx.x % P.n_combos, slice = (int)blockIdx.x / P.n_combos;
+    const PCombo& C = P.c[combo];
+    const BGroup& G = P.g[C.group];
+    const int T = P.T, E = G.E, dir = G.dir;
+    const float inv_e = 1.0f / (float)E;
+    unsigned* pub = P.pub + combo * 4 + wave;
+    const int rt = C.rt0 + wave;            // tw = 1: this wave's tile, if any
+    const bool mine = rt < C.rt1;
+    i32x4* wfrag = reinterpret_cast<i32x4*>(smem);   // [k-block][plane][64 lanes] x 16 bytes
+    float* scratch = reinterpret_cast<float*>(smem + NKB * 3 * 1024) + wave * 16 * 20;
+    // lane l of a fragment holds W_hh[k = 32 kb + 8 (l >> 4) + j][unit 16 slice + (l & 15)], j = 0..7 (k-major operand)
+    for (int kb = wave; kb < NKB; kb += 4) {
+        const float* w = G.w_hh + (int64_t)(kb * 32 + 8 * g4) * h + slice * 16 + i16;
+        f32x4 a, b;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { a[j] = w[(int64_t)j * h]; b[j] = w[(int64_t)(j + 4) * h]; }
+        bf16x8 ph, pm, pl;
+        split8(a, b, ph, pm, pl);
+        wfrag[(kb * 3 + 0) * 64 + lane] = __builtin_bit_cast(i32x4, ph);
+        wfrag[(kb * 3 + 1) * 64 + lane] = __builtin_bit_cast(i32x4, pm);
+        wfrag[(kb * 3 + 2) * 64 + lane] = __builtin_bit_cast(i32x4, pl);
+    }
+    __syncthreads();
+    if (!mine) return;
+    const __amdgpu_buffer_rsrc_t rs_dgh = __builtin_amdgcn_make_buffer_rsrc(G.d_gh, 0, 0xffffffff, 0x00020000);
+    const int col = slice * 16 + i16;
+    // element offset of row (b, e) at time x in a [bs][T][E][width] tensor
+    auto row_off = [&](int row, int x, int width) -> int64_t {
+        const int b = (int)(((float)row + 0.5f) * inv_e), e = row - b * E;
+        return (((int64_t)b * T + x) * E + e) * width;
+    };
+    float carry[4] = {0.f, 0.f, 0.f, 0.f};   // d h_t[rows 4 g4 + r][unit col] arriving from step s + 1
+    int rows4[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) rows4[r] = rt * 16 + 4 * g4 + r;
+    const int srow = lane >> 2, sc = (lane & 3) * 4;   // the 16-byte store form: row = lane / 4, 4 units
+    const int row_s = rt * 16 + srow;
+
+    // what the gate backward of a step reads (nothing of it depends on the chain): requested one step ahead, under the
+    // previous step's product
+    struct GateIn { float d[4], rg[4], z[4], n[4], hn[4], h0[4]; };
+    auto fetch_gate = [&](int s, GateIn& X) {
+        const int t = dir == 0 ? s : T - 1 - s, tp = dir == 0 ? t - 1 : t + 1;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = min(rows4[r], G.rows - 1);
+            const float* sv = G.save + (int64_t)dir * P.bs * T * E * 4 * h + row_off(row, t, 4 * h) + col;
+            X.d[r] = G.d_out[row_off(row, t, 2 * h) + dir * h + col];
+            X.rg[r] = sv[0]; X.z[r] = sv[h]; X.n[r] = sv[2 * h]; X.hn[r] = sv[3 * h];
+            X.h0[r] = s > 0 ? G.out[row_off(row, tp, 2 * h) + dir * h + col] : 0.f;
+        }
+    };
+    GateIn cur, nxt;
+    fetch_gate(T - 1, cur);
+    for (int s = T - 1; s >= 0; --s) {
+        const int t = dir == 0 ? s : T - 1 - s;
+        // ---- gate backward of the own 4 x 1 outputs per lane (torch.nn.GRU, gate order r z n; see gru_step_bwd_kernel)
+        float dgi_[3][4], dgh_[3][4], direct[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float d = cur.d[r] + carry[r];
+            const float rg = cur.rg[r], z = cur.z[r], n = cur.n[r], hn = cur.hn[r], h0 = cur.h0[r];
+            const float dn = d * (1.0f - z);
+            const float dz = d * (h0 - n);
+            direct[r] = d * z;
+            const float dn_pre = dn * (1.0f - n * n);
+            const float dr_pre = dn_pre * hn * rg * (1.0f - rg);
+            const float dz_pre = dz * z * (1.0f - z);
+            dgi_[0][r] = dr_pre; dgi_[1][r] = dz_pre; dgi_[2][r] = dn_pre;
+            dgh_[0][r] = dr_pre; dgh_[1][r] = dz_pre; dgh_[2][r] = dn_pre * rg;
+        }
+        // d_gh first (write-through: the other slices wait for it), then d_gi: 16 x 16 blocks through the wave's scratch,
+        // one 16-byte store per lane and gate
+        const int64_t o6 = row_off(min(row_s, G.rows - 1), t, 6 * h) + dir * 3 * h + slice * 16 + sc;
+#pragma unroll
+        for (int gte = 0; gte < 3; ++gte) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) scratch[(4 * g4 + r) * 20 + i16] = dgh_[gte][r];
+            lanes_sync();
+            const f32x4 v = row4(scratch + srow * 20 + sc);
+            if (row_s < G.rows)
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs_dgh, (int)(4 * (o6 + (int64_t)gte * h)), 0, SC1);
+            lanes_sync();
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_fetch_add(pub, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int gte = 0; gte < 3; ++gte) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) scratch[(4 * g4 + r) * 20 + i16] = dgi_[gte][r];
+            lanes_sync();
+            const f32x4 v = row4(scratch + srow * 20 + sc);
+            if (row_s < G.rows) *reinterpret_cast<f32x4*>(G.d_gi + o6 + (int64_t)gte * h) = v;
+            lanes_sync();
+        }
+        if (s == 0) break;   // no state before the first step
+        fetch_gate(s - 1, nxt);
+        // ---- every slice has published its d_gh columns of this step
+        if (lane == 0) {
+            const unsigned want = (unsigned)(T - s) * (unsigned)n_wg;
+            int spins = 0;
+            while (__hip_atomic_load(pub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > P.spin_limit) {
+                    __hip_atomic_store(P.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __builtin_trap();
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        // ---- carry = direct + d_gh[rows][0 : 3h] . W_hh[:, own units]
+        const uint32_t abase = (uint32_t)(4 * (row_off(min(rt * 16 + i16, G.rows - 1), t, 6 * h) + dir * 3 * h + 8 * g4));
+        f32x4 hi = {0.f, 0.f, 0.f, 0.f}, lo = {0.f, 0.f, 0.f, 0.f};
+        auto load_a = [&](int kb, f32x4 (&a)[2]) {
+            a[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_dgh, (int)(abase + 128u * kb), 0, SC1));
+            a[1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_dgh, (int)(abase + 128u * kb + 16u), 0, SC1));
+        };
+        auto mac = [&](int kb, const f32x4 (&a)[2]) {
+            bf16x8 ah, am, al;
+            split8(a[0], a[1], ah, am, al);
+            const bf16x8 wh = __builtin_bit_cast(bf16x8, wfrag[(kb * 3 + 0) * 64 + lane]);
+            const bf16x8 wm = __builtin_bit_cast(bf16x8, wfrag[(kb * 3 + 1) * 64 + lane]);
+            const bf16x8 wl = __builtin_bit_cast(bf16x8, wfrag[(kb * 3 + 2) * 64 + lane]);
+            hi = mfma(ah, wh, hi);
+            lo = mfma(ah, wm, lo);
+            lo = mfma(am, wh, lo);
+            lo = mfma(am, wm, lo);
+            lo = mfma(ah, wl, lo);
+            lo = mfma(al, wh, lo);
+        };
+        f32x4 ring[D][2];
+#pragma unroll
+        for (int kb = 0; kb < D; ++kb) load_a(kb, ring[kb]);
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) {
+            mac(kb, ring[kb % D]);
+            if (kb + D < NKB) load_a(kb + D, ring[kb % D]);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) carry[r] = direct[r] + (hi[r] + lo[r]);
+        cur = nxt;
+    }
+}
+
 }  // namespace
 
 // Plans the partition for (n_types entity counts E, bs, hidden) on n_cus compute units: per (type, direction) group the
@@ -271,14 +463,14 @@ __global__ __launch_bounds__(256, 1) void bigru_persist_fwd_kernel(const PArgs P
 // group with the longest chunk while the grid still fits. Returns the number of (group, chunk) combinations or -1 when
 // the shape is not served: hidden not 128 / 256 / 512, more combinations x slices than compute units, or a chunk of
 // more than 16 row tiles (four per wave).
-static int plan(const twog_bigru_t* types, int n_types, int bs, int hidden, int n_cus, PCombo* combos) {
+static int plan(const int* E_of_type, int n_types, int bs, int hidden, int n_cus, PCombo* combos) {
     if (hidden != 128 && hidden != 256 && hidden != 512) return -1;
     const int slices = hidden / 16, n_groups = 2 * n_types;
     if (n_groups > MAXG || n_groups * slices > n_cus) return -1;
     int total = n_groups, rt[MAXG], chunks[MAXG];
     for (int g = 0; g < n_groups; ++g) {
         chunks[g] = 1;
-        rt[g] = (bs * types[g / 2].E + 15) / 16;
+        rt[g] = (bs * E_of_type[g / 2] + 15) / 16;
         if (rt[g] == 0) return -1;
     }
     for (;;) {
@@ -315,7 +507,9 @@ extern "C" int twog_bigru_persistent_supported(const twog_bigru_t* types, int n_
     if (hipGetDevice(&dev) != hipSuccess) return 0;
     if (hipDeviceGetAttribute(&n_cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
     PCombo combos[MAXC];
-    const int n = plan(types, n_types, bs, hidden, n_cus, combos);
+    int Es[MAXG / 2];
+    for (int k = 0; k < n_types; ++k) Es[k] = types[k].E;
+    const int n = plan(Es, n_types, bs, hidden, n_cus, combos);
     if (n <= 0) return 0;
     for (int i = 0; i < n; ++i)
         if (combos[i].tw > 1) return 1;
@@ -334,7 +528,9 @@ extern "C" int twog_bigru_fwd_persistent(const twog_bigru_t* types, int n_types,
     e = hipDeviceGetAttribute(&n_cus, hipDeviceAttributeMultiprocessorCount, dev);
     if (e != hipSuccess) return -(int)e;
     PArgs P;
-    const int n_combos = plan(types, n_types, bs, hidden, n_cus, P.c);
+    int Es[MAXG / 2];
+    for (int k = 0; k < n_types; ++k) Es[k] = types[k].E;
+    const int n_combos = plan(Es, n_types, bs, hidden, n_cus, P.c);
     if (n_combos <= 0 || !sync) return -2;
     for (int k = 0; k < n_types; ++k)
         for (int dir = 0; dir < 2; ++dir) {
@@ -373,6 +569,68 @@ extern "C" int twog_bigru_fwd_persistent(const twog_bigru_t* types, int n_types,
     }
 #undef TWOG_GP_LAUNCH_H
 #undef TWOG_GP_LAUNCH
+    TWOG_CHECK_LAUNCH();
+    return 0;
+}
+
+// 2 if twog_bigru_bwd_persistent serves this shape (at most one row tile per wave), else 0.
+extern "C" int twog_bigru_bwd_persistent_supported(const twog_bigru_bwd_t* types, int n_types, int bs, int hidden) {
+    int dev = 0, n_cus = 0;
+    if (n_types <= 0 || n_types > MAXG / 2) return 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    if (hipDeviceGetAttribute(&n_cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+    PCombo combos[MAXC];
+    int Es[MAXG / 2];
+    for (int k = 0; k < n_types; ++k) Es[k] = types[k].E;
+    const int n = plan(Es, n_types, bs, hidden, n_cus, combos);
+    if (n <= 0) return 0;
+    for (int i = 0; i < n; ++i)
+        if (combos[i].tw > 1) return 0;
+    return 2;
+}
+
+extern "C" int twog_bigru_bwd_persistent(const twog_bigru_bwd_t* types, int n_types, int bs, int T, int hidden, void* sync,
+                                         void* stream) {
+    if (n_types <= 0 || T <= 0) return 0;
+    if (n_types > MAXG / 2) return -2;
+    int dev = 0, n_cus = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return -(int)e;
+    e = hipDeviceGetAttribute(&n_cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (e != hipSuccess) return -(int)e;
+    BArgs P;
+    int Es[MAXG / 2];
+    for (int k = 0; k < n_types; ++k) Es[k] = types[k].E;
+    const int n_combos = plan(Es, n_types, bs, hidden, n_cus, P.c);
+    if (n_combos <= 0 || !sync) return -2;
+    for (int i = 0; i < n_combos; ++i)
+        if (P.c[i].tw > 1) return -2;
+    for (int k = 0; k < n_types; ++k)
+        for (int dir = 0; dir < 2; ++dir) {
+            BGroup& G = P.g[2 * k + dir];
+            const twog_bigru_bwd_t& Y = types[k];
+            G.d_out = Y.d_out; G.save = Y.save; G.out = Y.out; G.w_hh = dir == 0 ? Y.w_hh_f : Y.w_hh_r;
+            G.d_gi = Y.d_gi; G.d_gh = Y.d_gh; G.E = Y.E; G.dir = dir; G.rows = bs * Y.E;
+        }
+    P.pub = static_cast<unsigned*>(sync);
+    P.error = P.pub + MAXC * 4;
+    P.n_combos = n_combos; P.bs = bs; P.T = T;
+    P.spin_limit = 1 << 24;
+    const int grid = n_combos * (hidden / 16);
+    const size_t lds = (size_t)(3 * hidden / 32) * 3 * 1024 + 4 * 16 * 20 * 4;
+    hipStream_t st = (hipStream_t)stream;
+#define TWOG_GPB_LAUNCH(NKH_)                                                                       \
+    do {                                                                                            \
+        static std::atomic<uint32_t> done{0};                                                       \
+        twog_allow_dynamic_lds(bigru_persist_bwd_kernel<NKH_>, 160 * 1024, done);                   \
+        hipLaunchKernelGGL(bigru_persist_bwd_kernel<NKH_>, dim3(grid), dim3(256), lds, st, P);      \
+    } while (0)
+    switch (hidden) {
+        case 128: TWOG_GPB_LAUNCH(4); break;
+        case 256: TWOG_GPB_LAUNCH(8); break;
+        default: TWOG_GPB_LAUNCH(16); break;
+    }
+#undef TWOG_GPB_LAUNCH
     TWOG_CHECK_LAUNCH();
     return 0;
 }

@@ -386,6 +386,14 @@ class HipKernels:
             a.w_hh_f, a.w_hh_r = y['w_hh_f'].data_ptr(), y['w_hh_r'].data_ptr()
             a.d_gi, a.d_gh, a.carry, a.E = d_gi.data_ptr(), d_gh.data_ptr(), carry.data_ptr(), E
             outs.append((d_gi, d_gh))
+        mode = os.environ.get('TWOG_BIGRU_PERSIST', 'auto')
+        self.last_bigru_bwd_persistent = mode != '0' and int(self.lib.twog_bigru_bwd_persistent_supported(arr, n, bs, h)) >= 2
+        if self.last_bigru_bwd_persistent:   # small batches: one persistent launch (csrc/gru_persist.hip)
+            sync = self.zeros(1024, device=dev)
+            keep.append(sync)
+            self._check(self.lib.twog_bigru_bwd_persistent(arr, n, bs, T, h, sync.data_ptr(), self._stream()),
+                        'twog_bigru_bwd_persistent')
+            return outs
         self._check(self.lib.twog_bigru_bwd(arr, n, bs, T, h, *self.chain_workspace(dev), self._stream()), 'twog_bigru_bwd')
         return outs
 

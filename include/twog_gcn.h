@@ -181,7 +181,7 @@ typedef struct {
     int32_t pad_;
 } twog_bigru_t;
 int twog_bigru_fwd(const twog_bigru_t* types, int n_types, int bs, int T, int hidden, void* chain_ws,
-                   size_t chain_ws_bytes, void* stream);
+                   size_t chain_ws_bytes, void* stream); /* chain_ws: see twog_gemm_f32_chain (NULL ok) */
 /* The same recurrence as ONE persistent launch (csrc/gru_persist.hip): a workgroup per compute unit owns 16 hidden
  * units x 3 gates of one (type, direction) weight for the whole sequence -- split once into bf16 planes, resident in
  * LDS as MFMA fragments -- and a chunk of the type's 16-row tiles, up to four per wave; the steps are ordered inside
@@ -191,7 +191,7 @@ int twog_bigru_fwd(const twog_bigru_t* types, int n_types, int bs, int T, int hi
  * hidden / 16 workgroups do not fit the device), 1 = served, 2 = served and the faster path (at most one tile per
  * wave: small batches). */
 int twog_bigru_persistent_supported(const twog_bigru_t* types, int n_types, int bs, int hidden);
-int twog_bigru_fwd_persistent(const twog_bigru_t* types, int n_types, int bs, int T, int hidden, void* sync, void* stream); /* chain_ws: see twog_gemm_f32_chain (NULL ok) */
+int twog_bigru_fwd_persistent(const twog_bigru_t* types, int n_types, int bs, int T, int hidden, void* sync, void* stream);
 
 typedef struct {
     const float* d_out;  /* [bs][T][E][2h] gradient wrt out                                              */
@@ -207,6 +207,14 @@ typedef struct {
 } twog_bigru_bwd_t;
 int twog_bigru_bwd(const twog_bigru_bwd_t* types, int n_types, int bs, int T, int hidden, void* chain_ws,
                    size_t chain_ws_bytes, void* stream);
+/* Backward through time as ONE persistent launch, the small-batch form (at most one 16-row tile per wave: the shapes
+ * for which twog_bigru_bwd_persistent_supported returns 2): a workgroup owns 16 hidden units of one (type, direction),
+ * keeps the 3h x 16 slice of W_hh that produces THEIR carried gradient in LDS as bf16x3 MFMA fragments and the carried
+ * gradient itself in registers; per step it runs the gate backward of its units, publishes their d_gh columns
+ * (write-through) and multiplies the complete d_gh rows -- all workgroups' columns -- with its slice. Same outputs as
+ * twog_bigru_bwd (carry unused). sync: device memory, >= 1024 uint32, ZERO when the launch starts. */
+int twog_bigru_bwd_persistent_supported(const twog_bigru_bwd_t* types, int n_types, int bs, int hidden);
+int twog_bigru_bwd_persistent(const twog_bigru_bwd_t* types, int n_types, int bs, int T, int hidden, void* sync, void* stream);
 
 /* ===============================================================================================================
  * Fusion-level attention message passing (vhoi/models.py:1004-1475, :1693-1754) for message_type 'v2', granularity

@@ -414,6 +414,38 @@ def test_bigru_persistent_launch_matches_the_stepwise_recurrence(K, h, bs, T, Es
         assert K.last_bigru_persistent == (bs == 8), (bs, Es)
 
 
+@pytest.mark.parametrize('h,bs,T,Es', [(512, 8, 7, (2, 4, 1)), (512, 8, 120, (2, 4, 1)), (256, 20, 4, (2, 3, 1)), (128, 3, 3, (1, 5, 1)),
+                                       (512, 5, 6, (2, 9, 2))])
+def test_bigru_persistent_backward_matches_the_stepwise_recurrence(K, h, bs, T, Es, monkeypatch):
+    """Backward through time as one persistent launch (small-batch form, csrc/gru_persist.hip) against the specification
+    and the launch-per-step path: d_gi and d_gh of every type; two runs bit-identical."""
+    types_c = []
+    ws = 0.2 if T < 100 else 0.2 * math.sqrt(64.0 / h)
+    for i, E in enumerate(Es):
+        types_c.append(dict(gi=rnd(bs, T, E, 6 * h, seed=i), w_hh_f=rnd(3 * h, h, seed=10 + i, scale=ws), b_hh_f=rnd(3 * h, seed=20 + i),
+                            w_hh_r=rnd(3 * h, h, seed=30 + i, scale=ws), b_hh_r=rnd(3 * h, seed=40 + i)))
+    res_c = F.bigru_fwd(types_c, bs, T, h)
+    bt_c, bt_g = [], []
+    for i, ((oc, sc), d) in enumerate(zip(res_c, types_c)):
+        bt_c.append(dict(d_out=rnd(*oc.shape, seed=50 + i), save=sc, out=oc, w_hh_f=d['w_hh_f'], w_hh_r=d['w_hh_r']))
+        bt_g.append({k: v.to(DEV) for k, v in bt_c[-1].items()})
+    want = F.bigru_bwd(bt_c, bs, T, h)
+    monkeypatch.setenv('TWOG_BIGRU_PERSIST', '0')
+    step = K.bigru_bwd(bt_g, bs, T, h)
+    assert not K.last_bigru_bwd_persistent
+    monkeypatch.delenv('TWOG_BIGRU_PERSIST')
+    p1 = K.bigru_bwd(bt_g, bs, T, h)
+    assert K.last_bigru_bwd_persistent, 'the persistent backward did not run'
+    p2 = K.bigru_bwd(bt_g, bs, T, h)
+    torch.cuda.synchronize()
+    for (gc, hc), (gs, hs_), (g1, h1), (g2, h2) in zip(want, step, p1, p2):
+        assert torch.isfinite(g1).all() and torch.isfinite(h1).all()
+        close(g1, gc, rtol=1e-4, atol=1e-5, what='persistent bigru d_gi vs spec')
+        close(h1, hc, rtol=1e-4, atol=1e-5, what='persistent bigru d_gh vs spec')
+        close(g1, gs, rtol=5e-5, atol=5e-6, what='persistent vs stepwise d_gi')
+        assert torch.equal(g1, g2) and torch.equal(h1, h2), 'two runs of the persistent backward differ'
+
+
 # ---------------------------------------------------------------------------------------------------- entity attention
 def _attn_case(dev, H, O, D, h, n_inst, ipc, geo, recv_mask, seed=0):
     t = lambda *s, sd=0: rnd(*s, seed=seed + sd).to(dev)
