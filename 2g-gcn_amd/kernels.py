@@ -367,7 +367,7 @@ class HipKernels:
             return False
         return int(self.lib.twog_bigru_persistent_supported(arr, n, bs, h)) >= (1 if mode == '1' else 2)
 
-    def bigru_bwd(self, types, bs, T, h):
+    def bigru_bwd(self, types, bs, T, h, allow_persistent=True):
         """types: list of dicts {d_out, save, out, w_hh_f, w_hh_r}. Returns [(d_gi, d_gh)] each (bs,T,E,6h)."""
         n = len(types)
         arr = (L.BiGruBwd * n)()
@@ -387,7 +387,8 @@ class HipKernels:
             a.d_gi, a.d_gh, a.carry, a.E = d_gi.data_ptr(), d_gh.data_ptr(), carry.data_ptr(), E
             outs.append((d_gi, d_gh))
         mode = os.environ.get('TWOG_BIGRU_PERSIST', 'auto')
-        self.last_bigru_bwd_persistent = mode != '0' and int(self.lib.twog_bigru_bwd_persistent_supported(arr, n, bs, h)) >= 2
+        self.last_bigru_bwd_persistent = (mode != '0' and allow_persistent and
+                                          int(self.lib.twog_bigru_bwd_persistent_supported(arr, n, bs, h)) >= 2)
         if self.last_bigru_bwd_persistent:   # small batches: one persistent launch (csrc/gru_persist.hip)
             sync = self.zeros(1024, device=dev)
             keep.append(sync)

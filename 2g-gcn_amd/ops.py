@@ -1793,7 +1793,10 @@ def tggcn_backward(K, plan: Plan, P, S, x_human, x_objects, objects_mask, d_outp
         dhfrs.append(dhfr)
         types.append(dict(d_out=dhfr, save=save, out=hfr, w_hh_f=P[name + '_bd_rnn.weight_hh_l0'],
                           w_hh_r=P[name + '_bd_rnn.weight_hh_l0_reverse']))
-    res = K.bigru_bwd(types, bs, T, h)
+    # (a persistent launch needs every compute unit: not while this backward pass has all-reduces of finished gradient
+    # stages in flight on another stream -- their kernels hold compute units until the peers arrive, and the launch would
+    # spin beside them instead of overlapping)
+    res = K.bigru_bwd(types, bs, T, h, allow_persistent=getattr(p, 'stage_hook', None) is None)
     for (name, Ev, dEv, E, _), hfr, (dgi, dgh) in zip(ents, HFR, res):
         dgiv, dghv = _v2(dgi), _v2(dgh)
         for d, sfx in enumerate(('', '_reverse')):

@@ -230,7 +230,7 @@ class FakeKernels:
             outs.append((out, save))
         return outs
 
-    def bigru_bwd(self, types, bs, T, h):
+    def bigru_bwd(self, types, bs, T, h, allow_persistent=True):
         outs = []
         for y in types:
             d_out, save, out = y['d_out'], y['save'], y['out']
