@@ -461,10 +461,10 @@ __global__ __launch_bounds__(256, 1) void bigru_persist_bwd_kernel(const BArgs P
 // Plans the partition for (n_types entity counts E, bs, hidden) on n_cus compute units: per (type, direction) group the
 // number of row-tile chunks (every chunk is worked by hidden / 16 workgroups, one per slice of 16 units), growing the
 // group with the longest chunk while the grid still fits. Returns the number of (group, chunk) combinations or -1 when
-// the shape is not served: hidden not 128 / 256 / 512, more combinations x slices than compute units, or a chunk of
+// the shape is not served: hidden not 64 / 128 / 256 / 512, more combinations x slices than compute units, or a chunk of
 // more than 16 row tiles (four per wave).
 static int plan(const int* E_of_type, int n_types, int bs, int hidden, int n_cus, PCombo* combos) {
-    if (hidden != 128 && hidden != 256 && hidden != 512) return -1;
+    if (hidden != 64 && hidden != 128 && hidden != 256 && hidden != 512) return -1;
     const int slices = hidden / 16, n_groups = 2 * n_types;
     if (n_groups > MAXG || n_groups * slices > n_cus) return -1;
     int total = n_groups, rt[MAXG], chunks[MAXG];
@@ -563,6 +563,7 @@ extern "C" int twog_bigru_fwd_persistent(const twog_bigru_t* types, int n_types,
         else TWOG_GP_LAUNCH(NKB_, 4);                                                                           \
     } while (0)
     switch (hidden) {
+        case 64: TWOG_GP_LAUNCH_H(2); break;
         case 128: TWOG_GP_LAUNCH_H(4); break;
         case 256: TWOG_GP_LAUNCH_H(8); break;
         default: TWOG_GP_LAUNCH_H(16); break;
@@ -626,6 +627,7 @@ extern "C" int twog_bigru_bwd_persistent(const twog_bigru_bwd_t* types, int n_ty
         hipLaunchKernelGGL(bigru_persist_bwd_kernel<NKH_>, dim3(grid), dim3(256), lds, st, P);      \
     } while (0)
     switch (hidden) {
+        case 64: TWOG_GPB_LAUNCH(2); break;
         case 128: TWOG_GPB_LAUNCH(4); break;
         case 256: TWOG_GPB_LAUNCH(8); break;
         default: TWOG_GPB_LAUNCH(16); break;

@@ -187,7 +187,7 @@ int twog_bigru_fwd(const twog_bigru_t* types, int n_types, int bs, int T, int hi
  * LDS as MFMA fragments -- and a chunk of the type's 16-row tiles, up to four per wave; the steps are ordered inside
  * the launch by agent-scope counters between same-numbered waves. Same inputs, outputs and saved tensors as
  * twog_bigru_fwd (tmp_gh / zeros unused). sync: device memory, >= 1024 uint32, ZERO when the launch starts.
- * twog_bigru_persistent_supported: 0 = shape not served (hidden not 128 / 256 / 512, or the (type, direction, chunk) x
+ * twog_bigru_persistent_supported: 0 = shape not served (hidden not 64 / 128 / 256 / 512, or the (type, direction, chunk) x
  * hidden / 16 workgroups do not fit the device), 1 = served, 2 = served and the faster path (at most one tile per
  * wave: small batches). */
 int twog_bigru_persistent_supported(const twog_bigru_t* types, int n_types, int bs, int hidden);

@@ -375,7 +375,7 @@ def test_bigru(K, h, bs, T, fusion, monkeypatch):
 
 
 @pytest.mark.parametrize('h,bs,T,Es', [(512, 64, 5, (2, 8, 1)), (512, 8, 7, (2, 4, 1)), (512, 64, 120, (2, 8, 1)),
-                                       (256, 50, 4, (2, 3, 1)), (128, 3, 3, (1, 5, 1)), (512, 37, 6, (2, 9, 2))])
+                                       (256, 50, 4, (2, 3, 1)), (128, 3, 3, (1, 5, 1)), (512, 37, 6, (2, 9, 2)), (64, 16, 9, (2, 9, 1))])
 def test_bigru_persistent_launch_matches_the_stepwise_recurrence(K, h, bs, T, Es, monkeypatch):
     """The frame-level recurrence as ONE persistent launch (csrc/gru_persist.hip: W_hh slices in registers, steps ordered
     inside the launch by agent-scope counters) against the specification and against the launch-per-step path: outputs
@@ -415,7 +415,7 @@ def test_bigru_persistent_launch_matches_the_stepwise_recurrence(K, h, bs, T, Es
 
 
 @pytest.mark.parametrize('h,bs,T,Es', [(512, 8, 7, (2, 4, 1)), (512, 8, 120, (2, 4, 1)), (256, 20, 4, (2, 3, 1)), (128, 3, 3, (1, 5, 1)),
-                                       (512, 5, 6, (2, 9, 2))])
+                                       (512, 5, 6, (2, 9, 2)), (64, 16, 9, (2, 9, 1))])
 def test_bigru_persistent_backward_matches_the_stepwise_recurrence(K, h, bs, T, Es, monkeypatch):
     """Backward through time as one persistent launch (small-batch form, csrc/gru_persist.hip) against the specification
     and the launch-per-step path: d_gi and d_gh of every type; two runs bit-identical."""
