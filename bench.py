@@ -709,7 +709,9 @@ def main():
                            'multiply-add): (1) the 128x128 class gemm_x3_kernel (forward, dX and dW projections, and the segment '
                            'level\'s per-step projections inside the library); (2) the 64x64 chain class gemm_x3s* / '
                            'gemm_gate_bwd_x3s* (launches with >= 96 tiles and K >= 256: sender MLPs, backward carries with the fused '
-                           'gate backward); (3) the fused frame-level GRU step gemm_gru_fwd_kernel<2, 2, true>. Error against fp64 '
+                           'gate backward); (3) the fused frame-level GRU step gemm_gru_fwd_kernel<2, 2, true>; (4) at small batches (at most one '
+                           '16-row tile per wave) the frame-level recurrence as persistent launches bigru_persist_fwd / _bwd_kernel (same '
+                           'split, v_mfma_f32_16x16x32_bf16; see roofline_chain.loops.*.kernels for what ran). Error against fp64 '
                            'within 1.25x the fp32-MFMA kernels on random operands; on SAME-SIGN operands the bf16 MFMA\'s '
                            'accumulate adds a relative bias (towards zero) of up to 4e-8 (chain class) / 4e-7 at K = 1 536 and '
                            '2e-6 at K = 61 440 (128x128 class) where the fp32 MFMA has 4e-10 '
@@ -770,6 +772,12 @@ def main():
         result['roofline'].update(result.pop('roofline_common'))   # traffic, launches, shares: common to both kernel families
         # ---- the recurrent chains (they run inside the library: timed per loop call, launch counts from the loops' code)
         cm = chain_model(bs, CFG['hidden_size'])
+        from twog_gcn_amd.kernels import get_kernels as _gk
+        _K = _gk()
+        for _n, _flag in (('bigru_fwd', 'last_bigru_persistent'), ('bigru_bwd', 'last_bigru_bwd_persistent')):
+            if getattr(_K, _flag, False):   # small batches: ONE persistent launch for all time steps (csrc/gru_persist.hip)
+                cm[_n].update(gemm_launches=1, kernel='bigru_persist_' + _n[6:] + '_kernel (one launch for all steps: W_hh slices resident in LDS as '
+                              'bf16x3 fragments, v_mfma_f32_16x16x32_bf16, steps ordered by agent-scope counters)')
         x3_on = os.environ.get('TWOG_GEMM_X3', '1') != '0' and CFG['hidden_size'] >= 256 and bs * (H + O + 1) >= 6 * 64
         src, pmc = latest_pmc_rows(('gemm_gate_bwd_x3s', 'gemm_x3s', 'gemm_gru_fwd', 'gemm_x3d', 'gemm_gate_bwd_x3d'))
         chain_total_ms = sum(v for v in chain_ms.values() if v)
