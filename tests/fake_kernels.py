@@ -20,6 +20,7 @@ class FakeKernels:
 
     def __init__(self):
         self.calls = []
+        self._tape = None
 
     def version(self):
         return 'fake'
@@ -27,8 +28,73 @@ class FakeKernels:
     def empty(self, *shape, like=None, dtype=torch.float32):
         return torch.empty(*shape, dtype=dtype, device=like.device)
 
+    # ------------------------------------------------------------------ recorded steps of an affine loop
+    # The double of HipKernels.tape_* (twog_tape_run): the six recordable calls are kept as (method, arguments) instead
+    # of descriptor bytes; "affine in the step index" becomes: every tensor argument of step a + k is the same view of
+    # the same storage as in step a, moved by k x (its offset in step b - its offset in step a) elements.
+    def tape_begin(self):
+        assert self._tape is None
+        self._tape = []
+
+    def tape_end(self):
+        t, self._tape = self._tape, None
+        return t
+
+    @staticmethod
+    def _walk(x, y, fn):
+        """fn(tensor_a, tensor_b) on every pair of tensors at the same place of two argument structures -> new structure."""
+        if torch.is_tensor(x):
+            assert torch.is_tensor(y) and x.shape == y.shape and x.stride() == y.stride(), 'not the same program'
+            return fn(x, y)
+        if isinstance(x, dict):
+            assert isinstance(y, dict) and x.keys() == y.keys(), 'not the same program'
+            return {k: FakeKernels._walk(x[k], y[k], fn) for k in x}
+        if isinstance(x, (list, tuple)):
+            assert type(x) is type(y) and len(x) == len(y), 'not the same program'
+            return type(x)(FakeKernels._walk(a, b, fn) for a, b in zip(x, y))
+        assert x == y or (x != x and y != y), ('not the same program', x, y)
+        return x
+
+    @staticmethod
+    def _moved(k):
+        def fn(ta, tb):
+            if ta.data_ptr() == tb.data_ptr():
+                return ta
+            assert ta.untyped_storage().data_ptr() == tb.untyped_storage().data_ptr(), 'operands of consecutive steps in different buffers'
+            off = ta.storage_offset() + k * (tb.storage_offset() - ta.storage_offset())
+            return torch.as_strided(ta, ta.shape, ta.stride(), off)
+        return fn
+
+    def tape_matches(self, a, b, c, k):
+        if not (len(a) == len(b) == len(c)) or any(x[0] != y[0] or x[0] != z[0] for x, y, z in zip(a, b, c)):
+            return False
+        ok = [True]
+
+        def check(pred, tc):
+            ok[0] = ok[0] and pred.data_ptr() == tc.data_ptr()
+            return pred
+        try:
+            for (_, xa, ka), (_, xb, kb), (_, xc, kc) in zip(a, b, c):
+                if ka != kb or ka != kc:
+                    return False
+                pred = self._walk(xa, xb, self._moved(k))
+                self._walk(pred, xc, check)
+        except AssertionError:
+            return False
+        return ok[0]
+
+    def tape_run(self, a, b, k_begin, k_end, device=None):
+        assert self._tape is None and len(a) == len(b)
+        for k in range(k_begin, k_end):
+            for (name, xa, kw), (nb, xb, _) in zip(a, b):
+                assert name == nb
+                getattr(self, name)(self._walk(xa, xb, self._moved(k)), **kw)
+
     # ------------------------------------------------------------------ GEMM
     def gemm(self, problems, a_kmajor=False, b_kmajor=False, split_k_workspace=True):
+        if self._tape is not None:
+            self._tape.append(('gemm', problems, dict(a_kmajor=a_kmajor, b_kmajor=b_kmajor)))
+            return
         self.calls.append(('gemm', len(problems)))
         for p in problems:
             batch = p.get('batch') or (1, 0, 0, 0)
@@ -184,6 +250,9 @@ class FakeKernels:
         return dgi, dgh, dprev, du
 
     def gru_step_fwd(self, steps):
+        if self._tape is not None:
+            self._tape.append(('gru_step_fwd', steps, {}))
+            return
         for d in steps:
             h = d['hidden']
             gi = d['gi'] if d.get('gi2') is None else d['gi'] + d['gi2'].reshape(d['gi'].shape)
@@ -196,6 +265,9 @@ class FakeKernels:
                 d['save'].copy_(torch.cat([r, z, n, hn], -1).reshape(d['save'].shape))
 
     def gru_step_bwd(self, steps):
+        if self._tape is not None:
+            self._tape.append(('gru_step_bwd', steps, {}))
+            return
         for d in steps:
             h = d['hidden']
             dh = d['dh'] if d.get('dh2') is None else d['dh'] + d['dh2'].reshape(d['dh'].shape)
@@ -681,14 +753,23 @@ class FakeKernels:
             d['att'].copy_(w.reshape(d['att'].shape))
 
     def relation_fwd_many(self, ds):
+        if self._tape is not None:
+            self._tape.append(('relation_fwd_many', ds, {}))
+            return
         for d in ds:
             self.relation_fwd(d)
 
     def relation_bwd_many(self, bs):
+        if self._tape is not None:
+            self._tape.append(('relation_bwd_many', bs, {}))
+            return
         for b in bs:
             self.relation_bwd(b)
 
     def rowops(self, ops):
+        if self._tape is not None:
+            self._tape.append(('rowops', ops, {}))
+            return
         """ops: ('relu_bwd', dy, y, dx) | ('add', src, dst) | ('rank1', dst, s, v) -- one launch on the device."""
         for op in ops:
             getattr(self, {'relu_bwd': 'relu_bwd', 'add': 'add_rows', 'rank1': 'rank1_update'}[op[0]])(*op[1:])

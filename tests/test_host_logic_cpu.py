@@ -394,3 +394,76 @@ def test_x3_operand_split_is_exact():
     ok = np.isfinite(exact) & (np.abs(exact) > 1e-290)
     rel = np.abs(six[ok] - exact[ok]) / np.abs(exact[ok])
     assert np.max(rel) <= 2.0 ** -21 and np.mean(rel) <= 2.0 ** -23
+
+
+GENERAL_FORMS = {
+    'relational': dict(message_type='v1'),
+    'specific': dict(message_type='v2', message_granularity='v2', attention_style='v3'),
+    'concat': dict(message_type='v2', message_granularity='v1', attention_style='v1'),
+    'bilinear': dict(message_type='v2', message_granularity='v1', attention_style='v4'),
+    'specific_mean_pool': dict(message_type='v2', message_granularity='v2', message_aggregation='mp'),
+    'distance': dict(message_type='v2', message_granularity='v1', attention_style='v3'),
+}
+
+
+@pytest.mark.parametrize('form', sorted(GENERAL_FORMS))
+def test_general_segment_loop_replay_logic_equals_the_composed_loop_and_the_oracle(form, fake_backend, monkeypatch):
+    """The HOST side of the replayed general segment loop (ops.segment_recurrence_general_*: which steps are composed,
+    which descriptors the backward pass finds, per-step slots, deferred parameter gradients) with the test double's
+    recorder -- every tensor argument of a replayed step is the recorded view moved by a constant -- at T = 10: replayed
+    and composed loops bit-identical, both against the oracle. (The library's replay of descriptor bytes is checked on the
+    GPU: tests/test_parity_gpu.py.)"""
+    from oracle import cpu_ref
+    bs, T, H, O, N, h = 2, 10, 2, 3, 26, 16
+    torch.manual_seed(5)
+    m = TGGCN(input_size=(2048 + 4 * N, 2048), num_classes=(13, None), hidden_size=h, gcn_node=N, message_segment=True,
+              **GENERAL_FORMS[form])
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    g = torch.Generator().manual_seed(3)
+    x_human, x_objects = torch.rand(bs, T, H, 2048 + 4 * N, generator=g), torch.rand(bs, T, O, 2048, generator=g)
+    mask = torch.ones(bs, O)
+    mask[1, O - 1] = 0.0
+    x_objects = x_objects * mask[:, None, :, None]
+    kw = dict(human_segmentation=(torch.rand(bs, T, H, generator=g) < 0.6).float())
+    if form == 'distance':
+        def dd(*shape):
+            d = torch.rand(*shape, generator=g) * 2 + 0.05
+            d[torch.rand(*shape, generator=g) < 0.15] = 0.0
+            return d
+        kw.update(human_human_distances=dd(bs, T, H, H), human_object_distances=dd(bs, T, H, O),
+                  object_object_distances=dd(bs, T, O, O))
+    noise = torch.distributions.gumbel.Gumbel(0.0, 1.0).sample((T * O, bs, 2))
+    m._gumbel_noise_override = noise
+    K = twog_kernels.get_kernels()
+    runs = {}
+    for mode in ('1', '0'):
+        monkeypatch.setenv('TWOG_GENERAL_TAPE', mode)
+        m.zero_grad(set_to_none=True)
+        replays = []
+        real = K.tape_run
+        K.tape_run = lambda a, b, k0, k1, dev=None: (replays.append((k0, k1)), real(a, b, k0, k1, dev))[1]
+        try:
+            out = m(x_human, x_objects, mask, **kw)
+            rs = [torch.randn(o.shape, generator=torch.Generator().manual_seed(i)) for i, o in enumerate(out)]
+            sum((o * r).sum() for o, r in zip(out, rs) if o.requires_grad).backward()
+        finally:
+            del K.tape_run
+        assert replays == ([(0, T - 1), (0, T - 2)] if mode == '1' else []), replays
+        runs[mode] = ([o.detach().clone() for o in out],
+                      {n: (None if p.grad is None else p.grad.clone()) for n, p in m.named_parameters()})
+    for a, b in zip(runs['1'][0], runs['0'][0]):
+        assert torch.equal(a, b)
+    for n, ga in runs['1'][1].items():
+        gb = runs['0'][1][n]
+        assert (ga is None) == (gb is None) and (ga is None or torch.equal(ga, gb)), n
+    osd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and 'running' not in k else v.clone()) for k, v in sd.items()}
+    ref = cpu_ref.tggcn_forward(osd, dict(m.cfg), x_human, x_objects, mask, training=True, gumbel_noise=noise, **kw)
+    sum((o * r).sum() for o, r in zip(ref, rs) if o.requires_grad).backward()
+    for o, r in zip(runs['1'][0], ref):
+        assert float((o - r.detach()).abs().max()) <= 1e-4 * max(1.0, float(r.detach().abs().max()))
+    for n, ga in runs['1'][1].items():
+        g_ref = osd[n].grad
+        if g_ref is None:
+            assert ga is None or float(ga.abs().max()) == 0.0, n
+            continue
+        assert float((ga - g_ref).abs().max()) <= 5e-4 * max(float(g_ref.abs().max()), 1e-6) + 5e-6, n
