@@ -12,6 +12,7 @@ per rank. Dead parameters (constructed by the reference but never used, SURVEY.m
 The three cross-sample couplings of SURVEY 8e have an exact-equivalence switch each: sync_bn (a), count_weighted_loss
 (b), global_noise_seed (c).
 """
+import os
 import weakref
 
 import torch
@@ -97,6 +98,24 @@ class FusedAdam:
                                 self.betas[1], self.eps, self.wd, self.step_count, grad_scale)
 
 
+def _ranks_share_a_device(group, world):
+    """True if two ranks of the group run on the same physical GPU (host name + PCI address of the current device,
+    gathered over the group; a collective -- every rank constructs its wrapper)."""
+    import socket
+    ident = [socket.gethostname()]
+    try:
+        pr = torch.cuda.get_device_properties(torch.cuda.current_device())
+        ident += [str(getattr(pr, 'uuid', '')), getattr(pr, 'pci_domain_id', -1), getattr(pr, 'pci_bus_id', -1),
+                  getattr(pr, 'pci_device_id', -1)]
+        if ident[1:] == ['', -1, -1, -1]:   # no hardware identity on this torch build: visible ordinal + visibility mask
+            ident += [torch.cuda.current_device(), os.environ.get('HIP_VISIBLE_DEVICES', os.environ.get('CUDA_VISIBLE_DEVICES', ''))]
+    except Exception:   # noqa: BLE001 -- identity is best effort; unknown means "assume shared" only if ordinals collide
+        ident += [torch.cuda.current_device(), os.environ.get('HIP_VISIBLE_DEVICES', os.environ.get('CUDA_VISIBLE_DEVICES', ''))]
+    seen = [None] * world
+    dist.all_gather_object(seen, tuple(ident), group=group)
+    return len(set(seen)) < world
+
+
 class DataParallel:
     """model + flat buffers + gradient all-reduce. Usage per step:
         dp.zero_grad(); loss = f(dp.model(...)); loss.backward(); dp.all_reduce_gradients(); opt.step(dp.grad_scale)"""
@@ -121,6 +140,10 @@ class DataParallel:
         if force_collectives and not (dist.is_available() and dist.is_initialized()):
             raise RuntimeError('force_collectives needs an initialised process group')
         self.collective = self.world > 1 or bool(force_collectives)
+        if self.world > 1 and torch.cuda.is_available() and _ranks_share_a_device(process_group, self.world):
+            # several ranks on one device (a test rig, not a deployment): no launch may assume it owns every compute unit
+            from . import kernels as _kernels
+            _kernels.HipKernels.device_is_exclusive = False
         rank = dist.get_rank(process_group) if self.collective else 0
         self._works, self._launched = [], set()
         self.collective_calls = 0   # collectives issued so far (tests assert the path really ran)

@@ -358,14 +358,30 @@ class HipKernels:
         self._check(self.lib.twog_bigru_fwd(arr, n, bs, T, h, *self.chain_workspace(dev), self._stream()), 'twog_bigru_fwd')
         return outs
 
+    # The persistent launches need every workgroup of their grid resident at once: true on a device this process has to
+    # itself (one rank per GPU), not when several processes share it (their grids would each hold part of the compute
+    # units and wait for the rest: the bounded spins end in a trap). distributed.DataParallel clears this when more ranks
+    # than devices are in the group.
+    device_is_exclusive = True
+
     def bigru_persistent(self, arr, n, bs, h):
         """True when the frame-level recurrence runs as the persistent launch: where the library serves the shape and
         rates it the faster path (small batches: at most one 16-row tile per wave). TWOG_BIGRU_PERSIST=1: wherever it is
         served; =0: never."""
         mode = os.environ.get('TWOG_BIGRU_PERSIST', 'auto')
-        if mode == '0':
+        if mode == '0' or not HipKernels.device_is_exclusive:
             return False
         return int(self.lib.twog_bigru_persistent_supported(arr, n, bs, h)) >= (1 if mode == '1' else 2)
+
+    def bigru_bwd_would_persist(self, Es, bs, h):
+        """Whether bigru_bwd takes the persistent launch for entity counts Es at this batch (asked before the operands exist:
+        the data-parallel backward pass orders its first gradient all-reduce around that launch)."""
+        if os.environ.get('TWOG_BIGRU_PERSIST', 'auto') == '0' or not HipKernels.device_is_exclusive:
+            return False
+        arr = (L.BiGruBwd * len(Es))()
+        for a, E in zip(arr, Es):
+            a.E = E
+        return int(self.lib.twog_bigru_bwd_persistent_supported(arr, len(Es), bs, h)) >= 2
 
     def bigru_bwd(self, types, bs, T, h, allow_persistent=True):
         """types: list of dicts {d_out, save, out, w_hh_f, w_hh_r}. Returns [(d_gi, d_gh)] each (bs,T,E,6h)."""
@@ -387,7 +403,7 @@ class HipKernels:
             a.d_gi, a.d_gh, a.carry, a.E = d_gi.data_ptr(), d_gh.data_ptr(), carry.data_ptr(), E
             outs.append((d_gi, d_gh))
         mode = os.environ.get('TWOG_BIGRU_PERSIST', 'auto')
-        self.last_bigru_bwd_persistent = (mode != '0' and allow_persistent and
+        self.last_bigru_bwd_persistent = (mode != '0' and allow_persistent and HipKernels.device_is_exclusive and
                                           int(self.lib.twog_bigru_bwd_persistent_supported(arr, n, bs, h)) >= 2)
         if self.last_bigru_bwd_persistent:   # small batches: one persistent launch (csrc/gru_persist.hip)
             sync = self.zeros(1024, device=dev)

@@ -1733,7 +1733,13 @@ def tggcn_backward(K, plan: Plan, P, S, x_human, x_objects, objects_mask, d_outp
     if p.time_u:
         pos_backward('time_u', 'time_position_mlp')
 
-    _stage_done(p, 0)
+    # Stage 0 (heads, segment level) is final here. Its all-reduce starts now -- unless the frame-level recurrence below
+    # runs as a persistent launch, which needs every compute unit: RCCL's kernels hold some until the peers arrive, so the
+    # hook is deferred to behind that launch (the all-reduce still has the rest of the backward pass to hide under).
+    defer_stage0 = (getattr(p, 'stage_hook', None) is not None and
+                    K.bigru_bwd_would_persist([H, O, 1], bs, h))
+    if not defer_stage0:
+        _stage_done(p, 0)
 
     # ---- D. frame-level attention + sender MLPs backward
     if p.general_frame():
@@ -1793,10 +1799,9 @@ def tggcn_backward(K, plan: Plan, P, S, x_human, x_objects, objects_mask, d_outp
         dhfrs.append(dhfr)
         types.append(dict(d_out=dhfr, save=save, out=hfr, w_hh_f=P[name + '_bd_rnn.weight_hh_l0'],
                           w_hh_r=P[name + '_bd_rnn.weight_hh_l0_reverse']))
-    # (a persistent launch needs every compute unit: not while this backward pass has all-reduces of finished gradient
-    # stages in flight on another stream -- their kernels hold compute units until the peers arrive, and the launch would
-    # spin beside them instead of overlapping)
-    res = K.bigru_bwd(types, bs, T, h, allow_persistent=getattr(p, 'stage_hook', None) is None)
+    res = K.bigru_bwd(types, bs, T, h, allow_persistent=defer_stage0 or getattr(p, 'stage_hook', None) is None)
+    if defer_stage0:
+        _stage_done(p, 0)
     for (name, Ev, dEv, E, _), hfr, (dgi, dgh) in zip(ents, HFR, res):
         dgiv, dghv = _v2(dgi), _v2(dgh)
         for d, sfx in enumerate(('', '_reverse')):
