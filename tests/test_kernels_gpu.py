@@ -446,6 +446,44 @@ def test_bigru_persistent_backward_matches_the_stepwise_recurrence(K, h, bs, T, 
         assert torch.equal(g1, g2) and torch.equal(h1, h2), 'two runs of the persistent backward differ'
 
 
+def test_bigru_persistent_hand_offs_hold_under_uneven_load(K):
+    """The persistent launches exchange states between workgroups through write-through stores, agent-scope counters and
+    sc1 loads. Hand-off mistakes hide on an idle chip (uniform timing, cold L1s): here the same forward + backward (8
+    clips, T = 120, h = 512) runs while a second stream keeps part of the chip busy with GEMMs of changing sizes -- the
+    persistent workgroups start staggered and progress unevenly -- and every word of every output must equal the
+    solo run's, five times over."""
+    bs, T, h, Es = 8, 120, 512, (2, 4, 1)
+    ws = 0.2 * math.sqrt(64.0 / h)
+    types = []
+    for i, E in enumerate(Es):
+        types.append({k: v.to(DEV) for k, v in dict(
+            gi=rnd(bs, T, E, 6 * h, seed=i), w_hh_f=rnd(3 * h, h, seed=10 + i, scale=ws), b_hh_f=rnd(3 * h, seed=20 + i),
+            w_hh_r=rnd(3 * h, h, seed=30 + i, scale=ws), b_hh_r=rnd(3 * h, seed=40 + i)).items()})
+
+    def run():
+        fw = K.bigru_fwd(types, bs, T, h)
+        assert K.last_bigru_persistent
+        bt = [dict(d_out=rnd(bs, T, E, 2 * h, seed=50 + i).to(DEV), save=sv, out=o, w_hh_f=y['w_hh_f'], w_hh_r=y['w_hh_r'])
+              for i, ((o, sv), y, E) in enumerate(zip(fw, types, Es))]
+        bw = K.bigru_bwd(bt, bs, T, h)
+        assert K.last_bigru_bwd_persistent
+        return [t for pair in fw for t in pair] + [t for pair in bw for t in pair]
+
+    solo = [t.clone() for t in run()]
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    mats = [torch.randn(n, n, device=DEV) for n in (512, 1024, 1536, 2048, 3072)]
+    for rep in range(5):
+        with torch.cuda.stream(side):
+            for j in range(40):
+                m = mats[(rep + j) % len(mats)]
+                torch.mm(m, m)
+        got = run()
+        torch.cuda.synchronize()
+        for a, b in zip(got, solo):
+            assert torch.equal(a, b), f'repetition {rep}: a persistent launch under load differs from the solo run'
+
+
 # ---------------------------------------------------------------------------------------------------- entity attention
 def _attn_case(dev, H, O, D, h, n_inst, ipc, geo, recv_mask, seed=0):
     t = lambda *s, sd=0: rnd(*s, seed=seed + sd).to(dev)
