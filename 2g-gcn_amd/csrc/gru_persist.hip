@@ -32,10 +32,6 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((__vector_size__(4 * sizeof(unsigned))));
 
-#ifndef TWOG_GP_ABLATE
-#define TWOG_GP_ABLATE 0   // measurement builds only (tools/bigru_persist_ablate.sh): 1 no MFMAs, 2 no state loads, 4 no poll,
-#endif                     // 8 no save stores, 16 no gi / h0 loads -- wrong results by design, only the times count
-
 constexpr int MAXG = 8;     // (entity type, direction) groups
 constexpr int MAXC = 32;    // (group, row chunk) combinations, each worked by hidden / 16 workgroups
 constexpr int MAXTW = 4;    // row tiles per wave at most: a chunk has at most 4 * MAXTW tiles
@@ -145,7 +141,7 @@ __global__ __launch_bounds__(256, 1) void bigru_persist_fwd_kernel(const PArgs P
         float gi[TW][4][3];
 #pragma unroll
         for (int i = 0; i < TW; ++i)
-            if (i < nt && !(TWOG_GP_ABLATE & 16)) {
+            if (i < nt) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int row = min((t0 + i) * 16 + 4 * g4 + r, G.rows - 1);
@@ -166,7 +162,7 @@ __global__ __launch_bounds__(256, 1) void bigru_persist_fwd_kernel(const PArgs P
             for (int r = 0; r < 4; ++r) h0[i][r] = 0.f;
         if (s > 0) {
             // every slice has published step s - 1 of this wave's tiles
-            if (lane == 0 && !(TWOG_GP_ABLATE & 4)) {
+            if (lane == 0) {
                 const unsigned want = (unsigned)s * (unsigned)n_wg;
                 int spins = 0;
                 while (__hip_atomic_load(pub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
@@ -183,11 +179,10 @@ __global__ __launch_bounds__(256, 1) void bigru_persist_fwd_kernel(const PArgs P
             for (int i = 0; i < TW; ++i) {
                 const int row = min((t0 + min(i, nt - 1)) * 16 + i16, G.rows - 1);
                 abase[i] = out_off(row, tp) + 4u * (uint32_t)(8 * g4);
-                if (TWOG_GP_ABLATE & 2) abase[i] = 4u * (uint32_t)(lane * 8);
             }
 #pragma unroll
             for (int i = 0; i < TW; ++i)
-                if (i < nt && !(TWOG_GP_ABLATE & 16)) {
+                if (i < nt) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int row = min((t0 + i) * 16 + 4 * g4 + r, G.rows - 1);
@@ -202,7 +197,6 @@ __global__ __launch_bounds__(256, 1) void bigru_persist_fwd_kernel(const PArgs P
                 }
             };
             auto mac = [&](int kb, const f32x4 (&a)[TW][2]) {
-                if (TWOG_GP_ABLATE & 1) return;
                 bf16x8 ah[TW], am[TW], al[TW];
 #pragma unroll
                 for (int i = 0; i < TW; ++i) split8(a[i][0], a[i][1], ah[i], am[i], al[i]);
@@ -265,7 +259,7 @@ __global__ __launch_bounds__(256, 1) void bigru_persist_fwd_kernel(const PArgs P
         if (lane == 0) __hip_atomic_fetch_add(pub, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
         for (int i = 0; i < TW; ++i) {
-            if (i < nt && !(TWOG_GP_ABLATE & 8)) {
+            if (i < nt) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int row = (t0 + i) * 16 + 4 * g4 + r;

@@ -1,5 +1,8 @@
 # Run on the GPU box: the persistent BiGRU forward (csrc/gru_persist.hip) with parts removed at build time
 # (-DTWOG_GP_ABLATE=bits; wrong results by design, only the times count), bench shape.
+# NOTE: the shipped kernel carries no measurement branches; the -DTWOG_GP_ABLATE hooks this script builds live in the
+# tree of commit c2dc749 (`git show c2dc749:2g-gcn_amd/csrc/gru_persist.hip`), whose numbers are in
+# profiles/r04_bigru_persistent.txt. Check that file out beside the shipped one to repeat them.
 #   usage: bash tools/bigru_persist_ablate.sh "0 1 2 4 8 16 3 7 31"
 set -e
 ROOT="$(cd "$(dirname "$0")/.." && pwd)"
