@@ -880,7 +880,7 @@ class _SegDeferred:
         """Time-major per-instance scalars [T][bs * n] -> [(b, t, e)] order of the steps that have a previous state."""
         K, bs, T = self.K, self.p.bs, self.p.T
         src = (tm[1:T] if d == 0 else tm[0:T - 1]).view(T - 1, bs, n).permute(1, 0, 2)
-        dst = K.zeros(bs * (T - 1), n, like=tm) if hasattr(K, 'zeros') else torch.zeros(bs * (T - 1), n)   # test double
+        dst = K.zeros(bs * (T - 1), n, like=tm)
         K.add_rows(src, dst)
         return dst.view(-1)
 

@@ -28,6 +28,9 @@ class FakeKernels:
     def empty(self, *shape, like=None, dtype=torch.float32):
         return torch.empty(*shape, dtype=dtype, device=like.device)
 
+    def zeros(self, *shape, like=None, dtype=torch.float32, device=None):
+        return torch.zeros(*shape, dtype=dtype, device=like.device if like is not None else device)
+
     # ------------------------------------------------------------------ recorded steps of an affine loop
     # The double of HipKernels.tape_* (twog_tape_run): the six recordable calls are kept as (method, arguments) instead
     # of descriptor bytes; "affine in the step index" becomes: every tensor argument of step a + k is the same view of
