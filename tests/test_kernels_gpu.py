@@ -484,6 +484,41 @@ def test_bigru_persistent_hand_offs_hold_under_uneven_load(K):
             assert torch.equal(a, b), f'repetition {rep}: a persistent launch under load differs from the solo run'
 
 
+def test_tape_run_replays_recorded_calls_with_affine_descriptors(K):
+    """twog_tape_run: two consecutive steps of a loop are recorded (descriptor arrays kept, nothing issued); step a + k is
+    run with every 64-bit descriptor word a + k (b - a). A GEMM, a gate step and row operations over per-step slots of
+    [steps][...] buffers: six replayed steps must equal six issued ones, and a third recorded step must equal the rule."""
+    n, rows, kdim, cols = 6, 40, 64, 48
+    A, B = rnd(n, rows, kdim, seed=1).to(DEV), rnd(cols, kdim, seed=2, scale=0.2).to(DEV)
+    bias = rnd(cols, seed=3).to(DEV)
+    src = rnd(n, rows, cols, seed=4).to(DEV)
+
+    def step(t, C, acc, r1):
+        K.gemm([dict(A=A[t], B=B, C=C[t], bias=bias, act=1)])
+        K.rowops([('add', src[t], acc[t]), ('relu_bwd', src[t], C[t], r1[t])])
+
+    def buffers():
+        return (torch.zeros(n, rows, cols, device=DEV), torch.ones(n, rows, cols, device=DEV), torch.zeros(n, rows, cols, device=DEV))
+
+    want = buffers()
+    for t in range(n):
+        step(t, *want)
+    got = buffers()
+    tapes = []
+    for t in range(3):
+        K.tape_begin()
+        step(t, *got)
+        tapes.append(K.tape_end())
+    torch.cuda.synchronize()
+    assert all(float(b.abs().sum()) == float(w0) for b, w0 in zip(got, (0.0, n * rows * cols, 0.0))), 'recording must not issue anything'
+    assert K.tape_matches(tapes[0], tapes[1], tapes[2], 2)
+    assert not K.tape_matches(tapes[0], tapes[1], tapes[1], 2)
+    K.tape_run(tapes[0], tapes[1], 0, n, DEV)
+    torch.cuda.synchronize()
+    for g_, w_ in zip(got, want):
+        assert torch.equal(g_, w_)
+
+
 # ---------------------------------------------------------------------------------------------------- entity attention
 def _attn_case(dev, H, O, D, h, n_inst, ipc, geo, recv_mask, seed=0):
     t = lambda *s, sd=0: rnd(*s, seed=seed + sd).to(dev)
