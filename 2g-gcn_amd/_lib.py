@@ -121,6 +121,13 @@ class RowOp(C.Structure):  # twog_rowop_t
                 ('rows', C.c_int32), ('cols', C.c_int32), ('pad_', C.c_int32)]
 
 
+class Copy(C.Structure):  # twog_copy_t
+    _fields_ = [('src', C.c_void_p), ('dst', C.c_void_p), ('n', C.c_int64)]
+
+
+COPY_MAX = 16   # TWOG_COPY_MAX
+PERSIST_NOT_RESIDENT = -3   # TWOG_PERSIST_NOT_RESIDENT
+
 TAPE_GEMM, TAPE_RELATION_FWD, TAPE_RELATION_BWD, TAPE_GRU_STEP_FWD, TAPE_GRU_STEP_BWD, TAPE_ROWOPS = range(6)   # TWOG_TAPE_*
 
 
@@ -200,6 +207,7 @@ SIGNATURES = {
     'twog_rowops': [C.POINTER(RowOp), _I, _P],
     'twog_tape_run': [C.POINTER(TapeEntry), C.POINTER(TapeEntry), _I, _I, _I, _P, C.c_size_t, _P],
     'twog_fill_zero': [_P, C.c_size_t, _P],
+    'twog_copy_blocks': [C.POINTER(Copy), _I, _P],
     'twog_adam_step': [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _F, _P],
     'twog_multitask_loss_fwd': [C.POINTER(Loss), _I, _P, _P, _P, _P],
     'twog_multitask_loss_bwd': [C.POINTER(Loss), _I, _P, _P, _P],

@@ -19,10 +19,13 @@
 // between same-numbered waves of those workgroups, per the agent-scope rules of gfx950 (per-XCD L2s are not coherent):
 // states stored write-through (16-byte sc1 stores), the storing wave drains them (s_waitcnt vmcnt(0)) and one of its
 // lanes adds to the combination's wave counter (agent scope); the consuming wave polls that counter with sc1 loads and
-// reads the states with sc1 loads only. Every spin is bounded (a trap, not a hang, if the grid is not fully resident).
+// reads the states with sc1 loads only. Every spin is bounded: a grid that is not fully resident (another tenant holds
+// compute units) ends with the error word set and every wave gone -- no trap, no hang; the host then re-runs the pass on
+// the launch-per-step path (kernels.py).
 // With 8 combinations (the bench shape) the 32 workgroups of a combination share blockIdx mod 8, i.e. an XCD: their
 // exchange stays in that XCD's L2 -- a matter of speed, never of correctness. Bit-reproducible: fixed summation order.
 #include "twog_common.h"
+#include "persist_common.h"
 
 namespace {
 
@@ -50,7 +53,7 @@ struct PArgs {
     PGroup g[MAXG];
     PCombo c[MAXC];
     unsigned* pub;       // [MAXC][4] zero at launch: arrivals (workgroups x steps) of each wave's tiles
-    unsigned* error;     // set to 1 before a trap (spin bound exceeded)
+    unsigned* error;     // set to 1 when a spin bound is exceeded: every wave then leaves the kernel (wait_counter)
     int n_combos, bs, T;
     int spin_limit;
 };
@@ -162,18 +165,7 @@ __global__ __launch_bounds__(256, 1) void bigru_persist_fwd_kernel(const PArgs P
             for (int r = 0; r < 4; ++r) h0[i][r] = 0.f;
         if (s > 0) {
             // every slice has published step s - 1 of this wave's tiles
-            if (lane == 0) {
-                const unsigned want = (unsigned)s * (unsigned)n_wg;
-                int spins = 0;
-                while (__hip_atomic_load(pub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
-                    __builtin_amdgcn_s_sleep(1);
-                    if (++spins > P.spin_limit) {
-                        __hip_atomic_store(P.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        __builtin_trap();
-                    }
-                }
-            }
-            __builtin_amdgcn_wave_barrier();
+            if (!twog_wait_counter(pub, (unsigned)s * (unsigned)n_wg, P.error, P.spin_limit, lane)) return;
             uint32_t abase[TW];
 #pragma unroll
             for (int i = 0; i < TW; ++i) {
@@ -404,18 +396,7 @@ __global__ __launch_bounds__(256, 1) void bigru_persist_bwd_kernel(const BArgs P
         if (s == 0) break;   // no state before the first step
         fetch_gate(s - 1, nxt);
         // ---- every slice has published its d_gh columns of this step
-        if (lane == 0) {
-            const unsigned want = (unsigned)(T - s) * (unsigned)n_wg;
-            int spins = 0;
-            while (__hip_atomic_load(pub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
-                __builtin_amdgcn_s_sleep(1);
-                if (++spins > P.spin_limit) {
-                    __hip_atomic_store(P.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __builtin_trap();
-                }
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
+        if (!twog_wait_counter(pub, (unsigned)(T - s) * (unsigned)n_wg, P.error, P.spin_limit, lane)) return;
         // ---- carry = direct + d_gh[rows][0 : 3h] . W_hh[:, own units]
         const uint32_t abase = (uint32_t)(4 * (row_off(min(rt * 16 + i16, G.rows - 1), t, 6 * h) + dir * 3 * h + 8 * g4));
         f32x4 hi = {0.f, 0.f, 0.f, 0.f}, lo = {0.f, 0.f, 0.f, 0.f};
@@ -511,7 +492,9 @@ extern "C" int twog_bigru_persistent_supported(const twog_bigru_t* types, int n_
 }
 
 // Same contract as twog_bigru_fwd (tmp_gh and zeros unused). sync: device memory, >= 1024 uint32, ZERO at launch
-// ([0, 128) the waves' arrival counters, [128] the error word).
+// ([0, 128) the waves' arrival counters, [128] the error word: non-zero after the launch = a wait ran out, the outputs are
+// incomplete and the caller must re-run the pass with twog_bigru_fwd). Returns TWOG_PERSIST_NOT_RESIDENT (-3), nothing
+// launched, when the runtime's occupancy figure says the grid cannot be resident at once.
 extern "C" int twog_bigru_fwd_persistent(const twog_bigru_t* types, int n_types, int bs, int T, int hidden, void* sync,
                                          void* stream) {
     if (n_types <= 0 || T <= 0) return 0;
@@ -536,7 +519,7 @@ extern "C" int twog_bigru_fwd_persistent(const twog_bigru_t* types, int n_types,
     P.pub = static_cast<unsigned*>(sync);
     P.error = P.pub + MAXC * 4;
     P.n_combos = n_combos; P.bs = bs; P.T = T;
-    P.spin_limit = 1 << 24;   // x ~0.1 us: seconds -- a grid that is not fully resident ends in a trap, not a hang
+    P.spin_limit = twog_persist_spin_limit();
     const int grid = n_combos * (hidden / 16);
     const size_t lds = (size_t)(hidden / 32) * 9 * 1024 + 4 * 16 * 20 * 4;
     int twc = 1;
@@ -548,6 +531,8 @@ extern "C" int twog_bigru_fwd_persistent(const twog_bigru_t* types, int n_types,
     do {                                                                                                        \
         static std::atomic<uint32_t> done{0};                                                                   \
         twog_allow_dynamic_lds(bigru_persist_fwd_kernel<NKB_, TWC_>, 160 * 1024, done);                         \
+        if (!twog_persist_grid_fits(bigru_persist_fwd_kernel<NKB_, TWC_>, grid, lds, n_cus))                    \
+            return TWOG_PERSIST_NOT_RESIDENT;                                                                   \
         hipLaunchKernelGGL((bigru_persist_fwd_kernel<NKB_, TWC_>), dim3(grid), dim3(256), lds, st, P);          \
     } while (0)
 #define TWOG_GP_LAUNCH_H(NKB_)                                                                                  \
@@ -610,7 +595,7 @@ extern "C" int twog_bigru_bwd_persistent(const twog_bigru_bwd_t* types, int n_ty
     P.pub = static_cast<unsigned*>(sync);
     P.error = P.pub + MAXC * 4;
     P.n_combos = n_combos; P.bs = bs; P.T = T;
-    P.spin_limit = 1 << 24;
+    P.spin_limit = twog_persist_spin_limit();
     const int grid = n_combos * (hidden / 16);
     const size_t lds = (size_t)(3 * hidden / 32) * 3 * 1024 + 4 * 16 * 20 * 4;
     hipStream_t st = (hipStream_t)stream;
@@ -618,6 +603,8 @@ extern "C" int twog_bigru_bwd_persistent(const twog_bigru_bwd_t* types, int n_ty
     do {                                                                                            \
         static std::atomic<uint32_t> done{0};                                                       \
         twog_allow_dynamic_lds(bigru_persist_bwd_kernel<NKH_>, 160 * 1024, done);                   \
+        if (!twog_persist_grid_fits(bigru_persist_bwd_kernel<NKH_>, grid, lds, n_cus))              \
+            return TWOG_PERSIST_NOT_RESIDENT;                                                       \
         hipLaunchKernelGGL(bigru_persist_bwd_kernel<NKH_>, dim3(grid), dim3(256), lds, st, P);      \
     } while (0)
     switch (hidden) {

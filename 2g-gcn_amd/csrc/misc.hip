@@ -302,6 +302,39 @@ extern "C" int twog_fill_zero(void* p, size_t nbytes, void* stream) {
     return 0;
 }
 
+// Copies of contiguous fp32 blocks, all in ONE launch (blockIdx.y = block): the packed forms of weights that the time loops
+// read as one operand (the segment level's sender MLPs, w_smsg_* / b_smsg_* of twog_segrnn_t) are rebuilt from the
+// parameters by this launch at EVERY forward call -- nothing derived from a weight outlives the call that derived it, so no
+// write to a parameter (optimizer, load_state_dict, p.data.mul_(), a kernel on a flat buffer) can leave it stale.
+struct CopyBatch { twog_copy_t c[TWOG_COPY_MAX]; };
+__global__ __launch_bounds__(256) void copy_blocks_kernel(const CopyBatch G) {
+    const twog_copy_t& c = G.c[blockIdx.y];
+    const int64_t n = c.n;
+    const bool vec = ((reinterpret_cast<uintptr_t>(c.src) | reinterpret_cast<uintptr_t>(c.dst)) & 15) == 0;
+    const int64_t n4 = vec ? n / 4 : 0;
+    const float4* s4 = reinterpret_cast<const float4*>(c.src);
+    float4* d4 = reinterpret_cast<float4*>(c.dst);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) d4[i] = s4[i];
+    for (int64_t i = n4 * 4 + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) c.dst[i] = c.src[i];
+}
+
+extern "C" int twog_copy_blocks(const twog_copy_t* blocks, int n_blocks, void* stream) {
+    if (n_blocks <= 0) return 0;
+    if (n_blocks > TWOG_COPY_MAX || !blocks) return -2;
+    CopyBatch G;
+    int64_t most = 0;
+    for (int i = 0; i < n_blocks; ++i) {
+        G.c[i] = blocks[i];
+        if (blocks[i].n < 0 || (blocks[i].n > 0 && (!blocks[i].src || !blocks[i].dst))) return -2;
+        if (blocks[i].n > most) most = blocks[i].n;
+    }
+    if (most == 0) return 0;
+    hipLaunchKernelGGL(copy_blocks_kernel, dim3(grid_for((most + 3) / 4, 256, 512), n_blocks), dim3(256), 0,
+                       (hipStream_t)stream, G);
+    TWOG_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int twog_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
                               float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale,
                               void* stream) {

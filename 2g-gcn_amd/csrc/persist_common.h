@@ -1,0 +1,61 @@
+// Shared by the persistent launches (gru_persist.hip, seg_persist.hip): kernels whose workgroups order their steps among
+// themselves through agent-scope counters and therefore need EVERY workgroup of the grid resident at once.
+//
+//  * before the launch the host asks the runtime how many workgroups of this kernel (its registers, its LDS) fit a compute
+//    unit (hipOccupancyMaxActiveBlocksPerMultiprocessor) and refuses a grid the device cannot hold
+//    (TWOG_PERSIST_NOT_RESIDENT: the caller runs the launch-per-step path instead);
+//  * what the runtime cannot know -- another tenant holding compute units (a second process, another stream's long
+//    kernel, a CU mask) -- is caught inside the launch: every wait is bounded; the first wave whose bound runs out sets the
+//    launch's error word and LEAVES, every other waiting wave sees the word within 256 spins and leaves too. No trap: the
+//    context survives, the host reads the word after the launch and re-runs the pass on the launch-per-step path (outputs
+//    are written in place, so the re-run is idempotent).
+#pragma once
+#include <stdlib.h>
+#include "twog_common.h"
+
+// spins of ~0.1 us each before a wait gives up: seconds by default; TWOG_PERSIST_SPIN_LIMIT overrides (tests force the
+// soft-failure path with 1)
+inline int twog_persist_spin_limit() {
+    const char* e = getenv("TWOG_PERSIST_SPIN_LIMIT");
+    if (e && *e) {
+        const long v = strtol(e, nullptr, 10);
+        if (v > 0) return (int)(v > (1L << 30) ? (1L << 30) : v);
+    }
+    return 1 << 24;
+}
+
+// true if `grid` workgroups of `kernel` (256 threads, `lds` bytes of dynamic LDS) can be resident at once on a device with
+// n_cus compute units that this process has to itself
+template <class K>
+inline bool twog_persist_grid_fits(K kernel, int grid, size_t lds, int n_cus) {
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, lds) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    return per_cu >= 1 && (int64_t)per_cu * n_cus >= grid;
+}
+
+// Waits until *counter >= want (agent scope). Returns false when the wave has to leave the kernel (see above).
+__device__ __forceinline__ bool twog_wait_counter(const unsigned* counter, unsigned want, unsigned* error, int spin_limit,
+                                                  int lane) {
+    int ok = 1;
+    if (lane == 0) {
+        int spins = 0;
+        while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+            __builtin_amdgcn_s_sleep(1);
+            ++spins;
+            if (spins > spin_limit) {
+                __hip_atomic_store(error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ok = 0;
+                break;
+            }
+            if ((spins & 255) == 0 && __hip_atomic_load(error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+                ok = 0;
+                break;
+            }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    return __builtin_amdgcn_readfirstlane(ok) != 0;
+}

@@ -21,8 +21,19 @@ import torch.distributed as dist
 from .kernels import get_kernels
 
 
-def _drop_extras(model_ref, wrapper_ref):
-    """weakref.finalize callback of a collected DataParallel: removes what it left beside a model that is still alive."""
+def _remove_installed(model, installed):
+    """Removes from the model's side table exactly the objects in `installed` (key -> object): an entry a LATER wrapper of
+    the same model put there under the same key is somebody else's and stays."""
+    from . import ops
+    for key, obj in installed.items():
+        if ops.get_model_extra(model, key) is obj:
+            ops.set_model_extra(model, key, None)
+
+
+def _drop_extras(model_ref, wrapper_ref, installed):
+    """weakref.finalize callback of a collected DataParallel: removes what THAT wrapper left beside a model that is still
+    alive. A re-wrap (`dp = DataParallel(model, ...)` rebinding `dp`) constructs the new wrapper before the old one is
+    collected; the old one's finalizer must not take the new one's sync-BN reducer / noise shard with it."""
     model = model_ref()
     if model is None:
         return
@@ -30,8 +41,7 @@ def _drop_extras(model_ref, wrapper_ref):
     hook = ops.get_model_extra(model, 'stage_hook')
     if isinstance(hook, weakref.WeakMethod) and hook() is None:
         ops.set_grad_stage_hook(model, None)
-    for key in ('bn_stats_reduce', 'noise_shard'):
-        ops.set_model_extra(model, key, None)
+    _remove_installed(model, installed)
 
 
 class FlatParameters:
@@ -92,8 +102,6 @@ class FusedAdam:
 
     def step(self, grad_scale=1.0):
         self.step_count += 1
-        from . import ops
-        ops.bump_weights_epoch()   # the kernel writes the parameters behind torch's version counters (ops.WeightCache)
         get_kernels().adam_step(self.flat.flat, self.flat.grad, self.exp_avg, self.exp_avg_sq, self.lr, self.betas[0],
                                 self.betas[1], self.eps, self.wd, self.step_count, grad_scale)
 
@@ -143,7 +151,7 @@ class DataParallel:
         if self.world > 1 and torch.cuda.is_available() and _ranks_share_a_device(process_group, self.world):
             # several ranks on one device (a test rig, not a deployment): no launch may assume it owns every compute unit
             from . import kernels as _kernels
-            _kernels.HipKernels.device_is_exclusive = False
+            _kernels.HipKernels.shared_devices.add(torch.cuda.current_device())   # per device, not per process
         rank = dist.get_rank(process_group) if self.collective else 0
         self._works, self._launched = [], set()
         self.collective_calls = 0   # collectives issued so far (tests assert the path really ran)
@@ -153,6 +161,7 @@ class DataParallel:
         # model and the flat parameter / gradient buffers alive for the life of the process (a discarded wrapper in a sweep
         # loop, an EMA re-wrap). A dead wrapper's callables are no-ops.
         me_ref = weakref.ref(self)
+        self._installed = {}   # key -> the object THIS wrapper put into the model's side table (none refers to the wrapper)
         if sync_bn:
             def reduce_stats(sums, n_frames, world=self.world, group=process_group, on=self.collective, me_ref=me_ref):
                 if on:
@@ -162,6 +171,7 @@ class DataParallel:
                         me.collective_calls += 1
                 return sums, n_frames * world
             ops.set_model_extra(model, 'bn_stats_reduce', reduce_stats)
+            self._installed['bn_stats_reduce'] = reduce_stats
         self._count_reducer = None
         if count_weighted_loss:
             def reduce_counts(counts, world=self.world, group=process_group, on=self.collective, me_ref=me_ref):
@@ -174,8 +184,9 @@ class DataParallel:
                 return counts / world
             self._count_reducer = reduce_counts
         if global_noise_seed is not None:
-            ops.set_model_extra(model, 'noise_shard',
-                                (rank, self.world, torch.Generator().manual_seed(int(global_noise_seed))))
+            shard = (rank, self.world, torch.Generator().manual_seed(int(global_noise_seed)))
+            ops.set_model_extra(model, 'noise_shard', shard)
+            self._installed['noise_shard'] = shard
         # gradients are laid out in the order the backward pass finishes them (ops.grad_ready_stage), so that each
         # stage's all-reduce can start from inside the backward pass and overlap with the rest of it
         self.flat = FlatParameters(model, stage_of=ops.grad_ready_stage if overlap else None)
@@ -183,8 +194,7 @@ class DataParallel:
         if overlap and self.collective:
             # scoped to this model; close() removes it. A WeakMethod: the table must not own the wrapper (see above)
             ops.set_grad_stage_hook(model, weakref.WeakMethod(self._stage_ready))
-        weakref.finalize(self, _drop_extras, weakref.ref(model), me_ref)
-        ops.bump_weights_epoch()   # the parameters moved into the flat buffer (and may be overwritten by the broadcast)
+        weakref.finalize(self, _drop_extras, weakref.ref(model), me_ref, self._installed)
         if self.collective and broadcast:
             dist.broadcast(self.flat.flat, src=0, group=self.group)
             for b in model.buffers():
@@ -197,8 +207,7 @@ class DataParallel:
         hook = ops.get_model_extra(self.model, 'stage_hook')
         if isinstance(hook, weakref.WeakMethod) and hook() == self._stage_ready:
             ops.set_grad_stage_hook(self.model, None)
-        for key in ('bn_stats_reduce', 'noise_shard'):
-            ops.set_model_extra(self.model, key, None)
+        _remove_installed(self.model, self._installed)
         self._count_reducer = None
 
     def loss_scope(self):

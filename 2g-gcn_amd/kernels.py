@@ -103,6 +103,19 @@ class HipKernels:
             self._check(self.lib.twog_fill_zero(t.data_ptr(), t.numel() * t.element_size(), self._stream()), 'twog_fill_zero')
         return t
 
+    def copy_blocks(self, pairs):
+        """pairs: (src, dst) contiguous fp32 tensors of equal element count; dst[...] = src[...] for all of them in ONE
+        launch (twog_copy_blocks) -- the per-forward build of the packed operands (ops.pack_weights)."""
+        pairs = [(s, d) for s, d in pairs if s.numel()]
+        for i in range(0, len(pairs), L.COPY_MAX):
+            chunk = pairs[i:i + L.COPY_MAX]
+            arr = (L.Copy * len(chunk))()
+            for a, (s, d) in zip(arr, chunk):
+                assert s.dtype == torch.float32 and d.dtype == torch.float32 and s.is_contiguous() and d.is_contiguous()
+                assert s.numel() == d.numel() and s.device == d.device
+                a.src, a.dst, a.n = s.data_ptr(), d.data_ptr(), s.numel()
+            self._check(self.lib.twog_copy_blocks(arr, len(chunk), self._stream()), 'twog_copy_blocks')
+
     def zeros_many(self, shapes, device, dtype=torch.float32):
         """Zeroed fp32 buffers of the given shapes carved out of ONE allocation and cleared by ONE launch (each view starts
         on a 256-byte boundary)."""
@@ -347,36 +360,75 @@ class HipKernels:
                                                              _ptr(y.get('b_hh_r')))
             a.out, a.save, a.tmp_gh, a.zeros, a.E = out.data_ptr(), save.data_ptr(), tmp.data_ptr(), zeros.data_ptr(), E
             outs.append((out, save))
-        self.last_bigru_persistent = self.bigru_persistent(arr, n, bs, h)
+        self.last_bigru_persistent = self.bigru_persistent(arr, n, bs, h, dev)
         if self.last_bigru_persistent:
-            # one persistent launch, W_hh slices resident in registers (csrc/gru_persist.hip); sync words zeroed per call
+            # one persistent launch, W_hh slices resident in LDS (csrc/gru_persist.hip); sync words zeroed per call
             sync = self.zeros(1024, device=dev)
             keep.append(sync)
-            self._check(self.lib.twog_bigru_fwd_persistent(arr, n, bs, T, h, sync.data_ptr(), self._stream()),
-                        'twog_bigru_fwd_persistent')
-            return outs
+            rc = self.lib.twog_bigru_fwd_persistent(arr, n, bs, T, h, sync.data_ptr(), self._stream())
+            if self._persistent_ok(rc, sync, dev, 'twog_bigru_fwd_persistent'):
+                return outs
+            self.last_bigru_persistent = False   # not resident / a wait ran out: the launch-per-step path re-runs the pass
         self._check(self.lib.twog_bigru_fwd(arr, n, bs, T, h, *self.chain_workspace(dev), self._stream()), 'twog_bigru_fwd')
         return outs
 
-    # The persistent launches need every workgroup of their grid resident at once: true on a device this process has to
-    # itself (one rank per GPU), not when several processes share it (their grids would each hold part of the compute
-    # units and wait for the rest: the bounded spins end in a trap). distributed.DataParallel clears this when more ranks
-    # than devices are in the group.
-    device_is_exclusive = True
+    # The persistent launches need every workgroup of their grid resident at once. Three lines of defence:
+    #  (1) a device this process shares with other ranks of its own group (distributed.DataParallel finds out at
+    #      construction: more ranks than devices) is listed in `shared_devices` and never gets a persistent launch;
+    #  (2) the library asks the runtime's occupancy figure before launching and refuses a grid the device cannot hold
+    #      (rc TWOG_PERSIST_NOT_RESIDENT);
+    #  (3) a tenant nobody told us about (another process, another stream's long kernel, a CU mask): every wait inside the
+    #      launch is bounded, a time-out sets the launch's error word and drains the grid; the host reads the word right
+    #      after the launch (one 4-byte read-back; the stream is drained at that point, which costs the pipeline about one
+    #      launch latency) and re-runs the pass on the launch-per-step path -- same buffers, written in place. A device on
+    #      which that happened gets no persistent launches for the next PERSISTENT_BACKOFF calls.
+    shared_devices = set()       # device indices (per process): ranks of one group share them
+    persistent_fallbacks = 0     # passes re-run on the launch-per-step path after a persistent launch gave up (tests)
+    persistent_refused = 0       # persistent launches the occupancy check refused
+    PERSISTENT_BACKOFF = 64
+    _backoff = {}                # device index -> calls left without persistent launches
 
-    def bigru_persistent(self, arr, n, bs, h):
+    @staticmethod
+    def _dev_index(dev):
+        return dev.index if dev.index is not None else torch.cuda.current_device()
+
+    def persistent_allowed(self, dev):
+        """False on a shared device, and for a while after a persistent launch on this device gave up."""
+        i = self._dev_index(dev)
+        if i in HipKernels.shared_devices:
+            return False
+        left = HipKernels._backoff.get(i, 0)
+        if left > 0:
+            HipKernels._backoff[i] = left - 1
+            return False
+        return True
+
+    def _persistent_ok(self, rc, sync, dev, what):
+        """True if the persistent launch ran to completion. False -> the caller re-runs the pass on the per-step path."""
+        if rc == L.PERSIST_NOT_RESIDENT:
+            HipKernels.persistent_refused += 1
+            return False
+        self._check(rc, what)
+        if int(sync.view(torch.int32)[128].item()) == 0:   # (drains the stream: see (3) above)
+            return True
+        HipKernels.persistent_fallbacks += 1
+        HipKernels._backoff[self._dev_index(dev)] = self.PERSISTENT_BACKOFF
+        return False
+
+    def bigru_persistent(self, arr, n, bs, h, dev=None):
         """True when the frame-level recurrence runs as the persistent launch: where the library serves the shape and
         rates it the faster path (small batches: at most one 16-row tile per wave). TWOG_BIGRU_PERSIST=1: wherever it is
         served; =0: never."""
         mode = os.environ.get('TWOG_BIGRU_PERSIST', 'auto')
-        if mode == '0' or not HipKernels.device_is_exclusive:
+        if mode == '0' or not self.persistent_allowed(dev if dev is not None else torch.device('cuda', torch.cuda.current_device())):
             return False
         return int(self.lib.twog_bigru_persistent_supported(arr, n, bs, h)) >= (1 if mode == '1' else 2)
 
     def bigru_bwd_would_persist(self, Es, bs, h):
         """Whether bigru_bwd takes the persistent launch for entity counts Es at this batch (asked before the operands exist:
         the data-parallel backward pass orders its first gradient all-reduce around that launch)."""
-        if os.environ.get('TWOG_BIGRU_PERSIST', 'auto') == '0' or not HipKernels.device_is_exclusive:
+        if (os.environ.get('TWOG_BIGRU_PERSIST', 'auto') == '0' or
+                self._dev_index(torch.device('cuda', torch.cuda.current_device())) in HipKernels.shared_devices):
             return False
         arr = (L.BiGruBwd * len(Es))()
         for a, E in zip(arr, Es):
@@ -403,14 +455,15 @@ class HipKernels:
             a.d_gi, a.d_gh, a.carry, a.E = d_gi.data_ptr(), d_gh.data_ptr(), carry.data_ptr(), E
             outs.append((d_gi, d_gh))
         mode = os.environ.get('TWOG_BIGRU_PERSIST', 'auto')
-        self.last_bigru_bwd_persistent = (mode != '0' and allow_persistent and HipKernels.device_is_exclusive and
+        self.last_bigru_bwd_persistent = (mode != '0' and allow_persistent and self.persistent_allowed(dev) and
                                           int(self.lib.twog_bigru_bwd_persistent_supported(arr, n, bs, h)) >= 2)
         if self.last_bigru_bwd_persistent:   # small batches: one persistent launch (csrc/gru_persist.hip)
             sync = self.zeros(1024, device=dev)
             keep.append(sync)
-            self._check(self.lib.twog_bigru_bwd_persistent(arr, n, bs, T, h, sync.data_ptr(), self._stream()),
-                        'twog_bigru_bwd_persistent')
-            return outs
+            rc = self.lib.twog_bigru_bwd_persistent(arr, n, bs, T, h, sync.data_ptr(), self._stream())
+            if self._persistent_ok(rc, sync, dev, 'twog_bigru_bwd_persistent'):
+                return outs
+            self.last_bigru_bwd_persistent = False
         self._check(self.lib.twog_bigru_bwd(arr, n, bs, T, h, *self.chain_workspace(dev), self._stream()), 'twog_bigru_bwd')
         return outs
 

@@ -262,7 +262,6 @@ class TGGCN(nn.Module):
         plan = ops.Plan(self.cfg, bs, T, H, O, self.gcn_node, x_objects.shape[-1], n_sub, n_aff,
                         human_segmentation is not None, objects_segmentation is not None)
         plan.stage_hook = ops.get_model_extra(self, 'stage_hook')   # data-parallel overlap (ops.set_grad_stage_hook)
-        plan.wcache = ops.weight_cache_of(self)   # weight-derived buffers that live from optimizer step to optimizer step
         plan.dists = dists or None
         plan.steps = None
         if steps_per_example is not None and (plan.time_s or plan.time_u or plan.seglen):

@@ -189,7 +189,16 @@ int twog_bigru_fwd(const twog_bigru_t* types, int n_types, int bs, int T, int hi
  * twog_bigru_fwd (tmp_gh / zeros unused). sync: device memory, >= 1024 uint32, ZERO when the launch starts.
  * twog_bigru_persistent_supported: 0 = shape not served (hidden not 64 / 128 / 256 / 512, or the (type, direction, chunk) x
  * hidden / 16 workgroups do not fit the device), 1 = served, 2 = served and the faster path (at most one tile per
- * wave: small batches). */
+ * wave: small batches).
+ * Residency (both persistent entry points, forward and backward): every workgroup of the grid must be resident at once.
+ * The launch first asks the runtime (hipOccupancyMaxActiveBlocksPerMultiprocessor x compute units >= grid) and returns
+ * TWOG_PERSIST_NOT_RESIDENT (-3) WITHOUT launching when the device cannot hold the grid. What the runtime cannot see --
+ * another tenant of the GPU holding compute units -- is caught inside the launch: every wait is bounded
+ * (TWOG_PERSIST_SPIN_LIMIT spins, default 2^24 ~ seconds); when a bound runs out the launch sets sync[128] != 0 and every
+ * wave leaves (no trap, the context survives). After the launch the CALLER reads sync[128]: non-zero means the outputs are
+ * incomplete and the pass must be re-run with the launch-per-step entry point (twog_bigru_fwd / twog_bigru_bwd: same
+ * buffers, written in place, so the re-run is idempotent). kernels.py does exactly that. */
+#define TWOG_PERSIST_NOT_RESIDENT (-3)
 int twog_bigru_persistent_supported(const twog_bigru_t* types, int n_types, int bs, int hidden);
 int twog_bigru_fwd_persistent(const twog_bigru_t* types, int n_types, int bs, int T, int hidden, void* sync, void* stream);
 
@@ -522,6 +531,17 @@ int twog_tape_run(const twog_tape_entry_t* step_a, const twog_tape_entry_t* step
 /* Zero fill of `nbytes` bytes at `p` (any alignment) on `stream`: the step's workspace / gradient clears (torch.zeros and
  * Tensor.zero_() on the reference's path, e.g. optimizer.zero_grad(), pyrutils/torch/train_utils.py:146). */
 int twog_fill_zero(void* p, size_t nbytes, void* stream);
+/* n_blocks <= TWOG_COPY_MAX copies dst[i] = src[i], i < n floats, of contiguous fp32 blocks in ONE launch. The host uses it
+ * to rebuild, at EVERY forward call, the packed operands the time loops read (w_smsg_* / b_smsg_* of twog_segrnn_t: the
+ * reference applies the four segment-level sender MLPs one by one, vhoi/models.py:1051-1098, :1145-1190, :1239-1285,
+ * :1334-1383; here two of them share a GEMM). Nothing derived from a parameter is kept across calls. */
+#define TWOG_COPY_MAX 16
+typedef struct {
+    const float* src;
+    float* dst;
+    int64_t n;
+} twog_copy_t;
+int twog_copy_blocks(const twog_copy_t* blocks, int n_blocks, void* stream);
 int twog_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
                    float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale, void* stream);
 

