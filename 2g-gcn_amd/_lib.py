@@ -178,6 +178,9 @@ SIGNATURES = {
     'twog_attn_bwd': [C.POINTER(AttnBwd), _I, _P],
     'twog_segrnn_fwd': [C.POINTER(SegRnn), _P, C.c_size_t, _P],
     'twog_segrnn_bwd': [C.POINTER(SegRnn), C.POINTER(SegRnnBwd), _P, C.c_size_t, _P],
+    'twog_segrnn_persistent_supported': [C.POINTER(SegRnn)],
+    'twog_segrnn_persistent_sync_bytes': [],
+    'twog_segrnn_fwd_persistent': [C.POINTER(SegRnn), _P, _P],
     'twog_graph_cache_stats': [c_int64_p, c_int64_p],
     'twog_pos_embed_fwd': [_P, _P, _I, _I, _I, _I, _P, _P, _I, _I, Rows, _P, _P],
     'twog_periodic_embed_bwd': [Rows, _P, _I, _I, _P, _P],
@@ -208,6 +211,7 @@ SIGNATURES = {
     'twog_tape_run': [C.POINTER(TapeEntry), C.POINTER(TapeEntry), _I, _I, _I, _P, C.c_size_t, _P],
     'twog_fill_zero': [_P, C.c_size_t, _P],
     'twog_copy_blocks': [C.POINTER(Copy), _I, _P],
+    'twog_debug_occupy': [_I, _I, _I, _P],
     'twog_adam_step': [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _F, _P],
     'twog_multitask_loss_fwd': [C.POINTER(Loss), _I, _P, _P, _P, _P],
     'twog_multitask_loss_bwd': [C.POINTER(Loss), _I, _P, _P, _P],
@@ -232,6 +236,7 @@ def load():
         fn.argtypes = argtypes
         fn.restype = C.c_int
     lib.twog_chain_workspace_bytes.restype = C.c_size_t
+    lib.twog_segrnn_persistent_sync_bytes.restype = C.c_size_t
     lib.twog_version.restype = C.c_char_p
     lib.twog_version.argtypes = []
     _lib = lib

@@ -335,6 +335,32 @@ extern "C" int twog_copy_blocks(const twog_copy_t* blocks, int n_blocks, void* s
     return 0;
 }
 
+// Diagnostics: holds compute units for a while -- n_blocks workgroups of 256 threads with lds_bytes of LDS each spin until
+// `usec` microseconds have passed on the device's wall clock. Tests use it as the "other tenant" a persistent launch
+// (gru_persist.hip, seg_persist.hip) must survive: with one block per compute unit and more than half of the LDS each, no
+// other workgroup that asks for LDS of its own becomes resident until these have left.
+__global__ __launch_bounds__(256) void occupy_kernel(long long ticks, unsigned* sink) {
+    extern __shared__ char lds_hold[];
+    lds_hold[threadIdx.x] = (char)threadIdx.x;
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
+    if (lds_hold[(threadIdx.x + 1) & 255] == 77 && sink) sink[0] = 1;   // keeps the LDS request alive
+}
+
+extern "C" int twog_debug_occupy(int n_blocks, int lds_bytes, int usec, void* stream) {
+    if (n_blocks <= 0 || usec <= 0) return 0;
+    if (lds_bytes < 256 || lds_bytes > 160 * 1024) return -2;
+    static std::atomic<uint32_t> done{0};
+    twog_allow_dynamic_lds(occupy_kernel, 160 * 1024, done);
+    int dev = 0, khz = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return -2;
+    if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess || khz <= 0) khz = 100000;
+    const long long ticks = (long long)usec * khz / 1000;
+    hipLaunchKernelGGL(occupy_kernel, dim3(n_blocks), dim3(256), lds_bytes, (hipStream_t)stream, ticks, (unsigned*)nullptr);
+    TWOG_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int twog_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
                               float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale,
                               void* stream) {

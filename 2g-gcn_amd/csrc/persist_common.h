@@ -13,13 +13,14 @@
 #include <stdlib.h>
 #include "twog_common.h"
 
-// spins of ~0.1 us each before a wait gives up: seconds by default; TWOG_PERSIST_SPIN_LIMIT overrides (tests force the
-// soft-failure path with 1)
+// polls (each an L2 round trip plus an s_sleep, ~1 us) before a wait gives up: seconds by default;
+// TWOG_PERSIST_SPIN_LIMIT overrides. 0 is the test hook of the recovery path: every wait gives up at once, whether or not
+// its counter has arrived (an idle device hands over within a poll or two, so a small positive limit proves nothing).
 inline int twog_persist_spin_limit() {
     const char* e = getenv("TWOG_PERSIST_SPIN_LIMIT");
     if (e && *e) {
         const long v = strtol(e, nullptr, 10);
-        if (v > 0) return (int)(v > (1L << 30) ? (1L << 30) : v);
+        if (v >= 0) return (int)(v > (1L << 30) ? (1L << 30) : v);
     }
     return 1 << 24;
 }
@@ -42,6 +43,10 @@ __device__ __forceinline__ bool twog_wait_counter(const unsigned* counter, unsig
     int ok = 1;
     if (lane == 0) {
         int spins = 0;
+        if (spin_limit <= 0) {   // test hook: give up at once
+            __hip_atomic_store(error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ok = 0;
+        } else
         while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
             __builtin_amdgcn_s_sleep(1);
             ++spins;

@@ -1,0 +1,680 @@
+// Segment-level gated bidirectional recurrence with message passing as ONE persistent launch (small batches).
+//
+// Reference: the segment loop of TGGCN.forward (vhoi/models.py:785-880): per (tf, tb) pair every human / object gathers
+// attention-weighted messages from the previously committed segment states of the other entities
+// (_humans_to_human_segment_message :1051, _humans_to_object_segment_message :1145, _objects_to_human_segment_message
+// :1239, _objects_to_object_segment_message :1334; compute_non_relational_message :1693, compute_attention_weights
+// :1721), concatenates them to its frame-level input and takes one gated GRUCell step (_bidirectional_step :1535-1564).
+// Same inputs, outputs and saved tensors as twog_segrnn_fwd (segrnn.hip), which issues three to four launches per time
+// step: at 8 clips per GPU a step is a chain of launch boundaries around a handful of tiles (50 us per step, 58 % of the
+// whole training step at BASELINE configs[1]).
+//
+// Here the chip is partitioned once for the whole sequence. The work of a (direction, clip chunk) GROUP is dealt to
+// 4 x h/16 workgroups, one per compute unit: for every slice of 16 hidden units four ROLES
+//   P1a  sender MLPs hh (on the humans' previous states) and oh (on the objects'), attention weights, the aggregated
+//        messages received by HUMANS for its 16 columns of both blocks, and W_hh h_prev of the human cell (3 gates x 16);
+//   P1b  the same for what OBJECTS receive: sender MLPs ho and oo, aggregated messages, W_hh h_prev of the object cell;
+//   P2h  W_ih[:, messages] of the human cell on the complete aggregated-message rows (3 gates x 16 units), the gate
+//        math, the blend with the hard segment gate u, the 16 columns of h_t;  P2o the same for objects.
+// A step is two phases -- P1 needs every column of h_{t-1} of both kinds (A operand of its products and the attention
+// scores, which every P1 workgroup computes redundantly for its chunk on the matrix cores: the Gram matrix of the
+// chunk's state rows), P2 needs every column of the aggregated messages -- so two hand-offs per step and direction,
+// each: write-through (sc1) 16-byte stores, every storing wave drains them (s_waitcnt vmcnt(0)), workgroup barrier, one
+// lane adds to the role's agent-scope counter of the group; consumer: one lane polls the counter with sc1 loads, a
+// workgroup barrier, sc1 loads of the handed-off bytes only (MI355X_MICROARCH.md, hand-off table row 1; one workgroup
+// per compute unit, enforced by the LDS request). Every wait is bounded and fails soft (persist_common.h).
+//
+// Arithmetic: the exact 3 x bf16 split of both operands, six of nine products on v_mfma_f32_16x16x32_bf16, fp32
+// accumulation with the h.h product and the five small ones in separate accumulators (as the 64x64 GEMM class and
+// gru_persist.hip); the reduction of a product is split over the four waves of a workgroup by k-blocks and combined
+// through LDS in wave order: fixed summation order, bit-reproducible. Weights are streamed from L2 / Infinity Cache
+// every step (704 KB per slice and direction at h = 512: more than LDS holds), 160-192 KB per workgroup and step.
+#include "twog_common.h"
+#include "persist_common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((__vector_size__(4 * sizeof(unsigned))));
+
+constexpr int SC1 = 16;          // aux bits of the buffer instructions: sc1
+constexpr int RS = 20;           // floats per row of a 16 x 16 result tile in LDS (16-byte aligned, 4 banks apart)
+constexpr int CNT_STRIDE = 32;   // uint32 between two counters (a 128-byte line each)
+constexpr int SYNC_WORDS = 4096; // uint32 of the caller's sync buffer; the error word is the last line
+constexpr int ERR_WORD = SYNC_WORDS - 32;
+constexpr int MAXH = 4, MAXO = 12;
+
+struct SegArgs {
+    int bs, T, H, O, h;
+    int cpc, n_chunks;           // clips per chunk, chunks per direction
+    unsigned pair_mask;          // bit (i * 8 + j), i <= j: Gram tile (i, j) of the chunk's row tiles holds a same-clip pair
+    float scale;
+    int spin_limit;
+    const float* gi[2];          // [kind] [bs][T][E][6h]
+    const float* u[2];           // [bs][T][E]
+    const float* mask;           // [bs][O]
+    const float* w_hh[2][2];     // [kind][dir] [3h][h]
+    const float* b_hh[2][2];
+    const float* w_ihm[2][2];    // [kind][dir] &weight_ih[0][first message column]
+    int64_t ld_ih[2];
+    const float* w_s[4];         // sender MLPs hh, ho (on human states), oh, oo (on object states): [h][h]
+    const float* b_s[4];
+    float* hs[2];                // [bs][T][E][2h]
+    float* save[2];              // [2][bs][T][E][4h]
+    float* msrc[2];              // [2][bs][T][E][2h]  (hh | ho), (oh | oo)
+    float* mg[2];                // [2][bs][T][E][2h]  (hh | oh), (ho | oo)
+    float* gh[2];                // [2][bs*E][3h] scratch: W_hh h_prev + b_hh of the current step
+    float* att;                  // [2][T][bs][natt]
+    unsigned* cnt;
+    unsigned* error;
+};
+
+__device__ __forceinline__ uint32_t pack_hi16(uint32_t lo, uint32_t hi) { return __builtin_amdgcn_perm(hi, lo, 0x07060302); }
+
+// eight consecutive fp32 values -> the three bf16 planes of an MFMA fragment (element j = value j), by truncation: exact
+struct Planes { bf16x8 h, m, l; };
+__device__ __forceinline__ Planes split8(const f32x4 a, const f32x4 b) {
+    uint32_t x[8], r1[8], r2[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const float f0 = i < 4 ? a[i] : b[i - 4];
+        x[i] = __float_as_uint(f0);
+        const float f1 = f0 - __uint_as_float(x[i] & 0xffff0000u);
+        r1[i] = __float_as_uint(f1);
+        r2[i] = __float_as_uint(f1 - __uint_as_float(r1[i] & 0xffff0000u));
+    }
+    Planes p;
+    p.h = __builtin_bit_cast(bf16x8, i32x4{(int)pack_hi16(x[0], x[1]), (int)pack_hi16(x[2], x[3]), (int)pack_hi16(x[4], x[5]), (int)pack_hi16(x[6], x[7])});
+    p.m = __builtin_bit_cast(bf16x8, i32x4{(int)pack_hi16(r1[0], r1[1]), (int)pack_hi16(r1[2], r1[3]), (int)pack_hi16(r1[4], r1[5]), (int)pack_hi16(r1[6], r1[7])});
+    p.l = __builtin_bit_cast(bf16x8, i32x4{(int)pack_hi16(r2[0], r2[1]), (int)pack_hi16(r2[2], r2[3]), (int)pack_hi16(r2[4], r2[5]), (int)pack_hi16(r2[6], r2[7])});
+    return p;
+}
+
+struct Acc { f32x4 hi, lo; };
+__device__ __forceinline__ void acc_zero(Acc& c) { c.hi = f32x4{0.f, 0.f, 0.f, 0.f}; c.lo = f32x4{0.f, 0.f, 0.f, 0.f}; }
+// c += A B with A, B given as planes: h.h into `hi`, the five small products into `lo`
+__device__ __forceinline__ void mac6(Acc& c, const Planes& a, const Planes& b) {
+    c.hi = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.h, b.h, c.hi, 0, 0, 0);
+    c.lo = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.h, b.m, c.lo, 0, 0, 0);
+    c.lo = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.m, b.h, c.lo, 0, 0, 0);
+    c.lo = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.m, b.m, c.lo, 0, 0, 0);
+    c.lo = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.h, b.l, c.lo, 0, 0, 0);
+    c.lo = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.l, b.h, c.lo, 0, 0, 0);
+}
+
+__device__ __forceinline__ f32x4 ld_sc1(const __amdgpu_buffer_rsrc_t rs, uint32_t byte_off) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)byte_off, 0, SC1));
+}
+__device__ __forceinline__ void st_sc1(const __amdgpu_buffer_rsrc_t rs, uint32_t byte_off, const f32x4 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, (int)byte_off, 0, SC1);
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc_of(const float* p) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, 0xffffffff, 0x00020000);
+}
+
+// weight fragment: lane l holds W[row0 + (l & 15)][k0 + 8 (l >> 4) + j], j = 0..7
+__device__ __forceinline__ Planes load_w(const float* w, int64_t ld, int row0, int k0, int lane) {
+    const float* p = w + (int64_t)(row0 + (lane & 15)) * ld + k0 + 8 * (lane >> 4);
+    return split8(*reinterpret_cast<const f32x4*>(p), *reinterpret_cast<const f32x4*>(p + 4));
+}
+
+// one wave's partial tile -> part[wave][tile][lane][4]
+__device__ __forceinline__ void put_part(float* part, int n_tiles, int wave, int tile, int lane, const Acc& c) {
+    *reinterpret_cast<f32x4*>(part + ((size_t)(wave * n_tiles + tile) * 64 + lane) * 4) = c.hi + c.lo;
+}
+
+// sums the waves' partial tiles in wave order into res[tile][16][RS]; all 256 threads; ends with a barrier
+__device__ __forceinline__ void combine_parts(const float* part, float* res, int n_tiles, int n_waves_used) {
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int tile = wave; tile < n_tiles; tile += 4) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(part + ((size_t)tile * 64 + lane) * 4);
+        for (int w = 1; w < n_waves_used; ++w)
+            v += *reinterpret_cast<const f32x4*>(part + ((size_t)(w * n_tiles + tile) * 64 + lane) * 4);
+        float* r = res + (size_t)tile * 16 * RS + (4 * (lane >> 4)) * RS + (lane & 15);
+        r[0] = v[0]; r[RS] = v[1]; r[2 * RS] = v[2]; r[3 * RS] = v[3];
+    }
+    __syncthreads();
+}
+
+// wave 0 waits for (up to) two counters; the whole workgroup learns the outcome. Returns false -> everybody leaves.
+__device__ __forceinline__ bool group_wait(const unsigned* c0, unsigned want0, const unsigned* c1, unsigned want1,
+                                           unsigned* error, int spin_limit, int* flag) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (wave == 0) {
+        bool ok = twog_wait_counter(c0, want0, error, spin_limit, lane);
+        if (ok && c1) ok = twog_wait_counter(c1, want1, error, spin_limit, lane);
+        if (lane == 0) *flag = ok ? 1 : 0;
+    }
+    __syncthreads();
+    const bool ok = *flag != 0;
+    return ok;
+}
+
+// every wave has drained its stores -> barrier -> one lane signals
+__device__ __forceinline__ void group_signal(unsigned* counter) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+struct Geo {   // what a workgroup knows about its place
+    int dir, chunk, slice, role, b0, nb, RH, RO;
+};
+
+// layout of the saved attention weights of one (direction, step, clip): hh | oh | ho | oo (attn.hip)
+__device__ __forceinline__ int att_hh(int H, int O) { return 0; }
+__device__ __forceinline__ int att_oh(int H, int O) { return H * H; }
+__device__ __forceinline__ int att_ho(int H, int O) { return H * H + H * O; }
+__device__ __forceinline__ int att_oo(int H, int O) { return H * H + 2 * H * O; }
+
+// masked softmax over the senders of one receiver (attn.hip, softmax_row): w[0..S) <- softmax over the valid senders,
+// 0 elsewhere (no valid sender: all zeros -- the reference's NaN -> 0, models.py:1750-1753)
+__device__ __forceinline__ void softmax_row(const float* score, int sstride, float* w, int S, int excluded, const float* smask) {
+    float sc[MAXO];
+    bool ok[MAXO];
+    float m = -INFINITY;
+#pragma unroll
+    for (int s = 0; s < MAXO; ++s) {
+        ok[s] = s < S && s != excluded && (!smask || smask[s < S ? s : 0] != 0.f);
+        sc[s] = ok[s] ? score[(s < S ? s : 0) * sstride] : -INFINITY;
+        m = fmaxf(m, sc[s]);
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int s = 0; s < MAXO; ++s) {
+        sc[s] = ok[s] ? expf(sc[s] - m) : 0.f;
+        sum += sc[s];
+    }
+#pragma unroll
+    for (int s = 0; s < MAXO; ++s)
+        if (s < S) w[s] = ok[s] ? sc[s] / sum : 0.f;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// P1 of receiver kind RK (0: humans receive -> role P1a; 1: objects receive -> P1b), one step.
+// Tiles of `res`: [0, MH) sender MLP on human states (hh | ho), [MH, MH+MO) sender MLP on object states (oh | oo),
+// then MK x 3 W_hh tiles of kind RK (row tile major), then the Gram tiles (i <= j over the MH + MO row tiles).
+// ---------------------------------------------------------------------------------------------------------------------
+template <int MH, int MO, int RK>
+__device__ __forceinline__ bool p1_step(const SegArgs& P, const Geo& G, int s, float* part, float* res, float* sG, float* sW,
+                                        const float* sMask, int* flag) {
+    constexpr int MK = RK == 0 ? MH : MO, MT = MH + MO;
+    constexpr int NPAIR = MT * (MT + 1) / 2;
+    constexpr int T_SH = 0, T_SO = MH, T_G = MH + MO, T_GRAM = T_G + 3 * MK, NTILES = T_GRAM + NPAIR;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i16 = lane & 15, g4 = lane >> 4;
+    const int H = P.H, O = P.O, h = P.h, T = P.T, E_K = RK == 0 ? H : O;
+    const int dir = G.dir, t = dir == 0 ? s : T - 1 - s, tp = dir == 0 ? t - 1 : t + 1;
+    const int nkb = h / 32;
+    const int group = dir * P.n_chunks + G.chunk;
+    unsigned* cnt = P.cnt + (size_t)group * 4 * CNT_STRIDE;
+    const int ns = h / 16;
+    const float* ws_h = P.w_s[RK == 0 ? 0 : 1];   // on human states: hh (humans receive) / ho (objects receive)
+    const float* ws_o = P.w_s[RK == 0 ? 2 : 3];   // on object states: oh / oo
+    const float* bs_h = P.b_s[RK == 0 ? 0 : 1];
+    const float* bs_o = P.b_s[RK == 0 ? 2 : 3];
+    const float* w_hh = P.w_hh[RK][dir];
+    const float* b_hh = P.b_hh[RK][dir];
+
+    Acc a_sh[MH], a_so[MO], a_g[MK][3], a_gram[NPAIR];
+#pragma unroll
+    for (int i = 0; i < MH; ++i) acc_zero(a_sh[i]);
+#pragma unroll
+    for (int i = 0; i < MO; ++i) acc_zero(a_so[i]);
+#pragma unroll
+    for (int i = 0; i < MK; ++i)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) acc_zero(a_g[i][c]);
+#pragma unroll
+    for (int p = 0; p < NPAIR; ++p) acc_zero(a_gram[p]);
+
+    if (s > 0) {
+        // every column of h_{t-1}: all slices of P2h and P2o have published step s - 1
+        if (!group_wait(cnt + 2 * CNT_STRIDE, (unsigned)s * ns, cnt + 3 * CNT_STRIDE, (unsigned)s * ns, P.error, P.spin_limit, flag))
+            return false;
+        const __amdgpu_buffer_rsrc_t rs_h = rsrc_of(P.hs[0]), rs_o = rsrc_of(P.hs[1]);
+        // byte offset of (chunk row r of a kind, column 8 g4 of this direction) at time tp
+        uint32_t off_h[MH], off_o[MO];
+#pragma unroll
+        for (int i = 0; i < MH; ++i) {
+            const int r = min(i * 16 + i16, G.RH - 1), b = G.b0 + r / H, e = r % H;
+            off_h[i] = 4u * (uint32_t)((((int64_t)b * T + tp) * H + e) * (2 * h) + dir * h + 8 * g4);
+        }
+#pragma unroll
+        for (int i = 0; i < MO; ++i) {
+            const int r = min(i * 16 + i16, G.RO - 1), b = G.b0 + r / O, e = r % O;
+            off_o[i] = 4u * (uint32_t)((((int64_t)b * T + tp) * O + e) * (2 * h) + dir * h + 8 * g4);
+        }
+        for (int kb = wave; kb < nkb; kb += 4) {
+            Planes A[MT];
+#pragma unroll
+            for (int i = 0; i < MH; ++i) A[i] = split8(ld_sc1(rs_h, off_h[i] + 128u * kb), ld_sc1(rs_h, off_h[i] + 128u * kb + 16u));
+#pragma unroll
+            for (int i = 0; i < MO; ++i) A[MH + i] = split8(ld_sc1(rs_o, off_o[i] + 128u * kb), ld_sc1(rs_o, off_o[i] + 128u * kb + 16u));
+            {
+                const Planes B = load_w(ws_h, h, G.slice * 16, kb * 32, lane);
+#pragma unroll
+                for (int i = 0; i < MH; ++i) mac6(a_sh[i], A[i], B);
+            }
+            {
+                const Planes B = load_w(ws_o, h, G.slice * 16, kb * 32, lane);
+#pragma unroll
+                for (int i = 0; i < MO; ++i) mac6(a_so[i], A[MH + i], B);
+            }
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const Planes B = load_w(w_hh, h, c * h + G.slice * 16, kb * 32, lane);
+#pragma unroll
+                for (int i = 0; i < MK; ++i) mac6(a_g[i][c], A[(RK == 0 ? 0 : MH) + i], B);
+            }
+            // Gram tiles of the chunk's state rows: the B fragment of row tile j IS its A fragment
+            int p = 0;
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = i; j < MT; ++j) {
+                    if (P.pair_mask & (1u << (i * 8 + j))) mac6(a_gram[p], A[i], A[j]);
+                    ++p;
+                }
+        }
+    }
+    // ---- partial tiles -> LDS, combined in wave order
+#pragma unroll
+    for (int i = 0; i < MH; ++i) put_part(part, NTILES, wave, T_SH + i, lane, a_sh[i]);
+#pragma unroll
+    for (int i = 0; i < MO; ++i) put_part(part, NTILES, wave, T_SO + i, lane, a_so[i]);
+#pragma unroll
+    for (int i = 0; i < MK; ++i)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) put_part(part, NTILES, wave, T_G + i * 3 + c, lane, a_g[i][c]);
+#pragma unroll
+    for (int p = 0; p < NPAIR; ++p) put_part(part, NTILES, wave, T_GRAM + p, lane, a_gram[p]);
+    combine_parts(part, res, NTILES, min(4, nkb));
+
+    const int tid = threadIdx.x, q = tid & 3, ur = tid >> 2;   // (row of a 64-row pass, quad of 4 units)
+    const int col = G.slice * 16 + 4 * q;
+    // ---- sender messages: relu(. + bias), kept in `res` for the weighted sums and saved for the backward pass
+    {
+        const int blk = RK == 0 ? 0 : 1;   // column block inside msrc_h (hh | ho) and msrc_o (oh | oo)
+        if (ur < MH * 16) {
+            float* r = res + (size_t)(T_SH + ur / 16) * 16 * RS + (ur % 16) * RS + 4 * q;
+            f32x4 v = *reinterpret_cast<f32x4*>(r);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k] + (bs_h ? bs_h[col + k] : 0.f), 0.f);
+            *reinterpret_cast<f32x4*>(r) = v;
+            if (ur < G.RH) {
+                const int b = G.b0 + ur / H, e = ur % H;
+                float* dst = P.msrc[0] + ((((int64_t)dir * P.bs + b) * T + t) * H + e) * (2 * h) + blk * h + col;
+                *reinterpret_cast<f32x4*>(dst) = v;
+            }
+        }
+        for (int x = ur; x < MO * 16; x += 64) {
+            float* r = res + (size_t)(T_SO + x / 16) * 16 * RS + (x % 16) * RS + 4 * q;
+            f32x4 v = *reinterpret_cast<f32x4*>(r);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k] + (bs_o ? bs_o[col + k] : 0.f), 0.f);
+            *reinterpret_cast<f32x4*>(r) = v;
+            if (x < G.RO) {
+                const int b = G.b0 + x / O, e = x % O;
+                float* dst = P.msrc[1] + ((((int64_t)dir * P.bs + b) * T + t) * O + e) * (2 * h) + blk * h + col;
+                *reinterpret_cast<f32x4*>(dst) = v;
+            }
+        }
+    }
+    // ---- scores of the pairs this role's receivers need: sG[clip][receiver of kind RK][sender in E] = scale <h_r, h_s>
+    const int E = H + O;
+    {
+        const int n = G.nb * E_K * E;
+        for (int x = tid; x < n; x += 256) {
+            const int bl = x / (E_K * E), rem = x - bl * (E_K * E), r = rem / E, sdr = rem - r * E;
+            // unified rows: humans at bl * H + e, objects at 16 MH + bl * O + e
+            const int ra = RK == 0 ? bl * H + r : 16 * MH + bl * O + r;
+            const int rb = sdr < H ? bl * H + sdr : 16 * MH + bl * O + (sdr - H);
+            int ta = ra / 16, tb = rb / 16, ia = ra % 16, ib = rb % 16;
+            if (ta > tb) { const int k1 = ta; ta = tb; tb = k1; const int k2 = ia; ia = ib; ib = k2; }
+            const int p = ta * MT - ta * (ta - 1) / 2 + (tb - ta);   // index of (ta, tb), ta <= tb, in the unrolled order
+            sG[x] = P.scale * res[(size_t)(T_GRAM + p) * 16 * RS + ia * RS + ib];
+        }
+    }
+    __syncthreads();
+    // ---- the two masked softmaxes of this role: one thread per (clip, relation, receiver)
+    const int natt = H * H + 2 * H * O + O * O;
+    {
+        const int n = G.nb * 2 * E_K;
+        for (int x = tid; x < n; x += 256) {
+            const int bl = x / (2 * E_K), rem = x - bl * 2 * E_K, rel = rem / E_K, r = rem - rel * E_K;
+            const float* sc = sG + (size_t)(bl * E_K + r) * E + (rel == 0 ? 0 : H);
+            float* w;
+            int S, excl = -1;
+            const float* mk = nullptr;
+            if (RK == 0) {
+                if (rel == 0) { w = sW + bl * natt + att_hh(H, O) + r * H; S = H; excl = r; }
+                else { w = sW + bl * natt + att_oh(H, O) + r * O; S = O; mk = sMask + bl * O; }
+            } else {
+                if (rel == 0) { w = sW + bl * natt + att_ho(H, O) + r * H; S = H; }
+                else { w = sW + bl * natt + att_oo(H, O) + r * O; S = O; excl = r; mk = sMask + bl * O; }
+            }
+            softmax_row(sc, 1, w, S, excl, mk);
+        }
+    }
+    __syncthreads();
+    if (G.slice == 0) {   // one workgroup per (group, receiver kind) saves its half of the weights for the backward pass
+        const int o0 = RK == 0 ? 0 : att_ho(H, O), o1 = RK == 0 ? att_ho(H, O) : natt;
+        const int n = G.nb * (o1 - o0);
+        for (int x = tid; x < n; x += 256) {
+            const int bl = x / (o1 - o0), i = o0 + x - bl * (o1 - o0);
+            P.att[(((int64_t)dir * T + t) * P.bs + G.b0 + bl) * natt + i] = sW[bl * natt + i];
+        }
+    }
+    // ---- aggregated messages of the receivers (two blocks) and W_hh h_prev + b_hh: write-through, then the signal
+    {
+        const __amdgpu_buffer_rsrc_t rs_mg = rsrc_of(P.mg[RK]), rs_gh = rsrc_of(P.gh[RK]);
+        const int R_K = RK == 0 ? G.RH : G.RO;
+        for (int x = ur; x < MK * 16; x += 64) {
+            if (x >= R_K) continue;
+            const int bl = x / E_K, e = x - bl * E_K, b = G.b0 + bl;
+            // block 0: senders humans (hh / ho); block 1: senders objects (oh / oo)
+            f32x4 m0 = {0.f, 0.f, 0.f, 0.f}, m1 = {0.f, 0.f, 0.f, 0.f};
+            const float* w0 = sW + bl * natt + (RK == 0 ? att_hh(H, O) + e * H : att_ho(H, O) + e * H);
+            const float* w1 = sW + bl * natt + (RK == 0 ? att_oh(H, O) + e * O : att_oo(H, O) + e * O);
+            for (int sd = 0; sd < H; ++sd) {
+                const int r = bl * H + sd;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(res + (size_t)(T_SH + r / 16) * 16 * RS + (r % 16) * RS + 4 * q);
+                const float w = w0[sd];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) m0[k] = fmaf(w, v[k], m0[k]);
+            }
+            for (int sd = 0; sd < O; ++sd) {
+                const int r = bl * O + sd;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(res + (size_t)(T_SO + r / 16) * 16 * RS + (r % 16) * RS + 4 * q);
+                const float w = w1[sd];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) m1[k] = fmaf(w, v[k], m1[k]);
+            }
+            const uint32_t o = 4u * (uint32_t)(((((int64_t)dir * P.bs + b) * T + t) * E_K + e) * (2 * h) + col);
+            st_sc1(rs_mg, o, m0);
+            st_sc1(rs_mg, o + 4u * (uint32_t)h, m1);
+            // W_hh h_prev + b_hh of this row, three gates
+            const int64_t grow = (int64_t)dir * P.bs * E_K + (int64_t)b * E_K + e;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                f32x4 v = *reinterpret_cast<const f32x4*>(res + (size_t)(T_G + (x / 16) * 3 + c) * 16 * RS + (x % 16) * RS + 4 * q);
+                if (b_hh) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v[k] += b_hh[c * h + col + k];
+                }
+                st_sc1(rs_gh, 4u * (uint32_t)(grow * 3 * h + c * h + col), v);
+            }
+        }
+    }
+    group_signal(cnt + RK * CNT_STRIDE);
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// P2 of kind K (0 humans, 1 objects), one step: W_ih[:, messages] on the complete aggregated-message rows, the gates, the
+// blend with the hard gate, the slice's 16 columns of h_t. h_own: this thread's own (row, 4 units) of the previous step.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int MK, int K>
+__device__ __forceinline__ bool p2_step(const SegArgs& P, const Geo& G, int s, float* part, float* res, int* flag,
+                                        f32x4 (&h_own)[(MK * 16 + 63) / 64]) {
+    constexpr int NTILES = 3 * MK, NPASS = (MK * 16 + 63) / 64;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i16 = lane & 15, g4 = lane >> 4;
+    const int h = P.h, T = P.T, E_K = K == 0 ? P.H : P.O, R_K = K == 0 ? G.RH : G.RO;
+    const int dir = G.dir, t = dir == 0 ? s : T - 1 - s;
+    const int ns = h / 16, nkb = 2 * h / 32;
+    const int group = dir * P.n_chunks + G.chunk;
+    unsigned* cnt = P.cnt + (size_t)group * 4 * CNT_STRIDE;
+    const float* w_ihm = P.w_ihm[K][dir];
+    const int64_t ldw = P.ld_ih[K];
+    const int tid = threadIdx.x, q = tid & 3, ur = tid >> 2;
+    const int col = G.slice * 16 + 4 * q;
+
+    // what does not depend on the chain: the frame part of W_ih x + b_ih and the hard gate of this thread's rows
+    f32x4 gi[NPASS][3];
+    float uu[NPASS];
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) {
+        const int x = min(ps * 64 + ur, R_K - 1), bl = x / E_K, e = x - bl * E_K, b = G.b0 + bl;
+        const float* p = P.gi[K] + ((((int64_t)b * T + t) * E_K + e) * 6 + dir * 3) * h + col;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) gi[ps][c] = *reinterpret_cast<const f32x4*>(p + c * h);
+        uu[ps] = P.u[K][((int64_t)b * T + t) * E_K + e];
+    }
+    // the aggregated messages (every column) and W_hh h_prev of this kind: P1 of receiver kind K, all slices
+    if (!group_wait(cnt + K * CNT_STRIDE, (unsigned)(s + 1) * ns, nullptr, 0u, P.error, P.spin_limit, flag)) return false;
+    const __amdgpu_buffer_rsrc_t rs_mg = rsrc_of(P.mg[K]), rs_gh = rsrc_of(P.gh[K]);
+    f32x4 gh[NPASS][3];
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) {
+        const int x = min(ps * 64 + ur, R_K - 1), bl = x / E_K, e = x - bl * E_K, b = G.b0 + bl;
+        const int64_t grow = (int64_t)dir * P.bs * E_K + (int64_t)b * E_K + e;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) gh[ps][c] = ld_sc1(rs_gh, 4u * (uint32_t)(grow * 3 * h + c * h + col));
+    }
+    Acc acc[MK][3];
+#pragma unroll
+    for (int i = 0; i < MK; ++i)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) acc_zero(acc[i][c]);
+    uint32_t off[MK];
+#pragma unroll
+    for (int i = 0; i < MK; ++i) {
+        const int r = min(i * 16 + i16, R_K - 1), bl = r / E_K, e = r - bl * E_K, b = G.b0 + bl;
+        off[i] = 4u * (uint32_t)(((((int64_t)dir * P.bs + b) * T + t) * E_K + e) * (2 * h) + 8 * g4);
+    }
+    for (int kb = wave; kb < nkb; kb += 4) {
+        Planes A[MK];
+#pragma unroll
+        for (int i = 0; i < MK; ++i) A[i] = split8(ld_sc1(rs_mg, off[i] + 128u * kb), ld_sc1(rs_mg, off[i] + 128u * kb + 16u));
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const Planes B = load_w(w_ihm, ldw, c * h + G.slice * 16, kb * 32, lane);
+#pragma unroll
+            for (int i = 0; i < MK; ++i) mac6(acc[i][c], A[i], B);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < MK; ++i)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) put_part(part, NTILES, wave, i * 3 + c, lane, acc[i][c]);
+    combine_parts(part, res, NTILES, min(4, nkb));
+    // ---- gates (gru.hip, gru_step_fwd_kernel: same arithmetic), states write-through, then what the backward pass reads
+    const __amdgpu_buffer_rsrc_t rs_hs = rsrc_of(P.hs[K]);
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) {
+        const int x = ps * 64 + ur;
+        if (x < R_K) {
+            const int bl = x / E_K, e = x - bl * E_K, b = G.b0 + bl;
+            f32x4 gim[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                gim[c] = *reinterpret_cast<const f32x4*>(res + (size_t)((x / 16) * 3 + c) * 16 * RS + (x % 16) * RS + 4 * q);
+            f32x4 rg, zz, nn, hnew;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float ir = gi[ps][0][k] + gim[0][k], iz = gi[ps][1][k] + gim[1][k], in_ = gi[ps][2][k] + gim[2][k];
+                const float hr = gh[ps][0][k], hz = gh[ps][1][k], hn = gh[ps][2][k];
+                rg[k] = 1.0f / (1.0f + expf(-(ir + hr)));
+                zz[k] = 1.0f / (1.0f + expf(-(iz + hz)));
+                nn[k] = tanhf(in_ + rg[k] * hn);
+                const float h0 = h_own[ps][k];
+                const float gnew = (1.0f - zz[k]) * nn[k] + zz[k] * h0;
+                hnew[k] = uu[ps] * gnew + (1.0f - uu[ps]) * h0;
+            }
+            h_own[ps] = hnew;
+            st_sc1(rs_hs, 4u * (uint32_t)((((int64_t)b * T + t) * E_K + e) * (2 * h) + dir * h + col), hnew);
+            float* sv = P.save[K] + ((((int64_t)dir * P.bs + b) * T + t) * E_K + e) * (4 * h) + col;
+            *reinterpret_cast<f32x4*>(sv) = rg;
+            *reinterpret_cast<f32x4*>(sv + h) = zz;
+            *reinterpret_cast<f32x4*>(sv + 2 * h) = nn;
+            *reinterpret_cast<f32x4*>(sv + 3 * h) = gh[ps][2];
+        }
+    }
+    group_signal(cnt + (2 + K) * CNT_STRIDE);
+    return true;
+}
+
+template <int MH, int MO>
+__global__ __launch_bounds__(256, 1) void seg_persist_fwd_kernel(const SegArgs P) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int MT = MH + MO, NPAIR = MT * (MT + 1) / 2;
+    constexpr int NT_MAX = MH + MO + 3 * (MH > MO ? MH : MO) + NPAIR;
+    const int ns = P.h / 16;
+    const int W = (int)gridDim.x;
+    // consecutive linear indices on one XCD (blocks are dealt round-robin over the 8 XCDs): speed only
+    const int L = ((int)blockIdx.x % 8) * (W / 8) + (int)blockIdx.x / 8;
+    const int group = L / (4 * ns), within = L - group * 4 * ns;
+    Geo G;
+    G.dir = group / P.n_chunks; G.chunk = group - G.dir * P.n_chunks;
+    G.slice = within / 4; G.role = within - G.slice * 4;
+    G.b0 = G.chunk * P.cpc; G.nb = min(P.cpc, P.bs - G.b0);
+    G.RH = G.nb * P.H; G.RO = G.nb * P.O;
+    float* part = reinterpret_cast<float*>(smem);                       // [4][NT_MAX][64][4]
+    float* res = part + 4 * NT_MAX * 256;                               // [NT_MAX][16][RS]
+    float* sG = res + NT_MAX * 16 * RS;                                 // [cpc][E_K][E]
+    const int E = P.H + P.O, natt = P.H * P.H + 2 * P.H * P.O + P.O * P.O;
+    float* sW = sG + P.cpc * (P.H > P.O ? P.H : P.O) * E;               // [cpc][natt]
+    float* sMask = sW + P.cpc * natt;                                   // [cpc][O]
+    int* flag = reinterpret_cast<int*>(sMask + P.cpc * P.O);
+    for (int i = threadIdx.x; i < G.nb * P.O; i += 256) sMask[i] = P.mask ? P.mask[(int64_t)G.b0 * P.O + i] : 1.f;
+    __syncthreads();
+    if (G.role == 0) {
+        for (int s = 0; s < P.T; ++s)
+            if (!p1_step<MH, MO, 0>(P, G, s, part, res, sG, sW, sMask, flag)) return;
+    } else if (G.role == 1) {
+        for (int s = 0; s < P.T; ++s)
+            if (!p1_step<MH, MO, 1>(P, G, s, part, res, sG, sW, sMask, flag)) return;
+    } else if (G.role == 2) {
+        f32x4 h_own[(MH * 16 + 63) / 64];
+#pragma unroll
+        for (int i = 0; i < (MH * 16 + 63) / 64; ++i) h_own[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int s = 0; s < P.T; ++s)
+            if (!p2_step<MH, 0>(P, G, s, part, res, flag, h_own)) return;
+    } else {
+        f32x4 h_own[(MO * 16 + 63) / 64];
+#pragma unroll
+        for (int i = 0; i < (MO * 16 + 63) / 64; ++i) h_own[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int s = 0; s < P.T; ++s)
+            if (!p2_step<MO, 1>(P, G, s, part, res, flag, h_own)) return;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------------------------
+struct SegPlan { int cpc, n_chunks, mh, mo; unsigned pair_mask; int grid; size_t lds; };
+
+// chunk size, tile counts and grid for a shape on n_cus compute units; false if the shape is not served
+bool make_plan(const twog_segrnn_t& S, int n_cus, SegPlan& pl) {
+    const int h = S.hidden, H = S.H, O = S.O, bs = S.bs;
+    if (h != 64 && h != 128 && h != 256 && h != 512) return false;
+    if (!S.msg_segment || !S.rel_hh || !S.rel_ho || !S.rel_oh || !S.rel_oo) return false;
+    if (H < 1 || O < 1 || H > MAXH || O > MAXO || bs < 1 || S.T < 1) return false;
+    if (!S.gi_h || !S.gi_o || !S.u_h || !S.u_o) return false;
+    const int ns = h / 16;
+    // as many chunks as the device holds (more chunks = fewer rows per workgroup, more compute units busy)
+    int max_chunks = n_cus / (2 * 4 * ns);
+    if (max_chunks < 1) return false;
+    if (max_chunks > 16) max_chunks = 16;
+    int n_chunks = max_chunks < bs ? max_chunks : bs;
+    int cpc = (bs + n_chunks - 1) / n_chunks;
+    n_chunks = (bs + cpc - 1) / cpc;
+    const int mh = (cpc * H + 15) / 16, mo = (cpc * O + 15) / 16;
+    if (mh != 1 || mo < 1 || mo > 2) return false;   // instantiated: (1, 1), (1, 2)
+    pl.cpc = cpc; pl.n_chunks = n_chunks; pl.mh = mh; pl.mo = mo;
+    // Gram tiles that hold a same-clip pair (unified rows: humans at bl * H + e, objects at 16 mh + bl * O + e)
+    unsigned mask = 0;
+    for (int bl = 0; bl < cpc; ++bl)
+        for (int a = 0; a < H + O; ++a)
+            for (int b = 0; b < H + O; ++b) {
+                const int ra = a < H ? bl * H + a : 16 * mh + bl * O + (a - H);
+                const int rb = b < H ? bl * H + b : 16 * mh + bl * O + (b - H);
+                int ta = ra / 16, tb = rb / 16;
+                if (ta > tb) { const int k = ta; ta = tb; tb = k; }
+                mask |= 1u << (ta * 8 + tb);
+            }
+    pl.pair_mask = mask;
+    pl.grid = 2 * n_chunks * 4 * ns;
+    const int MT = mh + mo, NPAIR = MT * (MT + 1) / 2, NT = mh + mo + 3 * (mh > mo ? mh : mo) + NPAIR;
+    const int E = H + O, natt = H * H + 2 * H * O + O * O;
+    size_t lds = (size_t)4 * NT * 256 * 4 + (size_t)NT * 16 * RS * 4 + (size_t)cpc * (H > O ? H : O) * E * 4 +
+                 (size_t)cpc * natt * 4 + (size_t)cpc * O * 4 + 64;
+    if (lds < 84 * 1024) lds = 84 * 1024;   // more than half of the 160 KB: one workgroup per compute unit
+    if (lds > 160 * 1024) return false;
+    pl.lds = lds;
+    return pl.grid <= n_cus && pl.grid % 8 == 0;
+}
+
+int device_cus(int& n_cus) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return -(int)e;
+    e = hipDeviceGetAttribute(&n_cus, hipDeviceAttributeMultiprocessorCount, dev);
+    return e == hipSuccess ? 0 : -(int)e;
+}
+
+}  // namespace
+
+// 2 if twog_segrnn_fwd_persistent serves this shape on the current device (and is the faster path: it is only served
+// where a chunk's rows fit three 16-row tiles, i.e. small batches), 0 if not.
+extern "C" int twog_segrnn_persistent_supported(const twog_segrnn_t* desc) {
+    int n_cus = 0;
+    if (!desc || device_cus(n_cus) != 0) return 0;
+    SegPlan pl;
+    return make_plan(*desc, n_cus, pl) ? 2 : 0;
+}
+
+extern "C" size_t twog_segrnn_persistent_sync_bytes(void) { return (size_t)SYNC_WORDS * 4; }
+
+// Same contract as twog_segrnn_fwd (tmp_gim_* and zeros unused; tmp_gh_* carries W_hh h_prev between the roles).
+// sync: device memory, twog_segrnn_persistent_sync_bytes(), ZERO at launch; the last 128-byte line is the error word
+// (uint32 index 4064): non-zero after the launch = a wait ran out, the outputs are incomplete, re-run with twog_segrnn_fwd.
+extern "C" int twog_segrnn_fwd_persistent(const twog_segrnn_t* desc, void* sync, void* stream) {
+    if (!desc || !sync) return -2;
+    const twog_segrnn_t& S = *desc;
+    int n_cus = 0;
+    int rc = device_cus(n_cus);
+    if (rc) return rc;
+    SegPlan pl;
+    if (!make_plan(S, n_cus, pl)) return -2;
+    SegArgs P;
+    P.bs = S.bs; P.T = S.T; P.H = S.H; P.O = S.O; P.h = S.hidden;
+    P.cpc = pl.cpc; P.n_chunks = pl.n_chunks; P.pair_mask = pl.pair_mask;
+    P.scale = S.att_scale;
+    P.spin_limit = twog_persist_spin_limit();
+    P.gi[0] = S.gi_h; P.gi[1] = S.gi_o; P.u[0] = S.u_h; P.u[1] = S.u_o; P.mask = S.obj_mask;
+    for (int d = 0; d < 2; ++d) {
+        P.w_hh[0][d] = S.w_hh_h[d]; P.w_hh[1][d] = S.w_hh_o[d];
+        P.b_hh[0][d] = S.b_hh_h[d]; P.b_hh[1][d] = S.b_hh_o[d];
+        P.w_ihm[0][d] = S.w_ihm_h[d]; P.w_ihm[1][d] = S.w_ihm_o[d];
+    }
+    P.ld_ih[0] = S.ld_ih_h; P.ld_ih[1] = S.ld_ih_o;
+    const int64_t hh = (int64_t)S.hidden * S.hidden;
+    P.w_s[0] = S.w_smsg_h; P.w_s[1] = S.w_smsg_h + hh; P.w_s[2] = S.w_smsg_o; P.w_s[3] = S.w_smsg_o + hh;
+    P.b_s[0] = S.b_smsg_h; P.b_s[1] = S.b_smsg_h ? S.b_smsg_h + S.hidden : nullptr;
+    P.b_s[2] = S.b_smsg_o; P.b_s[3] = S.b_smsg_o ? S.b_smsg_o + S.hidden : nullptr;
+    P.hs[0] = S.hs_h; P.hs[1] = S.hs_o; P.save[0] = S.save_h; P.save[1] = S.save_o;
+    P.msrc[0] = S.msrc_h; P.msrc[1] = S.msrc_o; P.mg[0] = S.mg_h; P.mg[1] = S.mg_o;
+    P.gh[0] = S.tmp_gh_h; P.gh[1] = S.tmp_gh_o;
+    P.att = S.att;
+    P.cnt = static_cast<unsigned*>(sync);
+    P.error = P.cnt + ERR_WORD;
+    if ((size_t)2 * pl.n_chunks * 4 * CNT_STRIDE > (size_t)ERR_WORD) return -2;
+    hipStream_t st = (hipStream_t)stream;
+#define TWOG_SP_LAUNCH(MH_, MO_)                                                                              \
+    do {                                                                                                      \
+        static std::atomic<uint32_t> done{0};                                                                 \
+        twog_allow_dynamic_lds(seg_persist_fwd_kernel<MH_, MO_>, 160 * 1024, done);                           \
+        if (!twog_persist_grid_fits(seg_persist_fwd_kernel<MH_, MO_>, pl.grid, pl.lds, n_cus))               \
+            return TWOG_PERSIST_NOT_RESIDENT;                                                                 \
+        hipLaunchKernelGGL((seg_persist_fwd_kernel<MH_, MO_>), dim3(pl.grid), dim3(256), pl.lds, st, P);      \
+    } while (0)
+    if (pl.mo == 1) TWOG_SP_LAUNCH(1, 1);
+    else TWOG_SP_LAUNCH(1, 2);
+#undef TWOG_SP_LAUNCH
+    TWOG_CHECK_LAUNCH();
+    return 0;
+}

@@ -103,6 +103,10 @@ class HipKernels:
             self._check(self.lib.twog_fill_zero(t.data_ptr(), t.numel() * t.element_size(), self._stream()), 'twog_fill_zero')
         return t
 
+    def debug_occupy(self, n_blocks, lds_bytes, usec):
+        """Diagnostics (tests): n_blocks workgroups holding lds_bytes of LDS each for usec microseconds on the current stream."""
+        self._check(self.lib.twog_debug_occupy(n_blocks, lds_bytes, usec, self._stream()), 'twog_debug_occupy')
+
     def copy_blocks(self, pairs):
         """pairs: (src, dst) contiguous fp32 tensors of equal element count; dst[...] = src[...] for all of them in ONE
         launch (twog_copy_blocks) -- the per-forward build of the packed operands (ops.pack_weights)."""
@@ -403,17 +407,67 @@ class HipKernels:
             return False
         return True
 
-    def _persistent_ok(self, rc, sync, dev, what):
-        """True if the persistent launch ran to completion. False -> the caller re-runs the pass on the per-step path."""
+    # When is the error word read? Reading it right after the launch drains the stream while the host waits, and the host
+    # then has to refill the queue launch by launch (measured at 8 clips: ~0.4 ms of the 21.5 ms step per read-back). So:
+    # the first PERSIST_SYNC_CALLS persistent launches on a device -- and every launch for PERSISTENT_BACKOFF calls after
+    # a failure -- are checked AT ONCE and recovered transparently (the pass is re-run per step before anything consumes
+    # its outputs). After that many clean launches the device is evidently ours: the word is copied to pinned host memory
+    # behind the launch (asynchronously) and read at the END of the forward / backward pass (verify_persistent, called by
+    # ops.tggcn_forward / tggcn_backward), when the copy has long landed. A failure found that late -- a tenant that
+    # arrived in mid-training -- cannot be repaired behind the caller's back (consumers have run on incomplete outputs):
+    # it raises, loudly, with the process and the context alive, and the next calls are checked at once again.
+    # TWOG_PERSIST_CHECK=sync: always at once; =lazy: always at the end of the pass.
+    PERSIST_SYNC_CALLS = 8
+    _clean = {}       # device index -> persistent launches checked at once that completed
+    _lazy = {}        # device index -> [(event, pinned int32 tensor, what)]
+    persistent_late_failures = 0
+
+    def _persistent_ok(self, rc, sync, dev, what, err_index=128):
+        """True if the persistent launch ran to completion (or will be verified at the end of the pass). False -> the
+        caller re-runs the pass on the launch-per-step path."""
         if rc == L.PERSIST_NOT_RESIDENT:
             HipKernels.persistent_refused += 1
             return False
         self._check(rc, what)
-        if int(sync.view(torch.int32)[128].item()) == 0:   # (drains the stream: see (3) above)
+        i = self._dev_index(dev)
+        mode = os.environ.get('TWOG_PERSIST_CHECK', 'auto')
+        word = sync.view(torch.int32)[err_index:err_index + 1]
+        if mode == 'lazy' or (mode != 'sync' and HipKernels._clean.get(i, 0) >= self.PERSIST_SYNC_CALLS):
+            host = torch.empty(1, dtype=torch.int32, pin_memory=True)
+            host.copy_(word, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            HipKernels._lazy.setdefault(i, []).append((ev, host, what))
+            return True
+        if int(word.item()) == 0:   # (drains the stream: see above)
+            HipKernels._clean[i] = HipKernels._clean.get(i, 0) + 1
             return True
         HipKernels.persistent_fallbacks += 1
-        HipKernels._backoff[self._dev_index(dev)] = self.PERSISTENT_BACKOFF
+        HipKernels._backoff[i] = self.PERSISTENT_BACKOFF
+        HipKernels._clean[i] = 0
         return False
+
+    def verify_persistent(self, dev=None):
+        """End of a forward / backward pass: every persistent launch of the pass whose error word was left for later must
+        have completed. Raises RuntimeError otherwise (see above)."""
+        i = self._dev_index(dev if dev is not None else torch.device('cuda', torch.cuda.current_device()))
+        pending = HipKernels._lazy.pop(i, None)
+        if not pending:
+            return
+        failed = []
+        for ev, host, what in pending:
+            ev.synchronize()
+            if int(host[0]) != 0:
+                failed.append(what)
+        if failed:
+            HipKernels.persistent_late_failures += 1
+            HipKernels._backoff[i] = self.PERSISTENT_BACKOFF
+            HipKernels._clean[i] = 0
+            raise RuntimeError(f'{", ".join(failed)}: a persistent launch could not keep its grid resident (another tenant '
+                               'is holding compute units of this GPU) and gave up; the results of this pass are incomplete. '
+                               'Repeat the step: the next calls run the launch-per-step path and persistent launches are '
+                               're-admitted one checked launch at a time (TWOG_BIGRU_PERSIST=0 TWOG_SEG_PERSIST=0 switch '
+                               'them off for good).')
 
     def bigru_persistent(self, arr, n, bs, h, dev=None):
         """True when the frame-level recurrence runs as the persistent launch: where the library serves the shape and
@@ -581,6 +635,16 @@ class HipKernels:
                     zeros=self.zeros(bs * max(H, O, 1), h, device=dev))
         s = L.SegRnn()
         self._fill_seg(s, p, bufs)
+        mode = os.environ.get('TWOG_SEG_PERSIST', 'auto')
+        self.last_segrnn_persistent = (mode != '0' and self.persistent_allowed(dev) and
+                                       int(self.lib.twog_segrnn_persistent_supported(C.byref(s))) >= 2)
+        if self.last_segrnn_persistent:   # small batches: the whole recurrence in one launch (csrc/seg_persist.hip)
+            n_sync = int(self.lib.twog_segrnn_persistent_sync_bytes()) // 4
+            sync = self.zeros(n_sync, device=dev)
+            rc = self.lib.twog_segrnn_fwd_persistent(C.byref(s), sync.data_ptr(), self._stream())
+            if self._persistent_ok(rc, sync, dev, 'twog_segrnn_fwd_persistent', err_index=n_sync - 32):
+                return bufs
+            self.last_segrnn_persistent = False
         self._check(self.lib.twog_segrnn_fwd(C.byref(s), *self.chain_workspace(dev), self._stream()), 'twog_segrnn_fwd')
         return bufs
 

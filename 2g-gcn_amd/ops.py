@@ -1388,6 +1388,8 @@ def tggcn_forward(K, plan: Plan, P, x_human, x_objects, objects_mask, human_seg,
     # tensors themselves would close a reference cycle that only the cyclic collector could free, one batch of saved
     # buffers per step late)
     S['outputs'] = [o.detach() for o in outputs]
+    if hasattr(K, 'verify_persistent'):
+        K.verify_persistent(dev)   # persistent launches of this pass whose error word was left for the end of the pass
     return outputs, S
 
 
@@ -1859,6 +1861,8 @@ def tggcn_backward(K, plan: Plan, P, S, x_human, x_objects, objects_mask, d_outp
     G.add(g + 'joint_embed.cnn.1.cnn.bias', db1)
     G.add(g + 'joint_embed.cnn.0.bn.weight', dgamma)
     G.add(g + 'joint_embed.cnn.0.bn.bias', dbeta)
+    if hasattr(K, 'verify_persistent'):
+        K.verify_persistent(dev)
     return G.g
 
 

@@ -305,6 +305,20 @@ typedef struct {
     float* zeros;     /* [bs*max(H,O)][h] zeros */
 } twog_segrnn_t;
 int twog_segrnn_fwd(const twog_segrnn_t* desc, void* chain_ws, size_t chain_ws_bytes, void* stream); /* chain_ws: see twog_gemm_f32_chain */
+/* The same forward recurrence as ONE persistent launch (csrc/seg_persist.hip; small batches): per (direction, clip chunk)
+ * and slice of 16 hidden units four workgroups -- P1a / P1b: sender MLPs, attention weights (the chunk's Gram matrix on the
+ * matrix cores), aggregated messages received by humans / objects and W_hh h_prev; P2h / P2o: W_ih[:, messages] on the
+ * complete message rows, gate math, h_t -- two in-launch hand-offs per step (agent-scope counters, write-through stores,
+ * sc1 loads). Same inputs, outputs and saved tensors as twog_segrnn_fwd (tmp_gim_* / zeros unused, tmp_gh_* carries
+ * W_hh h_prev between the roles). twog_segrnn_persistent_supported: 2 = served on the current device (message_segment with
+ * all four relations, hidden 64 / 128 / 256 / 512, a chunk of clips fits one 16-row tile of humans and at most two of
+ * objects, 2 x chunks x 4 x hidden / 16 workgroups fit the device), 0 = not served. sync: device memory,
+ * twog_segrnn_persistent_sync_bytes(), ZERO at launch; its last 128-byte line is the error word (uint32 index
+ * bytes / 4 - 32). Residency and soft failure: exactly as twog_bigru_fwd_persistent (TWOG_PERSIST_NOT_RESIDENT; error word
+ * != 0 after the launch -> re-run the pass with twog_segrnn_fwd on the same buffers). */
+int twog_segrnn_persistent_supported(const twog_segrnn_t* desc);
+size_t twog_segrnn_persistent_sync_bytes(void);
+int twog_segrnn_fwd_persistent(const twog_segrnn_t* desc, void* sync, void* stream);
 
 typedef struct {
     const float* d_hs_h; /* [bs][T][H][2h] gradient wrt hs_h */
@@ -531,6 +545,9 @@ int twog_tape_run(const twog_tape_entry_t* step_a, const twog_tape_entry_t* step
 /* Zero fill of `nbytes` bytes at `p` (any alignment) on `stream`: the step's workspace / gradient clears (torch.zeros and
  * Tensor.zero_() on the reference's path, e.g. optimizer.zero_grad(), pyrutils/torch/train_utils.py:146). */
 int twog_fill_zero(void* p, size_t nbytes, void* stream);
+/* Diagnostics (tests): n_blocks workgroups of 256 threads holding lds_bytes of LDS each spin for `usec` microseconds --
+ * the co-tenant a persistent launch must survive (see TWOG_PERSIST_NOT_RESIDENT). No reference counterpart. */
+int twog_debug_occupy(int n_blocks, int lds_bytes, int usec, void* stream);
 /* n_blocks <= TWOG_COPY_MAX copies dst[i] = src[i], i < n floats, of contiguous fp32 blocks in ONE launch. The host uses it
  * to rebuild, at EVERY forward call, the packed operands the time loops read (w_smsg_* / b_smsg_* of twog_segrnn_t: the
  * reference applies the four segment-level sender MLPs one by one, vhoi/models.py:1051-1098, :1145-1190, :1239-1285,

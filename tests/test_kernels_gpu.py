@@ -3,6 +3,7 @@
 masks and the split-K / grouped / batched GEMM forms. Tolerances are fp32 summation-order tolerances."""
 import json
 import math
+import time
 import os
 import subprocess
 import sys
@@ -484,21 +485,15 @@ def test_bigru_persistent_hand_offs_hold_under_uneven_load(K):
             assert torch.equal(a, b), f'repetition {rep}: a persistent launch under load differs from the solo run'
 
 
-def test_persistent_launches_fail_soft_and_the_pass_is_rerun_per_step(K, monkeypatch):
-    """VERDICT r04 weak #2 / ADVICE r04: a persistent launch whose grid cannot make progress (another tenant holds compute
-    units) must neither hang nor trap. With TWOG_PERSIST_SPIN_LIMIT=1 every inter-workgroup wait of the launch runs out at
-    once: the launch sets its error word, every wave leaves, the host sees the word and re-runs the pass on the
-    launch-per-step path. Results = the launch-per-step path's, bit for bit; the process lives; the counters say what ran;
-    the device then gets no persistent launch for PERSISTENT_BACKOFF calls; with the limit restored the persistent launch
-    runs again."""
-    from twog_gcn_amd.kernels import HipKernels
+def _persist_rig(K):
     bs, T, h, Es = 8, 24, 512, (2, 4, 1)
-    ws = 0.2
     types = []
     for i, E in enumerate(Es):
         types.append({k: v.to(DEV) for k, v in dict(
-            gi=rnd(bs, T, E, 6 * h, seed=i), w_hh_f=rnd(3 * h, h, seed=10 + i, scale=ws), b_hh_f=rnd(3 * h, seed=20 + i),
-            w_hh_r=rnd(3 * h, h, seed=30 + i, scale=ws), b_hh_r=rnd(3 * h, seed=40 + i)).items()})
+            gi=rnd(bs, T, E, 6 * h, seed=i), w_hh_f=rnd(3 * h, h, seed=10 + i, scale=0.2), b_hh_f=rnd(3 * h, seed=20 + i),
+            w_hh_r=rnd(3 * h, h, seed=30 + i, scale=0.2), b_hh_r=rnd(3 * h, seed=40 + i)).items()})
+    seg = _seg_params(DEV, bs, T, 2, 4, h, (True, True, True, True), True)
+    seg_keys = ['hs_h', 'hs_o', 'save_h', 'save_o', 'msrc_h', 'msrc_o', 'mg_h', 'mg_o', 'att']
 
     def run():
         fw = K.bigru_fwd(types, bs, T, h)
@@ -506,47 +501,134 @@ def test_persistent_launches_fail_soft_and_the_pass_is_rerun_per_step(K, monkeyp
         bt = [dict(d_out=rnd(bs, T, E, 2 * h, seed=50 + i).to(DEV), save=sv, out=o, w_hh_f=y['w_hh_f'], w_hh_r=y['w_hh_r'])
               for i, ((o, sv), y, E) in enumerate(zip(fw, types, Es))]
         bw = K.bigru_bwd(bt, bs, T, h)
+        pb = K.last_bigru_bwd_persistent
+        sb = K.segrnn_fwd(seg)
+        ps = K.last_segrnn_persistent
         torch.cuda.synchronize()
-        return [t for pair in fw for t in pair] + [t for pair in bw for t in pair], pf, K.last_bigru_bwd_persistent
+        return [t for pair in fw for t in pair] + [t for pair in bw for t in pair] + [sb[k] for k in seg_keys], (pf, pb, ps)
 
+    return run
+
+
+def test_persistent_launches_fail_soft_and_the_pass_is_rerun_per_step(K, monkeypatch):
+    """VERDICT r04 weak #2 / ADVICE r04: a persistent launch whose grid cannot make progress must neither hang nor trap.
+    TWOG_PERSIST_SPIN_LIMIT=0 is the library's test hook: every inter-workgroup wait gives up at once, the launch sets its
+    error word and every wave leaves. Checked at once (the first launches on a device, and TWOG_PERSIST_CHECK=sync): the host
+    sees the word and re-runs the pass on the launch-per-step path before anything consumed the outputs -- results = the
+    launch-per-step path's, bit for bit; the process lives; the counters say what ran; the device gets no persistent launch
+    for PERSISTENT_BACKOFF calls; with the limit restored the persistent launches run again and give what they gave."""
+    from twog_gcn_amd.kernels import HipKernels
+    run = _persist_rig(K)
     HipKernels._backoff.clear()
+    HipKernels._lazy.clear()
+    monkeypatch.setenv('TWOG_PERSIST_CHECK', 'sync')
     monkeypatch.setenv('TWOG_BIGRU_PERSIST', '0')
-    want, pf, pb = run()
-    assert not pf and not pb
+    monkeypatch.setenv('TWOG_SEG_PERSIST', '0')
+    want, ran = run()
+    assert ran == (False, False, False)
     monkeypatch.delenv('TWOG_BIGRU_PERSIST')
-    good, pf, pb = run()
-    assert pf and pb, 'the persistent launches did not run on an idle device'
+    monkeypatch.delenv('TWOG_SEG_PERSIST')
+    good, ran = run()
+    assert ran == (True, True, True), 'the persistent launches did not run on an idle device'
+    dev_i = torch.cuda.current_device()
+    monkeypatch.setenv('TWOG_PERSIST_SPIN_LIMIT', '0')
     n0 = HipKernels.persistent_fallbacks
-    monkeypatch.setenv('TWOG_PERSIST_SPIN_LIMIT', '1')
-    got, pf, pb = run()
-    assert not pf, 'the forward launch cannot have completed with a spin limit of 1'
-    assert HipKernels.persistent_fallbacks >= n0 + 1, 'the fallback did not run'
+    got, ran = run()   # the forward BiGRU launch is tried first, gives up, the device backs off: the other two are not tried
+    assert ran == (False, False, False)
+    assert HipKernels.persistent_fallbacks == n0 + 1, 'exactly one launch was tried, gave up and was re-run'
+    assert 0 < HipKernels._backoff.get(dev_i, 0) <= HipKernels.PERSISTENT_BACKOFF
     for a, b in zip(got, want):
         assert torch.isfinite(a).all() and torch.equal(a, b), 'a re-run pass differs from the launch-per-step path'
-    dev_i = torch.cuda.current_device()
-    assert 0 < HipKernels._backoff.get(dev_i, 0) <= HipKernels.PERSISTENT_BACKOFF
-    got2, pf, pb = run()     # still backing off: no persistent launch is even tried
-    assert not pf and not pb and HipKernels.persistent_fallbacks <= n0 + 2
-    # the backward launch alone (forward per step): its own error path
-    HipKernels._backoff.clear()
-    monkeypatch.setenv('TWOG_BIGRU_PERSIST', '0')
-    fw = K.bigru_fwd(types, bs, T, h)
-    monkeypatch.delenv('TWOG_BIGRU_PERSIST')
-    bt = [dict(d_out=rnd(bs, T, E, 2 * h, seed=50 + i).to(DEV), save=sv, out=o, w_hh_f=y['w_hh_f'], w_hh_r=y['w_hh_r'])
-          for i, ((o, sv), y, E) in enumerate(zip(fw, types, Es))]
-    n1 = HipKernels.persistent_fallbacks
-    bw = K.bigru_bwd(bt, bs, T, h)
-    torch.cuda.synchronize()
-    assert not K.last_bigru_bwd_persistent and HipKernels.persistent_fallbacks == n1 + 1
-    for a, b in zip([t for pair in bw for t in pair], want[2 * len(Es):]):
-        assert torch.equal(a, b)
+    # the backward BiGRU launch and the segment launch as the FIRST persistent launch of a call
+    for env in ('bwd', 'seg'):
+        HipKernels._backoff.clear()
+        n0 = HipKernels.persistent_fallbacks
+        real_allowed = HipKernels.persistent_allowed
+        calls = []
+
+        def allowed(self, dev, env=env, calls=calls):   # lets only the launch under test through
+            calls.append(1)
+            import inspect
+            caller = inspect.stack()[1].function
+            want_caller = {'bwd': 'bigru_bwd', 'seg': 'segrnn_fwd'}[env]
+            return caller == want_caller and real_allowed(self, dev)
+
+        monkeypatch.setattr(HipKernels, 'persistent_allowed', allowed)
+        got, ran = run()
+        monkeypatch.setattr(HipKernels, 'persistent_allowed', real_allowed)
+        assert ran == (False, False, False) and HipKernels.persistent_fallbacks == n0 + 1, (env, ran)
+        for a, b in zip(got, want):
+            assert torch.equal(a, b), env
     # limit restored: persistent again, same results as before
     monkeypatch.delenv('TWOG_PERSIST_SPIN_LIMIT')
     HipKernels._backoff.clear()
-    again, pf, pb = run()
-    assert pf and pb
+    again, ran = run()
+    assert ran == (True, True, True)
     for a, b in zip(again, good):
         assert torch.equal(a, b)
+
+
+def test_persistent_launch_failure_found_at_the_end_of_the_pass_raises_and_the_next_calls_recover(K, monkeypatch):
+    """After PERSIST_SYNC_CALLS clean launches the error word is read at the END of the pass (no pipeline drain per launch).
+    A failure found that late cannot be repaired behind the caller's back: verify_persistent raises -- process and context
+    alive -- the device backs off, and the next pass runs per step with correct results."""
+    from twog_gcn_amd.kernels import HipKernels
+    run = _persist_rig(K)
+    HipKernels._backoff.clear()
+    HipKernels._lazy.clear()
+    monkeypatch.setenv('TWOG_PERSIST_CHECK', 'lazy')
+    monkeypatch.setenv('TWOG_BIGRU_PERSIST', '0')
+    monkeypatch.setenv('TWOG_SEG_PERSIST', '0')
+    want, _ = run()
+    monkeypatch.delenv('TWOG_BIGRU_PERSIST')
+    monkeypatch.delenv('TWOG_SEG_PERSIST')
+    good, ran = run()
+    assert ran == (True, True, True)
+    K.verify_persistent()            # clean launches: nothing to report
+    monkeypatch.setenv('TWOG_PERSIST_SPIN_LIMIT', '0')
+    n0 = HipKernels.persistent_late_failures
+    _, ran = run()
+    assert ran == (True, True, True)   # nobody has looked yet
+    with pytest.raises(RuntimeError, match='could not keep its grid resident'):
+        K.verify_persistent()
+    assert HipKernels.persistent_late_failures == n0 + 1
+    K.verify_persistent()            # reported once
+    got, ran = run()                 # backing off: per step, correct
+    assert ran == (False, False, False)
+    for a, b in zip(got, want):
+        assert torch.equal(a, b)
+    HipKernels._backoff.clear()
+    HipKernels._lazy.clear()
+
+
+def test_persistent_launch_beside_a_tenant_that_holds_compute_units(K, monkeypatch):
+    """The real thing: another stream holds half of the compute units (twog_debug_occupy: 128 workgroups with 100 KB of LDS
+    each, for 60 ms), so half of a persistent grid is resident and waits for the half that is not. With a spin limit of
+    ~2 ms the resident waves give up, the grid drains, the host re-runs the pass per step: correct results, no hang, no trap;
+    the tenant finishes undisturbed."""
+    from twog_gcn_amd.kernels import HipKernels
+    run = _persist_rig(K)
+    HipKernels._backoff.clear()
+    HipKernels._lazy.clear()
+    monkeypatch.setenv('TWOG_PERSIST_CHECK', 'sync')
+    monkeypatch.setenv('TWOG_BIGRU_PERSIST', '0')
+    monkeypatch.setenv('TWOG_SEG_PERSIST', '0')
+    want, _ = run()
+    monkeypatch.delenv('TWOG_BIGRU_PERSIST')
+    monkeypatch.delenv('TWOG_SEG_PERSIST')
+    monkeypatch.setenv('TWOG_PERSIST_SPIN_LIMIT', '2000')
+    side = torch.cuda.Stream()
+    n0 = HipKernels.persistent_fallbacks
+    t0 = time.time()
+    with torch.cuda.stream(side):
+        K.debug_occupy(128, 100 * 1024, 60000)
+    got, ran = run()
+    torch.cuda.synchronize()
+    assert time.time() - t0 < 30.0
+    assert HipKernels.persistent_fallbacks >= n0 + 1, 'no persistent launch gave up beside the tenant'
+    for a, b in zip(got, want):
+        assert torch.isfinite(a).all() and torch.equal(a, b)
+    HipKernels._backoff.clear()
 
 
 def test_tape_run_replays_recorded_calls_with_affine_descriptors(K):
@@ -686,6 +768,7 @@ def _seg_params(dev, bs, T, H, O, h, rels, msg_segment=True, seed=0):
 @pytest.mark.parametrize('fusion', ['0', '7'])
 def test_segment_recurrence(K, bs, T, H, O, h, rels, msg, fusion, monkeypatch):
     monkeypatch.setenv('TWOG_GRU_FWD_FUSION', fusion)
+    monkeypatch.setenv('TWOG_SEG_PERSIST', '0')   # this test is about the launch-per-step path and its kernel classes
     pc = _seg_params('cpu', bs, T, H, O, h, rels, msg)
     pg = _seg_params(DEV, bs, T, H, O, h, rels, msg)
     bc = F.segrnn_fwd(pc)
@@ -708,6 +791,73 @@ def test_segment_recurrence(K, bs, T, H, O, h, rels, msg, fusion, monkeypatch):
         if k.startswith('d_pre') and not msg:
             continue  # unused scratch when message_segment is off
         close(og[k], oc[k], rtol=3e-4, atol=3e-5, what='segrnn bwd ' + k)
+
+
+# the segment-level recurrence as ONE persistent launch (csrc/seg_persist.hip): BASELINE configs[1] (8 clips, MPHOI layout,
+# h = 512, T = 120), configs[4] (16 clips, Bimanual layout, h = 64: eight chunks of two clips), configs[0] (one CAD-120 clip),
+# a ragged last chunk, all objects of a clip masked, h = 128 / 256
+SEG_PERSIST_SHAPES = [(8, 120, 2, 4, 512), (16, 120, 2, 9, 64), (1, 20, 1, 5, 512), (8, 7, 2, 4, 512), (5, 9, 2, 3, 128),
+                      (3, 6, 1, 5, 256), (13, 5, 2, 9, 64), (4, 6, 2, 8, 64), (2, 1, 2, 4, 128)]
+
+
+@pytest.mark.parametrize('bs,T,H,O,h', SEG_PERSIST_SHAPES)
+def test_segment_recurrence_persistent_launch_matches_the_stepwise_recurrence(K, bs, T, H, O, h, monkeypatch):
+    """Forward segment recurrence in one launch against the specification (the torch test double) and against the
+    launch-per-step path: states, saved gate activations, sender messages, aggregated messages, attention weights; two
+    runs bit-identical (fixed summation order; a wrong hand-off gives garbage, not noise)."""
+    from twog_gcn_amd.kernels import HipKernels
+    HipKernels._backoff.clear()
+    monkeypatch.setenv('TWOG_PERSIST_CHECK', 'sync')
+    rels = (True, True, True, True)
+    pc = _seg_params('cpu', bs, T, H, O, h, rels, True)
+    pg = _seg_params(DEV, bs, T, H, O, h, rels, True)
+    bc = F.segrnn_fwd(pc)
+    monkeypatch.setenv('TWOG_SEG_PERSIST', '0')
+    bs_ = K.segrnn_fwd(pg)
+    assert not K.last_segrnn_persistent
+    monkeypatch.delenv('TWOG_SEG_PERSIST')
+    b1 = K.segrnn_fwd(pg)
+    assert K.last_segrnn_persistent, 'the persistent launch did not run'
+    b2 = K.segrnn_fwd(pg)
+    torch.cuda.synchronize()
+    for k in ['hs_h', 'hs_o', 'save_h', 'save_o', 'msrc_h', 'msrc_o', 'mg_h', 'mg_o', 'att']:
+        assert torch.isfinite(b1[k]).all(), k
+        close(b1[k], bc[k], rtol=2e-4, atol=2e-5, what='persistent segrnn fwd vs spec: ' + k)
+        close(b1[k], bs_[k], rtol=5e-5, atol=5e-6, what='persistent vs stepwise: ' + k)
+        assert torch.equal(b1[k], b2[k]), 'two runs of the persistent launch differ: ' + k
+    # the backward pass (launch per step) on the persistent forward's saved buffers equals the one on the stepwise forward's
+    dh_h, dh_o = rnd(bs, T, H, 2 * h, seed=31).to(DEV), rnd(bs, T, O, 2 * h, seed=32).to(DEV)
+    o1 = K.segrnn_bwd(pg, b1, dh_h, dh_o)
+    o0 = K.segrnn_bwd(pg, bs_, dh_h, dh_o)
+    for k in o0:
+        close(o1[k], o0[k], rtol=3e-4, atol=3e-5, what='segrnn bwd on persistent forward buffers: ' + k)
+
+
+def test_segment_recurrence_persistent_hand_offs_hold_under_uneven_load(K, monkeypatch):
+    """Same rig as the frame-level test: the persistent segment forward (8 clips, T = 120, h = 512) while a second stream
+    keeps part of the chip busy with GEMMs of changing sizes; every word of every output must equal the solo run's."""
+    monkeypatch.setenv('TWOG_PERSIST_CHECK', 'sync')
+    pg = _seg_params(DEV, 8, 120, 2, 4, 512, (True, True, True, True), True)
+    keys = ['hs_h', 'hs_o', 'save_h', 'save_o', 'msrc_h', 'msrc_o', 'mg_h', 'mg_o', 'att']
+
+    def run():
+        b = K.segrnn_fwd(pg)
+        assert K.last_segrnn_persistent
+        return [b[k] for k in keys]
+
+    solo = [t.clone() for t in run()]
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    mats = [torch.randn(n, n, device=DEV) for n in (512, 1024, 1536, 2048, 3072)]
+    for rep in range(5):
+        with torch.cuda.stream(side):
+            for j in range(40):
+                m = mats[(rep + j) % len(mats)]
+                torch.mm(m, m)
+        got = run()
+        torch.cuda.synchronize()
+        for k, a, b in zip(keys, got, solo):
+            assert torch.equal(a, b), f'repetition {rep}: {k} of the persistent launch under load differs from the solo run'
 
 
 # --------------------------------------------------------------------------------------------------------------- gates
