@@ -181,6 +181,8 @@ SIGNATURES = {
     'twog_segrnn_persistent_supported': [C.POINTER(SegRnn)],
     'twog_segrnn_persistent_sync_bytes': [],
     'twog_segrnn_fwd_persistent': [C.POINTER(SegRnn), _P, _P],
+    'twog_segrnn_bwd_persistent_scratch_bytes': [C.POINTER(SegRnn)],
+    'twog_segrnn_bwd_persistent': [C.POINTER(SegRnn), C.POINTER(SegRnnBwd), _P, C.c_size_t, _P, _P],
     'twog_graph_cache_stats': [c_int64_p, c_int64_p],
     'twog_pos_embed_fwd': [_P, _P, _I, _I, _I, _I, _P, _P, _I, _I, Rows, _P, _P],
     'twog_periodic_embed_bwd': [Rows, _P, _I, _I, _P, _P],
@@ -237,6 +239,7 @@ def load():
         fn.restype = C.c_int
     lib.twog_chain_workspace_bytes.restype = C.c_size_t
     lib.twog_segrnn_persistent_sync_bytes.restype = C.c_size_t
+    lib.twog_segrnn_bwd_persistent_scratch_bytes.restype = C.c_size_t
     lib.twog_version.restype = C.c_char_p
     lib.twog_version.argtypes = []
     _lib = lib

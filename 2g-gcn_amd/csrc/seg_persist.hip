@@ -562,6 +562,450 @@ __global__ __launch_bounds__(256, 1) void seg_persist_fwd_kernel(const SegArgs P
     }
 }
 
+// =====================================================================================================================
+// Backward through time as ONE persistent launch. Reference: autograd through the segment loop (vhoi/models.py:785-880);
+// same outputs as twog_segrnn_bwd (segrnn.hip): d_gi, d_gh (gradients wrt the two GRUCell projections of every step),
+// d_pre (wrt the pre-ReLU sender-MLP activations), d_u (+= gradient wrt the hard gates).
+//
+// Per (direction, clip chunk) and slice of 16 columns four roles again, two hand-offs per step:
+//   Q2h / Q2o  own 16 hidden units of the rows of one kind. Keep the carried state gradient of their units in registers.
+//        Per step: carry <- direct part + W_hh part + sender-MLP part + attention-score part; gate backward of the own
+//        units -> d_gi, d_gh columns (write-through) -> SIGNAL X1; then, beside the Q1 workgroups' work, the W_hh part of
+//        the NEXT carry: the complete d_gh rows (all slices of the kind: X1) times W_hh[:, own units].
+//   Q1h / Q1o  own 16 columns of both message blocks a kind RECEIVES. Per step (after X1): d_mg = complete d_gi rows
+//        times W_ih[:, message columns]; from it, with the SAVED attention weights (no softmax backward needed for
+//        this), the gradient of the sender messages of its two relations -> ReLU mask -> d_pre columns (write-through;
+//        they are also an output), and the slice's share of the score gradients dL/dw[r][s] = <d_mg[r], msg[s]>
+//        (16 of the h columns) -> SIGNAL X2.
+//   Q2 (after X2 of both Q1 kinds): sender-MLP part = complete d_pre rows times W_s[:, own units]; dL/dw summed over
+//        the slices in slice order, softmax backward, the attention-score part of the carry from the saved states.
+// Everything else as in the forward launch: exact 3 x bf16 products, k-blocks dealt to the four waves and combined in
+// wave order, write-through hand-offs, bounded waits that fail soft. d_u: every Q2 workgroup parks the sum over its 16
+// units per (step, row); a second launch adds the h / 16 partials in slice order (bit-reproducible).
+// =====================================================================================================================
+struct SegBwdArgs {
+    int bs, T, H, O, h;
+    int cpc, n_chunks;
+    int dw_pad;                  // floats of one (direction, step, slice, receiver kind, chunk) block of dL/dw shares
+    float scale;
+    int spin_limit;
+    const float* u[2];
+    const float* w_hh[2][2];     // [kind][dir] [3h][h]
+    const float* w_ihm[2][2];
+    int64_t ld_ih[2];
+    const float* w_sp[2];        // packed sender MLPs on human / object states: [2h][h]
+    const float* hs[2];          // forward states [bs][T][E][2h]
+    const float* save[2];        // [2][bs][T][E][4h]
+    const float* msrc[2];        // [2][bs][T][E][2h]
+    const float* att;            // [2][T][bs][natt]
+    const float* d_hs[2];        // [bs][T][E][2h]
+    float* d_gi[2];              // [bs][T][E][6h]
+    float* d_gh[2];
+    float* d_pre[2];             // [2][bs][T][E][2h]
+    float* dwpart;               // [2][T][ns][2][n_chunks][dw_pad]
+    float* du_part[2];           // [2][T][ns][bs*E]
+    unsigned* cnt;
+    unsigned* error;
+};
+
+// k-major weight fragment: lane l holds W[k0 + 8 (l >> 4) + j][col0 + (l & 15)], j = 0..7 (W row-major, row stride ld)
+__device__ __forceinline__ Planes load_wk(const float* w, int64_t ld, int k0, int col0, int lane) {
+    const float* p = w + (int64_t)(k0 + 8 * (lane >> 4)) * ld + col0 + (lane & 15);
+    f32x4 a, b;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { a[j] = p[(int64_t)j * ld]; b[j] = p[(int64_t)(j + 4) * ld]; }
+    return split8(a, b);
+}
+
+// ---- Q1 of receiver kind RK: one step
+template <int MH, int MO, int RK>
+__device__ __forceinline__ bool q1_step(const SegBwdArgs& P, const Geo& G, int s, float* part, float* res, float* msT,
+                                        float* sW, float* sDW, int* flag) {
+    constexpr int MK = RK == 0 ? MH : MO, NTILES = 2 * MK;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i16 = lane & 15, g4 = lane >> 4;
+    const int H = P.H, O = P.O, h = P.h, T = P.T, E_K = RK == 0 ? H : O, R_K = RK == 0 ? G.RH : G.RO;
+    const int dir = G.dir, t = dir == 0 ? s : T - 1 - s;
+    const int ns = h / 16, nkb = 3 * h / 32;
+    const int group = dir * P.n_chunks + G.chunk;
+    unsigned* cnt = P.cnt + (size_t)group * 4 * CNT_STRIDE;
+    const int tid = threadIdx.x, q = tid & 3, ur = tid >> 2;
+    const int col = G.slice * 16 + 4 * q;
+    const int natt = H * H + 2 * H * O + O * O;
+    // chain-independent inputs first: the saved attention weights of (dir, t) and the sender-message columns of this slice
+    for (int x = tid; x < G.nb * natt; x += 256) {
+        const int bl = x / natt, i = x - bl * natt;
+        sW[x] = P.att[(((int64_t)dir * T + t) * P.bs + G.b0 + bl) * natt + i];
+    }
+    // msT: [RH + RO][RS] sender messages (post-ReLU) of the two relations this kind receives, 16 columns
+    const int sblk = RK == 0 ? 0 : 1;   // block inside msrc_h (hh | ho) and msrc_o (oh | oo)
+    for (int x = ur; x < G.RH + G.RO; x += 64) {
+        const bool hum = x < G.RH;
+        const int r = hum ? x : x - G.RH, Es = hum ? H : O, bl = r / Es, e = r - bl * Es, b = G.b0 + bl;
+        const float* src = P.msrc[hum ? 0 : 1] + ((((int64_t)dir * P.bs + b) * T + t) * Es + e) * (2 * h) + sblk * h + col;
+        *reinterpret_cast<f32x4*>(msT + (size_t)x * RS + 4 * q) = *reinterpret_cast<const f32x4*>(src);
+    }
+    // every column of d_gi of this kind at step s
+    if (!group_wait(cnt + (2 + RK) * CNT_STRIDE, (unsigned)(T - s) * ns, nullptr, 0u, P.error, P.spin_limit, flag)) return false;
+    const __amdgpu_buffer_rsrc_t rs_gi = rsrc_of(P.d_gi[RK]);
+    Acc acc[MK][2];
+#pragma unroll
+    for (int i = 0; i < MK; ++i) { acc_zero(acc[i][0]); acc_zero(acc[i][1]); }
+    uint32_t off[MK];
+#pragma unroll
+    for (int i = 0; i < MK; ++i) {
+        const int r = min(i * 16 + i16, R_K - 1), bl = r / E_K, e = r - bl * E_K, b = G.b0 + bl;
+        off[i] = 4u * (uint32_t)((((int64_t)b * T + t) * E_K + e) * (6 * h) + dir * 3 * h + 8 * g4);
+    }
+    const float* w_ihm = P.w_ihm[RK][dir];
+    const int64_t ldw = P.ld_ih[RK];
+    for (int kb = wave; kb < nkb; kb += 4) {
+        Planes A[MK];
+#pragma unroll
+        for (int i = 0; i < MK; ++i) A[i] = split8(ld_sc1(rs_gi, off[i] + 128u * kb), ld_sc1(rs_gi, off[i] + 128u * kb + 16u));
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) {
+            const Planes B = load_wk(w_ihm, ldw, kb * 32, blk * h + G.slice * 16, lane);
+#pragma unroll
+            for (int i = 0; i < MK; ++i) mac6(acc[i][blk], A[i], B);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < MK; ++i) { put_part(part, NTILES, wave, i * 2, lane, acc[i][0]); put_part(part, NTILES, wave, i * 2 + 1, lane, acc[i][1]); }
+    combine_parts(part, res, NTILES, min(4, nkb));
+    // res tile (i * 2 + blk): d_mg[receiver rows of kind RK][message block blk][16 columns]
+    // ---- gradient of the sender messages (saved weights), ReLU mask, d_pre columns: write-through
+    {
+        const __amdgpu_buffer_rsrc_t rs_ph = rsrc_of(P.d_pre[0]), rs_po = rsrc_of(P.d_pre[1]);
+        for (int x = ur; x < G.RH + G.RO; x += 64) {
+            const bool hum = x < G.RH;
+            const int r = hum ? x : x - G.RH, Es = hum ? H : O, bl = r / Es, sd = r - bl * Es, b = G.b0 + bl;
+            const int blk = hum ? 0 : 1;
+            // weights of the receivers of kind RK towards sender sd: hh / ho (senders humans), oh / oo (senders objects)
+            const float* w = sW + bl * natt + (RK == 0 ? (hum ? att_hh(H, O) : att_oh(H, O)) : (hum ? att_ho(H, O) : att_oo(H, O))) + sd;
+            f32x4 g = {0.f, 0.f, 0.f, 0.f};
+            for (int rc = 0; rc < E_K; ++rc) {
+                const int rr = bl * E_K + rc;
+                const f32x4 d = *reinterpret_cast<const f32x4*>(res + (size_t)((rr / 16) * 2 + blk) * 16 * RS + (rr % 16) * RS + 4 * q);
+                const float wv = w[rc * Es];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) g[k] = fmaf(wv, d[k], g[k]);
+            }
+            const f32x4 m = *reinterpret_cast<const f32x4*>(msT + (size_t)x * RS + 4 * q);
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (!(m[k] > 0.f)) g[k] = 0.f;
+            const uint32_t o = 4u * (uint32_t)(((((int64_t)dir * P.bs + b) * T + t) * Es + sd) * (2 * h) + sblk * h + col);
+            st_sc1(hum ? rs_ph : rs_po, o, g);
+        }
+    }
+    // ---- this slice's share of dL/dw[r][s] = <d_mg[r], msg[s]> (16 of the h columns), both relations; not needed at the
+    // chain start (no previous state, no score gradient)
+    const int nr = RK == 0 ? H * H + H * O : H * O + O * O;
+    if (s > 0) {
+        for (int x = tid; x < P.dw_pad; x += 256) {
+            float v = 0.f;
+            if (x < G.nb * nr) {
+                const int bl = x / nr, i = x - bl * nr;
+                int rc, sd, blk;
+                bool diag;
+                const int nfirst = E_K * H;   // slots of the relation with human senders (hh / ho)
+                if (i < nfirst) { rc = i / H; sd = i - rc * H; blk = 0; diag = RK == 0 && rc == sd; }
+                else { const int j = i - nfirst; rc = j / O; sd = j - rc * O; blk = 1; diag = RK == 1 && rc == sd; }
+                if (!diag) {
+                    const int rr = bl * E_K + rc;
+                    const float* d = res + (size_t)((rr / 16) * 2 + blk) * 16 * RS + (rr % 16) * RS;
+                    const float* m = msT + (size_t)(blk == 0 ? bl * H + sd : G.RH + bl * O + sd) * RS;
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) v = fmaf(d[k], m[k], v);
+                }
+            }
+            sDW[x] = v;
+        }
+        __syncthreads();
+        const __amdgpu_buffer_rsrc_t rs_dw = rsrc_of(P.dwpart);
+        const int64_t blk_off = ((((int64_t)dir * T + t) * ns + G.slice) * 2 + RK) * P.n_chunks + G.chunk;
+        for (int x = tid; x < P.dw_pad / 4; x += 256)
+            st_sc1(rs_dw, 4u * (uint32_t)(blk_off * P.dw_pad + 4 * x), *reinterpret_cast<const f32x4*>(sDW + 4 * x));
+    }
+    group_signal(cnt + RK * CNT_STRIDE);
+    return true;
+}
+
+// ---- Q2 of kind K: one step. carry / c_hh: this thread's (row, 4 units) of the carried gradient and of its W_hh part.
+template <int MK, int K>
+__device__ __forceinline__ bool q2_step(const SegBwdArgs& P, const Geo& G, int s, float* part, float* res, float* sW,
+                                        float* sDW, float* sC, int* flag, f32x4 (&direct)[(MK * 16 + 63) / 64],
+                                        f32x4 (&c_hh)[(MK * 16 + 63) / 64]) {
+    constexpr int NPASS = (MK * 16 + 63) / 64;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i16 = lane & 15, g4 = lane >> 4;
+    const int H = P.H, O = P.O, E = H + O, h = P.h, T = P.T, E_K = K == 0 ? H : O, R_K = K == 0 ? G.RH : G.RO;
+    const int dir = G.dir, t = dir == 0 ? s : T - 1 - s, tp = dir == 0 ? t - 1 : t + 1;
+    const int tn = dir == 0 ? t + 1 : t - 1;   // the time of chain step s + 1 (processed before this one)
+    const int ns = h / 16;
+    const int group = dir * P.n_chunks + G.chunk;
+    unsigned* cnt = P.cnt + (size_t)group * 4 * CNT_STRIDE;
+    const int tid = threadIdx.x, q = tid & 3, ur = tid >> 2;
+    const int col = G.slice * 16 + 4 * q;
+    const int natt = H * H + 2 * H * O + O * O;
+    const bool first = s == 0, last = s == T - 1;
+
+    // chain-independent inputs of the gate backward, requested before any wait
+    f32x4 dout[NPASS], sr[NPASS], sz[NPASS], sn[NPASS], shn[NPASS], h0[NPASS];
+    float uu[NPASS];
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) {
+        const int x = min(ps * 64 + ur, R_K - 1), bl = x / E_K, e = x - bl * E_K, b = G.b0 + bl;
+        const int64_t row = ((int64_t)b * T + t) * E_K + e;
+        dout[ps] = *reinterpret_cast<const f32x4*>(P.d_hs[K] + row * (2 * h) + dir * h + col);
+        const float* sv = P.save[K] + (((int64_t)dir * P.bs + b) * T * E_K + (int64_t)t * E_K + e) * (4 * h) + col;
+        sr[ps] = *reinterpret_cast<const f32x4*>(sv);
+        sz[ps] = *reinterpret_cast<const f32x4*>(sv + h);
+        sn[ps] = *reinterpret_cast<const f32x4*>(sv + 2 * h);
+        shn[ps] = *reinterpret_cast<const f32x4*>(sv + 3 * h);
+        h0[ps] = first ? f32x4{0.f, 0.f, 0.f, 0.f}
+                       : *reinterpret_cast<const f32x4*>(P.hs[K] + (((int64_t)b * T + tp) * E_K + e) * (2 * h) + dir * h + col);
+        uu[ps] = P.u[K][row];
+    }
+    f32x4 carry[NPASS];
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) carry[ps] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (!last) {
+        // saved attention weights of chain step s + 1 (time tn): chain-independent
+        for (int x = tid; x < G.nb * natt; x += 256) {
+            const int bl = x / natt, i = x - bl * natt;
+            sW[x] = P.att[(((int64_t)dir * T + tn) * P.bs + G.b0 + bl) * natt + i];
+        }
+        // d_pre columns and dL/dw shares of step s + 1: all slices of Q1h and Q1o
+        if (!group_wait(cnt + 0 * CNT_STRIDE, (unsigned)(T - 1 - s) * ns, cnt + 1 * CNT_STRIDE, (unsigned)(T - 1 - s) * ns, P.error,
+                        P.spin_limit, flag))
+            return false;
+        // ---- sender-MLP part: complete d_pre rows of this kind (time tn) x packed W_s[:, own units]
+        {
+            const __amdgpu_buffer_rsrc_t rs_p = rsrc_of(P.d_pre[K]);
+            const int nkb = 2 * h / 32;
+            Acc acc[MK];
+            uint32_t off[MK];
+#pragma unroll
+            for (int i = 0; i < MK; ++i) {
+                acc_zero(acc[i]);
+                const int r = min(i * 16 + i16, R_K - 1), bl = r / E_K, e = r - bl * E_K, b = G.b0 + bl;
+                off[i] = 4u * (uint32_t)(((((int64_t)dir * P.bs + b) * T + tn) * E_K + e) * (2 * h) + 8 * g4);
+            }
+            for (int kb = wave; kb < nkb; kb += 4) {
+                const Planes B = load_wk(P.w_sp[K], h, kb * 32, G.slice * 16, lane);
+#pragma unroll
+                for (int i = 0; i < MK; ++i) {
+                    const Planes A = split8(ld_sc1(rs_p, off[i] + 128u * kb), ld_sc1(rs_p, off[i] + 128u * kb + 16u));
+                    mac6(acc[i], A, B);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < MK; ++i) put_part(part, MK, wave, i, lane, acc[i]);
+        }
+        // ---- dL/dw of step s + 1: the slices' shares added in slice order (all four relations)
+        {
+            const __amdgpu_buffer_rsrc_t rs_dw = rsrc_of(P.dwpart);
+            const int nr0 = H * H + H * O;
+            for (int x = tid; x < G.nb * natt; x += 256) {
+                const int bl = x / natt, i = x - bl * natt;
+                const int rk = i < nr0 ? 0 : 1, nr = rk == 0 ? nr0 : natt - nr0, j = rk == 0 ? i : i - nr0;
+                const int64_t base = ((((int64_t)dir * T + tn) * ns) * 2 + rk) * P.n_chunks + G.chunk;
+                const int64_t stride = (int64_t)2 * P.n_chunks;
+                float v = 0.f;
+                for (int sl = 0; sl < ns; ++sl)
+                    v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                             rs_dw, (int)(4u * (uint32_t)((base + sl * stride) * P.dw_pad + bl * nr + j)), 0, SC1));
+                sDW[x] = v;
+            }
+        }
+        combine_parts(part, res, MK, min(4, 2 * h / 32));   // (its barriers also order sW / sDW)
+        // softmax backward per (clip, relation, receiver): dscore = w (dw - sum_s w dw) scale
+        for (int x = tid; x < G.nb * (2 * H + 2 * O); x += 256) {
+            const int bl = x / (2 * H + 2 * O), i = x - bl * (2 * H + 2 * O);
+            int off, S;
+            if (i < H) { off = att_hh(H, O) + i * H; S = H; }
+            else if (i < 2 * H) { off = att_oh(H, O) + (i - H) * O; S = O; }
+            else if (i < 2 * H + O) { off = att_ho(H, O) + (i - 2 * H) * H; S = H; }
+            else { off = att_oo(H, O) + (i - 2 * H - O) * O; S = O; }
+            const float* w = sW + bl * natt + off;
+            float* d = sDW + bl * natt + off;
+            float tt = 0.f;
+            for (int k = 0; k < S; ++k) tt = fmaf(w[k], d[k], tt);
+            for (int k = 0; k < S; ++k) d[k] = w[k] * (d[k] - tt) * P.scale;
+        }
+        __syncthreads();
+        // coefficient of F[b] in dF[a], a of kind K (attn.hip: every score sends its dscore to receiver and sender)
+        for (int x = tid; x < G.nb * E_K * E; x += 256) {
+            const int bl = x / (E_K * E), rem = x - bl * E_K * E, a = rem / E, b = rem - a * E;
+            const float* d = sDW + bl * natt;
+            float v;
+            if (K == 0) {
+                if (b < H) v = d[att_hh(H, O) + a * H + b] + d[att_hh(H, O) + b * H + a];
+                else v = d[att_oh(H, O) + a * O + (b - H)] + d[att_ho(H, O) + (b - H) * H + a];
+            } else {
+                if (b < H) v = d[att_ho(H, O) + a * H + b] + d[att_oh(H, O) + b * O + a];
+                else v = d[att_oo(H, O) + a * O + (b - H)] + d[att_oo(H, O) + (b - H) * O + a];
+            }
+            sC[x] = v;
+        }
+        __syncthreads();
+        // carry = direct + W_hh part + sender-MLP part + score part (features: the forward states at time t, both kinds)
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ++ps) {
+            const int x = ps * 64 + ur;
+            if (x < R_K) {
+                const int bl = x / E_K, a = x - bl * E_K, b = G.b0 + bl;
+                f32x4 df = {0.f, 0.f, 0.f, 0.f};
+                const float* c = sC + (size_t)(bl * E_K + a) * E;
+                for (int eb = 0; eb < E; ++eb) {
+                    const bool hum = eb < H;
+                    const int Es = hum ? H : O, ee = hum ? eb : eb - H;
+                    const f32x4 f = *reinterpret_cast<const f32x4*>(P.hs[hum ? 0 : 1] + (((int64_t)b * T + t) * Es + ee) * (2 * h) + dir * h + col);
+                    const float cv = c[eb];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) df[k] = fmaf(cv, f[k], df[k]);
+                }
+                const f32x4 cs = *reinterpret_cast<const f32x4*>(res + (size_t)(x / 16) * 16 * RS + (x % 16) * RS + 4 * q);
+                carry[ps] = ((direct[ps] + c_hh[ps]) + cs) + df;
+            }
+        }
+    }
+    // ---- gate backward of the own units (gru.hip, gru_step_bwd_kernel: same arithmetic)
+    const __amdgpu_buffer_rsrc_t rs_gi = rsrc_of(P.d_gi[K]), rs_gh = rsrc_of(P.d_gh[K]);
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) {
+        const int x = ps * 64 + ur;
+        float du = 0.f;
+        f32x4 gi_[3], gh_[3], dprev;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float d = dout[ps][k] + carry[ps][k];
+            const float rg = sr[ps][k], z = sz[ps][k], n = sn[ps][k], hn = shn[ps][k], hp = h0[ps][k];
+            const float gnew = (1.0f - z) * n + z * hp;
+            du += d * (gnew - hp);
+            const float dg = uu[ps] * d;
+            float dp = (1.0f - uu[ps]) * d;
+            const float dn = dg * (1.0f - z);
+            const float dz = dg * (hp - n);
+            dp += dg * z;
+            const float dn_pre = dn * (1.0f - n * n);
+            const float dr_pre = dn_pre * hn * rg * (1.0f - rg);
+            const float dz_pre = dz * z * (1.0f - z);
+            gi_[0][k] = dr_pre; gi_[1][k] = dz_pre; gi_[2][k] = dn_pre;
+            gh_[0][k] = dr_pre; gh_[1][k] = dz_pre; gh_[2][k] = dn_pre * rg;
+            dprev[k] = dp;
+        }
+        direct[ps] = dprev;
+        // the sum over this slice's 16 units of a row: the four quads of a row are adjacent lanes
+        du += __shfl_xor(du, 1, 64);
+        du += __shfl_xor(du, 2, 64);
+        if (x < R_K) {
+            const int bl = x / E_K, e = x - bl * E_K, b = G.b0 + bl;
+            const uint32_t o = 4u * (uint32_t)((((int64_t)b * T + t) * E_K + e) * (6 * h) + dir * 3 * h + col);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                st_sc1(rs_gh, o + 4u * (uint32_t)(c * h), gh_[c]);
+                st_sc1(rs_gi, o + 4u * (uint32_t)(c * h), gi_[c]);
+            }
+            if (q == 0)
+                P.du_part[K][(((int64_t)dir * T + t) * ns + G.slice) * ((int64_t)P.bs * E_K) + (int64_t)b * E_K + e] = du;
+        }
+    }
+    group_signal(cnt + (2 + K) * CNT_STRIDE);
+    if (first) return true;
+    // ---- W_hh part of the next carry: complete d_gh rows of this kind at step s (all slices) x W_hh[:, own units]
+    if (!group_wait(cnt + (2 + K) * CNT_STRIDE, (unsigned)(T - s) * ns, nullptr, 0u, P.error, P.spin_limit, flag)) return false;
+    {
+        const int nkb = 3 * h / 32;
+        Acc acc[MK];
+        uint32_t off[MK];
+#pragma unroll
+        for (int i = 0; i < MK; ++i) {
+            acc_zero(acc[i]);
+            const int r = min(i * 16 + i16, R_K - 1), bl = r / E_K, e = r - bl * E_K, b = G.b0 + bl;
+            off[i] = 4u * (uint32_t)((((int64_t)b * T + t) * E_K + e) * (6 * h) + dir * 3 * h + 8 * g4);
+        }
+        const float* w_hh = P.w_hh[K][dir];
+        for (int kb = wave; kb < nkb; kb += 4) {
+            const Planes B = load_wk(w_hh, h, kb * 32, G.slice * 16, lane);
+#pragma unroll
+            for (int i = 0; i < MK; ++i) {
+                const Planes A = split8(ld_sc1(rs_gh, off[i] + 128u * kb), ld_sc1(rs_gh, off[i] + 128u * kb + 16u));
+                mac6(acc[i], A, B);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < MK; ++i) put_part(part, MK, wave, i, lane, acc[i]);
+        combine_parts(part, res, MK, min(4, nkb));
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ++ps) {
+            const int x = min(ps * 64 + ur, MK * 16 - 1);
+            c_hh[ps] = *reinterpret_cast<const f32x4*>(res + (size_t)(x / 16) * 16 * RS + (x % 16) * RS + 4 * q);
+        }
+        __syncthreads();   // res is rewritten by the next step's first combine
+    }
+    return true;
+}
+
+template <int MH, int MO>
+__global__ __launch_bounds__(256, 1) void seg_persist_bwd_kernel(const SegBwdArgs P) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NT_MAX = 2 * (MH > MO ? MH : MO);
+    const int ns = P.h / 16;
+    const int W = (int)gridDim.x;
+    const int L = ((int)blockIdx.x % 8) * (W / 8) + (int)blockIdx.x / 8;
+    const int group = L / (4 * ns), within = L - group * 4 * ns;
+    Geo G;
+    G.dir = group / P.n_chunks; G.chunk = group - G.dir * P.n_chunks;
+    G.slice = within / 4; G.role = within - G.slice * 4;
+    G.b0 = G.chunk * P.cpc; G.nb = min(P.cpc, P.bs - G.b0);
+    G.RH = G.nb * P.H; G.RO = G.nb * P.O;
+    const int E = P.H + P.O, natt = P.H * P.H + 2 * P.H * P.O + P.O * P.O;
+    float* part = reinterpret_cast<float*>(smem);                       // [4][NT_MAX][64][4]
+    float* res = part + 4 * NT_MAX * 256;                               // [NT_MAX][16][RS]
+    float* msT = res + NT_MAX * 16 * RS;                                // [16 (MH + MO)][RS]
+    float* sW = msT + 16 * (MH + MO) * RS;                              // [cpc][natt]
+    float* sDW = sW + P.cpc * natt;                                     // [max(cpc natt, dw_pad)]
+    float* sC = sDW + (P.cpc * natt > P.dw_pad ? P.cpc * natt : P.dw_pad);   // [cpc][E_K][E]
+    int* flag = reinterpret_cast<int*>(sC + P.cpc * (P.H > P.O ? P.H : P.O) * E);
+    if (G.role == 0) {
+        for (int s = P.T - 1; s >= 0; --s)
+            if (!q1_step<MH, MO, 0>(P, G, s, part, res, msT, sW, sDW, flag)) return;
+    } else if (G.role == 1) {
+        for (int s = P.T - 1; s >= 0; --s)
+            if (!q1_step<MH, MO, 1>(P, G, s, part, res, msT, sW, sDW, flag)) return;
+    } else if (G.role == 2) {
+        constexpr int NP = (MH * 16 + 63) / 64;
+        f32x4 direct[NP], c_hh[NP];
+#pragma unroll
+        for (int i = 0; i < NP; ++i) { direct[i] = f32x4{0.f, 0.f, 0.f, 0.f}; c_hh[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        for (int s = P.T - 1; s >= 0; --s)
+            if (!q2_step<MH, 0>(P, G, s, part, res, sW, sDW, sC, flag, direct, c_hh)) return;
+    } else {
+        constexpr int NP = (MO * 16 + 63) / 64;
+        f32x4 direct[NP], c_hh[NP];
+#pragma unroll
+        for (int i = 0; i < NP; ++i) { direct[i] = f32x4{0.f, 0.f, 0.f, 0.f}; c_hh[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        for (int s = P.T - 1; s >= 0; --s)
+            if (!q2_step<MO, 1>(P, G, s, part, res, sW, sDW, sC, flag, direct, c_hh)) return;
+    }
+}
+
+// d_u[b][t][e] += the slices' parked sums, both directions, in fixed order: one thread per (clip, time, entity)
+__global__ __launch_bounds__(256) void seg_du_reduce_kernel(const float* part, float* du, int bs, int T, int E, int ns,
+                                                            const unsigned* error) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= bs * T * E || *error != 0u) return;   // a launch that gave up parked nothing complete: d_u stays as it was
+    const int e = i % E, t = (i / E) % T, b = i / (E * T);
+    const int64_t rows = (int64_t)bs * E, row = (int64_t)b * E + e;
+    float acc = 0.f;
+    for (int dir = 0; dir < 2; ++dir) {
+        const float* p = part + (((int64_t)dir * T + t) * ns) * rows + row;
+        for (int k = 0; k < ns; ++k) acc += p[(int64_t)k * rows];
+    }
+    du[i] += acc;
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------------------
@@ -675,6 +1119,102 @@ extern "C" int twog_segrnn_fwd_persistent(const twog_segrnn_t* desc, void* sync,
     if (pl.mo == 1) TWOG_SP_LAUNCH(1, 1);
     else TWOG_SP_LAUNCH(1, 2);
 #undef TWOG_SP_LAUNCH
+    TWOG_CHECK_LAUNCH();
+    return 0;
+}
+
+namespace {
+int bwd_dw_pad(const twog_segrnn_t& S, int cpc) {
+    const int nr0 = S.H * S.H + S.H * S.O, nr1 = S.H * S.O + S.O * S.O;
+    const int n = cpc * (nr0 > nr1 ? nr0 : nr1);
+    return (n + 3) / 4 * 4;
+}
+size_t bwd_lds(const twog_segrnn_t& S, const SegPlan& pl) {
+    const int mk = pl.mh > pl.mo ? pl.mh : pl.mo, NT = 2 * mk, E = S.H + S.O, natt = S.H * S.H + 2 * S.H * S.O + S.O * S.O;
+    const int dw_pad = bwd_dw_pad(S, pl.cpc);
+    size_t lds = (size_t)4 * NT * 256 * 4 + (size_t)NT * 16 * RS * 4 + (size_t)16 * (pl.mh + pl.mo) * RS * 4 +
+                 (size_t)pl.cpc * natt * 4 + (size_t)(pl.cpc * natt > dw_pad ? pl.cpc * natt : dw_pad) * 4 +
+                 (size_t)pl.cpc * (S.H > S.O ? S.H : S.O) * E * 4 + 64;
+    if (lds < 84 * 1024) lds = 84 * 1024;
+    return lds;
+}
+}  // namespace
+
+// bytes of the caller-owned scratch of twog_segrnn_bwd_persistent (the slices' dL/dw shares and d_u partial sums); 0 if the
+// shape is not served
+extern "C" size_t twog_segrnn_bwd_persistent_scratch_bytes(const twog_segrnn_t* desc) {
+    int n_cus = 0;
+    if (!desc || device_cus(n_cus) != 0) return 0;
+    SegPlan pl;
+    if (!make_plan(*desc, n_cus, pl)) return 0;
+    const twog_segrnn_t& S = *desc;
+    const int ns = S.hidden / 16;
+    const size_t dw = (size_t)2 * S.T * ns * 2 * pl.n_chunks * bwd_dw_pad(S, pl.cpc);
+    const size_t du = (size_t)2 * S.T * ns * ((size_t)S.bs * S.H + (size_t)S.bs * S.O);
+    return (dw + du) * 4 + 256;
+}
+
+// Same outputs as twog_segrnn_bwd (d_gi_*, d_gh_*, d_pre_*, d_u_* +=; carry_*, tmp_dmg_*, trash, du_part_* unused).
+// scratch: twog_segrnn_bwd_persistent_scratch_bytes(desc) of device memory (contents undefined); sync as for the forward.
+extern "C" int twog_segrnn_bwd_persistent(const twog_segrnn_t* desc, const twog_segrnn_bwd_t* bdesc, void* scratch,
+                                          size_t scratch_bytes, void* sync, void* stream) {
+    if (!desc || !bdesc || !sync || !scratch) return -2;
+    const twog_segrnn_t& S = *desc;
+    const twog_segrnn_bwd_t& B = *bdesc;
+    int n_cus = 0;
+    int rc = device_cus(n_cus);
+    if (rc) return rc;
+    SegPlan pl;
+    if (!make_plan(S, n_cus, pl)) return -2;
+    if (scratch_bytes < twog_segrnn_bwd_persistent_scratch_bytes(desc)) return -2;
+    if (!B.d_hs_h || !B.d_hs_o || !B.d_gi_h || !B.d_gi_o || !B.d_gh_h || !B.d_gh_o || !B.d_pre_h || !B.d_pre_o || !B.d_u_h || !B.d_u_o)
+        return -2;
+    const int ns = S.hidden / 16;
+    SegBwdArgs P;
+    P.bs = S.bs; P.T = S.T; P.H = S.H; P.O = S.O; P.h = S.hidden;
+    P.cpc = pl.cpc; P.n_chunks = pl.n_chunks; P.dw_pad = bwd_dw_pad(S, pl.cpc);
+    P.scale = S.att_scale;
+    P.spin_limit = twog_persist_spin_limit();
+    P.u[0] = S.u_h; P.u[1] = S.u_o;
+    for (int d = 0; d < 2; ++d) {
+        P.w_hh[0][d] = S.w_hh_h[d]; P.w_hh[1][d] = S.w_hh_o[d];
+        P.w_ihm[0][d] = S.w_ihm_h[d]; P.w_ihm[1][d] = S.w_ihm_o[d];
+    }
+    P.ld_ih[0] = S.ld_ih_h; P.ld_ih[1] = S.ld_ih_o;
+    P.w_sp[0] = S.w_smsg_h; P.w_sp[1] = S.w_smsg_o;
+    P.hs[0] = S.hs_h; P.hs[1] = S.hs_o; P.save[0] = S.save_h; P.save[1] = S.save_o;
+    P.msrc[0] = S.msrc_h; P.msrc[1] = S.msrc_o; P.att = S.att;
+    P.d_hs[0] = B.d_hs_h; P.d_hs[1] = B.d_hs_o;
+    P.d_gi[0] = B.d_gi_h; P.d_gi[1] = B.d_gi_o; P.d_gh[0] = B.d_gh_h; P.d_gh[1] = B.d_gh_o;
+    P.d_pre[0] = B.d_pre_h; P.d_pre[1] = B.d_pre_o;
+    float* sc = static_cast<float*>(scratch);
+    P.dwpart = sc;
+    const size_t dw = (size_t)2 * S.T * ns * 2 * pl.n_chunks * P.dw_pad;
+    P.du_part[0] = sc + dw;
+    P.du_part[1] = P.du_part[0] + (size_t)2 * S.T * ns * S.bs * S.H;
+    P.cnt = static_cast<unsigned*>(sync);
+    P.error = P.cnt + ERR_WORD;
+    if ((size_t)2 * pl.n_chunks * 4 * CNT_STRIDE > (size_t)ERR_WORD) return -2;
+    const size_t lds = bwd_lds(S, pl);
+    if (lds > 160 * 1024) return -2;
+    hipStream_t st = (hipStream_t)stream;
+#define TWOG_SPB_LAUNCH(MH_, MO_)                                                                             \
+    do {                                                                                                      \
+        static std::atomic<uint32_t> done{0};                                                                 \
+        twog_allow_dynamic_lds(seg_persist_bwd_kernel<MH_, MO_>, 160 * 1024, done);                           \
+        if (!twog_persist_grid_fits(seg_persist_bwd_kernel<MH_, MO_>, pl.grid, lds, n_cus))                  \
+            return TWOG_PERSIST_NOT_RESIDENT;                                                                 \
+        hipLaunchKernelGGL((seg_persist_bwd_kernel<MH_, MO_>), dim3(pl.grid), dim3(256), lds, st, P);         \
+    } while (0)
+    if (pl.mo == 1) TWOG_SPB_LAUNCH(1, 1);
+    else TWOG_SPB_LAUNCH(1, 2);
+#undef TWOG_SPB_LAUNCH
+    TWOG_CHECK_LAUNCH();
+    // the parked d_u sums (skipped after a launch that gave up: the caller re-runs the pass, which adds into d_u itself)
+    hipLaunchKernelGGL(seg_du_reduce_kernel, dim3((S.bs * S.T * S.H + 255) / 256), dim3(256), 0, st, P.du_part[0], B.d_u_h, S.bs,
+                       S.T, S.H, ns, P.error);
+    hipLaunchKernelGGL(seg_du_reduce_kernel, dim3((S.bs * S.T * S.O + 255) / 256), dim3(256), 0, st, P.du_part[1], B.d_u_o, S.bs,
+                       S.T, S.O, ns, P.error);
     TWOG_CHECK_LAUNCH();
     return 0;
 }

@@ -670,6 +670,19 @@ class HipKernels:
         b.d_hs_h, b.d_hs_o = _ptr(d_hs_h), _ptr(d_hs_o)
         for k, v in list(out.items()) + list(scratch.items()):
             setattr(b, k, _ptr(v))
+        mode = os.environ.get('TWOG_SEG_PERSIST', 'auto')
+        self.last_segrnn_bwd_persistent = (mode != '0' and self.persistent_allowed(dev) and
+                                           int(self.lib.twog_segrnn_persistent_supported(C.byref(s))) >= 2)
+        if self.last_segrnn_bwd_persistent:   # small batches: backward through time in one launch (csrc/seg_persist.hip)
+            n_scr = int(self.lib.twog_segrnn_bwd_persistent_scratch_bytes(C.byref(s)))
+            scr = self.workspace(n_scr, dev, 'segp_bwd')
+            n_sync = int(self.lib.twog_segrnn_persistent_sync_bytes()) // 4
+            sync = self.zeros(n_sync, device=dev)
+            rc = self.lib.twog_segrnn_bwd_persistent(C.byref(s), C.byref(b), scr.data_ptr(), scr.numel() * 4, sync.data_ptr(),
+                                                     self._stream())
+            if self._persistent_ok(rc, sync, dev, 'twog_segrnn_bwd_persistent', err_index=n_sync - 32):
+                return out
+            self.last_segrnn_bwd_persistent = False
         self._check(self.lib.twog_segrnn_bwd(C.byref(s), C.byref(b), *self.chain_workspace(dev), self._stream()), 'twog_segrnn_bwd')
         return out
 

@@ -344,6 +344,16 @@ typedef struct {
 } twog_segrnn_bwd_t;
 int twog_segrnn_bwd(const twog_segrnn_t* desc, const twog_segrnn_bwd_t* bdesc, void* chain_ws, size_t chain_ws_bytes,
                     void* stream);
+/* Backward through time as ONE persistent launch (csrc/seg_persist.hip; the shapes twog_segrnn_persistent_supported
+ * serves): per slice of 16 columns Q2h / Q2o keep the carried state gradient of their units in registers, run the gate
+ * backward and publish d_gi / d_gh columns; Q1h / Q1o turn the complete d_gi rows into the gradients of the aggregated
+ * messages, and those -- with the SAVED attention weights -- into d_pre columns and their slice's share of the score
+ * gradients; two in-launch hand-offs per step. Same outputs as twog_segrnn_bwd (carry_*, tmp_dmg_*, trash, du_part_* unused).
+ * scratch: twog_segrnn_bwd_persistent_scratch_bytes(desc) bytes of device memory, contents undefined. sync, residency and
+ * soft failure as for twog_segrnn_fwd_persistent (after a launch that gave up d_u_* are untouched). */
+size_t twog_segrnn_bwd_persistent_scratch_bytes(const twog_segrnn_t* desc);
+int twog_segrnn_bwd_persistent(const twog_segrnn_t* desc, const twog_segrnn_bwd_t* bdesc, void* scratch, size_t scratch_bytes,
+                               void* sync, void* stream);
 /* hipGraph cache of the time loops (twog_bigru_*, twog_segrnn_*): number of captured loops and of hash-bucket hits whose
  * descriptor bytes differed (each was resolved by the byte compare; see csrc/graph_cache.h). Diagnostics / tests. */
 int twog_graph_cache_stats(int64_t* entries, int64_t* collisions);

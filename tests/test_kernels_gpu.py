@@ -494,6 +494,7 @@ def _persist_rig(K):
             w_hh_r=rnd(3 * h, h, seed=30 + i, scale=0.2), b_hh_r=rnd(3 * h, seed=40 + i)).items()})
     seg = _seg_params(DEV, bs, T, 2, 4, h, (True, True, True, True), True)
     seg_keys = ['hs_h', 'hs_o', 'save_h', 'save_o', 'msrc_h', 'msrc_o', 'mg_h', 'mg_o', 'att']
+    dseg = (rnd(bs, T, 2, 2 * h, seed=61).to(DEV), rnd(bs, T, 4, 2 * h, seed=62).to(DEV))
 
     def run():
         fw = K.bigru_fwd(types, bs, T, h)
@@ -504,8 +505,11 @@ def _persist_rig(K):
         pb = K.last_bigru_bwd_persistent
         sb = K.segrnn_fwd(seg)
         ps = K.last_segrnn_persistent
+        so = K.segrnn_bwd(seg, sb, dseg[0], dseg[1])
+        psb = K.last_segrnn_bwd_persistent
         torch.cuda.synchronize()
-        return [t for pair in fw for t in pair] + [t for pair in bw for t in pair] + [sb[k] for k in seg_keys], (pf, pb, ps)
+        return ([t for pair in fw for t in pair] + [t for pair in bw for t in pair] + [sb[k] for k in seg_keys] +
+                [so[k] for k in sorted(so)]), (pf, pb, ps, psb)
 
     return run
 
@@ -525,22 +529,22 @@ def test_persistent_launches_fail_soft_and_the_pass_is_rerun_per_step(K, monkeyp
     monkeypatch.setenv('TWOG_BIGRU_PERSIST', '0')
     monkeypatch.setenv('TWOG_SEG_PERSIST', '0')
     want, ran = run()
-    assert ran == (False, False, False)
+    assert ran == (False, False, False, False)
     monkeypatch.delenv('TWOG_BIGRU_PERSIST')
     monkeypatch.delenv('TWOG_SEG_PERSIST')
     good, ran = run()
-    assert ran == (True, True, True), 'the persistent launches did not run on an idle device'
+    assert ran == (True, True, True, True), 'the persistent launches did not run on an idle device'
     dev_i = torch.cuda.current_device()
     monkeypatch.setenv('TWOG_PERSIST_SPIN_LIMIT', '0')
     n0 = HipKernels.persistent_fallbacks
     got, ran = run()   # the forward BiGRU launch is tried first, gives up, the device backs off: the other two are not tried
-    assert ran == (False, False, False)
+    assert ran == (False, False, False, False)
     assert HipKernels.persistent_fallbacks == n0 + 1, 'exactly one launch was tried, gave up and was re-run'
     assert 0 < HipKernels._backoff.get(dev_i, 0) <= HipKernels.PERSISTENT_BACKOFF
     for a, b in zip(got, want):
         assert torch.isfinite(a).all() and torch.equal(a, b), 'a re-run pass differs from the launch-per-step path'
     # the backward BiGRU launch and the segment launch as the FIRST persistent launch of a call
-    for env in ('bwd', 'seg'):
+    for env in ('bwd', 'seg', 'segb'):
         HipKernels._backoff.clear()
         n0 = HipKernels.persistent_fallbacks
         real_allowed = HipKernels.persistent_allowed
@@ -550,20 +554,20 @@ def test_persistent_launches_fail_soft_and_the_pass_is_rerun_per_step(K, monkeyp
             calls.append(1)
             import inspect
             caller = inspect.stack()[1].function
-            want_caller = {'bwd': 'bigru_bwd', 'seg': 'segrnn_fwd'}[env]
+            want_caller = {'bwd': 'bigru_bwd', 'seg': 'segrnn_fwd', 'segb': 'segrnn_bwd'}[env]
             return caller == want_caller and real_allowed(self, dev)
 
         monkeypatch.setattr(HipKernels, 'persistent_allowed', allowed)
         got, ran = run()
         monkeypatch.setattr(HipKernels, 'persistent_allowed', real_allowed)
-        assert ran == (False, False, False) and HipKernels.persistent_fallbacks == n0 + 1, (env, ran)
+        assert ran == (False, False, False, False) and HipKernels.persistent_fallbacks == n0 + 1, (env, ran)
         for a, b in zip(got, want):
             assert torch.equal(a, b), env
     # limit restored: persistent again, same results as before
     monkeypatch.delenv('TWOG_PERSIST_SPIN_LIMIT')
     HipKernels._backoff.clear()
     again, ran = run()
-    assert ran == (True, True, True)
+    assert ran == (True, True, True, True)
     for a, b in zip(again, good):
         assert torch.equal(a, b)
 
@@ -583,18 +587,18 @@ def test_persistent_launch_failure_found_at_the_end_of_the_pass_raises_and_the_n
     monkeypatch.delenv('TWOG_BIGRU_PERSIST')
     monkeypatch.delenv('TWOG_SEG_PERSIST')
     good, ran = run()
-    assert ran == (True, True, True)
+    assert ran == (True, True, True, True)
     K.verify_persistent()            # clean launches: nothing to report
     monkeypatch.setenv('TWOG_PERSIST_SPIN_LIMIT', '0')
     n0 = HipKernels.persistent_late_failures
     _, ran = run()
-    assert ran == (True, True, True)   # nobody has looked yet
+    assert ran == (True, True, True, True)   # nobody has looked yet
     with pytest.raises(RuntimeError, match='could not keep its grid resident'):
         K.verify_persistent()
     assert HipKernels.persistent_late_failures == n0 + 1
     K.verify_persistent()            # reported once
     got, ran = run()                 # backing off: per step, correct
-    assert ran == (False, False, False)
+    assert ran == (False, False, False, False)
     for a, b in zip(got, want):
         assert torch.equal(a, b)
     HipKernels._backoff.clear()
@@ -825,12 +829,33 @@ def test_segment_recurrence_persistent_launch_matches_the_stepwise_recurrence(K,
         close(b1[k], bc[k], rtol=2e-4, atol=2e-5, what='persistent segrnn fwd vs spec: ' + k)
         close(b1[k], bs_[k], rtol=5e-5, atol=5e-6, what='persistent vs stepwise: ' + k)
         assert torch.equal(b1[k], b2[k]), 'two runs of the persistent launch differ: ' + k
-    # the backward pass (launch per step) on the persistent forward's saved buffers equals the one on the stepwise forward's
-    dh_h, dh_o = rnd(bs, T, H, 2 * h, seed=31).to(DEV), rnd(bs, T, O, 2 * h, seed=32).to(DEV)
-    o1 = K.segrnn_bwd(pg, b1, dh_h, dh_o)
-    o0 = K.segrnn_bwd(pg, bs_, dh_h, dh_o)
-    for k in o0:
-        close(o1[k], o0[k], rtol=3e-4, atol=3e-5, what='segrnn bwd on persistent forward buffers: ' + k)
+    # backward through time: the persistent launch against the specification (on the specification's forward buffers, so
+    # that the comparison isolates the backward kernel), against the launch-per-step path, and against itself
+    dh_hc, dh_oc = rnd(bs, T, H, 2 * h, seed=31), rnd(bs, T, O, 2 * h, seed=32)
+    dh_h, dh_o = dh_hc.to(DEV), dh_oc.to(DEV)
+    oc = F.segrnn_bwd(pc, bc, dh_hc, dh_oc)
+    bg2 = {k: v.to(DEV) for k, v in bc.items()}
+    for k in b1:
+        if k not in bg2:
+            bg2[k] = b1[k]
+    monkeypatch.setenv('TWOG_SEG_PERSIST', '0')
+    o0 = K.segrnn_bwd(pg, bg2, dh_h, dh_o)
+    assert not K.last_segrnn_bwd_persistent
+    monkeypatch.delenv('TWOG_SEG_PERSIST')
+    o1 = K.segrnn_bwd(pg, bg2, dh_h, dh_o)
+    assert K.last_segrnn_bwd_persistent, 'the persistent backward launch did not run'
+    o2 = K.segrnn_bwd(pg, bg2, dh_h, dh_o)
+    torch.cuda.synchronize()
+    for k in oc:
+        assert torch.isfinite(o1[k]).all(), k
+        close(o1[k], oc[k], rtol=3e-4, atol=3e-5, what='persistent segrnn bwd vs spec: ' + k)
+        close(o1[k], o0[k], rtol=1e-4, atol=1e-5, what='persistent vs stepwise bwd: ' + k)
+        assert torch.equal(o1[k], o2[k]), 'two runs of the persistent backward launch differ: ' + k
+    # and the stepwise backward on the persistent forward's own buffers equals the one on the stepwise forward's
+    monkeypatch.setenv('TWOG_SEG_PERSIST', '0')
+    oa, ob = K.segrnn_bwd(pg, b1, dh_h, dh_o), K.segrnn_bwd(pg, bs_, dh_h, dh_o)
+    for k in oa:
+        close(oa[k], ob[k], rtol=3e-4, atol=3e-5, what='segrnn bwd on persistent forward buffers: ' + k)
 
 
 def test_segment_recurrence_persistent_hand_offs_hold_under_uneven_load(K, monkeypatch):
@@ -840,10 +865,14 @@ def test_segment_recurrence_persistent_hand_offs_hold_under_uneven_load(K, monke
     pg = _seg_params(DEV, 8, 120, 2, 4, 512, (True, True, True, True), True)
     keys = ['hs_h', 'hs_o', 'save_h', 'save_o', 'msrc_h', 'msrc_o', 'mg_h', 'mg_o', 'att']
 
+    dh_h, dh_o = rnd(8, 120, 2, 1024, seed=31).to(DEV), rnd(8, 120, 4, 1024, seed=32).to(DEV)
+
     def run():
         b = K.segrnn_fwd(pg)
         assert K.last_segrnn_persistent
-        return [b[k] for k in keys]
+        o = K.segrnn_bwd(pg, b, dh_h, dh_o)
+        assert K.last_segrnn_bwd_persistent
+        return [b[k] for k in keys] + [o[k] for k in sorted(o)]
 
     solo = [t.clone() for t in run()]
     torch.cuda.synchronize()
@@ -856,7 +885,7 @@ def test_segment_recurrence_persistent_hand_offs_hold_under_uneven_load(K, monke
                 torch.mm(m, m)
         got = run()
         torch.cuda.synchronize()
-        for k, a, b in zip(keys, got, solo):
+        for k, a, b in zip(keys + ['bwd'] * 16, got, solo):
             assert torch.equal(a, b), f'repetition {rep}: {k} of the persistent launch under load differs from the solo run'
 
 
