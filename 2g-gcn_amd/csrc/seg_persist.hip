@@ -104,6 +104,16 @@ __device__ __forceinline__ void mac6(Acc& c, const Planes& a, const Planes& b) {
     c.lo = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.l, b.h, c.lo, 0, 0, 0);
 }
 
+// the same six products into ONE accumulator
+__device__ __forceinline__ void mac6_one(f32x4& c, const Planes& a, const Planes& b) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.h, b.h, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.h, b.m, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.m, b.h, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.m, b.m, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.h, b.l, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.l, b.h, c, 0, 0, 0);
+}
+
 __device__ __forceinline__ f32x4 ld_sc1(const __amdgpu_buffer_rsrc_t rs, uint32_t byte_off) {
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)byte_off, 0, SC1));
 }
@@ -120,9 +130,88 @@ __device__ __forceinline__ Planes load_w(const float* w, int64_t ld, int row0, i
     return split8(*reinterpret_cast<const f32x4*>(p), *reinterpret_cast<const f32x4*>(p + 4));
 }
 
+// raw (fp32) weight fragments, kept in registers for the whole sequence: lane l holds W[row0 + (l & 15)][k0 + 8 (l >> 4) + j]
+// (row-major operand) or W[k0 + 8 (l >> 4) + j][col0 + (l & 15)] (k-major operand), j = 0..7
+struct WFrag { f32x4 a, b; };
+__device__ __forceinline__ WFrag load_w_raw(const float* w, int64_t ld, int row0, int k0, int lane) {
+    const float* p = w + (int64_t)(row0 + (lane & 15)) * ld + k0 + 8 * (lane >> 4);
+    WFrag f;
+    f.a = *reinterpret_cast<const f32x4*>(p);
+    f.b = *reinterpret_cast<const f32x4*>(p + 4);
+    return f;
+}
+__device__ __forceinline__ WFrag load_wk_raw(const float* w, int64_t ld, int k0, int col0, int lane) {
+    const float* p = w + (int64_t)(k0 + 8 * (lane >> 4)) * ld + col0 + (lane & 15);
+    WFrag f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { f.a[j] = p[(int64_t)j * ld]; f.b[j] = p[(int64_t)(j + 4) * ld]; }
+    return f;
+}
+__device__ __forceinline__ WFrag wfrag_zero() { WFrag f; f.a = f32x4{0.f, 0.f, 0.f, 0.f}; f.b = f.a; return f; }
+
+// c += A B on the fp32 matrix pipe (v_mfma_f32_16x16x4_f32, exact fp32 products, fp32 accumulate): the 32 k values of a
+// fragment pair are consumed 4 at a time, lane group g4 supplying k = 8 g4 + j in step j for BOTH operands (any pairing of
+// k values to (step, lane group) slots is a valid dot product as long as A and B agree). No operand split: where a weight
+// fragment meets only one or two row tiles (P2, Q1, Q2) the 3 x bf16 form spends more vector cycles splitting the fragment
+// than the matrix pipe saves, and it needs 36 more registers per lane for the planes.
+__device__ __forceinline__ void mac_f32(f32x4& c, const f32x4 a0, const f32x4 a1, const WFrag& w) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[j], w.a[j], c, 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[j], w.b[j], c, 0, 0, 0);
+}
+
+// The reduction loop of one product, this wave's k-blocks (kb = wave, wave + 4, ...; at most NJ of them): the A fragments of
+// MK row tiles come from a handed-off buffer (sc1 loads, byte offsets off[i] + 128 kb), four k-blocks in flight beside the
+// four being multiplied (a round trip to the other XCDs' L2 is ~2 us: with two in flight the loop waited for every pair); body(j, A) multiplies k-block number j of this wave with the weights the caller keeps in registers.
+template <int NJ, int MK, class F>
+__device__ __forceinline__ void k_stream(const __amdgpu_buffer_rsrc_t rs, const uint32_t (&off)[MK], int nkb, int wave, F&& body) {
+    constexpr int CH = NJ < 4 ? NJ : 4, NG = (NJ + CH - 1) / CH;
+    typedef f32x4 Buf[CH][MK][2];
+    Buf b0, b1;   // two named buffers (no run-time buffer index: that would put the fragments into scratch memory)
+    auto load = [&](int g, Buf& buf) {
+#pragma unroll
+        for (int jj = 0; jj < CH; ++jj) {
+            const int j = g * CH + jj, kb = wave + 4 * j;
+            if (j < NJ && kb < nkb) {
+#pragma unroll
+                for (int i = 0; i < MK; ++i) {
+                    buf[jj][i][0] = ld_sc1(rs, off[i] + 128u * kb);
+                    buf[jj][i][1] = ld_sc1(rs, off[i] + 128u * kb + 16u);
+                }
+            }
+        }
+    };
+    auto use = [&](int g, const Buf& buf) {
+#pragma unroll
+        for (int jj = 0; jj < CH; ++jj) {
+            const int j = g * CH + jj, kb = wave + 4 * j;
+            if (j < NJ && kb < nkb) body(j, buf[jj]);
+        }
+    };
+    load(0, b0);
+#pragma unroll
+    for (int g = 0; g < NG; g += 2) {
+        if (g + 1 < NG) load(g + 1, b1);
+        use(g, b0);
+        if (g + 1 < NG) {
+            if (g + 2 < NG) load(g + 2, b0);
+            use(g + 1, b1);
+        }
+    }
+}
+
+constexpr int KW1 = 4;    // k-blocks per wave at most: a reduction over h (h = 512: 16 k-blocks, 4 waves)
+constexpr int KW2 = 8;    // over 2h
+constexpr int KW3 = 12;   // over 3h
+
 // one wave's partial tile -> part[wave][tile][lane][4]
 __device__ __forceinline__ void put_part(float* part, int n_tiles, int wave, int tile, int lane, const Acc& c) {
     *reinterpret_cast<f32x4*>(part + ((size_t)(wave * n_tiles + tile) * 64 + lane) * 4) = c.hi + c.lo;
+}
+
+__device__ __forceinline__ void put_part1(float* part, int n_tiles, int wave, int tile, int lane, const f32x4 c) {
+    *reinterpret_cast<f32x4*>(part + ((size_t)(wave * n_tiles + tile) * 64 + lane) * 4) = c;
 }
 
 // sums the waves' partial tiles in wave order into res[tile][16][RS]; all 256 threads; ends with a barrier
@@ -159,6 +248,24 @@ __device__ __forceinline__ void group_signal(unsigned* counter) {
     __syncthreads();
     if (threadIdx.x == 0) __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+
+// Diagnostic build only (-DTWOG_SP_STAMPS, tools/seg_persist_stamps.sh): thread 0 of the workgroup (direction 0, chunk 0,
+// slice 0) of every role sums the wall-clock ticks (10 ns) between the phase boundaries of its steps and leaves the sums in
+// the sync buffer at word 2048 + 16 role + k. The shipped library carries none of this.
+#ifdef TWOG_SP_STAMPS
+#define SP_STAMP(k)                                                                                         \
+    do {                                                                                                    \
+        if (threadIdx.x == 0 && G.dir == 0 && G.chunk == 0 && G.slice == 0) {                               \
+            const long long now_ = wall_clock64();                                                          \
+            atomicAdd(P.cnt + 2048 + 16 * G.role + (k), (unsigned)(now_ - stamp_));                         \
+            stamp_ = now_;                                                                                  \
+        }                                                                                                   \
+    } while (0)
+#define SP_STAMP_BEGIN() long long stamp_ = wall_clock64()
+#else
+#define SP_STAMP(k) do {} while (0)
+#define SP_STAMP_BEGIN() do {} while (0)
+#endif
 
 struct Geo {   // what a workgroup knows about its place
     int dir, chunk, slice, role, b0, nb, RH, RO;
@@ -200,7 +307,7 @@ __device__ __forceinline__ void softmax_row(const float* score, int sstride, flo
 // ---------------------------------------------------------------------------------------------------------------------
 template <int MH, int MO, int RK>
 __device__ __forceinline__ bool p1_step(const SegArgs& P, const Geo& G, int s, float* part, float* res, float* sG, float* sW,
-                                        const float* sMask, int* flag) {
+                                        const float* sMask, const float* sBias, int* flag, const WFrag (&Wr)[KW1][5]) {
     constexpr int MK = RK == 0 ? MH : MO, MT = MH + MO;
     constexpr int NPAIR = MT * (MT + 1) / 2;
     constexpr int T_SH = 0, T_SO = MH, T_G = MH + MO, T_GRAM = T_G + 3 * MK, NTILES = T_GRAM + NPAIR;
@@ -211,14 +318,10 @@ __device__ __forceinline__ bool p1_step(const SegArgs& P, const Geo& G, int s, f
     const int group = dir * P.n_chunks + G.chunk;
     unsigned* cnt = P.cnt + (size_t)group * 4 * CNT_STRIDE;
     const int ns = h / 16;
-    const float* ws_h = P.w_s[RK == 0 ? 0 : 1];   // on human states: hh (humans receive) / ho (objects receive)
-    const float* ws_o = P.w_s[RK == 0 ? 2 : 3];   // on object states: oh / oo
-    const float* bs_h = P.b_s[RK == 0 ? 0 : 1];
-    const float* bs_o = P.b_s[RK == 0 ? 2 : 3];
-    const float* w_hh = P.w_hh[RK][dir];
-    const float* b_hh = P.b_hh[RK][dir];
 
-    Acc a_sh[MH], a_so[MO], a_g[MK][3], a_gram[NPAIR];
+    SP_STAMP_BEGIN();
+    Acc a_sh[MH], a_so[MO], a_g[MK][3];
+    f32x4 a_gram[NPAIR];
 #pragma unroll
     for (int i = 0; i < MH; ++i) acc_zero(a_sh[i]);
 #pragma unroll
@@ -228,12 +331,13 @@ __device__ __forceinline__ bool p1_step(const SegArgs& P, const Geo& G, int s, f
 #pragma unroll
         for (int c = 0; c < 3; ++c) acc_zero(a_g[i][c]);
 #pragma unroll
-    for (int p = 0; p < NPAIR; ++p) acc_zero(a_gram[p]);
+    for (int p = 0; p < NPAIR; ++p) a_gram[p] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     if (s > 0) {
         // every column of h_{t-1}: all slices of P2h and P2o have published step s - 1
         if (!group_wait(cnt + 2 * CNT_STRIDE, (unsigned)s * ns, cnt + 3 * CNT_STRIDE, (unsigned)s * ns, P.error, P.spin_limit, flag))
             return false;
+        SP_STAMP(0);   // waited for h_{t-1}
         const __amdgpu_buffer_rsrc_t rs_h = rsrc_of(P.hs[0]), rs_o = rsrc_of(P.hs[1]);
         // byte offset of (chunk row r of a kind, column 8 g4 of this direction) at time tp
         uint32_t off_h[MH], off_o[MO];
@@ -247,39 +351,66 @@ __device__ __forceinline__ bool p1_step(const SegArgs& P, const Geo& G, int s, f
             const int r = min(i * 16 + i16, G.RO - 1), b = G.b0 + r / O, e = r % O;
             off_o[i] = 4u * (uint32_t)((((int64_t)b * T + tp) * O + e) * (2 * h) + dir * h + 8 * g4);
         }
-        for (int kb = wave; kb < nkb; kb += 4) {
-            Planes A[MT];
+        // the A fragments of this wave's k-blocks, two k-blocks in flight beside the two being multiplied; the weights are
+        // in registers already
+        typedef f32x4 Buf[2][MT][2];
+        Buf b0, b1;
+        auto load = [&](int g, Buf& buf) {
 #pragma unroll
-            for (int i = 0; i < MH; ++i) A[i] = split8(ld_sc1(rs_h, off_h[i] + 128u * kb), ld_sc1(rs_h, off_h[i] + 128u * kb + 16u));
+            for (int jj = 0; jj < 2; ++jj) {
+                const int kb = wave + 4 * (2 * g + jj);
+                if (kb < nkb) {
 #pragma unroll
-            for (int i = 0; i < MO; ++i) A[MH + i] = split8(ld_sc1(rs_o, off_o[i] + 128u * kb), ld_sc1(rs_o, off_o[i] + 128u * kb + 16u));
-            {
-                const Planes B = load_w(ws_h, h, G.slice * 16, kb * 32, lane);
+                    for (int i = 0; i < MH; ++i) { buf[jj][i][0] = ld_sc1(rs_h, off_h[i] + 128u * kb); buf[jj][i][1] = ld_sc1(rs_h, off_h[i] + 128u * kb + 16u); }
 #pragma unroll
-                for (int i = 0; i < MH; ++i) mac6(a_sh[i], A[i], B);
-            }
-            {
-                const Planes B = load_w(ws_o, h, G.slice * 16, kb * 32, lane);
-#pragma unroll
-                for (int i = 0; i < MO; ++i) mac6(a_so[i], A[MH + i], B);
-            }
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const Planes B = load_w(w_hh, h, c * h + G.slice * 16, kb * 32, lane);
-#pragma unroll
-                for (int i = 0; i < MK; ++i) mac6(a_g[i][c], A[(RK == 0 ? 0 : MH) + i], B);
-            }
-            // Gram tiles of the chunk's state rows: the B fragment of row tile j IS its A fragment
-            int p = 0;
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-#pragma unroll
-                for (int j = i; j < MT; ++j) {
-                    if (P.pair_mask & (1u << (i * 8 + j))) mac6(a_gram[p], A[i], A[j]);
-                    ++p;
+                    for (int i = 0; i < MO; ++i) { buf[jj][MH + i][0] = ld_sc1(rs_o, off_o[i] + 128u * kb); buf[jj][MH + i][1] = ld_sc1(rs_o, off_o[i] + 128u * kb + 16u); }
                 }
-        }
+            }
+        };
+        auto use = [&](int g, const Buf& buf) {
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                const int j = 2 * g + jj, kb = wave + 4 * j;
+                if (kb < nkb) {
+                    Planes A[MT];
+#pragma unroll
+                    for (int i = 0; i < MT; ++i) A[i] = split8(buf[jj][i][0], buf[jj][i][1]);
+                    {
+                        const Planes B = split8(Wr[j][0].a, Wr[j][0].b);
+#pragma unroll
+                        for (int i = 0; i < MH; ++i) mac6(a_sh[i], A[i], B);
+                    }
+                    {
+                        const Planes B = split8(Wr[j][1].a, Wr[j][1].b);
+#pragma unroll
+                        for (int i = 0; i < MO; ++i) mac6(a_so[i], A[MH + i], B);
+                    }
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        const Planes B = split8(Wr[j][2 + c].a, Wr[j][2 + c].b);
+#pragma unroll
+                        for (int i = 0; i < MK; ++i) mac6(a_g[i][c], A[(RK == 0 ? 0 : MH) + i], B);
+                    }
+                    // Gram tiles of the chunk's state rows: the B fragment of row tile j IS its A fragment. One accumulator:
+                    // the scores go through a softmax, the split accumulators' last bits are not needed here
+                    int p = 0;
+#pragma unroll
+                    for (int i = 0; i < MT; ++i)
+#pragma unroll
+                        for (int i2 = i; i2 < MT; ++i2) {
+                            if (P.pair_mask & (1u << (i * 8 + i2))) mac6_one(a_gram[p], A[i], A[i2]);
+                            ++p;
+                        }
+                }
+            }
+        };
+        static_assert(KW1 == 4, "two groups of two k-blocks");
+        load(0, b0);
+        load(1, b1);
+        use(0, b0);
+        use(1, b1);
     }
+    SP_STAMP(1);   // loads + products
     // ---- partial tiles -> LDS, combined in wave order
 #pragma unroll
     for (int i = 0; i < MH; ++i) put_part(part, NTILES, wave, T_SH + i, lane, a_sh[i]);
@@ -290,8 +421,9 @@ __device__ __forceinline__ bool p1_step(const SegArgs& P, const Geo& G, int s, f
 #pragma unroll
         for (int c = 0; c < 3; ++c) put_part(part, NTILES, wave, T_G + i * 3 + c, lane, a_g[i][c]);
 #pragma unroll
-    for (int p = 0; p < NPAIR; ++p) put_part(part, NTILES, wave, T_GRAM + p, lane, a_gram[p]);
+    for (int p = 0; p < NPAIR; ++p) put_part1(part, NTILES, wave, T_GRAM + p, lane, a_gram[p]);
     combine_parts(part, res, NTILES, min(4, nkb));
+    SP_STAMP(2);   // combine
 
     const int tid = threadIdx.x, q = tid & 3, ur = tid >> 2;   // (row of a 64-row pass, quad of 4 units)
     const int col = G.slice * 16 + 4 * q;
@@ -301,8 +433,9 @@ __device__ __forceinline__ bool p1_step(const SegArgs& P, const Geo& G, int s, f
         if (ur < MH * 16) {
             float* r = res + (size_t)(T_SH + ur / 16) * 16 * RS + (ur % 16) * RS + 4 * q;
             f32x4 v = *reinterpret_cast<f32x4*>(r);
+            const f32x4 bias = *reinterpret_cast<const f32x4*>(sBias + 4 * q);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k] + (bs_h ? bs_h[col + k] : 0.f), 0.f);
+            for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k] + bias[k], 0.f);
             *reinterpret_cast<f32x4*>(r) = v;
             if (ur < G.RH) {
                 const int b = G.b0 + ur / H, e = ur % H;
@@ -313,8 +446,9 @@ __device__ __forceinline__ bool p1_step(const SegArgs& P, const Geo& G, int s, f
         for (int x = ur; x < MO * 16; x += 64) {
             float* r = res + (size_t)(T_SO + x / 16) * 16 * RS + (x % 16) * RS + 4 * q;
             f32x4 v = *reinterpret_cast<f32x4*>(r);
+            const f32x4 bias = *reinterpret_cast<const f32x4*>(sBias + 16 + 4 * q);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k] + (bs_o ? bs_o[col + k] : 0.f), 0.f);
+            for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k] + bias[k], 0.f);
             *reinterpret_cast<f32x4*>(r) = v;
             if (x < G.RO) {
                 const int b = G.b0 + x / O, e = x % O;
@@ -360,6 +494,7 @@ __device__ __forceinline__ bool p1_step(const SegArgs& P, const Geo& G, int s, f
         }
     }
     __syncthreads();
+    SP_STAMP(3);   // relu, scores, softmax
     if (G.slice == 0) {   // one workgroup per (group, receiver kind) saves its half of the weights for the backward pass
         const int o0 = RK == 0 ? 0 : att_ho(H, O), o1 = RK == 0 ? att_ho(H, O) : natt;
         const int n = G.nb * (o1 - o0);
@@ -401,15 +536,14 @@ __device__ __forceinline__ bool p1_step(const SegArgs& P, const Geo& G, int s, f
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 f32x4 v = *reinterpret_cast<const f32x4*>(res + (size_t)(T_G + (x / 16) * 3 + c) * 16 * RS + (x % 16) * RS + 4 * q);
-                if (b_hh) {
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) v[k] += b_hh[c * h + col + k];
-                }
+                v += *reinterpret_cast<const f32x4*>(sBias + 32 + 16 * c + 4 * q);
                 st_sc1(rs_gh, 4u * (uint32_t)(grow * 3 * h + c * h + col), v);
             }
         }
     }
+    SP_STAMP(4);   // weighted sums, stores issued
     group_signal(cnt + RK * CNT_STRIDE);
+    SP_STAMP(5);   // drained + signalled
     return true;
 }
 
@@ -419,7 +553,7 @@ __device__ __forceinline__ bool p1_step(const SegArgs& P, const Geo& G, int s, f
 // ---------------------------------------------------------------------------------------------------------------------
 template <int MK, int K>
 __device__ __forceinline__ bool p2_step(const SegArgs& P, const Geo& G, int s, float* part, float* res, int* flag,
-                                        f32x4 (&h_own)[(MK * 16 + 63) / 64]) {
+                                        f32x4 (&h_own)[(MK * 16 + 63) / 64], const WFrag (&Wr)[KW2][3]) {
     constexpr int NTILES = 3 * MK, NPASS = (MK * 16 + 63) / 64;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i16 = lane & 15, g4 = lane >> 4;
     const int h = P.h, T = P.T, E_K = K == 0 ? P.H : P.O, R_K = K == 0 ? G.RH : G.RO;
@@ -427,11 +561,10 @@ __device__ __forceinline__ bool p2_step(const SegArgs& P, const Geo& G, int s, f
     const int ns = h / 16, nkb = 2 * h / 32;
     const int group = dir * P.n_chunks + G.chunk;
     unsigned* cnt = P.cnt + (size_t)group * 4 * CNT_STRIDE;
-    const float* w_ihm = P.w_ihm[K][dir];
-    const int64_t ldw = P.ld_ih[K];
     const int tid = threadIdx.x, q = tid & 3, ur = tid >> 2;
     const int col = G.slice * 16 + 4 * q;
 
+    SP_STAMP_BEGIN();
     // what does not depend on the chain: the frame part of W_ih x + b_ih and the hard gate of this thread's rows
     f32x4 gi[NPASS][3];
     float uu[NPASS];
@@ -445,7 +578,28 @@ __device__ __forceinline__ bool p2_step(const SegArgs& P, const Geo& G, int s, f
     }
     // the aggregated messages (every column) and W_hh h_prev of this kind: P1 of receiver kind K, all slices
     if (!group_wait(cnt + K * CNT_STRIDE, (unsigned)(s + 1) * ns, nullptr, 0u, P.error, P.spin_limit, flag)) return false;
+    SP_STAMP(0);   // waited for the messages
     const __amdgpu_buffer_rsrc_t rs_mg = rsrc_of(P.mg[K]), rs_gh = rsrc_of(P.gh[K]);
+    f32x4 acc[MK][3];
+#pragma unroll
+    for (int i = 0; i < MK; ++i)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) acc[i][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    uint32_t off[MK];
+#pragma unroll
+    for (int i = 0; i < MK; ++i) {
+        const int r = min(i * 16 + i16, R_K - 1), bl = r / E_K, e = r - bl * E_K, b = G.b0 + bl;
+        off[i] = 4u * (uint32_t)(((((int64_t)dir * P.bs + b) * T + t) * E_K + e) * (2 * h) + 8 * g4);
+    }
+    // on the fp32 matrix pipe (see mac_f32). (Measured and not kept: 3 x bf16 with one accumulator per tile for the two-tile
+    // object rows -- 7.7 against 9.2 us of this loop at h = 512, but 26 registers per lane in scratch, and wrong results
+    // at h = 64 with eight chunks; profiles/r05_seg_persist_stamps.txt.)
+    k_stream<KW2, MK>(rs_mg, off, nkb, wave, [&](int j, const f32x4 (&A)[MK][2]) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int i = 0; i < MK; ++i) mac_f32(acc[i][c], A[i][0], A[i][1], Wr[j][c]);
+    });
     f32x4 gh[NPASS][3];
 #pragma unroll
     for (int ps = 0; ps < NPASS; ++ps) {
@@ -454,33 +608,14 @@ __device__ __forceinline__ bool p2_step(const SegArgs& P, const Geo& G, int s, f
 #pragma unroll
         for (int c = 0; c < 3; ++c) gh[ps][c] = ld_sc1(rs_gh, 4u * (uint32_t)(grow * 3 * h + c * h + col));
     }
-    Acc acc[MK][3];
+
+    SP_STAMP(1);   // loads + products
 #pragma unroll
     for (int i = 0; i < MK; ++i)
 #pragma unroll
-        for (int c = 0; c < 3; ++c) acc_zero(acc[i][c]);
-    uint32_t off[MK];
-#pragma unroll
-    for (int i = 0; i < MK; ++i) {
-        const int r = min(i * 16 + i16, R_K - 1), bl = r / E_K, e = r - bl * E_K, b = G.b0 + bl;
-        off[i] = 4u * (uint32_t)(((((int64_t)dir * P.bs + b) * T + t) * E_K + e) * (2 * h) + 8 * g4);
-    }
-    for (int kb = wave; kb < nkb; kb += 4) {
-        Planes A[MK];
-#pragma unroll
-        for (int i = 0; i < MK; ++i) A[i] = split8(ld_sc1(rs_mg, off[i] + 128u * kb), ld_sc1(rs_mg, off[i] + 128u * kb + 16u));
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const Planes B = load_w(w_ihm, ldw, c * h + G.slice * 16, kb * 32, lane);
-#pragma unroll
-            for (int i = 0; i < MK; ++i) mac6(acc[i][c], A[i], B);
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < MK; ++i)
-#pragma unroll
-        for (int c = 0; c < 3; ++c) put_part(part, NTILES, wave, i * 3 + c, lane, acc[i][c]);
+        for (int c = 0; c < 3; ++c) put_part1(part, NTILES, wave, i * 3 + c, lane, acc[i][c]);
     combine_parts(part, res, NTILES, min(4, nkb));
+    SP_STAMP(2);   // combine
     // ---- gates (gru.hip, gru_step_fwd_kernel: same arithmetic), states write-through, then what the backward pass reads
     const __amdgpu_buffer_rsrc_t rs_hs = rsrc_of(P.hs[K]);
 #pragma unroll
@@ -513,8 +648,66 @@ __device__ __forceinline__ bool p2_step(const SegArgs& P, const Geo& G, int s, f
             *reinterpret_cast<f32x4*>(sv + 3 * h) = gh[ps][2];
         }
     }
+    SP_STAMP(4);   // gates, stores issued
     group_signal(cnt + (2 + K) * CNT_STRIDE);
+    SP_STAMP(5);   // drained + signalled
     return true;
+}
+
+// One function per role, inlined into the kernel (as a real call the kernel's argument block would be passed through
+// scratch memory and re-read from there every step). Register note: the fragment buffers of the reduction loops are NAMED
+// arrays -- indexing them with a run-time buffer number put them (250-500 registers per lane) into scratch memory.
+struct FwdLds { float *part, *res, *sG, *sW, *sMask, *sBias; int* flag; };
+
+// The weights of a workgroup are the same every step: its slice is loaded ONCE, as raw fp32 MFMA fragments, into the
+// registers of the wave that multiplies it (k-block kb = wave + 4 j is fragment j) -- 160 / 192 VGPRs at h = 512 -- and split
+// into the bf16 planes at every use. Nothing but states and messages moves per step.
+template <int MH, int MO, int RK>
+__device__ __forceinline__ void role_p1(const SegArgs& P, const Geo& G, const FwdLds& M) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nkb = P.h / 32;
+    WFrag Wr[KW1][5];
+#pragma unroll
+    for (int j = 0; j < KW1; ++j) {
+        const int kb = wave + 4 * j;
+#pragma unroll
+        for (int n = 0; n < 5; ++n) {
+            if (kb < nkb) {
+                const float* w = n == 0 ? P.w_s[RK == 0 ? 0 : 1] : n == 1 ? P.w_s[RK == 0 ? 2 : 3] : P.w_hh[RK][G.dir];
+                Wr[j][n] = load_w_raw(w, P.h, (n < 2 ? 0 : (n - 2) * P.h) + G.slice * 16, kb * 32, lane);
+            } else {
+                Wr[j][n] = wfrag_zero();
+            }
+        }
+    }
+    // the slice's biases, once: [0, 16) sender MLP on human states, [16, 32) on object states, [32, 80) b_hh r | z | n
+    if (threadIdx.x < 80) {
+        const int i = threadIdx.x, c16 = G.slice * 16 + (i & 15);
+        const float* b = i < 16 ? P.b_s[RK == 0 ? 0 : 1] : i < 32 ? P.b_s[RK == 0 ? 2 : 3] : P.b_hh[RK][G.dir];
+        M.sBias[i] = b ? b[(i < 32 ? 0 : ((i - 32) / 16) * P.h) + c16] : 0.f;
+    }
+    __syncthreads();
+    for (int s = 0; s < P.T; ++s)
+        if (!p1_step<MH, MO, RK>(P, G, s, M.part, M.res, M.sG, M.sW, M.sMask, M.sBias, M.flag, Wr)) return;
+}
+
+template <int MK, int K>
+__device__ __forceinline__ void role_p2(const SegArgs& P, const Geo& G, const FwdLds& M) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nkb = 2 * P.h / 32;
+    WFrag Wr[KW2][3];
+#pragma unroll
+    for (int j = 0; j < KW2; ++j) {
+        const int kb = wave + 4 * j;
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+            Wr[j][c] = kb < nkb ? load_w_raw(P.w_ihm[K][G.dir], P.ld_ih[K], c * P.h + G.slice * 16, kb * 32, lane) : wfrag_zero();
+    }
+    f32x4 h_own[(MK * 16 + 63) / 64];
+#pragma unroll
+    for (int i = 0; i < (MK * 16 + 63) / 64; ++i) h_own[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < P.T; ++s)
+        if (!p2_step<MK, K>(P, G, s, M.part, M.res, M.flag, h_own, Wr)) return;
 }
 
 template <int MH, int MO>
@@ -538,28 +731,15 @@ __global__ __launch_bounds__(256, 1) void seg_persist_fwd_kernel(const SegArgs P
     const int E = P.H + P.O, natt = P.H * P.H + 2 * P.H * P.O + P.O * P.O;
     float* sW = sG + P.cpc * (P.H > P.O ? P.H : P.O) * E;               // [cpc][natt]
     float* sMask = sW + P.cpc * natt;                                   // [cpc][O]
-    int* flag = reinterpret_cast<int*>(sMask + P.cpc * P.O);
+    float* sBias = sMask + ((P.cpc * P.O + 3) & ~3);                    // [80]
+    int* flag = reinterpret_cast<int*>(sBias + 80);
     for (int i = threadIdx.x; i < G.nb * P.O; i += 256) sMask[i] = P.mask ? P.mask[(int64_t)G.b0 * P.O + i] : 1.f;
     __syncthreads();
-    if (G.role == 0) {
-        for (int s = 0; s < P.T; ++s)
-            if (!p1_step<MH, MO, 0>(P, G, s, part, res, sG, sW, sMask, flag)) return;
-    } else if (G.role == 1) {
-        for (int s = 0; s < P.T; ++s)
-            if (!p1_step<MH, MO, 1>(P, G, s, part, res, sG, sW, sMask, flag)) return;
-    } else if (G.role == 2) {
-        f32x4 h_own[(MH * 16 + 63) / 64];
-#pragma unroll
-        for (int i = 0; i < (MH * 16 + 63) / 64; ++i) h_own[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int s = 0; s < P.T; ++s)
-            if (!p2_step<MH, 0>(P, G, s, part, res, flag, h_own)) return;
-    } else {
-        f32x4 h_own[(MO * 16 + 63) / 64];
-#pragma unroll
-        for (int i = 0; i < (MO * 16 + 63) / 64; ++i) h_own[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int s = 0; s < P.T; ++s)
-            if (!p2_step<MO, 1>(P, G, s, part, res, flag, h_own)) return;
-    }
+    FwdLds M{part, res, sG, sW, sMask, sBias, flag};
+    if (G.role == 0) role_p1<MH, MO, 0>(P, G, M);
+    else if (G.role == 1) role_p1<MH, MO, 1>(P, G, M);
+    else if (G.role == 2) role_p2<MH, 0>(P, G, M);
+    else role_p2<MO, 1>(P, G, M);
 }
 
 // =====================================================================================================================
@@ -620,7 +800,7 @@ __device__ __forceinline__ Planes load_wk(const float* w, int64_t ld, int k0, in
 // ---- Q1 of receiver kind RK: one step
 template <int MH, int MO, int RK>
 __device__ __forceinline__ bool q1_step(const SegBwdArgs& P, const Geo& G, int s, float* part, float* res, float* msT,
-                                        float* sW, float* sDW, int* flag) {
+                                        float* sW, float* sDW, int* flag, const WFrag (&Wr)[KW3][2]) {
     constexpr int MK = RK == 0 ? MH : MO, NTILES = 2 * MK;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i16 = lane & 15, g4 = lane >> 4;
     const int H = P.H, O = P.O, h = P.h, T = P.T, E_K = RK == 0 ? H : O, R_K = RK == 0 ? G.RH : G.RO;
@@ -631,6 +811,7 @@ __device__ __forceinline__ bool q1_step(const SegBwdArgs& P, const Geo& G, int s
     const int tid = threadIdx.x, q = tid & 3, ur = tid >> 2;
     const int col = G.slice * 16 + 4 * q;
     const int natt = H * H + 2 * H * O + O * O;
+    SP_STAMP_BEGIN();
     // chain-independent inputs first: the saved attention weights of (dir, t) and the sender-message columns of this slice
     for (int x = tid; x < G.nb * natt; x += 256) {
         const int bl = x / natt, i = x - bl * natt;
@@ -646,32 +827,28 @@ __device__ __forceinline__ bool q1_step(const SegBwdArgs& P, const Geo& G, int s
     }
     // every column of d_gi of this kind at step s
     if (!group_wait(cnt + (2 + RK) * CNT_STRIDE, (unsigned)(T - s) * ns, nullptr, 0u, P.error, P.spin_limit, flag)) return false;
+    SP_STAMP(0);   // waited for d_gi
     const __amdgpu_buffer_rsrc_t rs_gi = rsrc_of(P.d_gi[RK]);
-    Acc acc[MK][2];
+    f32x4 acc[MK][2];
 #pragma unroll
-    for (int i = 0; i < MK; ++i) { acc_zero(acc[i][0]); acc_zero(acc[i][1]); }
+    for (int i = 0; i < MK; ++i) { acc[i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[i][1] = acc[i][0]; }
     uint32_t off[MK];
 #pragma unroll
     for (int i = 0; i < MK; ++i) {
         const int r = min(i * 16 + i16, R_K - 1), bl = r / E_K, e = r - bl * E_K, b = G.b0 + bl;
         off[i] = 4u * (uint32_t)((((int64_t)b * T + t) * E_K + e) * (6 * h) + dir * 3 * h + 8 * g4);
     }
-    const float* w_ihm = P.w_ihm[RK][dir];
-    const int64_t ldw = P.ld_ih[RK];
-    for (int kb = wave; kb < nkb; kb += 4) {
-        Planes A[MK];
+    k_stream<KW3, MK>(rs_gi, off, nkb, wave, [&](int j, const f32x4 (&A)[MK][2]) {
 #pragma unroll
-        for (int i = 0; i < MK; ++i) A[i] = split8(ld_sc1(rs_gi, off[i] + 128u * kb), ld_sc1(rs_gi, off[i] + 128u * kb + 16u));
+        for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
-        for (int blk = 0; blk < 2; ++blk) {
-            const Planes B = load_wk(w_ihm, ldw, kb * 32, blk * h + G.slice * 16, lane);
+            for (int i = 0; i < MK; ++i) mac_f32(acc[i][blk], A[i][0], A[i][1], Wr[j][blk]);
+    });
 #pragma unroll
-            for (int i = 0; i < MK; ++i) mac6(acc[i][blk], A[i], B);
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < MK; ++i) { put_part(part, NTILES, wave, i * 2, lane, acc[i][0]); put_part(part, NTILES, wave, i * 2 + 1, lane, acc[i][1]); }
+    for (int i = 0; i < MK; ++i) { put_part1(part, NTILES, wave, i * 2, lane, acc[i][0]); put_part1(part, NTILES, wave, i * 2 + 1, lane, acc[i][1]); }
+    SP_STAMP(1);   // loads + products
     combine_parts(part, res, NTILES, min(4, nkb));
+    SP_STAMP(2);   // combine
     // res tile (i * 2 + blk): d_mg[receiver rows of kind RK][message block blk][16 columns]
     // ---- gradient of the sender messages (saved weights), ReLU mask, d_pre columns: write-through
     {
@@ -698,6 +875,7 @@ __device__ __forceinline__ bool q1_step(const SegBwdArgs& P, const Geo& G, int s
             st_sc1(hum ? rs_ph : rs_po, o, g);
         }
     }
+    SP_STAMP(3);   // d_pre
     // ---- this slice's share of dL/dw[r][s] = <d_mg[r], msg[s]> (16 of the h columns), both relations; not needed at the
     // chain start (no previous state, no score gradient)
     const int nr = RK == 0 ? H * H + H * O : H * O + O * O;
@@ -727,15 +905,17 @@ __device__ __forceinline__ bool q1_step(const SegBwdArgs& P, const Geo& G, int s
         for (int x = tid; x < P.dw_pad / 4; x += 256)
             st_sc1(rs_dw, 4u * (uint32_t)(blk_off * P.dw_pad + 4 * x), *reinterpret_cast<const f32x4*>(sDW + 4 * x));
     }
+    SP_STAMP(4);   // dL/dw shares
     group_signal(cnt + RK * CNT_STRIDE);
+    SP_STAMP(5);   // drain + signal
     return true;
 }
 
 // ---- Q2 of kind K: one step. carry / c_hh: this thread's (row, 4 units) of the carried gradient and of its W_hh part.
 template <int MK, int K>
-__device__ __forceinline__ bool q2_step(const SegBwdArgs& P, const Geo& G, int s, float* part, float* res, float* sW,
+__device__ __forceinline__ bool q2_step(const SegBwdArgs& P, const Geo& G, int s, float* part, float* res, float* fT, float* sW,
                                         float* sDW, float* sC, int* flag, f32x4 (&direct)[(MK * 16 + 63) / 64],
-                                        f32x4 (&c_hh)[(MK * 16 + 63) / 64]) {
+                                        f32x4 (&c_hh)[(MK * 16 + 63) / 64], const WFrag (&We)[KW2], const WFrag (&Wh)[KW3]) {
     constexpr int NPASS = (MK * 16 + 63) / 64;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i16 = lane & 15, g4 = lane >> 4;
     const int H = P.H, O = P.O, E = H + O, h = P.h, T = P.T, E_K = K == 0 ? H : O, R_K = K == 0 ? G.RH : G.RO;
@@ -748,6 +928,7 @@ __device__ __forceinline__ bool q2_step(const SegBwdArgs& P, const Geo& G, int s
     const int col = G.slice * 16 + 4 * q;
     const int natt = H * H + 2 * H * O + O * O;
     const bool first = s == 0, last = s == T - 1;
+    SP_STAMP_BEGIN();
 
     // chain-independent inputs of the gate backward, requested before any wait
     f32x4 dout[NPASS], sr[NPASS], sz[NPASS], sn[NPASS], shn[NPASS], h0[NPASS];
@@ -775,49 +956,73 @@ __device__ __forceinline__ bool q2_step(const SegBwdArgs& P, const Geo& G, int s
             const int bl = x / natt, i = x - bl * natt;
             sW[x] = P.att[(((int64_t)dir * T + tn) * P.bs + G.b0 + bl) * natt + i];
         }
+        // fT: [RH + RO][RS] the features of step s + 1 = the forward states at time t, this slice's 16 columns (chain-independent)
+        for (int x = ur; x < G.RH + G.RO; x += 64) {
+            const bool hum = x < G.RH;
+            const int r = hum ? x : x - G.RH, Es = hum ? H : O, bl = r / Es, e = r - bl * Es, b = G.b0 + bl;
+            *reinterpret_cast<f32x4*>(fT + (size_t)x * RS + 4 * q) =
+                *reinterpret_cast<const f32x4*>(P.hs[hum ? 0 : 1] + (((int64_t)b * T + t) * Es + e) * (2 * h) + dir * h + col);
+        }
         // d_pre columns and dL/dw shares of step s + 1: all slices of Q1h and Q1o
         if (!group_wait(cnt + 0 * CNT_STRIDE, (unsigned)(T - 1 - s) * ns, cnt + 1 * CNT_STRIDE, (unsigned)(T - 1 - s) * ns, P.error,
                         P.spin_limit, flag))
             return false;
+        SP_STAMP(0);   // waited for d_pre / dL/dw shares
+        // ---- dL/dw shares of step s + 1 (all four relations, every slice): requested first, ALL at once -- 2 x 32 loads per
+        // thread in flight (one after the other they cost a round trip each: 12 us of a 38 us step) -- and added in slice
+        // order after the product below
+        constexpr int NRMAX = 2, NSMAX = 32;
+        const __amdgpu_buffer_rsrc_t rs_dw = rsrc_of(P.dwpart);
+        const int nr0 = H * H + H * O, n_dw = G.nb * natt;
+        float dwv[NRMAX][NSMAX];
+#pragma unroll
+        for (int r = 0; r < NRMAX; ++r) {
+            const int x = min(tid + 256 * r, n_dw - 1);
+            const int bl = x / natt, i = x - bl * natt;
+            const int rk = i < nr0 ? 0 : 1, nr = rk == 0 ? nr0 : natt - nr0, j = rk == 0 ? i : i - nr0;
+            const uint32_t o0 = 4u * (uint32_t)((((((int64_t)dir * T + tn) * ns) * 2 + rk) * P.n_chunks + G.chunk) * P.dw_pad + bl * nr + j);
+            const uint32_t st = 4u * (uint32_t)(2 * P.n_chunks * P.dw_pad);
+#pragma unroll
+            for (int sl = 0; sl < NSMAX; ++sl)
+                dwv[r][sl] = sl < ns ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_dw, (int)(o0 + st * sl), 0, SC1)) : 0.f;
+        }
         // ---- sender-MLP part: complete d_pre rows of this kind (time tn) x packed W_s[:, own units]
         {
             const __amdgpu_buffer_rsrc_t rs_p = rsrc_of(P.d_pre[K]);
             const int nkb = 2 * h / 32;
-            Acc acc[MK];
+            f32x4 acc[MK];
             uint32_t off[MK];
 #pragma unroll
             for (int i = 0; i < MK; ++i) {
-                acc_zero(acc[i]);
+                acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
                 const int r = min(i * 16 + i16, R_K - 1), bl = r / E_K, e = r - bl * E_K, b = G.b0 + bl;
                 off[i] = 4u * (uint32_t)(((((int64_t)dir * P.bs + b) * T + tn) * E_K + e) * (2 * h) + 8 * g4);
             }
-            for (int kb = wave; kb < nkb; kb += 4) {
-                const Planes B = load_wk(P.w_sp[K], h, kb * 32, G.slice * 16, lane);
+            k_stream<KW2, MK>(rs_p, off, nkb, wave, [&](int j, const f32x4 (&A)[MK][2]) {
 #pragma unroll
-                for (int i = 0; i < MK; ++i) {
-                    const Planes A = split8(ld_sc1(rs_p, off[i] + 128u * kb), ld_sc1(rs_p, off[i] + 128u * kb + 16u));
-                    mac6(acc[i], A, B);
-                }
-            }
+                for (int i = 0; i < MK; ++i) mac_f32(acc[i], A[i][0], A[i][1], We[j]);
+            });
 #pragma unroll
-            for (int i = 0; i < MK; ++i) put_part(part, MK, wave, i, lane, acc[i]);
+            for (int i = 0; i < MK; ++i) put_part1(part, MK, wave, i, lane, acc[i]);
         }
-        // ---- dL/dw of step s + 1: the slices' shares added in slice order (all four relations)
-        {
-            const __amdgpu_buffer_rsrc_t rs_dw = rsrc_of(P.dwpart);
-            const int nr0 = H * H + H * O;
-            for (int x = tid; x < G.nb * natt; x += 256) {
-                const int bl = x / natt, i = x - bl * natt;
-                const int rk = i < nr0 ? 0 : 1, nr = rk == 0 ? nr0 : natt - nr0, j = rk == 0 ? i : i - nr0;
-                const int64_t base = ((((int64_t)dir * T + tn) * ns) * 2 + rk) * P.n_chunks + G.chunk;
-                const int64_t stride = (int64_t)2 * P.n_chunks;
-                float v = 0.f;
-                for (int sl = 0; sl < ns; ++sl)
-                    v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                             rs_dw, (int)(4u * (uint32_t)((base + sl * stride) * P.dw_pad + bl * nr + j)), 0, SC1));
-                sDW[x] = v;
-            }
+#pragma unroll
+        for (int r = 0; r < NRMAX; ++r) {
+            float v = 0.f;
+#pragma unroll
+            for (int sl = 0; sl < NSMAX; ++sl) v += dwv[r][sl];   // (slices beyond ns hold zeros)
+            if (tid + 256 * r < n_dw) sDW[tid + 256 * r] = v;
         }
+        for (int x = tid + 256 * NRMAX; x < n_dw; x += 256) {   // chunks with more than 512 weights: the plain loop
+            const int bl = x / natt, i = x - bl * natt;
+            const int rk = i < nr0 ? 0 : 1, nr = rk == 0 ? nr0 : natt - nr0, j = rk == 0 ? i : i - nr0;
+            const int64_t base = ((((int64_t)dir * T + tn) * ns) * 2 + rk) * P.n_chunks + G.chunk;
+            float v = 0.f;
+            for (int sl = 0; sl < ns; ++sl)
+                v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                         rs_dw, (int)(4u * (uint32_t)((base + (int64_t)sl * 2 * P.n_chunks) * P.dw_pad + bl * nr + j)), 0, SC1));
+            sDW[x] = v;
+        }
+        SP_STAMP(1);   // sender-MLP product + dL/dw sums
         combine_parts(part, res, MK, min(4, 2 * h / 32));   // (its barriers also order sW / sDW)
         // softmax backward per (clip, relation, receiver): dscore = w (dw - sum_s w dw) scale
         for (int x = tid; x < G.nb * (2 * H + 2 * O); x += 256) {
@@ -854,13 +1059,11 @@ __device__ __forceinline__ bool q2_step(const SegBwdArgs& P, const Geo& G, int s
         for (int ps = 0; ps < NPASS; ++ps) {
             const int x = ps * 64 + ur;
             if (x < R_K) {
-                const int bl = x / E_K, a = x - bl * E_K, b = G.b0 + bl;
+                const int bl = x / E_K, a = x - bl * E_K;
                 f32x4 df = {0.f, 0.f, 0.f, 0.f};
                 const float* c = sC + (size_t)(bl * E_K + a) * E;
                 for (int eb = 0; eb < E; ++eb) {
-                    const bool hum = eb < H;
-                    const int Es = hum ? H : O, ee = hum ? eb : eb - H;
-                    const f32x4 f = *reinterpret_cast<const f32x4*>(P.hs[hum ? 0 : 1] + (((int64_t)b * T + t) * Es + ee) * (2 * h) + dir * h + col);
+                    const f32x4 f = *reinterpret_cast<const f32x4*>(fT + (size_t)(eb < H ? bl * H + eb : G.RH + bl * O + (eb - H)) * RS + 4 * q);
                     const float cv = c[eb];
 #pragma unroll
                     for (int k = 0; k < 4; ++k) df[k] = fmaf(cv, f[k], df[k]);
@@ -870,6 +1073,7 @@ __device__ __forceinline__ bool q2_step(const SegBwdArgs& P, const Geo& G, int s
             }
         }
     }
+    SP_STAMP(2);   // softmax backward, coefficients, carry
     // ---- gate backward of the own units (gru.hip, gru_step_bwd_kernel: same arithmetic)
     const __amdgpu_buffer_rsrc_t rs_gi = rsrc_of(P.d_gi[K]), rs_gh = rsrc_of(P.d_gh[K]);
 #pragma unroll
@@ -911,31 +1115,29 @@ __device__ __forceinline__ bool q2_step(const SegBwdArgs& P, const Geo& G, int s
                 P.du_part[K][(((int64_t)dir * T + t) * ns + G.slice) * ((int64_t)P.bs * E_K) + (int64_t)b * E_K + e] = du;
         }
     }
+    SP_STAMP(3);   // gate backward, stores issued
     group_signal(cnt + (2 + K) * CNT_STRIDE);
+    SP_STAMP(4);   // drain + signal
     if (first) return true;
     // ---- W_hh part of the next carry: complete d_gh rows of this kind at step s (all slices) x W_hh[:, own units]
     if (!group_wait(cnt + (2 + K) * CNT_STRIDE, (unsigned)(T - s) * ns, nullptr, 0u, P.error, P.spin_limit, flag)) return false;
+    SP_STAMP(5);   // waited for the kind's d_gh
     {
         const int nkb = 3 * h / 32;
-        Acc acc[MK];
+        f32x4 acc[MK];
         uint32_t off[MK];
 #pragma unroll
         for (int i = 0; i < MK; ++i) {
-            acc_zero(acc[i]);
+            acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
             const int r = min(i * 16 + i16, R_K - 1), bl = r / E_K, e = r - bl * E_K, b = G.b0 + bl;
             off[i] = 4u * (uint32_t)((((int64_t)b * T + t) * E_K + e) * (6 * h) + dir * 3 * h + 8 * g4);
         }
-        const float* w_hh = P.w_hh[K][dir];
-        for (int kb = wave; kb < nkb; kb += 4) {
-            const Planes B = load_wk(w_hh, h, kb * 32, G.slice * 16, lane);
+        k_stream<KW3, MK>(rs_gh, off, nkb, wave, [&](int j, const f32x4 (&A)[MK][2]) {
 #pragma unroll
-            for (int i = 0; i < MK; ++i) {
-                const Planes A = split8(ld_sc1(rs_gh, off[i] + 128u * kb), ld_sc1(rs_gh, off[i] + 128u * kb + 16u));
-                mac6(acc[i], A, B);
-            }
-        }
+            for (int i = 0; i < MK; ++i) mac_f32(acc[i], A[i][0], A[i][1], Wh[j]);
+        });
 #pragma unroll
-        for (int i = 0; i < MK; ++i) put_part(part, MK, wave, i, lane, acc[i]);
+        for (int i = 0; i < MK; ++i) put_part1(part, MK, wave, i, lane, acc[i]);
         combine_parts(part, res, MK, min(4, nkb));
 #pragma unroll
         for (int ps = 0; ps < NPASS; ++ps) {
@@ -944,7 +1146,49 @@ __device__ __forceinline__ bool q2_step(const SegBwdArgs& P, const Geo& G, int s
         }
         __syncthreads();   // res is rewritten by the next step's first combine
     }
+    SP_STAMP(6);   // W_hh part of the next carry
     return true;
+}
+
+struct BwdLds { float *part, *res, *msT, *sW, *sDW, *sC; int* flag; };
+
+// weights once, into registers (see the forward roles): k-major operands here
+template <int MH, int MO, int RK>
+__device__ __forceinline__ void role_q1(const SegBwdArgs& P, const Geo& G, const BwdLds& M) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nkb = 3 * P.h / 32;
+    WFrag Wr[KW3][2];
+#pragma unroll
+    for (int j = 0; j < KW3; ++j) {
+        const int kb = wave + 4 * j;
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk)
+            Wr[j][blk] = kb < nkb ? load_wk_raw(P.w_ihm[RK][G.dir], P.ld_ih[RK], kb * 32, blk * P.h + G.slice * 16, lane) : wfrag_zero();
+    }
+    for (int s = P.T - 1; s >= 0; --s)
+        if (!q1_step<MH, MO, RK>(P, G, s, M.part, M.res, M.msT, M.sW, M.sDW, M.flag, Wr)) return;
+}
+
+template <int MK, int K>
+__device__ __forceinline__ void role_q2(const SegBwdArgs& P, const Geo& G, const BwdLds& M) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    WFrag We[KW2], Wh[KW3];
+#pragma unroll
+    for (int j = 0; j < KW2; ++j) {
+        const int kb = wave + 4 * j;
+        We[j] = kb < 2 * P.h / 32 ? load_wk_raw(P.w_sp[K], P.h, kb * 32, G.slice * 16, lane) : wfrag_zero();
+    }
+#pragma unroll
+    for (int j = 0; j < KW3; ++j) {
+        const int kb = wave + 4 * j;
+        Wh[j] = kb < 3 * P.h / 32 ? load_wk_raw(P.w_hh[K][G.dir], P.h, kb * 32, G.slice * 16, lane) : wfrag_zero();
+    }
+    constexpr int NP = (MK * 16 + 63) / 64;
+    f32x4 direct[NP], c_hh[NP];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) { direct[i] = f32x4{0.f, 0.f, 0.f, 0.f}; c_hh[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    for (int s = P.T - 1; s >= 0; --s)
+        if (!q2_step<MK, K>(P, G, s, M.part, M.res, M.msT, M.sW, M.sDW, M.sC, M.flag, direct, c_hh, We, Wh)) return;
 }
 
 template <int MH, int MO>
@@ -968,27 +1212,11 @@ __global__ __launch_bounds__(256, 1) void seg_persist_bwd_kernel(const SegBwdArg
     float* sDW = sW + P.cpc * natt;                                     // [max(cpc natt, dw_pad)]
     float* sC = sDW + (P.cpc * natt > P.dw_pad ? P.cpc * natt : P.dw_pad);   // [cpc][E_K][E]
     int* flag = reinterpret_cast<int*>(sC + P.cpc * (P.H > P.O ? P.H : P.O) * E);
-    if (G.role == 0) {
-        for (int s = P.T - 1; s >= 0; --s)
-            if (!q1_step<MH, MO, 0>(P, G, s, part, res, msT, sW, sDW, flag)) return;
-    } else if (G.role == 1) {
-        for (int s = P.T - 1; s >= 0; --s)
-            if (!q1_step<MH, MO, 1>(P, G, s, part, res, msT, sW, sDW, flag)) return;
-    } else if (G.role == 2) {
-        constexpr int NP = (MH * 16 + 63) / 64;
-        f32x4 direct[NP], c_hh[NP];
-#pragma unroll
-        for (int i = 0; i < NP; ++i) { direct[i] = f32x4{0.f, 0.f, 0.f, 0.f}; c_hh[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-        for (int s = P.T - 1; s >= 0; --s)
-            if (!q2_step<MH, 0>(P, G, s, part, res, sW, sDW, sC, flag, direct, c_hh)) return;
-    } else {
-        constexpr int NP = (MO * 16 + 63) / 64;
-        f32x4 direct[NP], c_hh[NP];
-#pragma unroll
-        for (int i = 0; i < NP; ++i) { direct[i] = f32x4{0.f, 0.f, 0.f, 0.f}; c_hh[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-        for (int s = P.T - 1; s >= 0; --s)
-            if (!q2_step<MO, 1>(P, G, s, part, res, sW, sDW, sC, flag, direct, c_hh)) return;
-    }
+    BwdLds M{part, res, msT, sW, sDW, sC, flag};
+    if (G.role == 0) role_q1<MH, MO, 0>(P, G, M);
+    else if (G.role == 1) role_q1<MH, MO, 1>(P, G, M);
+    else if (G.role == 2) role_q2<MH, 0>(P, G, M);
+    else role_q2<MO, 1>(P, G, M);
 }
 
 // d_u[b][t][e] += the slices' parked sums, both directions, in fixed order: one thread per (clip, time, entity)
@@ -1045,7 +1273,7 @@ bool make_plan(const twog_segrnn_t& S, int n_cus, SegPlan& pl) {
     const int MT = mh + mo, NPAIR = MT * (MT + 1) / 2, NT = mh + mo + 3 * (mh > mo ? mh : mo) + NPAIR;
     const int E = H + O, natt = H * H + 2 * H * O + O * O;
     size_t lds = (size_t)4 * NT * 256 * 4 + (size_t)NT * 16 * RS * 4 + (size_t)cpc * (H > O ? H : O) * E * 4 +
-                 (size_t)cpc * natt * 4 + (size_t)cpc * O * 4 + 64;
+                 (size_t)cpc * natt * 4 + (size_t)cpc * O * 4 + 80 * 4 + 128;
     if (lds < 84 * 1024) lds = 84 * 1024;   // more than half of the 160 KB: one workgroup per compute unit
     if (lds > 160 * 1024) return false;
     pl.lds = lds;
