@@ -968,23 +968,27 @@ __device__ __forceinline__ bool q2_step(const SegBwdArgs& P, const Geo& G, int s
                         P.spin_limit, flag))
             return false;
         SP_STAMP(0);   // waited for d_pre / dL/dw shares
-        // ---- dL/dw shares of step s + 1 (all four relations, every slice): requested first, ALL at once -- 2 x 32 loads per
-        // thread in flight (one after the other they cost a round trip each: 12 us of a 38 us step) -- and added in slice
-        // order after the product below
-        constexpr int NRMAX = 2, NSMAX = 32;
+        // ---- dL/dw shares of step s + 1 (all four relations, every slice): requested first, ALL at once, 16 bytes per load
+        // -- thread (c, half) takes float4 column c of the two receiver kinds' blocks for the slices of its half, 16 loads in
+        // flight (one scalar after the other they cost a round trip each: 12 us of a 38 us step; as 13 000 scalar loads per
+        // workgroup they saturated the L2 request rate: 8 us) -- and added after the product below: slices in order within a
+        // half, then half 0 + half 1
+        constexpr int NSH = 16;
         const __amdgpu_buffer_rsrc_t rs_dw = rsrc_of(P.dwpart);
         const int nr0 = H * H + H * O, n_dw = G.nb * natt;
-        float dwv[NRMAX][NSMAX];
-#pragma unroll
-        for (int r = 0; r < NRMAX; ++r) {
-            const int x = min(tid + 256 * r, n_dw - 1);
-            const int bl = x / natt, i = x - bl * natt;
-            const int rk = i < nr0 ? 0 : 1, nr = rk == 0 ? nr0 : natt - nr0, j = rk == 0 ? i : i - nr0;
-            const uint32_t o0 = 4u * (uint32_t)((((((int64_t)dir * T + tn) * ns) * 2 + rk) * P.n_chunks + G.chunk) * P.dw_pad + bl * nr + j);
+        const int n4 = P.dw_pad / 4;                       // float4 columns per receiver kind
+        const bool dw_fast = 4 * n4 <= 256 && ns <= 2 * NSH;   // (else: the plain loop below)
+        f32x4 dwv[NSH];
+        const int dw_c = tid % (2 * n4 > 0 ? 2 * n4 : 1), dw_half = tid / (2 * n4 > 0 ? 2 * n4 : 1);
+        if (dw_fast) {
+            const int rk = dw_c / n4, c4 = dw_c - rk * n4;
+            const uint32_t o0 = 4u * (uint32_t)((((((int64_t)dir * T + tn) * ns) * 2 + rk) * P.n_chunks + G.chunk) * P.dw_pad + 4 * c4);
             const uint32_t st = 4u * (uint32_t)(2 * P.n_chunks * P.dw_pad);
 #pragma unroll
-            for (int sl = 0; sl < NSMAX; ++sl)
-                dwv[r][sl] = sl < ns ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_dw, (int)(o0 + st * sl), 0, SC1)) : 0.f;
+            for (int k = 0; k < NSH; ++k) {
+                const int sl = dw_half * NSH + k;
+                dwv[k] = (dw_half < 2 && sl < ns) ? ld_sc1(rs_dw, o0 + st * sl) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
         }
         // ---- sender-MLP part: complete d_pre rows of this kind (time tn) x packed W_s[:, own units]
         {
@@ -1005,22 +1009,30 @@ __device__ __forceinline__ bool q2_step(const SegBwdArgs& P, const Geo& G, int s
 #pragma unroll
             for (int i = 0; i < MK; ++i) put_part1(part, MK, wave, i, lane, acc[i]);
         }
+        if (dw_fast) {
+            f32x4 v = dwv[0];
 #pragma unroll
-        for (int r = 0; r < NRMAX; ++r) {
-            float v = 0.f;
-#pragma unroll
-            for (int sl = 0; sl < NSMAX; ++sl) v += dwv[r][sl];   // (slices beyond ns hold zeros)
-            if (tid + 256 * r < n_dw) sDW[tid + 256 * r] = v;
-        }
-        for (int x = tid + 256 * NRMAX; x < n_dw; x += 256) {   // chunks with more than 512 weights: the plain loop
-            const int bl = x / natt, i = x - bl * natt;
-            const int rk = i < nr0 ? 0 : 1, nr = rk == 0 ? nr0 : natt - nr0, j = rk == 0 ? i : i - nr0;
-            const int64_t base = ((((int64_t)dir * T + tn) * ns) * 2 + rk) * P.n_chunks + G.chunk;
-            float v = 0.f;
-            for (int sl = 0; sl < ns; ++sl)
-                v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                         rs_dw, (int)(4u * (uint32_t)((base + (int64_t)sl * 2 * P.n_chunks) * P.dw_pad + bl * nr + j)), 0, SC1));
-            sDW[x] = v;
+            for (int k = 1; k < NSH; ++k) v += dwv[k];   // (slices beyond ns hold zeros)
+            // res is free until the combine below: [half][kind][dw_pad] partial sums
+            if (dw_half < 2) *reinterpret_cast<f32x4*>(sC + (size_t)(dw_half * 2 * n4 + dw_c) * 4) = v;
+            __syncthreads();
+            for (int x = tid; x < n_dw; x += 256) {
+                const int bl = x / natt, i = x - bl * natt;
+                const int rk = i < nr0 ? 0 : 1, nr = rk == 0 ? nr0 : natt - nr0, j = rk == 0 ? i : i - nr0;
+                const int e = rk * P.dw_pad + bl * nr + j;
+                sDW[x] = sC[e] + sC[2 * P.dw_pad + e];
+            }
+        } else {
+            for (int x = tid; x < n_dw; x += 256) {
+                const int bl = x / natt, i = x - bl * natt;
+                const int rk = i < nr0 ? 0 : 1, nr = rk == 0 ? nr0 : natt - nr0, j = rk == 0 ? i : i - nr0;
+                const int64_t base = ((((int64_t)dir * T + tn) * ns) * 2 + rk) * P.n_chunks + G.chunk;
+                float v = 0.f;
+                for (int sl = 0; sl < ns; ++sl)
+                    v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                             rs_dw, (int)(4u * (uint32_t)((base + (int64_t)sl * 2 * P.n_chunks) * P.dw_pad + bl * nr + j)), 0, SC1));
+                sDW[x] = v;
+            }
         }
         SP_STAMP(1);   // sender-MLP product + dL/dw sums
         combine_parts(part, res, MK, min(4, 2 * h / 32));   // (its barriers also order sW / sDW)
@@ -1211,7 +1223,8 @@ __global__ __launch_bounds__(256, 1) void seg_persist_bwd_kernel(const SegBwdArg
     float* sW = msT + 16 * (MH + MO) * RS;                              // [cpc][natt]
     float* sDW = sW + P.cpc * natt;                                     // [max(cpc natt, dw_pad)]
     float* sC = sDW + (P.cpc * natt > P.dw_pad ? P.cpc * natt : P.dw_pad);   // [cpc][E_K][E]
-    int* flag = reinterpret_cast<int*>(sC + P.cpc * (P.H > P.O ? P.H : P.O) * E);
+    const int n_sc = P.cpc * (P.H > P.O ? P.H : P.O) * E;
+    int* flag = reinterpret_cast<int*>(sC + (n_sc > 4 * P.dw_pad ? n_sc : 4 * P.dw_pad));   // (sC also holds the dL/dw half sums)
     BwdLds M{part, res, msT, sW, sDW, sC, flag};
     if (G.role == 0) role_q1<MH, MO, 0>(P, G, M);
     else if (G.role == 1) role_q1<MH, MO, 1>(P, G, M);
@@ -1362,7 +1375,7 @@ size_t bwd_lds(const twog_segrnn_t& S, const SegPlan& pl) {
     const int dw_pad = bwd_dw_pad(S, pl.cpc);
     size_t lds = (size_t)4 * NT * 256 * 4 + (size_t)NT * 16 * RS * 4 + (size_t)16 * (pl.mh + pl.mo) * RS * 4 +
                  (size_t)pl.cpc * natt * 4 + (size_t)(pl.cpc * natt > dw_pad ? pl.cpc * natt : dw_pad) * 4 +
-                 (size_t)pl.cpc * (S.H > S.O ? S.H : S.O) * E * 4 + 64;
+                 (size_t)(pl.cpc * (S.H > S.O ? S.H : S.O) * E > 4 * dw_pad ? pl.cpc * (S.H > S.O ? S.H : S.O) * E : 4 * dw_pad) * 4 + 64;
     if (lds < 84 * 1024) lds = 84 * 1024;
     return lds;
 }

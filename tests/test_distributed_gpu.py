@@ -112,3 +112,67 @@ def test_rccl_single_rank_collective_path_on_the_device():
         assert torch.equal(a, b)                  # a one-rank all-reduce is the identity
     assert torch.equal(p_f, p_p)
     assert all(torch.isfinite(g).all() for g in g_f)
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# Ordering of the first gradient all-reduce around the persistent backward launches (VERDICT r04
+# item 8): RCCL's kernels hold compute units until the peers arrive, a persistent launch needs all of them -- so the
+# stage-0 all-reduce (heads + segment level) is issued BEHIND the persistent frame-level backward launch, and nothing
+# is in flight when the persistent segment-level backward launch runs. One rank over RCCL with force_collectives=True
+# executes exactly that path on this box; the log of (launch, collective) events must show the order, the persistent
+# launches must really have run, and the gradients must equal the collective-free step's.
+def _order_worker(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+    torch.cuda.set_device(0)
+    dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', 0))
+    import twog_gcn_amd  # noqa: F401
+    from twog_gcn_amd import kernels
+    from twog_gcn_amd.distributed import DataParallel
+    from twog_gcn_amd.models import TGGCN
+    K = kernels.get_kernels()
+    log = []
+    for name in ('twog_bigru_bwd_persistent', 'twog_segrnn_bwd_persistent', 'twog_bigru_fwd_persistent', 'twog_segrnn_fwd_persistent'):
+        real = getattr(K.lib, name)
+        setattr(K.lib, name, (lambda real, name: lambda *a: (log.append(name), real(*a))[1])(real, name))
+    real_ready = DataParallel._stage_ready
+
+    def ready(self, stage):
+        log.append(f'stage{stage}')
+        return real_ready(self, stage)
+
+    DataParallel._stage_ready = ready
+    torch.manual_seed(0)
+    res = {}
+    xh, xo, mask, tgt, noise = (t.to(DEV) for t in _batch(4, T=6))
+    for forced in (True, False):
+        torch.manual_seed(0)
+        model = TGGCN(input_size=(2048 + 4 * 26, 2048), num_classes=(13, None), hidden_size=64, gcn_node=26,
+                      attention_style='v3', discrete_optimization_strategy='gs', message_segment=True, message_type='v2',
+                      message_granularity='v1', message_aggregation='att', object_segment_update_strategy='ind').to(DEV).train()
+        dp = DataParallel(model, bucket_mb=1, force_collectives=forced)
+        model._gumbel_noise_override = noise
+        del log[:]
+        dp.zero_grad()
+        out = model(xh, xo, mask, human_segmentation=torch.ones(xh.shape[:3], device=DEV))
+        (torch.nn.functional.nll_loss(out[4], tgt) + torch.nn.functional.nll_loss(out[5], tgt)).backward()
+        dp.all_reduce_gradients()
+        torch.cuda.synchronize()
+        res[forced] = (list(log), dp.flat.grad.clone().cpu(), dp.collective_calls)
+        dp.close()
+    ret['forced'], ret['plain'] = res[True], res[False]
+    dist.destroy_process_group()
+
+
+def test_first_gradient_all_reduce_is_issued_behind_the_persistent_backward_launches():
+    port = 38500 + os.getpid() % 2000
+    ret = mp.Manager().dict()
+    mp.spawn(_order_worker, args=(1, port, ret), nprocs=1, join=True)
+    (log_f, g_f, calls_f), (log_p, g_p, calls_p) = ret['forced'], ret['plain']
+    for name in ('twog_bigru_fwd_persistent', 'twog_segrnn_fwd_persistent', 'twog_segrnn_bwd_persistent', 'twog_bigru_bwd_persistent'):
+        assert name in log_f, (name, log_f)
+    i_seg, i_gru, i_s0 = log_f.index('twog_segrnn_bwd_persistent'), log_f.index('twog_bigru_bwd_persistent'), log_f.index('stage0')
+    assert i_seg < i_gru < i_s0, log_f            # no collective in flight under either persistent backward launch
+    assert log_f.index('stage0') < log_f.index('stage1') < log_f.index('stage2'), log_f
+    assert calls_f >= 3 and calls_p == 0
+    assert torch.equal(g_f, g_p) and torch.isfinite(g_f).all()

@@ -134,7 +134,61 @@ def _record(**kw):
         pass
 
 
-def _oracle_vs_hip(bs, T, H, O, N, h, backward, seed=3, n_sub=13, n_aff=None, both_given=False, virtual='clip1'):
+def _grad_errors(m, osd):
+    """Per parameter tensor (name, error / scale, scale, inside the 5e-4 gate) of the HIP gradients against the oracle's."""
+    rows = []
+    for pname, p in m.named_parameters():
+        g_ref = osd[pname].grad
+        if g_ref is None or p.grad is None:
+            continue
+        scale = max(g_ref.abs().max().item(), 1e-6)
+        err = (p.grad.cpu() - g_ref).abs().max().item()
+        rows.append((pname, err / scale, scale, err < GRAD_REL * scale + GRAD_ABS))
+    return rows
+
+
+def _raw_deviation(m, fwd, x_human, x_objects, mask, kw, noise, buffers, rs_of):
+    """what the UN-conditioned case deviates by. The same comparison as the gate below, run once on the
+    weights as drawn (before tests/relu_boundary.py moves any bias): per tensor the gradient error against the oracle; for
+    every tensor beyond 5e-4 of its scale, whether the fp64 yardstick (HIP no further from the fp64 oracle than 3 x the
+    fp32 oracle itself) explains it. Returns the record; the caller decides (a tensor beyond BOTH gates is only tolerated
+    in a case where the conditioning then finds and confirms ReLU boundary units)."""
+    f64 = torch.float64
+    sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    osd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and 'running' not in k else v.clone()) for k, v in sd.items()}
+    ref = cpu_ref.tggcn_forward(osd, dict(m.cfg), x_human, x_objects, mask, training=True, gumbel_noise=noise, **kw)
+    out = fwd()
+    rs = rs_of(ref)
+    sum((o * r).sum() for o, r in zip(ref, rs) if o.requires_grad).backward()
+    m.zero_grad(set_to_none=True)
+    sum((o * r.to(DEV)).sum() for o, r in zip(out, rs) if o.requires_grad).backward()
+    rows = _grad_errors(m, osd)
+    hard_equal = all(torch.equal(o.detach().cpu(), r.detach()) for o, r in list(zip(out, ref))[:1])
+    beyond = [(n, e, sc) for n, e, sc, ok in rows if not ok]
+    explained = {}
+    if beyond:
+        osd64 = {k: (v.detach().to(f64).requires_grad_(True) if v.is_floating_point() and 'running' not in k
+                     else (v.detach().to(f64) if v.is_floating_point() else v.clone())) for k, v in sd.items()}
+        ref64 = cpu_ref.tggcn_forward(osd64, dict(m.cfg), x_human.to(f64), x_objects.to(f64), mask.to(f64), training=True,
+                                      gumbel_noise=None if noise is None else noise.to(f64),
+                                      **{k: v.to(f64) for k, v in kw.items()})
+        sum((o * r.to(f64)).sum() for o, r in zip(ref64, rs) if o.requires_grad).backward()
+        P = dict(m.named_parameters())
+        for n, e, sc in beyond:
+            g64 = osd64[n].grad
+            own = (osd[n].grad.to(f64) - g64).abs().max().item()
+            err64 = (P[n].grad.cpu().to(f64) - g64).abs().max().item()
+            explained[n] = bool(err64 <= 3.0 * own + 2e-5 * sc)
+    m.zero_grad(set_to_none=True)
+    m.load_state_dict(buffers, strict=False)   # the train-mode forward moved the BatchNorm running statistics
+    return dict(raw_worst_grad_rel=max((e for _, e, _, _ in rows), default=0.0),
+                raw_tensors_beyond_5e4=[(n, float(f'{e:.3e}'), explained[n]) for n, e, _ in beyond],
+                raw_tensors_beyond_both_gates=[n for n, _, _ in beyond if not explained[n]],
+                raw_hard_gates_equal=bool(hard_equal), raw_tensors_compared=len(rows))
+
+
+def _oracle_vs_hip(bs, T, H, O, N, h, backward, seed=3, n_sub=13, n_aff=None, both_given=False, virtual='clip1',
+                   max_nudged_share=0.04):
     """The full path on the HIP kernels against the CPU oracle on the same weights, inputs and noise: every output at
     1e-4, every parameter gradient at 5e-4 of its scale -- no escape clause.
 
@@ -170,12 +224,25 @@ def _oracle_vs_hip(bs, T, H, O, N, h, backward, seed=3, n_sub=13, n_aff=None, bo
     def fwd():
         return m(xh_d, xo_d, mask_d, **dkw)
 
+    def rs_of(outs):
+        return [torch.randn(o.shape, generator=torch.Generator().manual_seed(i)) for i, o in enumerate(outs)]
+
+    raw = _raw_deviation(m, fwd, x_human, x_objects, mask, kw, noise, buffers, rs_of) if backward else None
     rounds, nudged = condition_case(m, fwd) if backward else (0, {})
     from tests import relu_boundary as _rb
     totals = dict(_rb.LAST_TOTALS)
     if backward and totals['units']:
         n_nudged = sum(nudged.values())
         assert n_nudged <= MAX_NUDGED_UNIT_SHARE * totals['units'], ('too many ReLU units nudged', nudged, totals)
+        # per shape class: 1 % at the configs[2] shapes, 4 % at configs[0] / [1], 10 % at configs[4]
+        assert n_nudged <= max_nudged_share * totals['units'], ('nudged share above the bound of this shape class', n_nudged,
+                                                                 totals['units'], max_nudged_share)
+    if backward and raw['raw_tensors_beyond_both_gates']:
+        # a raw tensor beyond BOTH gates is tolerated only where the conditioning found (and confirmed, by re-checking after the
+        # nudge) ReLU units inside their rounding band: those are what moves a gradient row by percents between two summation
+        # orders. Without a single such unit in the case there is nothing to blame but the kernels.
+        assert sum(nudged.values()) > 0, ('un-conditioned gradients beyond 5e-4 AND beyond the fp64 yardstick, and no ReLU '
+                                          'boundary unit in the case', raw)
         assert totals['boundary_activations'] <= max(8, MAX_BOUNDARY_ACTIVATION_SHARE * totals['activations']), (nudged, totals)
     m.load_state_dict(buffers, strict=False)   # the conditioning passes moved the BatchNorm running statistics
     sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
@@ -195,8 +262,9 @@ def _oracle_vs_hip(bs, T, H, O, N, h, backward, seed=3, n_sub=13, n_aff=None, bo
         assert err < REL, (i, err)
     if not backward:
         return
-    rs = [torch.randn(o.shape, generator=torch.Generator().manual_seed(i)) for i, o in enumerate(ref)]
+    rs = rs_of(ref)
     sum((o * r).sum() for o, r in zip(ref, rs) if o.requires_grad).backward()
+    m.zero_grad(set_to_none=True)
     sum((o * r.to(DEV)).sum() for o, r in zip(out, rs) if o.requires_grad).backward()
     worst, worst_rel_only, off, abs_only = 0.0, 0.0, [], []
     for pname, p in m.named_parameters():
@@ -236,7 +304,8 @@ def _oracle_vs_hip(bs, T, H, O, N, h, backward, seed=3, n_sub=13, n_aff=None, bo
             assert err64 <= 3.0 * own + 2e-5 * scale, ('beyond the fp64 yardstick', pname, e, err64 / scale, own / scale)
     print(f'worst output {worst_out:.2e}; worst gradient within 5e-4: {worst:.2e}; judged by the fp64 yardstick: '
           f'{[(n, f"{e:.1e}", f"hip-fp64 {a:.1e}", f"oracle32-fp64 {b:.1e}") for n, e, a, b in yard]}; '
-          f'ReLU-boundary units nudged in {rounds} round(s): {nudged}')
+          f'ReLU-boundary units nudged in {rounds} round(s): {nudged}; UN-conditioned case: worst gradient '
+          f'{raw["raw_worst_grad_rel"]:.2e}, beyond 5e-4: {raw["raw_tensors_beyond_5e4"]}')
     _record(case=dict(bs=bs, T=T, H=H, O=O, N=N, h=h, seed=seed, n_aff=n_aff, both_given=both_given, virtual=virtual),
             worst_output_rel=worst_out, worst_grad_rel_within_tolerance=worst, tensors_on_fp64_yardstick=yard,
             tensors_within_the_gate_only_by_its_absolute_floor=[(n, float(f'{e:.3e}'), float(f'{sc:.3e}')) for n, e, sc in abs_only],
@@ -244,12 +313,14 @@ def _oracle_vs_hip(bs, T, H, O, N, h, backward, seed=3, n_sub=13, n_aff=None, bo
             conditioning_rounds=rounds, relu_units_nudged=nudged, relu_units_covered=totals.get('units'),
             relu_activations_covered=totals.get('activations'),
             relu_activations_in_the_rounding_band=totals.get('boundary_activations'),
+            relu_units_nudged_share=(sum(nudged.values()) / totals['units']) if totals.get('units') else 0.0,
+            nudged_share_bound_of_the_shape_class=max_nudged_share, unconditioned=raw,
             gemm_x3=os.environ.get('TWOG_GEMM_X3', '1'))
 
 
 def test_oracle_parity_c3_layout_reduced_width():
     """Synthetic layout of BASELINE configs[2] (H=2, O=8, N=34) at h=64, T=16: forward + backward vs the oracle."""
-    _oracle_vs_hip(bs=3, T=16, H=2, O=8, N=34, h=64, backward=True)
+    _oracle_vs_hip(bs=3, T=16, H=2, O=8, N=34, h=64, backward=True, max_nudged_share=0.01)
 
 
 def test_oracle_parity_c2_layout_hs128():
@@ -260,7 +331,7 @@ def test_oracle_parity_full_width_forward_backward():
     """BASELINE shape of the metric (configs[2]): T=120, N=34, h=512, forward AND backward -- a 120-step BPTT through the
     fused gate-epilogue chains and the split-K weight gradients, every parameter gradient against the oracle (one clip
     pair; the oracle needs a few minutes on the host cores)."""
-    _oracle_vs_hip(bs=2, T=120, H=2, O=8, N=34, h=512, backward=True, seed=7)
+    _oracle_vs_hip(bs=2, T=120, H=2, O=8, N=34, h=512, backward=True, seed=7, max_nudged_share=0.01)
 
 
 def test_oracle_parity_bench_batch_short_clips():
@@ -268,13 +339,13 @@ def test_oracle_parity_bench_batch_short_clips():
     the variants the tile-count policies pick only there -- the fused frame-level GRU step (22 row tiles x 8 unit tiles),
     the 128x128 class with split-K for the weight gradients, the grouped tile order -- run against the oracle, forward and
     backward."""
-    _oracle_vs_hip(bs=64, T=3, H=2, O=8, N=34, h=512, backward=True, seed=11)
+    _oracle_vs_hip(bs=64, T=3, H=2, O=8, N=34, h=512, backward=True, seed=11, max_nudged_share=0.01)
 
 
 def test_oracle_parity_bench_batch_virtual_objects_on_half_the_clips():
     """SURVEY 8d's input variant at the bench batch: the last two objects are virtual on every second clip (masked
     senders and receivers inside every attention instance, masked gate rows), T = 3, forward and backward."""
-    _oracle_vs_hip(bs=64, T=3, H=2, O=8, N=34, h=512, backward=True, seed=23, virtual='half')
+    _oracle_vs_hip(bs=64, T=3, H=2, O=8, N=34, h=512, backward=True, seed=23, virtual='half', max_nudged_share=0.01)
 
 
 def test_oracle_parity_c1_full_width():
@@ -303,7 +374,7 @@ def test_oracle_parity_c2_full_size():
 
 def test_oracle_parity_c5_full_size():
     """BASELINE configs[4] per-GPU shard at size: Bimanual layout (H=2, O=9, N=30), h=64, 16 clips, T=120."""
-    _oracle_vs_hip(bs=16, T=120, H=2, O=9, N=30, h=64, backward=True, seed=13, n_sub=14)
+    _oracle_vs_hip(bs=16, T=120, H=2, O=9, N=30, h=64, backward=True, seed=13, n_sub=14, max_nudged_share=0.10)
 
 
 def test_oracle_parity_at_bench_size():
@@ -415,7 +486,10 @@ def test_full_size_determinism_and_batch_independence():
 
 def test_graph_replay_path_matches_direct_launches(monkeypatch):
     """The opt-in hipGraph path of the four time loops (TWOG_GRAPHS=1: first sighting direct, then capture, then replays)
-    gives bit for bit what the default direct launches give, forward and backward, step after step."""
+    gives bit for bit what the default direct launches give, forward and backward, step after step. (The launch-per-step
+    loops are what is captured: the persistent launches that would serve this small batch are switched off.)"""
+    monkeypatch.setenv('TWOG_BIGRU_PERSIST', '0')
+    monkeypatch.setenv('TWOG_SEG_PERSIST', '0')
     bs, T, H, O, N, h = 4, 12, 2, 4, 26, 64
     torch.manual_seed(2)
     m = TGGCN(input_size=(2048 + 4 * N, 2048), num_classes=(13, None), hidden_size=h, gcn_node=N, **STAGE1).to(DEV).train()
