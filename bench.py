@@ -711,7 +711,9 @@ def main():
                            'gemm_gate_bwd_x3s* (launches with >= 96 tiles and K >= 256: sender MLPs, backward carries with the fused '
                            'gate backward); (3) the fused frame-level GRU step gemm_gru_fwd_kernel<2, 2, true>; (4) at small batches (at most one '
                            '16-row tile per wave) the frame-level recurrence as persistent launches bigru_persist_fwd / _bwd_kernel (same '
-                           'split, v_mfma_f32_16x16x32_bf16; see roofline_chain.loops.*.kernels for what ran). Error against fp64 '
+                           'split, v_mfma_f32_16x16x32_bf16) and the segment-level recurrence as seg_persist_fwd / _bwd_kernel (the same split for the '
+                           'products a weight fragment shares between several row tiles, the native fp32 matrix pipe v_mfma_f32_16x16x4_f32 '
+                           'for the others; see roofline_chain.loops.*.kernels for what ran). Error against fp64 '
                            'within 1.25x the fp32-MFMA kernels on random operands; on SAME-SIGN operands the bf16 MFMA\'s '
                            'accumulate adds a relative bias (towards zero) of up to 4e-8 (chain class) / 4e-7 at K = 1 536 and '
                            '2e-6 at K = 61 440 (128x128 class) where the fp32 MFMA has 4e-10 '
@@ -778,6 +780,12 @@ def main():
             if getattr(_K, _flag, False):   # small batches: ONE persistent launch for all time steps (csrc/gru_persist.hip)
                 cm[_n].update(gemm_launches=1, kernel='bigru_persist_' + _n[6:] + '_kernel (one launch for all steps: W_hh slices resident in LDS as '
                               'bf16x3 fragments, v_mfma_f32_16x16x32_bf16, steps ordered by agent-scope counters)')
+        for _n, _flag in (('segrnn_fwd', 'last_segrnn_persistent'), ('segrnn_bwd', 'last_segrnn_bwd_persistent')):
+            if getattr(_K, _flag, False):   # small batches: the segment level as ONE persistent launch (csrc/seg_persist.hip)
+                cm[_n].update(gemm_launches=1, kernel='seg_persist_' + _n[7:] + '_kernel (one launch for all steps: four roles per slice of 16 '
+                              'units, weights resident in registers for the whole sequence, two in-launch hand-offs per step; sender MLPs, '
+                              'W_hh and the attention Gram matrix on 3 x bf16 (v_mfma_f32_16x16x32_bf16), the W_ih[:, messages] '
+                              'products / backward products on the fp32 matrix pipe (v_mfma_f32_16x16x4_f32))')
         x3_on = os.environ.get('TWOG_GEMM_X3', '1') != '0' and CFG['hidden_size'] >= 256 and bs * (H + O + 1) >= 6 * 64
         src, pmc = latest_pmc_rows(('gemm_gate_bwd_x3s', 'gemm_x3s', 'gemm_gru_fwd', 'gemm_x3d', 'gemm_gate_bwd_x3d'))
         chain_total_ms = sum(v for v in chain_ms.values() if v)
