@@ -976,7 +976,11 @@ __device__ __forceinline__ void gemm_tile(const Group& g, const GateArgs* ga) {
     // 64x64 class, the previous C values of accumulate launches. XS kernels fetch them only in the workgroup that
     // combines the slices (next to its slab loads), not in every slice.
     constexpr bool PREFETCH_C = (TM * TN == 1);
-    const bool epi_here = XS || g.splitk == 1;
+    // LA: the deterministic split-K of the non-chain launches (tall dW reductions) combined INSIDE the launch by the last
+    // arriver of each tile, as the XS kernels do (round 5; built, bit-identical to the two-launch form,
+    // measured slower and left OFF: see prepare_group). Tickets: g.xcnt (host: the first 16 KB of the split-K workspace).
+    const bool la = !XS && g.splitk > 1 && g.xcnt != nullptr;
+    const bool epi_here = XS || g.splitk == 1 || la;
     float bv[TN];
     float cprev[PREFETCH_C ? 16 : 1];
     // fused gate epilogue: its operands do not depend on this launch, so they are requested here, next to the first
@@ -1034,7 +1038,7 @@ __device__ __forceinline__ void gemm_tile(const Group& g, const GateArgs* ga) {
             }
         }
     };
-    const bool early = !XS || xs_slices == 1 || g.xs_early;
+    const bool early = XS ? (xs_slices == 1 || g.xs_early) : !la;
     if (early) fetch_epilogue();
 
     // uniform per workgroup: aligned operands and a reduction range made of whole k-tiles -> branch-free staging
@@ -1118,8 +1122,63 @@ __device__ __forceinline__ void gemm_tile(const Group& g, const GateArgs* ga) {
         }
     }
 
+    if constexpr (!XS && KS == 1) {
+        if (la) {   // uniform over the workgroup
+            // partial tile of slice `split`: [wave][TM x TN x 4 register quads][lane] x 16 bytes -- every store / load
+            // instruction of a wave covers 1 KB of whole 128-byte lines; the layout is private to this kernel
+            constexpr int QN = TM * TN * 4;
+            const int S = g.splitk;
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(g.slabs, 0, 0xffffffff, 0x00020000);
+            const uint32_t tile_bytes = BM * BN * 4u;
+            const uint32_t slice_stride = (uint32_t)g.total_tiles * tile_bytes;   // (host: S * slice_stride < 2^32)
+            const int tile_off = (int)((uint32_t)bid * tile_bytes);
+            const int wv = (int)(threadIdx.x >> 6);
+            const int lane_off = (int)(((uint32_t)wv * QN * 64u + (uint32_t)lane) * 16u);
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int b = 0; b < TN; ++b)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        f32x4 v = {acc[a][b][4 * q], acc[a][b][4 * q + 1], acc[a][b][4 * q + 2], acc[a][b][4 * q + 3]};
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, v), rs,
+                                                               lane_off + ((a * TN + b) * 4 + q) * 1024, tile_off + (int)((uint32_t)split * slice_stride), 16);
+                    }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains its write-through stores
+            __syncthreads();                                   // (also: every wave is done with the operand tiles in LDS)
+            unsigned* flag = reinterpret_cast<unsigned*>(smem);
+            if (threadIdx.x == 0)
+                *flag = __hip_atomic_fetch_add(g.xcnt + bid, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+            if (*flag != (unsigned)(S - 1)) return;
+            if (threadIdx.x == 0) __hip_atomic_store(g.xcnt + bid, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            fetch_epilogue();   // in flight together with the slab loads below
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int b = 0; b < TN; ++b)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+            for (int s0 = 0; s0 < S; ++s0) {   // added in slice order: bit-identical whoever arrives last
+                f32x4 v[QN];
+#pragma unroll
+                for (int i = 0; i < QN; ++i)
+                    v[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, lane_off + i * 1024, tile_off + (int)((uint32_t)s0 * slice_stride), 16));
+#pragma unroll
+                for (int a = 0; a < TM; ++a)
+#pragma unroll
+                    for (int b = 0; b < TN; ++b)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const f32x4 w = v[(a * TN + b) * 4 + q];
+                            acc[a][b][4 * q] += w.x; acc[a][b][4 * q + 1] += w.y; acc[a][b][4 * q + 2] += w.z; acc[a][b][4 * q + 3] += w.w;
+                        }
+            }
+        }
+    }
+
     // epilogue. C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
-    if (!XS && g.splitk > 1) {
+    if (!XS && g.splitk > 1 && !la) {
         // raw partials: slab[split][tile][BM][BN]
         float* slab = g.slabs + ((int64_t)split * g.total_tiles + bid) * (BM * BN);
 #pragma unroll
@@ -1504,7 +1563,7 @@ int launch(Group& g, int akm, int bkm, hipStream_t st) {
             else hipLaunchKernelGGL((gemm_x3_kernel<true, false, true>), grid, block, 0, st, g);
             TWOG_CHECK_LAUNCH();
             g_last_class_x3 = 1;
-            if (g.splitk > 1) {
+            if (g.splitk > 1 && !g.xcnt) {
                 hipLaunchKernelGGL((splitk_reduce_kernel<BM, BN>), dim3(g.total_tiles, (BM * BN) / 1024), dim3(256), 0, st, g);
                 TWOG_CHECK_LAUNCH();
             }
@@ -1522,7 +1581,7 @@ int launch(Group& g, int akm, int bkm, hipStream_t st) {
     else if (!kg) hipLaunchKernelGGL((gemm_kernel<BM, BN, NT, true, false, D, false>), grid, block, 0, st, g);
     else hipLaunchKernelGGL((gemm_kernel<BM, BN, NT, true, false, D, true>), grid, block, 0, st, g);
     TWOG_CHECK_LAUNCH();
-    if (g.splitk > 1) {
+    if (g.splitk > 1 && !g.xcnt) {
         hipLaunchKernelGGL((splitk_reduce_kernel<BM, BN>), dim3(g.total_tiles, (BM * BN) / 1024), dim3(256), 0, st, g);
         TWOG_CHECK_LAUNCH();
     }
@@ -1537,6 +1596,8 @@ extern "C" int twog_gemm_last_class(void) { return g_last_class; }
 
 // Builds the launch descriptor of one chunk (<= MAXP problems): tile class, class-sorted problem list (order[i] = index of
 // the caller's problem that became sorted problem i), XCD map, split-K. Shared by the plain and the gate-fused launch.
+constexpr size_t SPLITK_TICKET_BYTES = 16384;   // 4096 tickets at the start of the split-K workspace (see prepare_group)
+
 static void prepare_group(const twog_gemm_t* pr, int n, int a_kmajor, int b_kmajor, void* workspace,
                           size_t workspace_bytes, Group& g, int* order, bool& big, int& bm) {
     // tile choice: 128x128 tiles (4 MFMA tiles per wave, half the LDS traffic per FLOP) whenever the problems are
@@ -1646,7 +1707,7 @@ static void prepare_group(const twog_gemm_t* pr, int n, int a_kmajor, int b_kmaj
             // (splits of at least 1 024 k: below that the slabs -- 64 KB written and read per tile and split -- weigh more
             // than the operand re-reads saved; measured on the K = 15 360 shapes: 0.365 -> 0.426 ms with 24 splits of 640)
             for (int s8 = 8; s8 <= 64 && s8 <= kmax / 1024; s8 += 8) {
-                if ((size_t)s8 * t * BMN * BMN * sizeof(float) > workspace_bytes) break;
+                if ((size_t)s8 * t * BMN * BMN * sizeof(float) + SPLITK_TICKET_BYTES > workspace_bytes) break;
                 const int64_t per_xcd = (int64_t)t * s8 / 8;
                 const double e8 = (double)per_xcd / (double)(((per_xcd + 63) / 64) * 64);
                 if (e8 > best8 + 1e-9) { best8 = e8; want8 = s8; }
@@ -1655,13 +1716,22 @@ static void prepare_group(const twog_gemm_t* pr, int n, int a_kmajor, int b_kmaj
             if (want8 && best8 + 0.08 < best) want8 = 0;   // (48 tiles x 8 splits of 1 920 at K = 15 360: 0.150 against 0.138 ms)
         }
         if (want8) want = want8;
-        const size_t need = (size_t)want * t * BMN * BMN * sizeof(float);
+        // the first 16 KB of the workspace are the arrival tickets of the in-launch combine (LA, gemm_tile): zero when the
+        // workspace is first handed over, returned to zero by every launch. OFF by default -- measured on one box, same
+        // session: bs64 step 69.32 ms with it against 68.57 ms with slabs + splitk_reduce_kernel, 8-clip step 16.32 against
+        // 16.28 (profiles/r05_splitk_in_launch_combine_ab.txt): the one workgroup per tile that arrives last re-reads S slabs
+        // of 64 KB alone, where the reduce launch spreads the same bytes over 16 workgroups per tile at 5 TB/s; what the
+        // launch boundary costs is less than that. TWOG_GEMM_LA=1 selects it (tests run both).
+        static const int la_on = getenv("TWOG_GEMM_LA") ? atoi(getenv("TWOG_GEMM_LA")) : 0;
+        const size_t need = (size_t)want * t * BMN * BMN * sizeof(float) + SPLITK_TICKET_BYTES;
         if (want > 1 && need <= workspace_bytes) {
             int kps = (kmax + want - 1) / want;
             g.k_per_split = ((kps + BK - 1) / BK) * BK;
             g.splitk = (kmax + g.k_per_split - 1) / g.k_per_split;
-            g.slabs = reinterpret_cast<float*>(workspace);
+            g.slabs = reinterpret_cast<float*>(static_cast<char*>(workspace) + SPLITK_TICKET_BYTES);
             g.xcd_split = (want8 && g.splitk % 8 == 0) ? 1 : 0;
+            const bool fits32 = (uint64_t)g.splitk * t * BMN * BMN * sizeof(float) < (uint64_t(1) << 32);
+            if (la_on && bm == BMN && t <= (int)(SPLITK_TICKET_BYTES / sizeof(unsigned)) && fits32) g.xcnt = static_cast<unsigned*>(workspace);
         }
     }
 }

@@ -139,6 +139,10 @@ class HipKernels:
         buf = self._ws.get(k)
         if buf is None or buf.numel() * 4 < nbytes:
             buf = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=device)
+            if key == 'splitk':
+                # the first 16 KB of the split-K workspace are the arrival tickets of the in-launch combine (include/twog_gcn.h,
+                # twog_gemm_f32): zero when first handed over, returned to zero by every launch
+                self.fill_zero(buf[:4096])
             self._ws_put(k, buf)
         else:
             self._ws_touch(k)

@@ -44,7 +44,12 @@ const char* twog_version(void);
  * a_kmajor = 0: A stored [M rows][K contiguous];            1: A stored [K rows][M contiguous].
  * b_kmajor = 0: B stored [N rows][K contiguous] (nn.Linear weight); 1: B stored [K rows][N contiguous].
  * The strided index of each operand goes through twog_rows_t. All problems of one call share the layout flags and run
- * as grouped launches. `workspace` (may be NULL) enables deterministic split-K for tall-reduction/small-output shapes.
+ * as grouped launches. `workspace` (may be NULL) enables deterministic split-K for tall-reduction/small-output shapes:
+ * caller-owned scratch whose first 16 KB (arrival tickets) are ZERO when it is first handed over and are afterwards left to
+ * the library; the k-slices of a tile write partial tiles (slabs) behind the tickets and an ordered-reduce launch adds them
+ * in slice order (bit-reproducible) and runs the epilogue. TWOG_GEMM_LA=1: the slice that arrives last at a tile's ticket
+ * adds them inside the launch instead (same results bit for bit; measured slower, off by default). One workspace must not
+ * be used by launches that can run concurrently (different streams): give each stream its own.
  * =============================================================================================================== */
 typedef struct {
     twog_rows_t A, B, C;
