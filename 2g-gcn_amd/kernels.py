@@ -437,9 +437,8 @@ class HipKernels:
         mode = os.environ.get('TWOG_PERSIST_CHECK', 'auto')
         word = sync.view(torch.int32)[err_index:err_index + 1]
         if mode == 'lazy' or (mode != 'sync' and HipKernels._clean.get(i, 0) >= self.PERSIST_SYNC_CALLS):
-            host = torch.empty(1, dtype=torch.int32, pin_memory=True)
+            host, ev = self._lazy_slot(i)
             host.copy_(word, non_blocking=True)
-            ev = torch.cuda.Event()
             ev.record()
             HipKernels._lazy.setdefault(i, []).append((ev, host, what))
             return True
@@ -450,6 +449,18 @@ class HipKernels:
         HipKernels._backoff[i] = self.PERSISTENT_BACKOFF
         HipKernels._clean[i] = 0
         return False
+
+    _slots = {}   # device index -> ([pinned int32 [1] tensors], [events], next): a ring, so that a training step allocates nothing
+
+    def _lazy_slot(self, i, n=32):
+        ring = HipKernels._slots.get(i)
+        if ring is None:
+            pinned = torch.zeros(n, dtype=torch.int32).pin_memory()
+            ring = [[pinned[k:k + 1] for k in range(n)], [torch.cuda.Event() for _ in range(n)], 0]
+            HipKernels._slots[i] = ring
+        k = ring[2]
+        ring[2] = (k + 1) % n
+        return ring[0][k], ring[1][k]
 
     def verify_persistent(self, dev=None):
         """End of a forward / backward pass: every persistent launch of the pass whose error word was left for later must

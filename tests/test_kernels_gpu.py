@@ -188,6 +188,51 @@ def _gemm128_run(K, akm, bkm, M, N, K_, *, bias, act, acc, ws=True, group=None, 
     return cls
 
 
+_LA_CHILD = r"""
+import os, sys, torch
+sys.path.insert(0, sys.argv[1])
+import twog_gcn_amd
+from twog_gcn_amd import kernels
+K = kernels.get_kernels()
+out = {}
+for name, (akm, bkm, M, N, Kd, bias, act, acc, seed) in dict(
+        tt=(True, True, 512, 2048, 61440, False, 0, False, 4), tt2=(True, True, 1536, 2560, 30720, True, 1, True, 5),
+        nt=(False, True, 20000, 1000, 1536, False, 0, False, 3), small=(True, True, 192, 192, 8192, True, 0, True, 9)).items():
+    g = torch.Generator().manual_seed(1000 + seed)
+    A = (torch.randn((Kd, M) if akm else (M, Kd), generator=g)).cuda()
+    B = (torch.randn((Kd, N) if bkm else (N, Kd), generator=g) * 0.1).cuda()
+    b = torch.randn(N, generator=g).cuda() if bias else None
+    C = torch.randn(M, N, generator=g).cuda()
+    for rep in range(2):   # twice: the tickets must be back at zero after the first launch
+        Cg = C.clone()
+        K.gemm([dict(A=A, B=B, C=Cg, bias=b, act=act, accumulate=acc)], a_kmajor=akm, b_kmajor=bkm)
+        out[f'{name}{rep}'] = (Cg.cpu(), K.gemm_last_class())
+torch.cuda.synchronize()
+torch.save(out, sys.argv[2])
+"""
+
+
+def test_gemm_split_k_in_launch_combine_equals_the_reduce_launch_bit_for_bit(K, tmp_path):
+    """TWOG_GEMM_LA=1 (the k-slices of a tile combined inside the launch by the slice that arrives last; off by default:
+    measured slower, profiles/r05_splitk_in_launch_combine_ab.txt) against the default slabs + ordered-reduce launch: both add
+    the slices in slice order, so every output word must be equal -- tall dW reductions (8-wave X3 class, XCD-dealt splits),
+    a dX shape, a small-output shape of the 64x64 class; every case twice (the tickets return to zero)."""
+    res = {}
+    for la in ('0', '1'):
+        f = tmp_path / f'la{la}.pt'
+        env = dict(os.environ, TWOG_GEMM_LA=la)
+        r = subprocess.run([sys.executable, '-c', _LA_CHILD, ROOT, str(f)], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[la] = torch.load(f)
+    split_seen = False
+    for k in res['0']:
+        (a, ca), (b, cb) = res['0'][k], res['1'][k]
+        assert ca == cb, (k, hex(ca), hex(cb))
+        split_seen = split_seen or bool(ca & K.GEMM_SPLITK)
+        assert torch.isfinite(b).all() and torch.equal(a, b), f'{k}: in-launch combine differs from the reduce launch'
+    assert split_seen, 'no case took the split-K path'
+
+
 def _gemm128_cases(K, w8=True):
     T128, W8, KG, SK = K.GEMM_TILE128, K.GEMM_WAVES8, K.GEMM_KG, K.GEMM_SPLITK
     full = T128 | W8 | KG | SK

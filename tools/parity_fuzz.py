@@ -108,7 +108,7 @@ def one_case(rng, idx, dev=DEV, dry=False, run_seed=0):
         if rng2.random() < 0.125:
             bs, T = rng2.randint(6, 14), rng2.randint(10, 18)
     O, N = rng.randint(1, 12), rng.choice([19, 26, 30, 34, 21, 40])
-    h = rng.choice([16, 32, 48, 64, 80, 16, 32, 48, 64, 80, 256])   # 256: four column tiles per GEMM problem
+    h = rng.choice([16, 32, 48, 64, 80, 16, 32, 48, 64, 80, 256, 128, 64])   # 256: four column tiles per GEMM problem; 64 / 128 / 256: the persistent segment launches (round 5)
     if H == 1:
         cfg['message_humans_to_human'] = False
     if O == 1:
