@@ -75,10 +75,15 @@ class HipKernels:
         self._tape = None
 
     # ---------------------------------------------------------------- utilities
-    @staticmethod
-    def _stream():
+    def _stream(self):
         # the raw handle of torch's current stream on the current device: two C calls (~0.3 us) instead of the
         # torch.cuda.current_stream() Stream object (~8 us) -- a host-composed step asks for it thousands of times
+        if self._tape is not None:
+            # Between tape_begin() and tape_end() only the recordable entry points may be called (they return before they get
+            # here): anything else would launch NOW, for the composed steps only, and be missing from every replayed step --
+            # and the replay could not know. A programming error, raised where it happens.
+            raise RuntimeError('a kernel entry point that cannot be recorded was called while a step is being taped '
+                               '(kernels.tape_begin): only gemm (not chain), gru_step_*, relation_*_many and rowops may run there')
         if _RAW_STREAM is not None:
             return _RAW_STREAM(_CUR_DEVICE())
         return torch.cuda.current_stream().cuda_stream
@@ -223,6 +228,7 @@ class HipKernels:
             else:
                 g.batch, g.a_batch_stride, g.b_batch_stride, g.c_batch_stride = b
         if chain:
+            assert self._tape is None, 'chain launches cannot be recorded (kernels.tape_begin)'
             rc = self.lib.twog_gemm_f32_chain(arr, n, int(a_kmajor), int(b_kmajor), *self.chain_workspace(dev), self._stream())
             self._check(rc, 'twog_gemm_f32_chain')
             return
