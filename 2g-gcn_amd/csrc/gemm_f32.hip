@@ -1265,7 +1265,7 @@ __device__ __forceinline__ void gemm_tile(const Group& g, const GateArgs* ga) {
                 if (col >= N) continue;
                 float v = acc[a][b][r];
                 if constexpr (PREFETCH_C) {
-                    v += bv[b] + cprev[r];
+                    v = (v + bv[b]) + cprev[r];   // (the order of splitk_reduce_kernel and of the 128x128 branch below)
                 } else {  // 128x128 class: registers are full, and its long reduction makes the epilogue latency immaterial
                     if (bias) v += bias[col];
                     if (accumulate) v += crow[col];
