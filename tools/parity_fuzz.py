@@ -351,11 +351,18 @@ def main():
                    cases_with_a_relu_unit_on_the_other_side_of_zero=sum(1 for r in ok if r.get('relu_boundary')),
                    cases_with_a_hard_decision_on_the_rounding_boundary=sum(1 for r in ok if r.get('decision_on_rounding_boundary')),
                    seconds=time.time() - t0)
+    # every case accepted by the ReLU-signature rule, with whether tests/relu_boundary.py CONFIRMED the unit (recomputed the
+    # owner layer's pre-activations in fp64 and found the unit within rounding of zero); an unconfirmed acceptance fails the sweep
+    accepted = [dict(idx=r['idx'], layout=dict(bs=r['bs'], T=r['T'], H=r['H'], O=r['O'], N=r['N'], h=r['h']),
+                     candidate_owners=r['relu_boundary'], confirmed_by_fp64=bool(r.get('relu_boundary_confirmed')),
+                     worst_grad_rel_of_the_case=r.get('relu_boundary_worst_rel')) for r in ok if r.get('relu_boundary')]
+    summary['cases_accepted_by_the_relu_signature_rule'] = accepted
+    summary['unconfirmed_acceptances'] = sum(1 for a in accepted if not a['confirmed_by_fp64'])
     os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
     json.dump(dict(summary=summary, failures=failures, results=results),
               open(os.path.join(ROOT, 'gpurun_out', 'parity_fuzz.json'), 'w'), indent=1)
     print(json.dumps(summary))
-    sys.exit(1 if failures else 0)
+    sys.exit(1 if failures or summary['unconfirmed_acceptances'] else 0)
 
 
 if __name__ == '__main__':
