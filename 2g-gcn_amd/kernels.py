@@ -108,6 +108,43 @@ class HipKernels:
             self._check(self.lib.twog_fill_zero(t.data_ptr(), t.numel() * t.element_size(), self._stream()), 'twog_fill_zero')
         return t
 
+    # ---------------------------------------------------------------- side stream (independent work beside a launch chain)
+    class _Side:
+        """`with side:` issues launches on a second stream of the device; it starts behind everything the caller's stream
+        holds at construction, join() makes the caller's stream wait for it. Tensors allocated inside belong to the side
+        stream's pool (torch's allocator handles their reuse); tensors of the caller's stream that the side launches read must
+        stay referenced until join() (ops keeps them in the saved state of the pass)."""
+
+        def __init__(self, stream):
+            self.main = torch.cuda.current_stream()
+            self.stream = stream
+            ev = torch.cuda.Event()
+            ev.record(self.main)
+            stream.wait_event(ev)
+            self._ctx = None
+
+        def __enter__(self):
+            self._ctx = torch.cuda.stream(self.stream)
+            self._ctx.__enter__()
+            return self
+
+        def __exit__(self, *a):
+            return self._ctx.__exit__(*a)
+
+        def join(self):
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+            self.main.wait_event(ev)
+
+    _side_streams = {}
+
+    def side_stream(self, dev):
+        i = self._dev_index(dev)
+        st = HipKernels._side_streams.get(i)
+        if st is None:
+            st = HipKernels._side_streams[i] = torch.cuda.Stream(device=dev)
+        return HipKernels._Side(st)
+
     def debug_occupy(self, n_blocks, lds_bytes, usec):
         """Diagnostics (tests): n_blocks workgroups holding lds_bytes of LDS each for usec microseconds on the current stream."""
         self._check(self.lib.twog_debug_occupy(n_blocks, lds_bytes, usec, self._stream()), 'twog_debug_occupy')

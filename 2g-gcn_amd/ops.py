@@ -1492,6 +1492,11 @@ def tggcn_backward(K, plan: Plan, P, S, x_human, x_objects, objects_mask, d_outp
     dHUMv, dOBJv, dGEOv = _v2(dHUM), _v2(dOBJ), _v2(dGEO)
     cells = {('h', 0): 'human_segment_rnn_fcell', ('h', 1): 'human_segment_rnn_bcell',
              ('o', 0): 'object_segment_rnn_fcell', ('o', 1): 'object_segment_rnn_bcell'}
+    # The PARAMETER gradients of the segment level (tall dW GEMMs over all bs T E rows, bias column sums) depend only on what
+    # the recurrence backward left behind and nothing downstream reads them: they are collected here and issued together --
+    # on the caller's stream, or (TWOG_SIDE_DW=1) on a side stream that runs beside the rest of the backward pass, in
+    # particular beside the frame-level BiGRU chain whose per-step launches leave a third of the chip idle.
+    pgrads = []
     for kind, E, Ev, dEv, fw, dgi, dgh, HS, mg in (('h', H, HUMv, dHUMv, p.fw_h, so['d_gi_h'], so['d_gh_h'], sb['hs_h'], sb['mg_h']),
                                                     ('o', O, OBJv, dOBJv, p.fw_o, so['d_gi_o'], so['d_gh_o'], sb['hs_o'], sb['mg_o'])):
         if E == 0:
@@ -1501,11 +1506,8 @@ def tggcn_backward(K, plan: Plan, P, S, x_human, x_objects, objects_mask, d_outp
             c = cells[(kind, d)]
             dgi_d = dgiv[:, d * 3 * h:(d + 1) * 3 * h]
             w_ih = P[c + '.weight_ih']
-            dW_ih = empty(*w_ih.shape)
             ssp = p.ssp_blocks() if kind == 'o' else None
-            if ssp is None:
-                K.gemm([dict(A=dgi_d, B=Ev[:, h:h + fw], C=dW_ih[:, :fw])], a_kmajor=True, b_kmajor=True)
-            else:
+            if ssp is not None:
                 # sender-side projection (see forward): the receivers' rows only for the blocks outside [c0, c1); the
                 # sender blocks reduce over the H + 1 sender rows of every frame, weighted sums qh / qs of d_gi
                 c0, c1 = ssp
@@ -1516,55 +1518,68 @@ def tggcn_backward(K, plan: Plan, P, S, x_human, x_objects, objects_mask, d_outp
                                        dw=dw_extra)
                     sx.update(qh=qh, qs=qs, dw_extra=dw_extra,
                               dmsg_ho=zeros(nF * H, h) if sx['ho_on'] else None, dmsg_so=zeros(nF, h) if sx['so_on'] else None)
-                K.gemm([dict(A=dgi_d, B=Ev[:, h:c0], C=dW_ih[:, :c0 - h])], a_kmajor=True, b_kmajor=True)
-                if c1 < h + fw:
-                    K.gemm([dict(A=dgi_d, B=Ev[:, c1:h + fw], C=dW_ih[:, c1 - h:fw])], a_kmajor=True, b_kmajor=True)
-                for on, q, msgs, rel, dm in ((sx['ho_on'], sx['qh'], S['MSGH'], 'ho', sx['dmsg_ho']),
-                                             (sx['so_on'], sx['qs'], S['MSGS'], 'so', sx['dmsg_so'])):
-                    if not on:
-                        continue
-                    rels = p.snd_h if rel == 'ho' else p.snd_s
-                    i_ = rels.index(rel)
-                    cc = p.col_o[rel] - h
-                    q_d = q[:, d * 3 * h:(d + 1) * 3 * h]
-                    K.gemm([dict(A=q_d, B=msgs[:, i_ * h:(i_ + 1) * h], C=dW_ih[:, cc:cc + h])], a_kmajor=True, b_kmajor=True)
-                    K.gemm([dict(A=q_d, B=w_ih[:, cc:cc + h], C=dm, accumulate=True)], b_kmajor=True)
-            if w_ih.shape[1] > fw:
-                seg_rels_k = p.seg_mh if kind == 'h' else p.seg_mo
-                ssp_seg = (kind == 'o' and 'ho' in seg_rels_k and H < O and not p.general_segment()
-                           and not p.no_ssp)
-                if not ssp_seg:
-                    K.gemm([dict(A=dgi_d, B=_v2(mg[d]), C=dW_ih[:, fw:])], a_kmajor=True, b_kmajor=True)
+                for on, q, rel, dm in ((sx['ho_on'], sx['qh'], 'ho', sx['dmsg_ho']), (sx['so_on'], sx['qs'], 'so', sx['dmsg_so'])):
+                    if on:
+                        cc = p.col_o[rel] - h
+                        K.gemm([dict(A=q[:, d * 3 * h:(d + 1) * 3 * h], B=w_ih[:, cc:cc + h], C=dm, accumulate=True)], b_kmajor=True)
+
+            def weight_grads(kind=kind, E=E, Ev=Ev, fw=fw, dgi=dgi, dgh=dgh, HS=HS, mg=mg, d=d, c=c, dgi_d=dgi_d, w_ih=w_ih, ssp=ssp,
+                             dghv=dghv):
+                dW_ih = empty(*w_ih.shape)
+                if ssp is None:
+                    K.gemm([dict(A=dgi_d, B=Ev[:, h:h + fw], C=dW_ih[:, :fw])], a_kmajor=True, b_kmajor=True)
                 else:
-                    # sender-side form of the human->object block (see ssp.hip): mg_ho[k] = sum_h att[k][h] msrc_ho[h], so
-                    # its weight gradient reduces over the H sender rows of every (clip, step) with q = sum_k att d_gi
-                    mgv = _v2(mg[d])
-                    for i_, rel_ in enumerate(seg_rels_k):
-                        blk = dW_ih[:, fw + i_ * h:fw + (i_ + 1) * h]
-                        if rel_ != 'ho':
-                            K.gemm([dict(A=dgi_d, B=mgv[:, i_ * h:(i_ + 1) * h], C=blk)], a_kmajor=True, b_kmajor=True)
+                    c0, c1 = ssp
+                    sx = S['ssp']
+                    K.gemm([dict(A=dgi_d, B=Ev[:, h:c0], C=dW_ih[:, :c0 - h])], a_kmajor=True, b_kmajor=True)
+                    if c1 < h + fw:
+                        K.gemm([dict(A=dgi_d, B=Ev[:, c1:h + fw], C=dW_ih[:, c1 - h:fw])], a_kmajor=True, b_kmajor=True)
+                    for on, q, msgs, rel in ((sx['ho_on'], sx['qh'], S['MSGH'], 'ho'), (sx['so_on'], sx['qs'], S['MSGS'], 'so')):
+                        if not on:
                             continue
-                        natt = sb['att'].shape[-1]
-                        qh = K.ssp_gather(dgi_d, sb['att'][d], natt, bs * natt, H * H + H * O, nF, T, H, O)
-                        i_s = S['seg_rels'][0].index('ho')
-                        K.gemm([dict(A=qh, B=_v2(sb['msrc_h'][d])[:, i_s * h:(i_s + 1) * h], C=blk)],
+                        rels = p.snd_h if rel == 'ho' else p.snd_s
+                        i_ = rels.index(rel)
+                        cc = p.col_o[rel] - h
+                        K.gemm([dict(A=q[:, d * 3 * h:(d + 1) * 3 * h], B=msgs[:, i_ * h:(i_ + 1) * h], C=dW_ih[:, cc:cc + h])],
                                a_kmajor=True, b_kmajor=True)
-            G.add(c + '.weight_ih', dW_ih)
-            _gru_bias_grads(K, G, c + '.bias_ih', c + '.bias_hh', dgi_d, dghv[:, d * 3 * h:(d + 1) * 3 * h], h)
-            # dW_hh = sum over steps with a previous state: forward chain pairs (t, t-1), backward chain (t, t+1)
-            dW_hh = empty(3 * h, h)
-            if T > 1:
-                if d == 0:
-                    A = dgh[:, 1:, :, 0:3 * h].reshape(bs, (T - 1) * E, 3 * h)
-                    B = HS[:, :T - 1, :, 0:h].reshape(bs, (T - 1) * E, h)
+                if w_ih.shape[1] > fw:
+                    seg_rels_k = p.seg_mh if kind == 'h' else p.seg_mo
+                    ssp_seg = (kind == 'o' and 'ho' in seg_rels_k and H < O and not p.general_segment()
+                               and not p.no_ssp)
+                    if not ssp_seg:
+                        K.gemm([dict(A=dgi_d, B=_v2(mg[d]), C=dW_ih[:, fw:])], a_kmajor=True, b_kmajor=True)
+                    else:
+                        # sender-side form of the human->object block (see ssp.hip): mg_ho[k] = sum_h att[k][h] msrc_ho[h], so
+                        # its weight gradient reduces over the H sender rows of every (clip, step) with q = sum_k att d_gi
+                        mgv = _v2(mg[d])
+                        for i_, rel_ in enumerate(seg_rels_k):
+                            blk = dW_ih[:, fw + i_ * h:fw + (i_ + 1) * h]
+                            if rel_ != 'ho':
+                                K.gemm([dict(A=dgi_d, B=mgv[:, i_ * h:(i_ + 1) * h], C=blk)], a_kmajor=True, b_kmajor=True)
+                                continue
+                            natt = sb['att'].shape[-1]
+                            qh_ = K.ssp_gather(dgi_d, sb['att'][d], natt, bs * natt, H * H + H * O, nF, T, H, O)
+                            i_s = S['seg_rels'][0].index('ho')
+                            K.gemm([dict(A=qh_, B=_v2(sb['msrc_h'][d])[:, i_s * h:(i_s + 1) * h], C=blk)],
+                                   a_kmajor=True, b_kmajor=True)
+                G.add(c + '.weight_ih', dW_ih)
+                _gru_bias_grads(K, G, c + '.bias_ih', c + '.bias_hh', dgi_d, dghv[:, d * 3 * h:(d + 1) * 3 * h], h)
+                # dW_hh = sum over steps with a previous state: forward chain pairs (t, t-1), backward chain (t, t+1)
+                dW_hh = empty(3 * h, h)
+                if T > 1:
+                    if d == 0:
+                        A = dgh[:, 1:, :, 0:3 * h].reshape(bs, (T - 1) * E, 3 * h)
+                        B = HS[:, :T - 1, :, 0:h].reshape(bs, (T - 1) * E, h)
+                    else:
+                        A = dgh[:, :T - 1, :, 3 * h:6 * h].reshape(bs, (T - 1) * E, 3 * h)
+                        B = HS[:, 1:, :, h:2 * h].reshape(bs, (T - 1) * E, h)
+                    assert A.data_ptr() != 0 and A._base is not None and B._base is not None  # views, not copies
+                    K.gemm([dict(A=A, B=B, C=dW_hh)], a_kmajor=True, b_kmajor=True)
                 else:
-                    A = dgh[:, :T - 1, :, 3 * h:6 * h].reshape(bs, (T - 1) * E, 3 * h)
-                    B = HS[:, 1:, :, h:2 * h].reshape(bs, (T - 1) * E, h)
-                assert A.data_ptr() != 0 and A._base is not None and B._base is not None  # views, not copies
-                K.gemm([dict(A=A, B=B, C=dW_hh)], a_kmajor=True, b_kmajor=True)
-            else:
-                dW_hh.zero_()
-            G.add(c + '.weight_hh', dW_hh)
+                    dW_hh.zero_()
+                G.add(c + '.weight_hh', dW_hh)
+
+            pgrads.append(weight_grads)
             # d xx (frame-level part of the GRUCell input) -> entity-row gradient columns [h, h+fw)
             if ssp is None:
                 K.gemm([dict(A=dgi_d, B=w_ih[:, :fw], C=dEv[:, h:h + fw], accumulate=True)], b_kmajor=True)
@@ -1577,19 +1592,35 @@ def tggcn_backward(K, plan: Plan, P, S, x_human, x_objects, objects_mask, d_outp
         for rels, E, dpre, HS, key in ((sh_rel, H, so['d_pre_h'], sb['hs_h'], 'h'), (so_rel, O, so['d_pre_o'], sb['hs_o'], 'o')):
             if not rels or E == 0:
                 continue
-            n = len(rels)
-            dWp = empty(n * h, h)
-            if T > 1:
-                K.gemm([dict(A=dpre[0][:, 1:].reshape(bs, (T - 1) * E, n * h), B=HS[:, :T - 1, :, 0:h].reshape(bs, (T - 1) * E, h),
-                             C=dWp)], a_kmajor=True, b_kmajor=True)
-                K.gemm([dict(A=dpre[1][:, :T - 1].reshape(bs, (T - 1) * E, n * h), B=HS[:, 1:, :, h:2 * h].reshape(bs, (T - 1) * E, h),
-                             C=dWp, accumulate=True)], a_kmajor=True, b_kmajor=True)
-            else:
-                dWp.zero_()
-            dbp = K.colsum(dpre.view(-1, n * h))
-            for i, r in enumerate(rels):
-                G.add(_SEG_MLP[r] + '.0.weight', dWp[i * h:(i + 1) * h])
-                G.add(_SEG_MLP[r] + '.0.bias', dbp[i * h:(i + 1) * h])
+
+            def sender_grads(rels=rels, E=E, dpre=dpre, HS=HS):
+                n = len(rels)
+                dWp = empty(n * h, h)
+                if T > 1:
+                    K.gemm([dict(A=dpre[0][:, 1:].reshape(bs, (T - 1) * E, n * h), B=HS[:, :T - 1, :, 0:h].reshape(bs, (T - 1) * E, h),
+                                 C=dWp)], a_kmajor=True, b_kmajor=True)
+                    K.gemm([dict(A=dpre[1][:, :T - 1].reshape(bs, (T - 1) * E, n * h), B=HS[:, 1:, :, h:2 * h].reshape(bs, (T - 1) * E, h),
+                                 C=dWp, accumulate=True)], a_kmajor=True, b_kmajor=True)
+                else:
+                    dWp.zero_()
+                dbp = K.colsum(dpre.view(-1, n * h))
+                for i, r in enumerate(rels):
+                    G.add(_SEG_MLP[r] + '.0.weight', dWp[i * h:(i + 1) * h])
+                    G.add(_SEG_MLP[r] + '.0.bias', dbp[i * h:(i + 1) * h])
+
+            pgrads.append(sender_grads)
+    side = None
+    # Default on where the frame-level BiGRU backward runs launch by launch (real batches); not beside its persistent launch
+    # (small batches: that one needs every compute unit), not with a stage hook (the stage-0 all-reduce needs these gradients
+    # right away). Measured at 64 clips, same box, alternating: 66.85 / 66.33 ms without, 65.75 / 65.74 ms with (another box:
+    # 68.08 / 67.88 against 67.21 / 66.97). TWOG_SIDE_DW=0: everything on the caller's stream.
+    side_on = (bool(pgrads) and os.environ.get('TWOG_SIDE_DW', '1') == '1' and hasattr(K, 'side_stream')
+               and not p.general_segment() and getattr(p, 'stage_hook', None) is None and x_human.is_cuda
+               and not K.bigru_bwd_would_persist([H, O, 1], bs, h))
+    if not side_on:
+        for fn in pgrads:
+            fn()
+        pgrads = []
 
     # ---- position features appended to the GRUCell inputs: parameter gradients, and -- segment lengths -- the gradient
     # that reaches the hard decisions through the length scan (straight-through values carry it on to the soft ones)
@@ -1771,6 +1802,12 @@ def tggcn_backward(K, plan: Plan, P, S, x_human, x_objects, objects_mask, d_outp
         dhfrs.append(dhfr)
         types.append(dict(d_out=dhfr, save=save, out=hfr, w_hh_f=P[name + '_bd_rnn.weight_hh_l0'],
                           w_hh_r=P[name + '_bd_rnn.weight_hh_l0_reverse']))
+    if side_on and pgrads:
+        # beside the frame-level BiGRU chain (launch per step: 176 of 256 compute units busy at ~10 % of the matrix pipe)
+        side = K.side_stream(dev)      # starts behind everything issued so far on the caller's stream
+        with side:
+            for fn in pgrads:
+                fn()
     res = K.bigru_bwd(types, bs, T, h, allow_persistent=defer_stage0 or getattr(p, 'stage_hook', None) is None)
     if defer_stage0:
         _stage_done(p, 0)
@@ -1861,6 +1898,8 @@ def tggcn_backward(K, plan: Plan, P, S, x_human, x_objects, objects_mask, d_outp
     G.add(g + 'joint_embed.cnn.1.cnn.bias', db1)
     G.add(g + 'joint_embed.cnn.0.bn.weight', dgamma)
     G.add(g + 'joint_embed.cnn.0.bn.bias', dbeta)
+    if side is not None:
+        side.join()
     if hasattr(K, 'verify_persistent'):
         K.verify_persistent(dev)
     return G.g
