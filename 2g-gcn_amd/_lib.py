@@ -121,6 +121,14 @@ class RowOp(C.Structure):  # twog_rowop_t
                 ('rows', C.c_int32), ('cols', C.c_int32), ('pad_', C.c_int32)]
 
 
+class ColSum(C.Structure):  # twog_colsum_t
+    _fields_ = [('x', Rows), ('rowscale', C.c_void_p), ('out', C.c_void_p), ('rows', C.c_int32), ('cols', C.c_int32),
+                ('accumulate', C.c_int32), ('pad_', C.c_int32)]
+
+
+COLSUM_MAX = 16   # TWOG_COLSUM_MAX
+
+
 class Copy(C.Structure):  # twog_copy_t
     _fields_ = [('src', C.c_void_p), ('dst', C.c_void_p), ('n', C.c_int64)]
 
@@ -202,6 +210,8 @@ SIGNATURES = {
     'twog_gate_bwd': [C.POINTER(Gate), _P, _P, _P, _P, _P],
     'twog_rank1_update': [Rows, _P, _P, _I, _I, _P],
     'twog_colsum': [Rows, _P, _I, _I, _P, _I, _P, _I, _P],
+    'twog_colsum_n_partial_floats': [C.POINTER(ColSum), _I],
+    'twog_colsum_n': [C.POINTER(ColSum), _I, _P, C.c_size_t, _P],
     'twog_filter_fwd': [_P, _P, _P, _I, _I, _I, _F, _P],
     'twog_reorder_fwd': [_P, _P, _P, _I, _I, _I, _I, _P],
     'twog_reorder_bwd': [_P, _P, _P, _I, _I, _I, _I, _P],
@@ -238,6 +248,7 @@ def load():
         fn.argtypes = argtypes
         fn.restype = C.c_int
     lib.twog_chain_workspace_bytes.restype = C.c_size_t
+    lib.twog_colsum_n_partial_floats.restype = C.c_size_t
     lib.twog_segrnn_persistent_sync_bytes.restype = C.c_size_t
     lib.twog_segrnn_bwd_persistent_scratch_bytes.restype = C.c_size_t
     lib.twog_version.restype = C.c_char_p

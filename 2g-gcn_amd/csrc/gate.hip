@@ -86,14 +86,14 @@ __global__ __launch_bounds__(256) void rank1_kernel(twog_rows_t dst, const float
 // VEC: every lane owns 4 consecutive columns (one 16-byte load per row: 1 KiB per wave instruction) and 4 independent
 // row streams are kept in flight; block = 64 column-quads x 4 row lanes.
 template <bool VEC>
-__global__ __launch_bounds__(256) void wcolsum_partial_kernel(twog_rows_t x, const float* s, int rows, int cols,
-                                                              float* partials) {
+__device__ __forceinline__ void wcolsum_partial_body(const twog_rows_t& x, const float* s, int rows, int cols, float* partials,
+                                                     int col_block, int row_block, int n_row_blocks) {
     constexpr int CW = VEC ? 4 : 1;
     __shared__ float red[4][64 * CW];
     const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
-    const int c = (blockIdx.x * 64 + cl) * CW;
-    const int per = (rows + gridDim.y - 1) / gridDim.y;
-    const int r0 = blockIdx.y * per, r1 = min(rows, r0 + per);
+    const int c = (col_block * 64 + cl) * CW;
+    const int per = (rows + n_row_blocks - 1) / n_row_blocks;
+    const int r0 = row_block * per, r1 = min(rows, r0 + per);
     float acc[CW];
 #pragma unroll
     for (int i = 0; i < CW; ++i) acc[i] = 0.f;
@@ -131,17 +131,23 @@ __global__ __launch_bounds__(256) void wcolsum_partial_kernel(twog_rows_t x, con
     if (rl == 0 && c < cols) {
 #pragma unroll
         for (int i = 0; i < CW; ++i)
-            partials[(int64_t)blockIdx.y * cols + c + i] =
+            partials[(int64_t)row_block * cols + c + i] =
                 (red[0][cl * CW + i] + red[1][cl * CW + i]) + (red[2][cl * CW + i] + red[3][cl * CW + i]);
     }
 }
 
-__global__ __launch_bounds__(1024) void wcolsum_final_kernel(const float* partials, int n_blocks, int cols, float* out,
-                                                             int accumulate) {
+template <bool VEC>
+__global__ __launch_bounds__(256) void wcolsum_partial_kernel(twog_rows_t x, const float* s, int rows, int cols,
+                                                              float* partials) {
+    wcolsum_partial_body<VEC>(x, s, rows, cols, partials, blockIdx.x, blockIdx.y, gridDim.y);
+}
+
+__device__ __forceinline__ void wcolsum_final_body(const float* partials, int n_blocks, int cols, float* out, int accumulate,
+                                                   int col_block) {
     // 64 columns x 16 lanes over the partial rows, then an ordered LDS reduction (deterministic)
     __shared__ float red[16][64];
     const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + cl;
+    const int c = col_block * 64 + cl;
     float acc = 0.f;
     if (c < cols)
         for (int b = rl; b < n_blocks; b += 16) acc += partials[(int64_t)b * cols + c];
@@ -153,6 +159,45 @@ __global__ __launch_bounds__(1024) void wcolsum_final_kernel(const float* partia
         for (int i = 0; i < 16; ++i) t += red[i][cl];
         out[c] = accumulate ? out[c] + t : t;
     }
+}
+
+__global__ __launch_bounds__(1024) void wcolsum_final_kernel(const float* partials, int n_blocks, int cols, float* out,
+                                                             int accumulate) {
+    wcolsum_final_body(partials, n_blocks, cols, out, accumulate, blockIdx.x);
+}
+
+// Several column sums in ONE pair of launches (twog_colsum_n): the bias gradients of a backward stage -- 45 column sums per
+// step, each a partial + a final launch until round 5 -- are collected by the host and issued together. Workgroup ->
+// (problem, column block, row block) through the prefix tables; each problem keeps the arithmetic (and so the results,
+// bit for bit) of its own twog_colsum call.
+struct ColsumBatch {
+    twog_colsum_t op[TWOG_COLSUM_MAX];
+    int n;
+    int first_block[TWOG_COLSUM_MAX + 1];   // partial launch: blocks of problem i are [first_block[i], first_block[i + 1])
+    int first_final[TWOG_COLSUM_MAX + 1];   // final launch
+    int col_blocks[TWOG_COLSUM_MAX];        // column blocks of the partial launch (256 columns vectorised, else 64)
+    int row_blocks[TWOG_COLSUM_MAX];
+    int vec[TWOG_COLSUM_MAX];
+    int64_t part_off[TWOG_COLSUM_MAX];      // floats
+};
+__global__ __launch_bounds__(256) void wcolsum_partial_n_kernel(const ColsumBatch G, float* partials) {
+    int pi = 0;
+#pragma unroll 1
+    for (int i = 1; i < G.n; ++i)
+        if ((int)blockIdx.x >= G.first_block[i]) pi = i;
+    const twog_colsum_t& o = G.op[pi];
+    const int local = (int)blockIdx.x - G.first_block[pi];
+    const int cb = local % G.col_blocks[pi], rb = local / G.col_blocks[pi];
+    if (G.vec[pi]) wcolsum_partial_body<true>(o.x, o.rowscale, o.rows, o.cols, partials + G.part_off[pi], cb, rb, G.row_blocks[pi]);
+    else wcolsum_partial_body<false>(o.x, o.rowscale, o.rows, o.cols, partials + G.part_off[pi], cb, rb, G.row_blocks[pi]);
+}
+__global__ __launch_bounds__(1024) void wcolsum_final_n_kernel(const ColsumBatch G, const float* partials) {
+    int pi = 0;
+#pragma unroll 1
+    for (int i = 1; i < G.n; ++i)
+        if ((int)blockIdx.x >= G.first_final[i]) pi = i;
+    const twog_colsum_t& o = G.op[pi];
+    wcolsum_final_body(partials + G.part_off[pi], G.row_blocks[pi], o.cols, o.out, o.accumulate, (int)blockIdx.x - G.first_final[pi]);
 }
 
 }  // namespace
@@ -182,6 +227,61 @@ extern "C" int twog_rank1_update(twog_rows_t dst, const float* s, const float* v
     int grid = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
     hipLaunchKernelGGL(rank1_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, dst, s, v, rows, cols);
     TWOG_CHECK_LAUNCH();
+    return 0;
+}
+
+// row slices of one problem: enough to fill the chip (~1024 workgroups over column blocks x row slices), >= 64 rows per slice
+static int colsum_row_blocks(int rows, int cols) {
+    const int cb = (cols + 255) / 256;
+    int most = 1024 / (cb > 0 ? cb : 1);
+    if (most < 1) most = 1;
+    int n = rows / 64;
+    if (n > most) n = most;
+    return n < 1 ? 1 : n;
+}
+
+extern "C" size_t twog_colsum_n_partial_floats(const twog_colsum_t* ops, int n) {
+    size_t total = 0;
+    for (int i = 0; i < n; ++i)
+        if (ops[i].cols > 0 && ops[i].rows >= 0) total += (size_t)colsum_row_blocks(ops[i].rows, ops[i].cols) * ops[i].cols;
+    return total;
+}
+
+extern "C" int twog_colsum_n(const twog_colsum_t* ops, int n, float* partials, size_t partial_floats, void* stream) {
+    if (n <= 0) return 0;
+    if (!ops || !partials) return -2;
+    hipStream_t st = (hipStream_t)stream;
+    for (int done = 0; done < n; done += TWOG_COLSUM_MAX) {
+        ColsumBatch G;
+        G.n = 0;
+        int blocks = 0, finals = 0;
+        size_t off = 0;
+        for (int i = done; i < n && G.n < TWOG_COLSUM_MAX; ++i) {
+            const twog_colsum_t& o = ops[i];
+            if (o.cols <= 0) continue;
+            if (o.rows < 0 || !o.out || (o.rows > 0 && !o.x.ptr)) return -2;
+            const int k = G.n++;
+            G.op[k] = o;
+            G.vec[k] = (o.cols % 4 == 0) && (reinterpret_cast<uintptr_t>(o.x.ptr) % 16 == 0) && (o.x.ld_outer % 4 == 0) &&
+                       (o.x.inner <= 1 || o.x.ld_inner % 4 == 0);
+            G.col_blocks[k] = G.vec[k] ? (o.cols + 255) / 256 : (o.cols + 63) / 64;
+            G.row_blocks[k] = colsum_row_blocks(o.rows, o.cols);
+            G.first_block[k] = blocks;
+            G.first_final[k] = finals;
+            G.part_off[k] = (int64_t)off;
+            blocks += G.col_blocks[k] * G.row_blocks[k];
+            finals += (o.cols + 63) / 64;
+            off += (size_t)G.row_blocks[k] * o.cols;
+        }
+        if (G.n == 0) continue;
+        if (off > partial_floats) return -2;
+        G.first_block[G.n] = blocks;
+        G.first_final[G.n] = finals;
+        hipLaunchKernelGGL(wcolsum_partial_n_kernel, dim3(blocks), dim3(256), 0, st, G, partials);
+        TWOG_CHECK_LAUNCH();
+        hipLaunchKernelGGL(wcolsum_final_n_kernel, dim3(finals), dim3(1024), 0, st, G, partials);
+        TWOG_CHECK_LAUNCH();
+    }
     return 0;
 }
 

@@ -797,6 +797,21 @@ class HipKernels:
                                          partials.data_ptr(), nblk, self._stream()), 'twog_colsum')
         return out
 
+    def colsum_many(self, ops):
+        """ops: (x, rowscale or None, out [cols], accumulate) -- several column sums in one pair of launches (twog_colsum_n);
+        each with the arithmetic of its own colsum() call."""
+        if not ops:
+            return
+        arr = (L.ColSum * len(ops))()
+        for a, (x, rs, out, acc) in zip(arr, ops):
+            assert out.is_contiguous() and out.numel() == x.shape[-1]
+            a.x, a.rowscale, a.out = rows_of(x), _ptr(rs), out.data_ptr()
+            a.rows, a.cols, a.accumulate = n_rows(x), x.shape[-1], int(bool(acc))
+        dev = ops[0][0].device
+        need = int(self.lib.twog_colsum_n_partial_floats(arr, len(ops)))
+        partials = self.workspace(max(need, 1) * 4, dev, 'colsum')
+        self._check(self.lib.twog_colsum_n(arr, len(ops), partials.data_ptr(), partials.numel(), self._stream()), 'twog_colsum_n')
+
     def filter_fwd(self, soft, threshold):
         bs, T, E = soft.shape
         hard, gmask = torch.empty_like(soft), torch.empty_like(soft)

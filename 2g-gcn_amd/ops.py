@@ -341,7 +341,9 @@ def enable_grad_sinks(params, on: bool = True):
         p._twog_grad_sink = bool(on)
 
 
-def _stage_done(plan, stage):
+def _stage_done(plan, stage, G=None):
+    if G is not None:
+        G.flush()   # pending `grad += g` launches: the hook's all-reduce reads the gradients
     hook = getattr(plan, 'stage_hook', None)
     if isinstance(hook, weakref.WeakMethod):   # the data-parallel wrapper registers itself weakly (distributed.py)
         hook = hook()
@@ -368,6 +370,9 @@ class _Grads:
 
     def __init__(self, K, sinks=None, known=None):
         self.K, self.g, self.sinks, self.known = K, {}, sinks or {}, known
+        self._pending, self._pending_dst = [], set()   # `dst += t` operations not yet issued (one launch per 16: flush())
+        self._pend_cs, self._pend_cp = [], []          # column sums / copies not yet issued (issued before the additions)
+        self._defer = hasattr(K, 'colsum_many') and os.environ.get('TWOG_BATCH_ADDS', '1') != '0'
 
     def sink(self, name):
         return self.sinks.get(name)
@@ -383,9 +388,51 @@ class _Grads:
         if dst is None:
             dst = self.g.get(name)
         if dst is not None:
-            self.K.add_rows(_v2(t.reshape(1, -1)), _v2(dst.view(1, -1)))
+            # batched: the 57 separate `grad += g` launches of a step become four (twog_rowops, 16 additions per launch).
+            # Two additions into the same buffer never share a launch; t stays referenced until the launch is issued.
+            if not hasattr(self.K, 'rowops') or os.environ.get('TWOG_BATCH_ADDS', '1') == '0':
+                self.K.add_rows(_v2(t.reshape(1, -1)), _v2(dst.view(1, -1)))
+                return
+            key = dst.data_ptr()
+            if key in self._pending_dst or len(self._pending) >= 16:
+                self.flush()
+            self._pending.append(('add', _v2(t.reshape(1, -1)), _v2(dst.view(1, -1))))
+            self._pending_dst.add(key)
         else:
             self.g[name] = t
+
+    def colsum(self, x, out=None, accumulate=False):
+        """Column sums of x (a bias gradient), DEFERRED: `out` is returned at once and filled at the next flush() -- the
+        45 column sums of a step become a few grouped launches (twog_colsum_n). x must not change until then (the callers
+        pass gradients of layer outputs, which nothing writes again)."""
+        if out is None:
+            out, accumulate = torch.empty(x.shape[-1], dtype=torch.float32, device=x.device), False
+        if not self._defer:
+            return self.K.colsum(x, out=out, accumulate=accumulate)
+        if len(self._pend_cs) >= 16 or any(o.data_ptr() == out.data_ptr() for _, _, o, _ in self._pend_cs):
+            self.flush()   # (two sums into one buffer -- shared heads -- never share a launch)
+        self._pend_cs.append((x, None, out, accumulate))
+        return out
+
+    def copy(self, src, dst):
+        """dst[...] = src[...] (contiguous, same size) after the pending column sums (it usually copies one)."""
+        if not self._defer:
+            dst.copy_(src)
+            return
+        self._pend_cp.append((src, dst))
+
+    def flush(self):
+        """Issues the pending column sums, copies and additions, in that order (on the current stream). Called before
+        anything reads the gradients: a stage hook, the end of the backward pass, a change of stream."""
+        if self._pend_cs:
+            self.K.colsum_many(self._pend_cs)
+            self._pend_cs = []
+        if self._pend_cp:
+            self.K.copy_blocks(self._pend_cp)
+            self._pend_cp = []
+        if self._pending:
+            self.K.rowops(self._pending)
+            self._pending, self._pending_dst = [], set()
 
 
 def _gru_bias_grads(K, G, b_ih, b_hh, dgi, dgh, h):
@@ -394,11 +441,11 @@ def _gru_bias_grads(K, G, b_ih, b_hh, dgi, dgh, h):
     d_gh is read for its n third only."""
     if not (G.has(b_ih) or G.has(b_hh)):
         return
-    db_ih = K.colsum(dgi)
+    db_ih = G.colsum(dgi)
     if G.has(b_hh):
         db_hh = torch.empty(3 * h, dtype=torch.float32, device=dgi.device)
-        db_hh[:2 * h].copy_(db_ih[:2 * h])
-        K.colsum(dgh[:, 2 * h:], out=db_hh[2 * h:])
+        G.copy(db_ih[:2 * h], db_hh[:2 * h])
+        G.colsum(dgh[:, 2 * h:], out=db_hh[2 * h:])
         G.add(b_hh, db_hh)
     G.add(b_ih, db_ih)
 
@@ -568,9 +615,9 @@ def _bias_grad(K, G, bname, dY):
         return
     dstb = G.sink(bname)
     if dstb is not None:
-        K.colsum(dY, out=dstb.view(-1), accumulate=True)
+        G.colsum(dY, out=dstb.view(-1), accumulate=True)
     else:
-        G.add(bname, K.colsum(dY))
+        G.add(bname, G.colsum(dY))
 
 
 class _NowCtx:
@@ -1603,7 +1650,7 @@ def tggcn_backward(K, plan: Plan, P, S, x_human, x_objects, objects_mask, d_outp
                                  C=dWp, accumulate=True)], a_kmajor=True, b_kmajor=True)
                 else:
                     dWp.zero_()
-                dbp = K.colsum(dpre.view(-1, n * h))
+                dbp = G.colsum(dpre.view(-1, n * h))
                 for i, r in enumerate(rels):
                     G.add(_SEG_MLP[r] + '.0.weight', dWp[i * h:(i + 1) * h])
                     G.add(_SEG_MLP[r] + '.0.bias', dbp[i * h:(i + 1) * h])
@@ -1742,7 +1789,7 @@ def tggcn_backward(K, plan: Plan, P, S, x_human, x_objects, objects_mask, d_outp
     defer_stage0 = (getattr(p, 'stage_hook', None) is not None and
                     K.bigru_bwd_would_persist([H, O, 1], bs, h))
     if not defer_stage0:
-        _stage_done(p, 0)
+        _stage_done(p, 0, G)
 
     # ---- D. frame-level attention + sender MLPs backward
     if p.general_frame():
@@ -1804,13 +1851,15 @@ def tggcn_backward(K, plan: Plan, P, S, x_human, x_objects, objects_mask, d_outp
                           w_hh_r=P[name + '_bd_rnn.weight_hh_l0_reverse']))
     if side_on and pgrads:
         # beside the frame-level BiGRU chain (launch per step: 176 of 256 compute units busy at ~10 % of the matrix pipe)
+        G.flush()
         side = K.side_stream(dev)      # starts behind everything issued so far on the caller's stream
         with side:
             for fn in pgrads:
                 fn()
+            G.flush()
     res = K.bigru_bwd(types, bs, T, h, allow_persistent=defer_stage0 or getattr(p, 'stage_hook', None) is None)
     if defer_stage0:
-        _stage_done(p, 0)
+        _stage_done(p, 0, G)
     for (name, Ev, dEv, E, _), hfr, (dgi, dgh) in zip(ents, HFR, res):
         dgiv, dghv = _v2(dgi), _v2(dgh)
         for d, sfx in enumerate(('', '_reverse')):
@@ -1832,7 +1881,7 @@ def tggcn_backward(K, plan: Plan, P, S, x_human, x_objects, objects_mask, d_outp
             G.add(f'{name}_bd_rnn.weight_hh_l0{sfx}', dW_hh)
             K.gemm([dict(A=dgi_d, B=P[f'{name}_bd_rnn.weight_ih_l0{sfx}'], C=dEv[:, :h], accumulate=True)], b_kmajor=True)
 
-    _stage_done(p, 1)
+    _stage_done(p, 1, G)
 
     # ---- B. embeddings backward
     xh_in = x_human.view(nF * H, x_human.shape[-1])[:, :2048]
@@ -1898,6 +1947,7 @@ def tggcn_backward(K, plan: Plan, P, S, x_human, x_objects, objects_mask, d_outp
     G.add(g + 'joint_embed.cnn.1.cnn.bias', db1)
     G.add(g + 'joint_embed.cnn.0.bn.weight', dgamma)
     G.add(g + 'joint_embed.cnn.0.bn.bias', dbeta)
+    G.flush()
     if side is not None:
         side.join()
     if hasattr(K, 'verify_persistent'):

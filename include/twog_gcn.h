@@ -503,6 +503,21 @@ int twog_rank1_update(twog_rows_t dst, const float* s, const float* v, int rows,
  * Deterministic two-pass reduction; partials: scratch [n_blocks][cols]. */
 int twog_colsum(twog_rows_t x, const float* rowscale, int rows, int cols, float* out, int accumulate,
                 float* partials, int n_blocks, void* stream);
+/* Several column sums in one pair of launches (the bias gradients of a backward stage collected by the host: 45 per training
+ * step). Problem i: out[c] (+)= sum_r rowscale[r] * x[r][c] with the arithmetic -- and so, bit for bit, the results -- of its own
+ * twog_colsum call with the default row slicing. partials: scratch of twog_colsum_n_partial_floats(ops, n) floats (the chunks of
+ * TWOG_COLSUM_MAX problems of one call run one after the other and share it). */
+#define TWOG_COLSUM_MAX 16
+typedef struct {
+    twog_rows_t x;
+    const float* rowscale;  /* [rows] or NULL */
+    float* out;             /* [cols] */
+    int32_t rows, cols;
+    int32_t accumulate;
+    int32_t pad_;
+} twog_colsum_t;
+size_t twog_colsum_n_partial_floats(const twog_colsum_t* ops, int n);
+int twog_colsum_n(const twog_colsum_t* ops, int n, float* partials, size_t partial_floats, void* stream);
 
 /* filter_soft_decisions (vhoi/models.py:1637-1664): local-maximum filter on soft gates [bs][T][E];
  * grad_mask = d hard / d soft (0 or 1) under the reference's straight-through + clamp semantics. */

@@ -623,6 +623,10 @@ class FakeKernels:
             out.copy_(r)
         return out
 
+    def colsum_many(self, ops):
+        for x, rs, out, acc in ops:
+            self.colsum(x, rowscale=rs, out=out, accumulate=acc)
+
     def filter_fwd(self, soft, threshold):
         um1 = torch.cat([torch.zeros_like(soft[:, :1]), soft[:, :-1]], 1)
         up1 = torch.cat([soft[:, 1:], torch.zeros_like(soft[:, :1])], 1)
