@@ -934,6 +934,31 @@ def test_segment_recurrence_persistent_hand_offs_hold_under_uneven_load(K, monke
             assert torch.equal(a, b), f'repetition {rep}: {k} of the persistent launch under load differs from the solo run'
 
 
+def test_grouped_column_sums_equal_the_single_calls_bit_for_bit(K):
+    """twog_colsum_n (the bias gradients of a backward stage in one pair of launches) against one twog_colsum call per
+    problem: strided views, a row scale, ragged column counts (vector and scalar paths), accumulation into existing values,
+    more than TWOG_COLSUM_MAX problems (two chunks)."""
+    g = torch.Generator().manual_seed(5)
+    base = torch.randn(20000, 700, generator=g).to(DEV)
+    probs = []
+    for i, (r0, r1, c0, c1, scaled, acc) in enumerate([(0, 20000, 0, 512, False, False), (5, 7001, 4, 260, True, True),
+                                                       (0, 64, 0, 700, False, False), (100, 163, 1, 14, True, False),
+                                                       (0, 15360, 64, 576, False, True)] * 4):
+        x = base[r0:r1, c0:c1]
+        rs = torch.randn(r1 - r0, generator=g).to(DEV) if scaled else None
+        out0 = torch.randn(c1 - c0, generator=g).to(DEV)
+        probs.append((x, rs, out0, acc))
+    assert len(probs) > 16
+    single = [K.colsum(x, rowscale=rs, out=o.clone(), accumulate=acc) for x, rs, o, acc in probs]
+    many = [o.clone() for _, _, o, _ in probs]
+    K.colsum_many([(x, rs, m, acc) for (x, rs, _, acc), m in zip(probs, many)])
+    torch.cuda.synchronize()
+    for a, b in zip(single, many):
+        assert torch.equal(a, b)
+    ref = (base[0:20000, 0:512].double()).sum(0)
+    assert float((many[0].double() - ref).abs().max()) < 1e-3 * float(ref.abs().max())
+
+
 # --------------------------------------------------------------------------------------------------------------- gates
 @pytest.mark.parametrize('gs', [True, False])
 def test_gates_filter_reorder_heads(K, gs):
