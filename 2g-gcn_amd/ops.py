@@ -372,6 +372,7 @@ class _Grads:
         self.K, self.g, self.sinks, self.known = K, {}, sinks or {}, known
         self._pending, self._pending_dst = [], set()   # `dst += t` operations not yet issued (one launch per 16: flush())
         self._pend_cs, self._pend_cp = [], []          # column sums / copies not yet issued (issued before the additions)
+        self._pend_mm, self._pend_mm_c = [], set()     # weight-gradient GEMMs (dW = dY^T X) not yet issued: grouped launches
         self._defer = hasattr(K, 'colsum_many') and os.environ.get('TWOG_BATCH_ADDS', '1') != '0'
 
     def sink(self, name):
@@ -401,6 +402,34 @@ class _Grads:
         else:
             self.g[name] = t
 
+    def dw_gemm(self, problem):
+        """dW = dY^T X (both operands k-major), DEFERRED: the weight-gradient GEMMs of a backward stage are collected and
+        issued as grouped launches of up to eight problems (at 8 clips per GPU a dW problem is a few dozen tiles: alone it is
+        split over k and followed by a reduce launch; eight together fill the chip). Operands must not change until
+        flush(); two problems that write the same C never share a launch."""
+        A, B = problem['A'], problem['B']
+
+        def plain(t):   # 16-byte loads legal, whole k-tiles: what the bf16x3 128x128 class asks of EVERY problem of a launch
+            n = t.shape[0] if t.dim() == 2 else t.shape[0] * t.shape[1]
+            return (t.shape[-1] % 4 == 0 and t.data_ptr() % 16 == 0 and all(st % 4 == 0 for st in t.stride()[:-1]) and n % 16 == 0)
+
+        # only problems that would take the 128x128 class on their own share a launch: one narrow or unaligned problem would
+        # move the whole group to another kernel class
+        # ... and only SHORT reductions (small batches): measured, same box, alternating -- 8 clips per GPU 16.21 / 15.98 ms per
+        # step one by one against 15.03 / 14.75 grouped; 64 clips 66.61 / 66.05 one by one against 69.41 / 69.36 grouped (a tall
+        # reduction alone gets the XCD-dealt split-K that a mixed group does not)
+        rows = A.shape[0] if A.dim() == 2 else A.shape[0] * A.shape[1]
+        if (not self._defer or os.environ.get('TWOG_BATCH_DW', '1') == '0' or A.shape[-1] < 128 or B.shape[-1] < 128
+                or rows > 8192 or not plain(A) or not plain(B)):
+            self.flush()   # (keeps the order of launches that write the same buffers)
+            self.K.gemm([problem], a_kmajor=True, b_kmajor=True)
+            return
+        key = problem['C'].data_ptr()
+        if key in self._pend_mm_c or len(self._pend_mm) >= 8:
+            self.flush()
+        self._pend_mm.append(problem)
+        self._pend_mm_c.add(key)
+
     def colsum(self, x, out=None, accumulate=False):
         """Column sums of x (a bias gradient), DEFERRED: `out` is returned at once and filled at the next flush() -- the
         45 column sums of a step become a few grouped launches (twog_colsum_n). x must not change until then (the callers
@@ -424,6 +453,9 @@ class _Grads:
     def flush(self):
         """Issues the pending column sums, copies and additions, in that order (on the current stream). Called before
         anything reads the gradients: a stage hook, the end of the backward pass, a change of stream."""
+        if self._pend_mm:
+            self.K.gemm(self._pend_mm, a_kmajor=True, b_kmajor=True)
+            self._pend_mm, self._pend_mm_c = [], set()
         if self._pend_cs:
             self.K.colsum_many(self._pend_cs)
             self._pend_cs = []
@@ -462,12 +494,12 @@ def _lin_w_grads(K, G, wname, bname, dY, X, cols=None, total=None):
             if dst is None:   # first block of this weight: a zeroed full-width gradient the blocks accumulate into
                 dst = torch.zeros(N, total, dtype=torch.float32, device=dY.device)
                 G.g[wname] = dst
-        K.gemm([dict(A=dY, B=X, C=dst.view(N, total)[:, c0:c1], accumulate=True)], a_kmajor=True, b_kmajor=True)
+        G.dw_gemm(dict(A=dY, B=X, C=dst.view(N, total)[:, c0:c1], accumulate=True))
     elif dst is not None:
-        K.gemm([dict(A=dY, B=X, C=dst.view(N, Kin), accumulate=True)], a_kmajor=True, b_kmajor=True)
+        G.dw_gemm(dict(A=dY, B=X, C=dst.view(N, Kin), accumulate=True))
     else:
         dW = torch.empty(N, Kin, dtype=torch.float32, device=dY.device)
-        K.gemm([dict(A=dY, B=X, C=dW)], a_kmajor=True, b_kmajor=True)
+        G.dw_gemm(dict(A=dY, B=X, C=dW))
         G.add(wname, dW)
     _bias_grad(K, G, bname, dY)
 
@@ -1574,27 +1606,26 @@ def tggcn_backward(K, plan: Plan, P, S, x_human, x_objects, objects_mask, d_outp
                              dghv=dghv):
                 dW_ih = empty(*w_ih.shape)
                 if ssp is None:
-                    K.gemm([dict(A=dgi_d, B=Ev[:, h:h + fw], C=dW_ih[:, :fw])], a_kmajor=True, b_kmajor=True)
+                    G.dw_gemm(dict(A=dgi_d, B=Ev[:, h:h + fw], C=dW_ih[:, :fw]))
                 else:
                     c0, c1 = ssp
                     sx = S['ssp']
-                    K.gemm([dict(A=dgi_d, B=Ev[:, h:c0], C=dW_ih[:, :c0 - h])], a_kmajor=True, b_kmajor=True)
+                    G.dw_gemm(dict(A=dgi_d, B=Ev[:, h:c0], C=dW_ih[:, :c0 - h]))
                     if c1 < h + fw:
-                        K.gemm([dict(A=dgi_d, B=Ev[:, c1:h + fw], C=dW_ih[:, c1 - h:fw])], a_kmajor=True, b_kmajor=True)
+                        G.dw_gemm(dict(A=dgi_d, B=Ev[:, c1:h + fw], C=dW_ih[:, c1 - h:fw]))
                     for on, q, msgs, rel in ((sx['ho_on'], sx['qh'], S['MSGH'], 'ho'), (sx['so_on'], sx['qs'], S['MSGS'], 'so')):
                         if not on:
                             continue
                         rels = p.snd_h if rel == 'ho' else p.snd_s
                         i_ = rels.index(rel)
                         cc = p.col_o[rel] - h
-                        K.gemm([dict(A=q[:, d * 3 * h:(d + 1) * 3 * h], B=msgs[:, i_ * h:(i_ + 1) * h], C=dW_ih[:, cc:cc + h])],
-                               a_kmajor=True, b_kmajor=True)
+                        G.dw_gemm(dict(A=q[:, d * 3 * h:(d + 1) * 3 * h], B=msgs[:, i_ * h:(i_ + 1) * h], C=dW_ih[:, cc:cc + h]))
                 if w_ih.shape[1] > fw:
                     seg_rels_k = p.seg_mh if kind == 'h' else p.seg_mo
                     ssp_seg = (kind == 'o' and 'ho' in seg_rels_k and H < O and not p.general_segment()
                                and not p.no_ssp)
                     if not ssp_seg:
-                        K.gemm([dict(A=dgi_d, B=_v2(mg[d]), C=dW_ih[:, fw:])], a_kmajor=True, b_kmajor=True)
+                        G.dw_gemm(dict(A=dgi_d, B=_v2(mg[d]), C=dW_ih[:, fw:]))
                     else:
                         # sender-side form of the human->object block (see ssp.hip): mg_ho[k] = sum_h att[k][h] msrc_ho[h], so
                         # its weight gradient reduces over the H sender rows of every (clip, step) with q = sum_k att d_gi
@@ -1602,13 +1633,12 @@ def tggcn_backward(K, plan: Plan, P, S, x_human, x_objects, objects_mask, d_outp
                         for i_, rel_ in enumerate(seg_rels_k):
                             blk = dW_ih[:, fw + i_ * h:fw + (i_ + 1) * h]
                             if rel_ != 'ho':
-                                K.gemm([dict(A=dgi_d, B=mgv[:, i_ * h:(i_ + 1) * h], C=blk)], a_kmajor=True, b_kmajor=True)
+                                G.dw_gemm(dict(A=dgi_d, B=mgv[:, i_ * h:(i_ + 1) * h], C=blk))
                                 continue
                             natt = sb['att'].shape[-1]
                             qh_ = K.ssp_gather(dgi_d, sb['att'][d], natt, bs * natt, H * H + H * O, nF, T, H, O)
                             i_s = S['seg_rels'][0].index('ho')
-                            K.gemm([dict(A=qh_, B=_v2(sb['msrc_h'][d])[:, i_s * h:(i_s + 1) * h], C=blk)],
-                                   a_kmajor=True, b_kmajor=True)
+                            G.dw_gemm(dict(A=qh_, B=_v2(sb['msrc_h'][d])[:, i_s * h:(i_s + 1) * h], C=blk))
                 G.add(c + '.weight_ih', dW_ih)
                 _gru_bias_grads(K, G, c + '.bias_ih', c + '.bias_hh', dgi_d, dghv[:, d * 3 * h:(d + 1) * 3 * h], h)
                 # dW_hh = sum over steps with a previous state: forward chain pairs (t, t-1), backward chain (t, t+1)
@@ -1621,7 +1651,7 @@ def tggcn_backward(K, plan: Plan, P, S, x_human, x_objects, objects_mask, d_outp
                         A = dgh[:, :T - 1, :, 3 * h:6 * h].reshape(bs, (T - 1) * E, 3 * h)
                         B = HS[:, 1:, :, h:2 * h].reshape(bs, (T - 1) * E, h)
                     assert A.data_ptr() != 0 and A._base is not None and B._base is not None  # views, not copies
-                    K.gemm([dict(A=A, B=B, C=dW_hh)], a_kmajor=True, b_kmajor=True)
+                    G.dw_gemm(dict(A=A, B=B, C=dW_hh))
                 else:
                     dW_hh.zero_()
                 G.add(c + '.weight_hh', dW_hh)
@@ -1644,10 +1674,10 @@ def tggcn_backward(K, plan: Plan, P, S, x_human, x_objects, objects_mask, d_outp
                 n = len(rels)
                 dWp = empty(n * h, h)
                 if T > 1:
-                    K.gemm([dict(A=dpre[0][:, 1:].reshape(bs, (T - 1) * E, n * h), B=HS[:, :T - 1, :, 0:h].reshape(bs, (T - 1) * E, h),
-                                 C=dWp)], a_kmajor=True, b_kmajor=True)
-                    K.gemm([dict(A=dpre[1][:, :T - 1].reshape(bs, (T - 1) * E, n * h), B=HS[:, 1:, :, h:2 * h].reshape(bs, (T - 1) * E, h),
-                                 C=dWp, accumulate=True)], a_kmajor=True, b_kmajor=True)
+                    G.dw_gemm(dict(A=dpre[0][:, 1:].reshape(bs, (T - 1) * E, n * h), B=HS[:, :T - 1, :, 0:h].reshape(bs, (T - 1) * E, h),
+                                   C=dWp))
+                    G.dw_gemm(dict(A=dpre[1][:, :T - 1].reshape(bs, (T - 1) * E, n * h), B=HS[:, 1:, :, h:2 * h].reshape(bs, (T - 1) * E, h),
+                                   C=dWp, accumulate=True))
                 else:
                     dWp.zero_()
                 dbp = G.colsum(dpre.view(-1, n * h))
@@ -1875,7 +1905,7 @@ def tggcn_backward(K, plan: Plan, P, S, x_human, x_objects, objects_mask, d_outp
                 else:
                     A = dgh[:, :T - 1, :, 3 * h:6 * h].reshape(bs, (T - 1) * E, 3 * h)
                     B = hfr[:, 1:, :, h:2 * h].reshape(bs, (T - 1) * E, h)
-                K.gemm([dict(A=A, B=B, C=dW_hh)], a_kmajor=True, b_kmajor=True)
+                G.dw_gemm(dict(A=A, B=B, C=dW_hh))
             else:
                 dW_hh.zero_()
             G.add(f'{name}_bd_rnn.weight_hh_l0{sfx}', dW_hh)
