@@ -34,6 +34,17 @@ inline bool twog_persist_grid_fits(K kernel, int grid, size_t lds, int n_cus) {
         (void)hipGetLastError();
         return false;
     }
+    // A persistent kernel must not use scratch (private) memory: a build of seg_persist_fwd_kernel that spilled 26 registers
+    // per lane gave wrong results with the full 256-workgroup grid and right ones with 32-96 workgroups (round 5, unexplained);
+    // if a compiler update ever makes one of these kernels spill, the launch-per-step path runs instead.
+    hipFuncAttributes attr;
+    if (hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(kernel)) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+#ifndef TWOG_SP_STAMPS   // (the diagnostic build with phase stamps may spill a few registers; its numbers are read as shares)
+    if (attr.localSizeBytes != 0) return false;
+#endif
     return per_cu >= 1 && (int64_t)per_cu * n_cus >= grid;
 }
 

@@ -421,7 +421,8 @@ class _Grads:
         rows = A.shape[0] if A.dim() == 2 else A.shape[0] * A.shape[1]
         if (not self._defer or os.environ.get('TWOG_BATCH_DW', '1') == '0' or A.shape[-1] < 128 or B.shape[-1] < 128
                 or rows > 8192 or not plain(A) or not plain(B)):
-            self.flush()   # (keeps the order of launches that write the same buffers)
+            if problem['C'].data_ptr() in self._pend_mm_c:
+                self.flush()   # (a collected problem writes the same buffer: keep the order)
             self.K.gemm([problem], a_kmajor=True, b_kmajor=True)
             return
         key = problem['C'].data_ptr()
