@@ -1302,7 +1302,7 @@ __global__ __launch_bounds__(256 * KS, KS == 2 ? 1 : 2) void gemm_x3su_kernel(co
     gemm_tile<64, 64, 256 * KS, false, BKM, 2, false, false, KS, false, true, KU>(g, nullptr);
 }
 template <int KS, int KU>
-__global__ __launch_bounds__(256 * KS, 1) void gemm_gate_bwd_x3su_kernel(const Group g, const GateArgs ga) {
+__global__ __launch_bounds__(256 * KS, KS == 2 ? 1 : 2) void gemm_gate_bwd_x3su_kernel(const Group g, const GateArgs ga) {
     gemm_tile<64, 64, 256 * KS, false, true, 2, false, true, KS, false, true, KU>(g, &ga);
 }
 
@@ -1818,6 +1818,52 @@ static bool try_xsplit(Group& g, int bm, int kmax, void* chain_ws, size_t chain_
     return true;
 }
 
+// XL: chain launches of the X3 64x64 class at real batches (96+ tiles). Such a launch is bound by the bytes a CU takes in
+// (~0.5 us per 32-deep k-tile of a 64x64 tile whether one 8-wave workgroup or two 4-wave ones share the CU; section 8 of
+// DESIGN.md), and its tile count rarely fills the chip in whole rounds: 176 tiles leave 80 CUs idle, 320 put two tiles on 64
+// CUs and one on the rest. Splitting every reduction into S slices (4-wave workgroups, two resident per CU, so that one's
+// prologue and hand-off hide under the other's loop) evens the per-CU byte count; the slices are combined inside the launch
+// by the tile's last arriver in slice order (the LA branch of gemm_tile): deterministic, and the fused gate epilogue runs
+// on the complete sum as before. TWOG_X3_XL: 0 = the model below, 1 = never, n > 1 = always n slices.
+static int pick_xl_split(int tiles, int kmax, size_t ws_bytes) {
+    static const int force = getenv("TWOG_X3_XL") ? atoi(getenv("TWOG_X3_XL")) : 0;
+    if (force == 1 || tiles < 96 || tiles > 4096 || ws_bytes <= XS_COUNTER_BYTES || kmax % 32) return 1;
+    const int kt = kmax / 32;
+    const int by_ws = (int)((ws_bytes - XS_COUNTER_BYTES) / ((size_t)64 * 64 * sizeof(float) * (size_t)tiles));
+    // cost in k-tile times of the busiest CU: its workgroups' k-tiles one after the other + what a split adds (hand-off,
+    // the last arriver's combine, one prologue per further round). Fitted to tools/gemm_chain_bench.py on the bs64 shapes
+    // (us, S = 1 / 2 / 3 / 4 / 6 / 8): 176 tiles K = 1 536: 26.0 / 28.1 / 27.4 / 25.3 / 27.7 / 28.4; 160 tiles: 25.7 / 27.7 /
+    // 23.6 / 24.2 / 24.7 / 25.7; 320 tiles K = 1 536: 40.8 / 36.6 / 37.0 / 36.4 / 39.2 / 41.7; 320 tiles K = 512: 18.6 /
+    // 17.6 / 18.7 / 20.2 -- the gains are a third of what the byte count alone predicts (every workgroup pays ~4 us of
+    // prologue and hand-off that only its sibling on the CU can hide), so a split must promise 10 %.
+    auto cost = [&](int S) {
+        const int r = (tiles * S + 255) / 256;
+        return r * ((kt + S - 1) / S) + (S > 1 ? 3 + r : 0);
+    };
+    int best = 1;
+    int best_c = cost(1);
+    static const int cand[] = {2, 3, 4};
+    for (int S : cand) {
+        if (S > by_ws || kt / S < 8) break;
+        const int c = force > 1 ? (S == force ? -1 : (1 << 20)) : cost(S);
+        if (c * 10 <= best_c * 9) { best_c = c; best = S; }
+    }
+    return best;
+}
+static bool xl_setup(Group& g, int kmax, void* chain_ws, size_t chain_ws_bytes) {
+    if (!chain_ws) return false;
+    const int S = pick_xl_split(g.total_tiles, kmax, chain_ws_bytes);
+    if (S <= 1) return false;
+    const int kt = kmax / 32;
+    g.k_per_split = ((kt + S - 1) / S) * 32;
+    g.splitk = (kmax + g.k_per_split - 1) / g.k_per_split;
+    if (g.splitk <= 1) { g.splitk = 1; g.k_per_split = ((kmax + BK - 1) / BK) * BK; return false; }
+    g.xcnt = reinterpret_cast<unsigned*>(chain_ws);
+    g.slabs = reinterpret_cast<float*>(reinterpret_cast<char*>(chain_ws) + XS_COUNTER_BYTES);
+    g.xcd_split = 0;
+    return true;
+}
+
 static int gemm_impl(const twog_gemm_t* problems, int n_problems, int a_kmajor, int b_kmajor, void* workspace,
                      size_t workspace_bytes, void* chain_ws, size_t chain_ws_bytes, void* stream);
 
@@ -1867,6 +1913,15 @@ static int gemm_impl(const twog_gemm_t* problems, int n_problems, int a_kmajor, 
         int kmax_ = 0;
         for (int i = 0; i < n; ++i) kmax_ = pr[i].K > kmax_ ? pr[i].K : kmax_;
         const bool ks = ks_on && !big && !a_kmajor && !grouped && g.splitk == 1 && g.total_tiles <= 384 && kmax_ >= 256;
+        if (!big && bm == 64 && !grouped && chain_ws && x3s_ok(g, a_kmajor, 32) && xl_setup(g, kmax_, chain_ws, chain_ws_bytes)) {
+            g_last_class |= TWOG_GEMM_CLASS_X3 | TWOG_GEMM_CLASS_XSPLIT;
+            dim3 grid(g.total_tiles, g.splitk), block(256);
+            if (b_kmajor) hipLaunchKernelGGL((gemm_x3su_kernel<true, 1, 2>), grid, block, 0, st, g);
+            else hipLaunchKernelGGL((gemm_x3su_kernel<false, 1, 2>), grid, block, 0, st, g);
+            TWOG_CHECK_LAUNCH();
+            done += n;
+            continue;
+        }
         if (bm == 32) {   // decided in prepare_group; implies the conditions of `ks`
             g_last_class |= TWOG_GEMM_CLASS_KSPLIT | TWOG_GEMM_CLASS_ROWS32;
             if (try_xsplit(g, 32, kmax_, chain_ws, chain_ws_bytes, [&](dim3 grid) {
@@ -1985,6 +2040,12 @@ int twog_internal_gemm_gate_bwd(const twog_gemm_t* pr, int n, const twog_gru_ste
     static const int ks_on = getenv("TWOG_GEMM_KS") ? atoi(getenv("TWOG_GEMM_KS")) : 1;
     int kmax = 0;
     for (int i = 0; i < n; ++i) kmax = pr[i].K > kmax ? pr[i].K : kmax;
+    if (bm == 64 && chain_ws && x3s_ok(g, 0, 32) && xl_setup(g, kmax, chain_ws, chain_ws_bytes)) {
+        g_last_class |= TWOG_GEMM_CLASS_X3 | TWOG_GEMM_CLASS_XSPLIT;
+        hipLaunchKernelGGL((gemm_gate_bwd_x3su_kernel<1, 2>), dim3(g.total_tiles, g.splitk), dim3(256), 0, (hipStream_t)stream, g, ga);
+        TWOG_CHECK_LAUNCH();
+        return 0;
+    }
     if (bm == 32) {
         g_last_class |= TWOG_GEMM_CLASS_KSPLIT | TWOG_GEMM_CLASS_ROWS32;
         if (try_xsplit(g, 32, kmax, chain_ws, chain_ws_bytes, [&](dim3 xgrid) {

@@ -1763,13 +1763,97 @@ torch.save(outs, sys.argv[1])
     got = {}
     for ku in ('1', '2'):
         with tempfile.NamedTemporaryFile(suffix='.pt') as f:
-            r = subprocess.run([sys.executable, '-c', code, f.name], env=dict(os.environ, TWOG_X3S_KU=ku, TWOG_GEMM_XSPLIT='1'),
+            r = subprocess.run([sys.executable, '-c', code, f.name], env=dict(os.environ, TWOG_X3S_KU=ku, TWOG_GEMM_XSPLIT='1', TWOG_X3_XL='1'),
                                capture_output=True, text=True, timeout=600)
             assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
             got[ku] = torch.load(f.name)
     assert len(got['1']) == len(got['2']) >= 14
     for a, b in zip(got['1'], got['2']):
         assert torch.equal(a, b), float((a - b).abs().max())
+
+
+def test_gemm_x3_chain_reduction_split_over_workgroups():
+    """XL (csrc/gemm_f32.hip::pick_xl_split): the X3 64x64 chain launches of real batches (96+ tiles) split every reduction
+    into S slices of 4-wave workgroups and combine them inside the launch by the tile's last arriver, in slice order. In a
+    child process per setting (TWOG_X3_XL: 1 = never, 0 = the library's rule, 2 / 3 / 4 forced): plain launches (accumulate,
+    bias + ReLU, ragged edges, a grouped launch mixing reduction lengths) against fp64, the BiGRU backward chain (gate
+    backward fused into the combining workgroup's epilogue) against the unsplit kernels, every launch twice (bit-identical:
+    the slices are added in slice order whoever arrives last) and the tickets back at zero."""
+    code = r"""
+import sys, torch
+sys.path.insert(0, %r)
+import twog_gcn_amd
+from twog_gcn_amd.kernels import get_kernels
+K = get_kernels(); DEV = 'cuda:0'; force = sys.argv[2]
+g = torch.Generator().manual_seed(12)
+outs, split_seen = [], 0
+def prob(M, N, Kk, bkm, bias, act, acc):
+    A = torch.randn(M, Kk, generator=g).to(DEV)
+    B = (torch.randn((Kk, N) if bkm else (N, Kk), generator=g) * 0.1).to(DEV)
+    return dict(A=A, B=B, C0=torch.randn(M, N, generator=g).to(DEV), bias=torch.randn(N, generator=g).to(DEV) if bias else None,
+                act=act, accumulate=acc)
+def run(probs, bkm):
+    global split_seen
+    res = []
+    for rep in range(2):
+        ps = [dict({k: v for k, v in p.items() if k != 'C0'}, C=p['C0'].clone()) for p in probs]
+        K.gemm(ps, b_kmajor=bkm, chain=True)
+        res.append([p['C'] for p in ps])
+    cls = K.gemm_last_class()
+    assert cls & K.GEMM_X3, hex(cls)
+    assert force in ('0', '1') or cls & K.GEMM_XSPLIT, hex(cls)
+    assert force != '1' or not cls & K.GEMM_XSPLIT, hex(cls)
+    split_seen += bool(cls & K.GEMM_XSPLIT)
+    for p, C, C2 in zip(probs, res[0], res[1]):
+        assert torch.equal(C, C2), 'launch-to-launch difference'
+        ref = p['A'].double() @ (p['B'].double() if bkm else p['B'].double().t())
+        if p['bias'] is not None: ref = ref + p['bias'].double()
+        if p['accumulate']: ref = ref + p['C0'].double()
+        if p['act']: ref = torch.relu(ref)
+        err = (C.double() - ref).abs().max().item()
+        assert err <= 2e-6 * ref.abs().max().item(), (err / ref.abs().max().item(), tuple(C.shape))
+        outs.append(C.cpu())
+run([prob(1408, 512, 1536, True, False, 0, True)], True)     # BiGRU backward carry, bs64: 176 tiles
+run([prob(1280, 512, 1536, True, False, 0, True)], True)     # segment backward carry: 160 tiles
+run([prob(1280, 1024, 1536, True, False, 0, False)], True)   # segment d_mg: 320 tiles
+run([prob(1000, 520, 1024, False, True, 1, False)], False)   # ragged rows and columns, bias + ReLU
+run([prob(1040, 512, 1536, True, False, 0, True)], True)     # 136 tiles, the last row tile ragged (beyond the 32-row class: 264 tiles of 32 x 64)
+run([prob(640, 1536, 512, False, True, 0, False), prob(640, 1536, 1024, False, False, 0, True)], False)   # mixed K
+h, bs, T = 512, 64, 4
+types = []
+for i, E in enumerate((2, 8, 1)):
+    types.append(dict(gi=torch.randn(bs, T, E, 6 * h, generator=g).to(DEV), w_hh_f=(torch.randn(3 * h, h, generator=g) * 0.07).to(DEV),
+                      b_hh_f=torch.randn(3 * h, generator=g).to(DEV), w_hh_r=(torch.randn(3 * h, h, generator=g) * 0.07).to(DEV),
+                      b_hh_r=torch.randn(3 * h, generator=g).to(DEV)))
+res = K.bigru_fwd(types, bs, T, h)
+bt = [dict(d_out=torch.randn(o.shape, generator=g).to(DEV), save=sv, out=o, w_hh_f=d['w_hh_f'], w_hh_r=d['w_hh_r'])
+      for (o, sv), d in zip(res, types)]
+first = [(a.clone(), b.clone()) for a, b in K.bigru_bwd(bt, bs, T, h)]
+cls = K.gemm_last_class()
+assert cls & K.GEMM_GATE and cls & K.GEMM_X3, hex(cls)
+assert force == '0' or bool(cls & K.GEMM_XSPLIT) == (force != '1'), hex(cls)
+for (a, b), (a2, b2) in zip(first, K.bigru_bwd(bt, bs, T, h)):
+    assert torch.equal(a, a2) and torch.equal(b, b2), 'gate-fused chain: launch-to-launch difference'
+    outs += [a.cpu(), b.cpu()]
+tickets = K._ws[(str(DEV), 'chain', int(K._stream() or 0))][:4096].view(torch.int32)
+assert int(tickets.abs().max()) == 0, 'tickets not returned to zero'
+torch.save(dict(outs=outs, split_seen=split_seen), sys.argv[1])
+""" % (ROOT,)
+    import tempfile
+    got = {}
+    for force in ('1', '0', '2', '3', '4'):
+        with tempfile.NamedTemporaryFile(suffix='.pt') as f:
+            r = subprocess.run([sys.executable, '-c', code, f.name, force], env=dict(os.environ, TWOG_X3_XL=force, TWOG_GEMM_XSPLIT='1'),
+                               capture_output=True, text=True, timeout=600)
+            assert r.returncode == 0, force + ': ' + r.stdout[-1500:] + r.stderr[-3000:]
+            got[force] = torch.load(f.name)
+    assert got['1']['split_seen'] == 0 and got['0']['split_seen'] >= 3 and got['4']['split_seen'] == 6
+    base = got['1']['outs']
+    for force in ('0', '2', '3', '4'):
+        assert len(got[force]['outs']) == len(base) >= 13
+        for a, b in zip(base, got[force]['outs']):
+            assert torch.isfinite(b).all()
+            assert float((a - b).abs().max()) <= 2e-6 * float(a.abs().max()) + 1e-7, (force, float((a - b).abs().max()), float(a.abs().max()))
 
 
 def test_ssp_gather_with_segment_level_placement(K):
