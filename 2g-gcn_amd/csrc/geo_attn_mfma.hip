@@ -60,6 +60,34 @@ __device__ __forceinline__ void stage_rows64(const float* src, int N, int NP, fl
     }
 }
 
+// The same in two halves, so that the NEXT frame's rows travel while this frame is computed: fetch_rows64 issues the loads of
+// a [N][64] block into registers (two float4 per thread cover NP <= 64 rows at 512 threads), put_rows64 writes them to LDS.
+struct Rows64 { float4 v[2]; };
+__device__ __forceinline__ void fetch_rows64(const float* src, int N, int NP, Rows64& R) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int i = threadIdx.x + u * 512, r = i >> 4, c = (i & 15) * 4;
+        R.v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < NP * 16 && r < N) R.v[u] = *reinterpret_cast<const float4*>(src + (int64_t)r * 64 + c);
+    }
+}
+__device__ __forceinline__ void put_rows64(const Rows64& R, int NP, float* dst, float* dstT, int ldn) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int i = threadIdx.x + u * 512, r = i >> 4, c = (i & 15) * 4;
+        if (i < NP * 16) {
+            const float4 v = R.v[u];
+            *reinterpret_cast<float4*>(dst + r * LDK + c) = v;
+            if (dstT) {
+                dstT[(c + 0) * ldn + r] = v.x;
+                dstT[(c + 1) * ldn + r] = v.y;
+                dstT[(c + 2) * ldn + r] = v.z;
+                dstT[(c + 3) * ldn + r] = v.w;
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(512, 1) void gcn_attn2_fwd_kernel(const float* xin, const float* md, int n_frames, int N,
                                                                float* adj, float* z) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -76,10 +104,13 @@ __global__ __launch_bounds__(512, 1) void gcn_attn2_fwd_kernel(const float* xin,
         *reinterpret_cast<float4*>(sMt + r * LDK + c) = *reinterpret_cast<const float4*>(md + r * 64 + c);
     }
     if (threadIdx.x < 64) sd[threadIdx.x] = md[64 * 64 + threadIdx.x];
+    Rows64 rx;
+    if ((int)blockIdx.x < n_frames) fetch_rows64(xin + (int64_t)blockIdx.x * N * 64, N, NP, rx);
     for (int f = blockIdx.x; f < n_frames; f += gridDim.x) {
         const int64_t r0 = (int64_t)f * N;
         __syncthreads();
-        stage_rows64(xin + r0 * 64, N, NP, sX, sXt, LDN);
+        put_rows64(rx, NP, sX, sXt, LDN);
+        if (f + (int)gridDim.x < n_frames) fetch_rows64(xin + (r0 + (int64_t)gridDim.x * N) * 64, N, NP, rx);   // next frame, in flight under this one
         __syncthreads();
         // P = X M + d
         for (int t = wv; t < RT * 4; t += nw) {
@@ -160,17 +191,34 @@ __global__ __launch_bounds__(512, 1) void gcn_attn2_bwd_kernel(const float* xin,
     // dMt accumulators: 16 tiles (nt, kt) of 16x16, tile t owned by wave t % nw (two tiles per wave at 8 waves)
     f32x4m accM[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
     float dd_acc = 0.f;  // threads 0..63: dd[n]
+    // the next frame's X, dZ and S rows are fetched into registers while this frame is computed (the frame loop is a chain
+    // of six barrier-separated phases on ONE workgroup per CU: nothing else would hide the loads)
+    Rows64 rx, rz;
+    float ra[8];   // S: NP * NP <= 4096 values over 512 threads
+    auto fetch_frame = [&](int64_t r0) {
+        fetch_rows64(xin + r0 * 64, N, NP, rx);
+        fetch_rows64(dz + r0 * 64, N, NP, rz);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = threadIdx.x + u * 512, r = i / NP, c = i - r * NP;
+            ra[u] = (i < NP * NP && r < N && c < N) ? adj[(r0 + r) * N + c] : 0.f;
+        }
+    };
+    if ((int)blockIdx.x < n_frames) fetch_frame((int64_t)blockIdx.x * N);
     for (int f = blockIdx.x; f < n_frames; f += gridDim.x) {
         const int64_t r0 = (int64_t)f * N;
         __syncthreads();
-        stage_rows64(xin + r0 * 64, N, NP, sX, sXt, LDN);
-        stage_rows64(dz + r0 * 64, N, NP, sdZ, sdZt, LDN);
-        for (int i = threadIdx.x; i < NP * NP; i += blockDim.x) {
-            const int r = i / NP, c = i - r * NP;
-            const float v = (r < N && c < N) ? adj[(r0 + r) * N + c] : 0.f;
-            sA[r * LDN + c] = v;
-            sAt[c * LDN + r] = v;
+        put_rows64(rx, NP, sX, sXt, LDN);
+        put_rows64(rz, NP, sdZ, sdZt, LDN);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = threadIdx.x + u * 512, r = i / NP, c = i - r * NP;
+            if (i < NP * NP) {
+                sA[r * LDN + c] = ra[u];
+                sAt[c * LDN + r] = ra[u];
+            }
         }
+        if (f + (int)gridDim.x < n_frames) fetch_frame(r0 + (int64_t)gridDim.x * N);
         __syncthreads();
         // P^T (recomputed) and dA; dX1 = S^T dZ starts the dX accumulators
         for (int t = wv; t < RT * 4; t += nw) {
