@@ -24,7 +24,8 @@ class Rows(C.Structure):  # twog_rows_t
 class Gemm(C.Structure):  # twog_gemm_t
     _fields_ = [('A', Rows), ('B', Rows), ('C', Rows), ('bias', C.c_void_p), ('M', C.c_int32), ('N', C.c_int32),
                 ('K', C.c_int32), ('act', C.c_int32), ('accumulate', C.c_int32), ('batch', C.c_int32),
-                ('a_batch_stride', C.c_int64), ('b_batch_stride', C.c_int64), ('c_batch_stride', C.c_int64)]
+                ('a_batch_stride', C.c_int64), ('b_batch_stride', C.c_int64), ('c_batch_stride', C.c_int64),
+                ('a_colsum', C.c_void_p), ('a_colsum_accumulate', C.c_int32), ('pad2_', C.c_int32)]
 
 
 class GruStep(C.Structure):  # twog_gru_step_t
@@ -159,6 +160,7 @@ LOSS_MAX_TERMS, LOSS_BLOCKS = 16, 64  # TWOG_LOSS_MAX_TERMS, TWOG_LOSS_BLOCKS
 _I, _L, _F, _P = C.c_int, C.c_int64, C.c_float, C.c_void_p
 SIGNATURES = {
     'twog_gemm_f32': [C.POINTER(Gemm), _I, _I, _I, _P, C.c_size_t, _P],
+    'twog_gemm_colsum_fused': [C.POINTER(Gemm), _I, _I, _I, _P, C.c_size_t],
     'twog_gemm_last_class': [],
     'twog_chain_workspace_bytes': [],
     'twog_gemm_f32_chain': [C.POINTER(Gemm), _I, _I, _I, _P, C.c_size_t, _P],

@@ -36,6 +36,8 @@ struct Prob {
     int n_major;       // logical tile order: consecutive tiles share the B column panel (weights larger than activations)
     int batch;         // independent problems sharing shapes; operand b of batch i = ptr + i * *_bs
     int64_t a_bs, b_bs, c_bs;
+    float* cs;         // column sums of the k-major A operand (twog_gemm_t::a_colsum), or nullptr
+    int cs_acc;
 };
 
 struct Group {
@@ -49,6 +51,7 @@ struct Group {
     int group;       // tile order inside a problem: groups of `group` panels of the major dimension (tile_coords)
     int xcd_split;   // split-K launches with splitk % 8 == 0: XCD x works the k-splits x, x + 8, ... of ALL tiles (see gemm_tile)
     float* slabs;    // split-K partials: [problem-tile-major] see below
+    float* cs_part;  // split-K launches with a_colsum requests: [split][tile][128] partial column sums (tiles with tn == 0)
     unsigned* xcnt;  // XS kernels (split-K over workgroups, combined in the launch): arrival ticket per tile, zero between launches
     int xs_early;    // XS: every slice requests the epilogue operands before its reduction loop (small launches: the
                      // combining workgroup then has them when it draws the last ticket; large ones fetch them once, late)
@@ -455,9 +458,11 @@ constexpr int X3_TPLANE = X3_BK * 256;       // [16 k][128 rows] image: 4 096
 constexpr int X3_STAGE = 6 * X3_RPLANE;      // one LDS stage (three planes of both operands): 24 576 bytes; two stages = 49 152
 __device__ __forceinline__ int x3_swz(int k) { return ((k & 3) << 2) | ((k >> 2) & 3); }
 
+// cs (k-major A only): when cs_on, every thread also adds the A values it stages (4 consecutive tile columns of one k row per
+// k-tile) into cs -- the column sums of A over this workgroup's k-range, finished by gemm_tile (twog_gemm_t::a_colsum).
 template <bool AKM, bool BKM, bool KG>
 __device__ __forceinline__ void gemm_mainloop_x3(const twog_rows_t A, const twog_rows_t B, int M, int N, int m0, int n0,
-                                                 int k_begin, int k_end, float* smem, f32x16 (&acc)[1][2]) {
+                                                 int k_begin, int k_end, float* smem, f32x16 (&acc)[1][2], f32x4& cs, bool cs_on) {
     constexpr int BM = 128, BN = 128, NT = 512, XK = X3_BK;
     constexpr int PA = AKM ? X3_TPLANE : X3_RPLANE, PB = BKM ? X3_TPLANE : X3_RPLANE;
     char* lds = reinterpret_cast<char*>(smem);   // stage b: A planes at b * X3_STAGE, B planes behind them
@@ -525,9 +530,13 @@ __device__ __forceinline__ void gemm_mainloop_x3(const twog_rows_t A, const twog
             r.b = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_b, (int)ob, sb, 0));
         }
     };
-    auto split_store = [&](const Stage& r, int buf) {
+    const int nkt = (k_end - k_begin) / XK;
+    auto split_store = [&](const Stage& r, int buf, int t) {   // t: index of the k-tile held by r (clamped repeats: t >= nkt)
         char* base = lds + buf * X3_STAGE;
         i32x2 ph, pm, pl;
+        if constexpr (AKM && BKM && !KG) {
+            if (cs_on && t < nkt) cs += r.a;
+        }
         split3(r.a, ph, pm, pl);
         *reinterpret_cast<i32x2*>(base + sa_off) = ph;
         *reinterpret_cast<i32x2*>(base + sa_off + PA) = pm;
@@ -613,7 +622,6 @@ __device__ __forceinline__ void gemm_mainloop_x3(const twog_rows_t A, const twog
     // tile t + 1 is split and stored into the other LDS stage in the same basic block as the MFMAs of tile t (the VALU work
     // of the split issues between the MFMAs). Loads past the last k-tile are clamped to it instead of branched around (see
     // gemm_mainloop); the redundant tiles are stored but never read.
-    const int nkt = (k_end - k_begin) / XK;
     if (nkt <= 0) return;
     const int k_last = k_begin + (nkt - 1) * XK;
     auto kof = [&](int t) { return min(k_begin + t * XK, k_last); };
@@ -622,12 +630,12 @@ __device__ __forceinline__ void gemm_mainloop_x3(const twog_rows_t A, const twog
     Stage r0, r1;
     gload(r0, kof(0));
     gload(r1, kof(1));
-    split_store(r0, 0);
+    split_store(r0, 0, 0);
     __syncthreads();
     int kt = 0;
     for (; kt + 1 < nkt; kt += 2) {
-        gload(r0, kof(kt + 2)); compute(0); split_store(r1, 1); __syncthreads();
-        gload(r1, kof(kt + 3)); compute(1); split_store(r0, 0); __syncthreads();
+        gload(r0, kof(kt + 2)); compute(0); split_store(r1, 1, kt + 1); __syncthreads();
+        gload(r1, kof(kt + 3)); compute(1); split_store(r0, 0, kt + 2); __syncthreads();
     }
     if (kt < nkt) compute(0);
 #else
@@ -636,19 +644,19 @@ __device__ __forceinline__ void gemm_mainloop_x3(const twog_rows_t A, const twog
     gload(r1, kof(1));
     gload(r2, kof(2));
     gload(r3, kof(3));
-    split_store(r0, 0);
+    split_store(r0, 0, 0);
     __syncthreads();
     int kt = 0;
     for (; kt + 3 < nkt; kt += 4) {
-        gload(r0, kof(kt + 4)); compute(0); split_store(r1, 1); __syncthreads();
-        gload(r1, kof(kt + 5)); compute(1); split_store(r2, 0); __syncthreads();
-        gload(r2, kof(kt + 6)); compute(0); split_store(r3, 1); __syncthreads();
-        gload(r3, kof(kt + 7)); compute(1); split_store(r0, 0); __syncthreads();
+        gload(r0, kof(kt + 4)); compute(0); split_store(r1, 1, kt + 1); __syncthreads();
+        gload(r1, kof(kt + 5)); compute(1); split_store(r2, 0, kt + 2); __syncthreads();
+        gload(r2, kof(kt + 6)); compute(0); split_store(r3, 1, kt + 3); __syncthreads();
+        gload(r3, kof(kt + 7)); compute(1); split_store(r0, 0, kt + 4); __syncthreads();
     }
     // up to three k-tiles left: tile kt sits in LDS stage 0, tiles kt + 1, kt + 2 in r1, r2
     if (kt < nkt) compute(0);
-    if (kt + 1 < nkt) { split_store(r1, 1); __syncthreads(); compute(1); }
-    if (kt + 2 < nkt) { split_store(r2, 0); __syncthreads(); compute(0); }
+    if (kt + 1 < nkt) { split_store(r1, 1, kt + 1); __syncthreads(); compute(1); }
+    if (kt + 2 < nkt) { split_store(r2, 0, kt + 2); __syncthreads(); compute(0); }
 #endif
 }
 
@@ -1047,7 +1055,27 @@ __device__ __forceinline__ void gemm_tile(const Group& g, const GateArgs* ga) {
         // (the host launches X3 kernels for aligned operands and whole k-tiles only)
         if constexpr (BM == 128) {
             static_assert(!X3 || BM != 128 || (BN == 128 && NT == 512 && !GATE && KS == 1 && !XS), "X3: the 8-wave 128x128 class");
-            gemm_mainloop_x3<AKM, BKM, KG>(A, B, M, N, m0, n0, k_begin, k_end, smem, acc);
+            f32x4 cs = {0.f, 0.f, 0.f, 0.f};
+            const bool cs_on = AKM && BKM && !KG && G.cs != nullptr && tn_idx == 0;   // uniform over the workgroup
+            gemm_mainloop_x3<AKM, BKM, KG>(A, B, M, N, m0, n0, k_begin, k_end, smem, acc, cs, cs_on);
+            if constexpr (AKM && BKM && !KG) {
+                if (cs_on) {
+                    // thread (k row tid / 32, column quad tid % 32) holds its k rows' sums: the 16 k rows are added in row order
+                    // (fixed: bit-reproducible); split-K launches park the slice's sums for splitk_reduce_kernel
+                    __syncthreads();   // every wave is done with the operand tiles
+                    *reinterpret_cast<f32x4*>(smem + (threadIdx.x >> 5) * 128 + (threadIdx.x & 31) * 4) = cs;
+                    __syncthreads();
+                    if (threadIdx.x < 128) {
+                        float v = 0.f;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) v += smem[r * 128 + threadIdx.x];
+                        const int col = m0 + (int)threadIdx.x;
+                        if (g.splitk > 1) g.cs_part[((int64_t)split * g.total_tiles + bid) * 128 + threadIdx.x] = v;
+                        else if (col < M) G.cs[col] = G.cs_acc ? G.cs[col] + v : v;
+                    }
+                    __syncthreads();   // (the LA branch below reuses smem[0])
+                }
+            }
         } else {
             static_assert(!X3 || BM == 128 || (BM == 64 && BN == 64 && !AKM && !KG && !XS), "X3: 64x64 tiles, row-major A");
             gemm_mainloop_x3s<BM, BN, NT, BKM, KS, 1, false, (GATE || KU > 1 ? 2 : TWOG_X3S_RS), true, KU>(A, B, M, N, m0, n0, k_begin, k_end, smem, acc);
@@ -1496,6 +1524,12 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const Group g) {
     int tm_idx, tn_idx;
     tile_coords(P, tile, g.group, tm_idx, tn_idx);
     const int m0 = tm_idx * BM, n0 = tn_idx * BN;
+    if (P.cs && tn_idx == 0 && blockIdx.y == gridDim.y - 1 && threadIdx.x < 128 && m0 + (int)threadIdx.x < P.M) {
+        float v = 0.f;   // the slices' column sums of A, in slice order
+        for (int s = 0; s < g.splitk; ++s) v += g.cs_part[((int64_t)s * g.total_tiles + bid) * 128 + threadIdx.x];
+        float* o = P.cs + m0 + threadIdx.x;
+        *o = P.cs_acc ? *o + v : v;
+    }
     // grid.y slices the tile so that small-output / deep-split problems still spread over the chip
     const int chunk = (BM * BN) / gridDim.y;
     // 16-byte path: four columns per lane when the output rows allow it (whole column quads inside N, aligned rows)
@@ -1541,6 +1575,14 @@ inline int vec_ok(const twog_rows_t& m, int64_t batch_stride, int contiguous_ext
 
 thread_local int g_last_class_x3 = 0;
 
+// the bf16x3 128x128 class serves this group: aligned operands, whole 16-deep k-tiles (TWOG_GEMM_X3=0: native fp32 MFMA)
+static bool x3_128_ok(const Group& g) {
+    static const int x3_on = getenv("TWOG_GEMM_X3") ? atoi(getenv("TWOG_GEMM_X3")) : 1;
+    bool ok = x3_on != 0 && (g.k_per_split % X3_BK) == 0;
+    for (int i = 0; i < g.n; ++i) ok = ok && g.p[i].a_vec && g.p[i].b_vec && (g.p[i].K % X3_BK) == 0 && g.p[i].M >= 4 && g.p[i].N >= 4;
+    return ok;
+}
+
 template <int BM, int BN, int NT, int D>
 int launch(Group& g, int akm, int bkm, hipStream_t st) {
     g_last_class_x3 = 0;
@@ -1550,10 +1592,7 @@ int launch(Group& g, int akm, int bkm, hipStream_t st) {
     for (int i = 0; i < g.n; ++i) kg = kg || (akm && g.p[i].A.inner > 1) || (bkm && g.p[i].B.inner > 1);
     if constexpr (BM == 128 && NT == 512) {
         // X3 (fp32-exact operands on the bf16 matrix cores, gemm_mainloop_x3): aligned operands, whole k-tiles, plain rows
-        static const int x3_on = getenv("TWOG_GEMM_X3") ? atoi(getenv("TWOG_GEMM_X3")) : 1;   // default on; 0: native fp32 MFMA
-        bool ok = x3_on != 0 && (g.k_per_split % X3_BK) == 0;
-        for (int i = 0; i < g.n; ++i) ok = ok && g.p[i].a_vec && g.p[i].b_vec && (g.p[i].K % X3_BK) == 0 && g.p[i].M >= 4 && g.p[i].N >= 4;
-        if (ok) {
+        if (x3_128_ok(g)) {
             if (!akm && !bkm) hipLaunchKernelGGL((gemm_x3_kernel<false, false, false>), grid, block, 0, st, g);
             else if (!akm && bkm && !kg) hipLaunchKernelGGL((gemm_x3_kernel<false, true, false>), grid, block, 0, st, g);
             else if (!akm && bkm) hipLaunchKernelGGL((gemm_x3_kernel<false, true, true>), grid, block, 0, st, g);
@@ -1648,6 +1687,7 @@ static void prepare_group(const twog_gemm_t* pr, int n, int a_kmajor, int b_kmaj
         P.A = q.A; P.B = q.B; P.C = q.C; P.bias = q.bias;
         P.M = q.M; P.N = q.N; P.K = q.K;
         P.act = q.act; P.accumulate = q.accumulate;
+        P.cs = q.a_colsum; P.cs_acc = q.a_colsum_accumulate;
         P.tiles_m = (P.M + bm - 1) / bm;
         P.tiles_n = (P.N + BMN - 1) / BMN;
         P.tile_start = t;
@@ -1678,6 +1718,7 @@ static void prepare_group(const twog_gemm_t* pr, int n, int a_kmajor, int b_kmaj
     g.splitk = 1;
     g.k_per_split = ((kmax + BK - 1) / BK) * BK;
     g.slabs = nullptr;
+    g.cs_part = nullptr;
     g.xcnt = nullptr;
     g.xs_early = 0;
     g.xcd_split = 0;
@@ -1723,7 +1764,10 @@ static void prepare_group(const twog_gemm_t* pr, int n, int a_kmajor, int b_kmaj
         // of 64 KB alone, where the reduce launch spreads the same bytes over 16 workgroups per tile at 5 TB/s; what the
         // launch boundary costs is less than that. TWOG_GEMM_LA=1 selects it (tests run both).
         static const int la_on = getenv("TWOG_GEMM_LA") ? atoi(getenv("TWOG_GEMM_LA")) : 0;
-        const size_t need = (size_t)want * t * BMN * BMN * sizeof(float) + SPLITK_TICKET_BYTES;
+        bool any_cs = false;
+        for (int i = 0; i < n; ++i) any_cs = any_cs || pr[i].a_colsum != nullptr;
+        const size_t cs_bytes = any_cs ? (size_t)(want + 1) * t * 128 * sizeof(float) : 0;   // (+1: the split count is rounded below)
+        const size_t need = (size_t)want * t * BMN * BMN * sizeof(float) + SPLITK_TICKET_BYTES + cs_bytes;
         if (want > 1 && need <= workspace_bytes) {
             int kps = (kmax + want - 1) / want;
             g.k_per_split = ((kps + BK - 1) / BK) * BK;
@@ -1731,7 +1775,8 @@ static void prepare_group(const twog_gemm_t* pr, int n, int a_kmajor, int b_kmaj
             g.slabs = reinterpret_cast<float*>(static_cast<char*>(workspace) + SPLITK_TICKET_BYTES);
             g.xcd_split = (want8 && g.splitk % 8 == 0) ? 1 : 0;
             const bool fits32 = (uint64_t)g.splitk * t * BMN * BMN * sizeof(float) < (uint64_t(1) << 32);
-            if (la_on && bm == BMN && t <= (int)(SPLITK_TICKET_BYTES / sizeof(unsigned)) && fits32) g.xcnt = static_cast<unsigned*>(workspace);
+            if (la_on && !any_cs && bm == BMN && t <= (int)(SPLITK_TICKET_BYTES / sizeof(unsigned)) && fits32) g.xcnt = static_cast<unsigned*>(workspace);
+            if (any_cs) g.cs_part = g.slabs + (size_t)g.splitk * t * BMN * BMN;
         }
     }
 }
@@ -1864,8 +1909,35 @@ static bool xl_setup(Group& g, int kmax, void* chain_ws, size_t chain_ws_bytes) 
     return true;
 }
 
+// a_colsum requests are served by the 8-wave X3 128x128 kernels with k-major A and B only (gemm_mainloop_x3): true when the
+// group has no request or takes that class
+static bool colsums_served(const twog_gemm_t* pr, int n, int a_kmajor, int b_kmajor, const Group& g, bool big) {
+    bool any = false, plain = true;
+    for (int i = 0; i < n; ++i) {
+        any = any || pr[i].a_colsum != nullptr;
+        plain = plain && pr[i].batch <= 1 && pr[i].M % 4 == 0 && pr[i].A.inner <= 1 && pr[i].B.inner <= 1;   // (no grouped rows: the KG kernels have no register left)
+    }
+    if (!any) return true;
+    static const int w8 = getenv("TWOG_GEMM_W8") ? atoi(getenv("TWOG_GEMM_W8")) : 1;
+    return a_kmajor && b_kmajor && big && w8 && plain && x3_128_ok(g);
+}
+
 static int gemm_impl(const twog_gemm_t* problems, int n_problems, int a_kmajor, int b_kmajor, void* workspace,
                      size_t workspace_bytes, void* chain_ws, size_t chain_ws_bytes, void* stream);
+
+extern "C" int twog_gemm_colsum_fused(const twog_gemm_t* problems, int n_problems, int a_kmajor, int b_kmajor, void* workspace,
+                                      size_t workspace_bytes) {
+    for (int done = 0; done < n_problems; done += MAXP) {
+        const int n = (n_problems - done) < MAXP ? (n_problems - done) : MAXP;
+        Group g;
+        int order[MAXP];
+        bool big;
+        int bm;
+        prepare_group(problems + done, n, a_kmajor, b_kmajor, workspace, workspace_bytes, g, order, big, bm);
+        if (!colsums_served(problems + done, n, a_kmajor, b_kmajor, g, big)) return 0;
+    }
+    return 1;
+}
 
 extern "C" int twog_gemm_f32(const twog_gemm_t* problems, int n_problems, int a_kmajor, int b_kmajor, void* workspace,
                              size_t workspace_bytes, void* stream) {
@@ -1897,6 +1969,7 @@ static int gemm_impl(const twog_gemm_t* problems, int n_problems, int a_kmajor, 
         bool big;
         int bm;
         prepare_group(pr, n, a_kmajor, b_kmajor, workspace, workspace_bytes, g, order, big, bm);
+        if (!colsums_served(pr, n, a_kmajor, b_kmajor, g, big)) return -5;   // an a_colsum request this launch would not serve
         static const int depth = getenv("TWOG_GEMM_DEPTH") ? atoi(getenv("TWOG_GEMM_DEPTH")) : 0;  // tuning knob
         const int d128 = depth ? (depth & 3) : 2, d64 = depth ? ((depth >> 2) & 3) : 2;
         int rc;

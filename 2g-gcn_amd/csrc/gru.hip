@@ -199,7 +199,7 @@ static int bigru_fwd_impl(const twog_bigru_t* types, int n_types, int bs, int T,
                 G.C = rows_plain(tmp, 3 * h);
                 G.bias = dir == 0 ? Y.b_hh_f : Y.b_hh_r;
                 G.M = rows; G.N = 3 * h; G.K = h; G.act = 0; G.accumulate = 0; G.batch = 1;
-                G.a_batch_stride = G.b_batch_stride = G.c_batch_stride = 0;
+                G.a_batch_stride = G.b_batch_stride = G.c_batch_stride = 0; G.a_colsum = nullptr; G.a_colsum_accumulate = 0; G.pad2_ = 0;
                 twog_gru_step_t& S = st[n];
                 S.gi = rows_be(Y.gi + (int64_t)t * E * 6 * h + dir * 3 * h, E, 6 * h, T);
                 S.gi2.ptr = nullptr; S.gi2.inner = 1; S.gi2.ld_inner = S.gi2.ld_outer = 0;
@@ -263,7 +263,7 @@ static int bigru_bwd_impl(const twog_bigru_bwd_t* types, int n_types, int bs, in
                     G.C = rows_plain(carry, h);
                     G.bias = nullptr;
                     G.M = rows; G.N = h; G.K = 3 * h; G.act = 0; G.accumulate = 1; G.batch = 1;
-                    G.a_batch_stride = G.b_batch_stride = G.c_batch_stride = 0;
+                    G.a_batch_stride = G.b_batch_stride = G.c_batch_stride = 0; G.a_colsum = nullptr; G.a_colsum_accumulate = 0; G.pad2_ = 0;
                 }
                 ++n;
             }

@@ -38,6 +38,7 @@ inline void gemm_set(twog_gemm_t& G, twog_rows_t A, twog_rows_t B, twog_rows_t C
                      int K, int act, int acc) {
     G.A = A; G.B = B; G.C = C; G.bias = bias; G.M = M; G.N = N; G.K = K; G.act = act; G.accumulate = acc; G.batch = 1;
     G.a_batch_stride = G.b_batch_stride = G.c_batch_stride = 0;
+    G.a_colsum = nullptr; G.a_colsum_accumulate = 0; G.pad2_ = 0;
 }
 
 struct Dims {

@@ -226,16 +226,9 @@ class HipKernels:
         return self.lib.twog_version().decode()
 
     # ---------------------------------------------------------------- GEMM
-    def gemm(self, problems, a_kmajor=False, b_kmajor=False, split_k_workspace=True, chain=False):
-        """problems: list of dicts with keys A, B, C (row-strided views), bias (1-D or None), act (0/1), accumulate.
-        Logical shapes: A (M,K) [or stored (K,M) if a_kmajor], B (N,K) [or (K,N) if b_kmajor], C (M,N).
-        Optional 'batch': (n, a_stride, b_stride, c_stride) in elements. chain=True: a launch of a recurrent chain
-        (twog_gemm_f32_chain: the reduction may be split over workgroups and combined inside the launch)."""
+    def _gemm_array(self, problems, a_kmajor, b_kmajor):
         n = len(problems)
-        if n == 0:
-            return
         arr = (L.Gemm * n)()
-        dev = problems[0]['C'].device
         for i, p in enumerate(problems):
             A, B, Cm = p['A'], p['B'], p['C']
             g = arr[i]
@@ -264,6 +257,39 @@ class HipKernels:
                 g.batch, g.a_batch_stride, g.b_batch_stride, g.c_batch_stride = 1, 0, 0, 0
             else:
                 g.batch, g.a_batch_stride, g.b_batch_stride, g.c_batch_stride = b
+            cs = p.get('colsum')
+            if cs is not None:
+                assert a_kmajor and cs.numel() == M and cs.is_contiguous() and cs.dtype == torch.float32
+            g.a_colsum = _ptr(cs)
+            g.a_colsum_accumulate = int(bool(p.get('colsum_accumulate', False)))
+        return arr
+
+    def gemm_colsum_ok(self, problem):
+        """True if gemm([problem], a_kmajor=True, b_kmajor=True) with a 'colsum' entry takes the column sums of A inside the
+        GEMM launch (twog_gemm_colsum_fused); False: the caller takes them with colsum()."""
+        key = tuple((tuple(t.shape), tuple(t.stride()), t.data_ptr() % 16) for t in (problem['A'], problem['B'], problem['C']))
+        ok = self._colsum_ok.get(key)
+        if ok is None:
+            arr = self._gemm_array([dict(problem, colsum=None)], True, True)
+            arr[0].a_colsum = arr[0].C.ptr   # (any non-null pointer: the query launches nothing)
+            ws = self.workspace(320 << 20, problem['C'].device, 'splitk')
+            ok = self._colsum_ok[key] = bool(self.lib.twog_gemm_colsum_fused(arr, 1, 1, 1, ws.data_ptr(), ws.numel() * 4))
+        return ok
+
+    _colsum_ok = {}
+
+    def gemm(self, problems, a_kmajor=False, b_kmajor=False, split_k_workspace=True, chain=False):
+        """problems: list of dicts with keys A, B, C (row-strided views), bias (1-D or None), act (0/1), accumulate.
+        Logical shapes: A (M,K) [or stored (K,M) if a_kmajor], B (N,K) [or (K,N) if b_kmajor], C (M,N).
+        Optional 'batch': (n, a_stride, b_stride, c_stride) in elements. chain=True: a launch of a recurrent chain
+        (twog_gemm_f32_chain: the reduction may be split over workgroups and combined inside the launch).
+        Optional 'colsum' ([M] fp32, with 'colsum_accumulate'): the column sums of a k-major A from the same pass over A
+        (twog_gemm_t::a_colsum; only where gemm_colsum_ok(problem) holds)."""
+        n = len(problems)
+        if n == 0:
+            return
+        dev = problems[0]['C'].device
+        arr = self._gemm_array(problems, a_kmajor, b_kmajor)
         if chain:
             assert self._tape is None, 'chain launches cannot be recorded (kernels.tape_begin)'
             rc = self.lib.twog_gemm_f32_chain(arr, n, int(a_kmajor), int(b_kmajor), *self.chain_workspace(dev), self._stream())

@@ -373,6 +373,7 @@ class _Grads:
         self._pending, self._pending_dst = [], set()   # `dst += t` operations not yet issued (one launch per 16: flush())
         self._pend_cs, self._pend_cp = [], []          # column sums / copies not yet issued (issued before the additions)
         self._pend_mm, self._pend_mm_c = [], set()     # weight-gradient GEMMs (dW = dY^T X) not yet issued: grouped launches
+        self._held = None                              # a tall dW GEMM waiting one call for its bias gradient (dw_gemm)
         self._defer = hasattr(K, 'colsum_many') and os.environ.get('TWOG_BATCH_ADDS', '1') != '0'
 
     def sink(self, name):
@@ -421,8 +422,16 @@ class _Grads:
         rows = A.shape[0] if A.dim() == 2 else A.shape[0] * A.shape[1]
         if (not self._defer or os.environ.get('TWOG_BATCH_DW', '1') == '0' or A.shape[-1] < 128 or B.shape[-1] < 128
                 or rows > 8192 or not plain(A) or not plain(B)):
+            self._issue_held()
             if problem['C'].data_ptr() in self._pend_mm_c:
                 self.flush()   # (a collected problem writes the same buffer: keep the order)
+            # a tall problem waits for ONE more call: the bias gradient of the same layer is asked for right after its weight
+            # gradient (colsum(dY) after dW = dY^T X), and the GEMM that already streams dY takes the column sums on the
+            # way (twog_gemm_t::a_colsum) -- 1.3 ms of column-sum launches re-reading 4 GB per bs64 step otherwise
+            if (self._defer and A.dim() == 2 and os.environ.get('TWOG_DW_COLSUM', '1') != '0'
+                    and hasattr(self.K, 'gemm_colsum_ok') and self.K.gemm_colsum_ok(problem)):
+                self._held = problem
+                return
             self.K.gemm([problem], a_kmajor=True, b_kmajor=True)
             return
         key = problem['C'].data_ptr()
@@ -439,6 +448,15 @@ class _Grads:
             out, accumulate = torch.empty(x.shape[-1], dtype=torch.float32, device=x.device), False
         if not self._defer:
             return self.K.colsum(x, out=out, accumulate=accumulate)
+        h = self._held
+        if h is not None:
+            A = h['A']
+            if (A.data_ptr() == x.data_ptr() and A.shape == x.shape and A.stride() == x.stride() and out.is_contiguous()
+                    and not any(o.data_ptr() == out.data_ptr() for _, _, o, _ in self._pend_cs)):
+                h['colsum'], h['colsum_accumulate'] = out, accumulate
+            self._issue_held()
+            if 'colsum' in h:
+                return out
         if len(self._pend_cs) >= 16 or any(o.data_ptr() == out.data_ptr() for _, _, o, _ in self._pend_cs):
             self.flush()   # (two sums into one buffer -- shared heads -- never share a launch)
         self._pend_cs.append((x, None, out, accumulate))
@@ -451,9 +469,15 @@ class _Grads:
             return
         self._pend_cp.append((src, dst))
 
+    def _issue_held(self):
+        h, self._held = self._held, None
+        if h is not None:
+            self.K.gemm([h], a_kmajor=True, b_kmajor=True)
+
     def flush(self):
         """Issues the pending column sums, copies and additions, in that order (on the current stream). Called before
         anything reads the gradients: a stage hook, the end of the backward pass, a change of stream."""
+        self._issue_held()
         if self._pend_mm:
             self.K.gemm(self._pend_mm, a_kmajor=True, b_kmajor=True)
             self._pend_mm, self._pend_mm_c = [], set()

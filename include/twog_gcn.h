@@ -59,9 +59,20 @@ typedef struct {
     int32_t accumulate; /* 0: C = ..., 1: C += ... */
     int32_t batch;      /* >= 1 independent problems of this shape; operand of batch i = ptr + i * *_batch_stride */
     int64_t a_batch_stride, b_batch_stride, c_batch_stride;
+    float* a_colsum;            /* NULL, or [M]: a_colsum[m] (+)= sum_k A(m,k) from the same pass over A -- the bias gradient that
+                                   belongs to a weight gradient dW = dY^T X (nn.Linear / GRU input projection backward:
+                                   pyrutils/torch/models.py:31-36, vhoi/models.py:267-320). Served only where
+                                   twog_gemm_colsum_fused() says so; asked for elsewhere the call returns -5, nothing launched */
+    int32_t a_colsum_accumulate; /* 0: a_colsum = ..., 1: a_colsum += ... */
+    int32_t pad2_;
 } twog_gemm_t;
 int twog_gemm_f32(const twog_gemm_t* problems, int n_problems, int a_kmajor, int b_kmajor, void* workspace,
                   size_t workspace_bytes, void* stream);
+/* 1 if twog_gemm_f32 with these arguments computes the a_colsum of every problem that asks for one inside the GEMM launch
+ * (k-major A and B, the bf16x3 128x128 class: aligned operands, M % 4 == 0, whole 16-deep k-tiles, plain or grouped rows),
+ * 0 if the caller has to take the column sums with twog_colsum / twog_colsum_n instead. No launch. */
+int twog_gemm_colsum_fused(const twog_gemm_t* problems, int n_problems, int a_kmajor, int b_kmajor, void* workspace,
+                           size_t workspace_bytes);
 
 /* Which kernel variant the calling thread's most recent twog_gemm_f32 chunk (or fused gate launch) selected -- lets a
  * test assert that it exercised the variant it was written for. Bit field: */

@@ -121,6 +121,16 @@ class FakeKernels:
                 if p.get('act', 0) == 1:
                     out = torch.relu(out)
                 Cm.copy_(out.reshape(Cm.shape))
+            cs = p.get('colsum')
+            if cs is not None:   # twog_gemm_t::a_colsum: column sums of the k-major A from the same pass
+                assert a_kmajor and nb == 1
+                v = _mat(p['A']).sum(0)
+                cs.copy_(cs + v if p.get('colsum_accumulate') else v)
+
+    def gemm_colsum_ok(self, problem):
+        """The HIP library serves the fused column sums for aligned operands of the 128x128 class; the double says yes for
+        every plain 2-D problem so that the CPU suite exercises the pairing logic of ops._Grads."""
+        return problem['A'].dim() == 2 and problem['B'].dim() == 2
 
     @staticmethod
     def _shift(t, off):

@@ -233,6 +233,50 @@ def test_gemm_split_k_in_launch_combine_equals_the_reduce_launch_bit_for_bit(K, 
     assert split_seen, 'no case took the split-K path'
 
 
+def test_gemm_column_sums_of_a_from_the_same_pass(K):
+    """twog_gemm_t::a_colsum: the dW = dY^T X launch of the bf16x3 128x128 class (k-major A and B) also returns the column sums
+    of dY -- the layer's bias gradient -- from the values it stages anyway (workgroups of the first column panel add them per
+    k-slice; splitk_reduce_kernel adds the slices in order). Against fp64, with and without split-K, write and accumulate, a
+    ragged last row panel; C must be the bits of the launch without the request; two launches agree bit for bit; a request the
+    launch would not serve is refused (rc -5), never dropped."""
+    for (M, N, Kd, acc, cacc, seed, expect_split) in ((512, 2048, 61440, False, False, 1, True), (1536, 512, 30720, True, True, 2, True),
+                                                      (520, 640, 8192, False, True, 3, True), (2048, 2048, 512, False, False, 4, False)):
+        g = torch.Generator().manual_seed(300 + seed)
+        A = (torch.randn(Kd, M, generator=g) + 0.25).to(DEV)   # a non-zero mean: the sums grow with K
+        B = (torch.randn(Kd, N, generator=g) * 0.1).to(DEV)
+        C0 = torch.randn(M, N, generator=g).to(DEV)
+        cs0 = torch.randn(M, generator=g).to(DEV)
+        p = dict(A=A, B=B, accumulate=acc)
+        assert K.gemm_colsum_ok(dict(p, C=C0)), (M, N, Kd)
+        Cref = C0.clone()
+        K.gemm([dict(p, C=Cref)], a_kmajor=True, b_kmajor=True)
+        outs = []
+        for _ in range(2):
+            C, cs = C0.clone(), cs0.clone()
+            K.gemm([dict(p, C=C, colsum=cs, colsum_accumulate=cacc)], a_kmajor=True, b_kmajor=True)
+            cls = K.gemm_last_class()
+            assert cls & K.GEMM_TILE128 and cls & K.GEMM_X3 and bool(cls & K.GEMM_SPLITK) == expect_split, hex(cls)
+            outs.append((C, cs))
+        assert torch.equal(outs[0][0], Cref), 'the request changed C'
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+        ref = A.double().sum(0) + (cs0.double() if cacc else 0.0)
+        err = (outs[0][1].double() - ref).abs().max().item()
+        assert err <= 3e-6 * ref.abs().max().item(), (M, N, Kd, err / ref.abs().max().item())
+    # two problems in one launch, one with a request; then a shape of the 64x64 class: refused
+    g = torch.Generator().manual_seed(9)
+    A1, A2 = torch.randn(16384, 256, generator=g).to(DEV), torch.randn(16384, 384, generator=g).to(DEV)
+    B1 = torch.randn(16384, 512, generator=g).to(DEV)
+    C1, C2, cs = torch.empty(256, 512, device=DEV), torch.empty(384, 512, device=DEV), torch.zeros(384, device=DEV)
+    K.gemm([dict(A=A1, B=B1, C=C1), dict(A=A2, B=B1, C=C2, colsum=cs)], a_kmajor=True, b_kmajor=True)
+    ref = A2.double().sum(0)
+    assert (cs.double() - ref).abs().max().item() <= 3e-6 * ref.abs().max().item()
+    close(C2, (A2.double().t() @ B1.double()).float(), rtol=3e-5, atol=3e-5 * float(ref.abs().max()), what='C of the grouped launch')
+    small = dict(A=torch.randn(512, 64, generator=g).to(DEV), B=torch.randn(512, 64, generator=g).to(DEV), C=torch.empty(64, 64, device=DEV))
+    assert not K.gemm_colsum_ok(small)
+    with pytest.raises(RuntimeError):
+        K.gemm([dict(small, colsum=torch.zeros(64, device=DEV))], a_kmajor=True, b_kmajor=True)
+
+
 def _gemm128_cases(K, w8=True):
     T128, W8, KG, SK = K.GEMM_TILE128, K.GEMM_WAVES8, K.GEMM_KG, K.GEMM_SPLITK
     full = T128 | W8 | KG | SK
