@@ -448,6 +448,10 @@ __device__ __forceinline__ void split3(const f32x4 v, i32x2& ph, i32x2& pm, i32x
 #ifndef TWOG_X3_TMPACC
 #define TWOG_X3_TMPACC 0   // 1: 128x128 class with each k-step's products through a fresh accumulator, added by fp32 VALU adds (see
 #endif                     // compute()): removes the accumulate bias, but at 128 VGPRs (two workgroups per CU) the temporary spills
+// (TTMP, a template flag of the TT kernels selected at run time by TWOG_X3_DW_SPLIT_ACC=1: the same fresh-accumulator form with
+// ONE workgroup per CU -- 256 VGPRs, no spill, four register stages kept. Same-sign K = 61 440: bias -2.07e-6 -> -4.5e-8, rms
+// 2.08e-6 -> 9.3e-8 (the fp32-MFMA kernel: 1.07e-7); the dW launches +18 ... 25 %, the bs64 step 65.9 -> 68.9 ms: off by default,
+// profiles/r05_dw_split_accumulator.txt)
 
 constexpr int X3_PRODUCTS = TWOG_X3_PRODUCTS;  // chunk products per element product: 8 (exact to 2^-30) or 6 (drops m l, l m)
 constexpr int X3_BK = 16;                    // one v_mfma_f32_32x32x16_bf16 k-step per k-tile
@@ -460,10 +464,11 @@ __device__ __forceinline__ int x3_swz(int k) { return ((k & 3) << 2) | ((k >> 2)
 
 // cs (k-major A only): when cs_on, every thread also adds the A values it stages (4 consecutive tile columns of one k row per
 // k-tile) into cs -- the column sums of A over this workgroup's k-range, finished by gemm_tile (twog_gemm_t::a_colsum).
-template <bool AKM, bool BKM, bool KG>
+template <bool AKM, bool BKM, bool KG, bool TTMP = false>
 __device__ __forceinline__ void gemm_mainloop_x3(const twog_rows_t A, const twog_rows_t B, int M, int N, int m0, int n0,
                                                  int k_begin, int k_end, float* smem, f32x16 (&acc)[1][2], f32x4& cs, bool cs_on) {
     constexpr int BM = 128, BN = 128, NT = 512, XK = X3_BK;
+    constexpr bool TMP = TWOG_X3_TMPACC || TTMP;
     constexpr int PA = AKM ? X3_TPLANE : X3_RPLANE, PB = BKM ? X3_TPLANE : X3_RPLANE;
     char* lds = reinterpret_cast<char*>(smem);   // stage b: A planes at b * X3_STAGE, B planes behind them
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -589,7 +594,7 @@ __device__ __forceinline__ void gemm_mainloop_x3(const twog_rows_t A, const twog
         bf16x8 af[3];
 #pragma unroll
         for (int p = 0; p < 3; ++p) af[p] = AKM ? frag_t(base + p * PA, tchA) : frag_r(base + p * PA, fa_r);
-#if TWOG_X3_TMPACC
+        if constexpr (TMP) {
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
             bf16x8 bf[3];
@@ -603,7 +608,7 @@ __device__ __forceinline__ void gemm_mainloop_x3(const twog_rows_t A, const twog
             for (int i = 0; i < 16; ++i) acc[0][b][i] += t[i];
             __builtin_amdgcn_sched_barrier(0);   // one temporary: the compiler must not run the two blocks' chains side by side
         }
-#else
+        } else {
         bf16x8 bf[2][3];
 #pragma unroll
         for (int b = 0; b < 2; ++b)
@@ -615,7 +620,7 @@ __device__ __forceinline__ void gemm_mainloop_x3(const twog_rows_t A, const twog
 #pragma unroll
             for (int b = 0; b < 2; ++b)
                 acc[0][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[PI[t]], bf[b][PJ[t]], acc[0][b], 0, 0, 0);
-#endif
+        }
     };
     // Four register stages and two LDS stages, one barrier per k-tile: the loads of k-tile t + 4 are issued before the MFMAs
     // of tile t (a k-tile of 16 lasts under two microseconds at this matrix rate: two stages do not cover a miss to HBM);
@@ -895,7 +900,7 @@ __device__ __forceinline__ void gemm_mainloop_x3s(const twog_rows_t A, const two
 // counters are zero again at the launch boundary (graph replays need no memset node). The hand-off form is the
 // guide's split-K recipe (cdna_hip_programming.md section 5 item 2 / MI355X_MICROARCH.md "Valid forms": sc1 payload,
 // every storing wave drained, workgroup barrier, one relaxed agent atomic; the last arriver's loads all sc1).
-template <int BM, int BN, int NT, bool AKM, bool BKM, int D, bool KG, bool GATE, int KS = 1, bool XS = false, bool X3 = false, int KU = 1>
+template <int BM, int BN, int NT, bool AKM, bool BKM, int D, bool KG, bool GATE, int KS = 1, bool XS = false, bool X3 = false, int KU = 1, bool TTMP = false>
 __device__ __forceinline__ void gemm_tile(const Group& g, const GateArgs* ga) {
     constexpr int NTG = NT / KS;
     constexpr int WM = BM / (NTG / 128), WN = BN / 2;  // per-wave tile; the waves of a k-group in a (NTG/128) x 2 grid
@@ -1057,7 +1062,7 @@ __device__ __forceinline__ void gemm_tile(const Group& g, const GateArgs* ga) {
             static_assert(!X3 || BM != 128 || (BN == 128 && NT == 512 && !GATE && KS == 1 && !XS), "X3: the 8-wave 128x128 class");
             f32x4 cs = {0.f, 0.f, 0.f, 0.f};
             const bool cs_on = AKM && BKM && !KG && G.cs != nullptr && tn_idx == 0;   // uniform over the workgroup
-            gemm_mainloop_x3<AKM, BKM, KG>(A, B, M, N, m0, n0, k_begin, k_end, smem, acc, cs, cs_on);
+            gemm_mainloop_x3<AKM, BKM, KG, TTMP>(A, B, M, N, m0, n0, k_begin, k_end, smem, acc, cs, cs_on);
             if constexpr (AKM && BKM && !KG) {
                 if (cs_on) {
                     // thread (k row tid / 32, column quad tid % 32) holds its k rows' sums: the 16 k rows are added in row order
@@ -1312,6 +1317,11 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(const Group g) {
 template <bool AKM, bool BKM, bool KG>
 __global__ __launch_bounds__(512, 4) void gemm_x3_kernel(const Group g) {   // 4 waves per SIMD = two workgroups per CU: <= 128 VGPRs
     gemm_tile<128, 128, 512, AKM, BKM, 2, KG, false, 1, false, true>(g, nullptr);
+}
+// dW = dY^T X with every k-step's products through a fresh accumulator (TTMP): one workgroup per CU
+template <bool KG>
+__global__ __launch_bounds__(512, 2) void gemm_x3_tt_split_acc_kernel(const Group g) {
+    gemm_tile<128, 128, 512, true, true, 2, KG, false, 1, false, true, 1, true>(g, nullptr);
 }
 
 // X3 on the 64x64 class (gemm_mainloop_x3s): 4 waves, or 8 waves = two k-groups; plain and gate-fused epilogues
@@ -1593,9 +1603,12 @@ int launch(Group& g, int akm, int bkm, hipStream_t st) {
     if constexpr (BM == 128 && NT == 512) {
         // X3 (fp32-exact operands on the bf16 matrix cores, gemm_mainloop_x3): aligned operands, whole k-tiles, plain rows
         if (x3_128_ok(g)) {
+            static const int split_acc = getenv("TWOG_X3_DW_SPLIT_ACC") ? atoi(getenv("TWOG_X3_DW_SPLIT_ACC")) : 0;
             if (!akm && !bkm) hipLaunchKernelGGL((gemm_x3_kernel<false, false, false>), grid, block, 0, st, g);
             else if (!akm && bkm && !kg) hipLaunchKernelGGL((gemm_x3_kernel<false, true, false>), grid, block, 0, st, g);
             else if (!akm && bkm) hipLaunchKernelGGL((gemm_x3_kernel<false, true, true>), grid, block, 0, st, g);
+            else if (akm && bkm && split_acc && !kg) hipLaunchKernelGGL((gemm_x3_tt_split_acc_kernel<false>), grid, block, 0, st, g);
+            else if (akm && bkm && split_acc) hipLaunchKernelGGL((gemm_x3_tt_split_acc_kernel<true>), grid, block, 0, st, g);
             else if (akm && bkm && !kg) hipLaunchKernelGGL((gemm_x3_kernel<true, true, false>), grid, block, 0, st, g);
             else if (akm && bkm) hipLaunchKernelGGL((gemm_x3_kernel<true, true, true>), grid, block, 0, st, g);
             else if (!kg) hipLaunchKernelGGL((gemm_x3_kernel<true, false, false>), grid, block, 0, st, g);

@@ -1745,6 +1745,43 @@ def test_gemm_x3_same_sign_and_wide_exponent_operands():
             assert abs(row['mean_err_over_sum_abs']) <= 1e-7, row
 
 
+def test_gemm_x3_dw_split_accumulator_option_removes_the_same_sign_bias(K):
+    """TWOG_X3_DW_SPLIT_ACC=1 (off by default: the dW launches cost +18 ... 25 %, profiles/
+    r05_dw_split_accumulator.txt): the TT launches of the 128x128 class chain every k-step's six products through a fresh
+    accumulator and add it to the running sum with fp32 VALU adds, one workgroup per CU. On the same-sign K = 61 440 case the
+    bias falls from -2.1e-6 to the native fp32-MFMA kernel's level: required |bias| <= 1e-7 and rms <= 2.2e-7 (2 x the fp32-MFMA
+    kernel's 1.07e-7); the signed cases keep their bounds; a launch with a column-sum request agrees with fp64."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'x3_bias_probe.py'), '--json'],
+                       env=dict(os.environ, TWOG_GEMM_XSPLIT='1', TWOG_X3_DW_SPLIT_ACC='1'), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    rows = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('ROWS ')][0][5:])
+    tt = [row for row in rows if ' TT ' in row['case']]
+    assert len(tt) >= 3
+    for row in tt:
+        assert row['x3'] and row['tile128'], row
+        assert row['max'] <= 1e-6, row
+        if 'mean_rel_err_same_sign' in row:
+            assert abs(row['mean_rel_err_same_sign']) <= 1e-7 and row['rms'] <= 2.2e-7, row
+        else:
+            assert abs(row['mean_err_over_sum_abs']) <= 1e-7, row
+    code = r"""
+import sys, torch
+sys.path.insert(0, %r)
+import twog_gcn_amd
+from twog_gcn_amd.kernels import get_kernels
+K = get_kernels(); g = torch.Generator().manual_seed(5)
+A = (torch.randn(30720, 640, generator=g) + 0.25).cuda(); B = (torch.randn(30720, 512, generator=g) * 0.1).cuda()
+C, cs = torch.empty(640, 512, device='cuda'), torch.empty(640, device='cuda')
+K.gemm([dict(A=A, B=B, C=C, colsum=cs)], a_kmajor=True, b_kmajor=True)
+ref, rcs = A.double().t() @ B.double(), A.double().sum(0)
+assert float((C.double() - ref).abs().max() / ref.abs().max()) <= 1e-6
+assert float((cs.double() - rcs).abs().max() / rcs.abs().max()) <= 3e-6
+print('OK')
+""" % (ROOT,)
+    r = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, TWOG_X3_DW_SPLIT_ACC='1'), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and 'OK' in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
+
+
 def test_gemm_x3_nonfinite_operands_stay_nonfinite(K):
     """Documented difference of the X3 kernels (csrc/gemm_f32.hip, split3): an operand of +-Inf gives NaN where an fp32
     multiply gives +-Inf (the split subtracts Inf - Inf); a NaN stays a NaN. Either way the affected outputs are NOT finite
