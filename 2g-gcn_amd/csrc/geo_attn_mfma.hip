@@ -61,20 +61,22 @@ __device__ __forceinline__ void stage_rows64(const float* src, int N, int NP, fl
 }
 
 // The same in two halves, so that the NEXT frame's rows travel while this frame is computed: fetch_rows64 issues the loads of
-// a [N][64] block into registers (two float4 per thread cover NP <= 64 rows at 512 threads), put_rows64 writes them to LDS.
-struct Rows64 { float4 v[2]; };
-__device__ __forceinline__ void fetch_rows64(const float* src, int N, int NP, Rows64& R) {
+// a [N][64] block into registers (1024 / NT float4 per thread cover NP <= 64 rows), put_rows64 writes them to LDS.
+template <int NT> struct Rows64 { float4 v[1024 / NT]; };
+template <int NT>
+__device__ __forceinline__ void fetch_rows64(const float* src, int N, int NP, Rows64<NT>& R) {
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        const int i = threadIdx.x + u * 512, r = i >> 4, c = (i & 15) * 4;
+    for (int u = 0; u < 1024 / NT; ++u) {
+        const int i = threadIdx.x + u * NT, r = i >> 4, c = (i & 15) * 4;
         R.v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (i < NP * 16 && r < N) R.v[u] = *reinterpret_cast<const float4*>(src + (int64_t)r * 64 + c);
     }
 }
-__device__ __forceinline__ void put_rows64(const Rows64& R, int NP, float* dst, float* dstT, int ldn) {
+template <int NT>
+__device__ __forceinline__ void put_rows64(const Rows64<NT>& R, int NP, float* dst, float* dstT, int ldn) {
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        const int i = threadIdx.x + u * 512, r = i >> 4, c = (i & 15) * 4;
+    for (int u = 0; u < 1024 / NT; ++u) {
+        const int i = threadIdx.x + u * NT, r = i >> 4, c = (i & 15) * 4;
         if (i < NP * 16) {
             const float4 v = R.v[u];
             *reinterpret_cast<float4*>(dst + r * LDK + c) = v;
@@ -104,7 +106,7 @@ __global__ __launch_bounds__(512, 1) void gcn_attn2_fwd_kernel(const float* xin,
         *reinterpret_cast<float4*>(sMt + r * LDK + c) = *reinterpret_cast<const float4*>(md + r * 64 + c);
     }
     if (threadIdx.x < 64) sd[threadIdx.x] = md[64 * 64 + threadIdx.x];
-    Rows64 rx;
+    Rows64<512> rx;
     if ((int)blockIdx.x < n_frames) fetch_rows64(xin + (int64_t)blockIdx.x * N * 64, N, NP, rx);
     for (int f = blockIdx.x; f < n_frames; f += gridDim.x) {
         const int64_t r0 = (int64_t)f * N;
@@ -159,7 +161,8 @@ __global__ __launch_bounds__(512, 1) void gcn_attn2_fwd_kernel(const float* xin,
 
 // Backward per frame (dZ given):   dA = dZ X^T;  dS = S o (dA - rowsum(S o dA));  dP = dS X;
 //   dX = S^T dZ + dS^T P + dP M^T;   dMt += dP^T X;   dd += colsum(dP)        (P = X M + d is recomputed)
-__global__ __launch_bounds__(512, 1) void gcn_attn2_bwd_kernel(const float* xin, const float* md, const float* adj,
+template <int NT>
+__global__ __launch_bounds__(NT, 1) void gcn_attn2_bwd_kernel(const float* xin, const float* md, const float* adj,
                                                                const float* dz, int n_frames, int N, float* dx,
                                                                float* partials, int with_m) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -189,18 +192,21 @@ __global__ __launch_bounds__(512, 1) void gcn_attn2_bwd_kernel(const float* xin,
     }
     if (threadIdx.x < 64) sd[threadIdx.x] = md[64 * 64 + threadIdx.x];
     // dMt accumulators: 16 tiles (nt, kt) of 16x16, tile t owned by wave t % nw (two tiles per wave at 8 waves)
-    f32x4m accM[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    constexpr int TU = 1024 / NT;   // tiles of a 16-tile list per wave: 2 with 8 waves, 1 with 16
+    f32x4m accM[TU];
+#pragma unroll
+    for (int u = 0; u < TU; ++u) accM[u] = f32x4m{0.f, 0.f, 0.f, 0.f};
     float dd_acc = 0.f;  // threads 0..63: dd[n]
     // the next frame's X, dZ and S rows are fetched into registers while this frame is computed (the frame loop is a chain
     // of six barrier-separated phases on ONE workgroup per CU: nothing else would hide the loads)
-    Rows64 rx, rz;
-    float ra[8];   // S: NP * NP <= 4096 values over 512 threads
+    Rows64<NT> rx, rz;
+    float ra[4096 / NT];   // S: NP * NP <= 4096 values
     auto fetch_frame = [&](int64_t r0) {
         fetch_rows64(xin + r0 * 64, N, NP, rx);
         fetch_rows64(dz + r0 * 64, N, NP, rz);
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int i = threadIdx.x + u * 512, r = i / NP, c = i - r * NP;
+        for (int u = 0; u < 4096 / NT; ++u) {
+            const int i = threadIdx.x + u * NT, r = i / NP, c = i - r * NP;
             ra[u] = (i < NP * NP && r < N && c < N) ? adj[(r0 + r) * N + c] : 0.f;
         }
     };
@@ -211,8 +217,8 @@ __global__ __launch_bounds__(512, 1) void gcn_attn2_bwd_kernel(const float* xin,
         put_rows64(rx, NP, sX, sXt, LDN);
         put_rows64(rz, NP, sdZ, sdZt, LDN);
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int i = threadIdx.x + u * 512, r = i / NP, c = i - r * NP;
+        for (int u = 0; u < 4096 / NT; ++u) {
+            const int i = threadIdx.x + u * NT, r = i / NP, c = i - r * NP;
             if (i < NP * NP) {
                 sA[r * LDN + c] = ra[u];
                 sAt[c * LDN + r] = ra[u];
@@ -240,9 +246,11 @@ __global__ __launch_bounds__(512, 1) void gcn_attn2_bwd_kernel(const float* xin,
             for (int r = 0; r < 4; ++r) sdS[(rt * 16 + 4 * g + r) * LDN + ct * 16 + i16] = acc[r];
         }
         // this wave's dX tiles (at most 2 with 8 waves and RT <= 4): tile u -> t = wv + u * nw
-        f32x4m accX[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        f32x4m accX[TU];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < TU; ++u) accX[u] = f32x4m{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < TU; ++u) {
             const int t = wv + u * nw;
             if (t < RT * 4) {
                 const int rt = t >> 2, ct = t & 3;
@@ -278,7 +286,7 @@ __global__ __launch_bounds__(512, 1) void gcn_attn2_bwd_kernel(const float* xin,
         __syncthreads();
         // dX += dS^T P + dP M^T ; store
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < TU; ++u) {
             const int t = wv + u * nw;
             if (t < RT * 4) {
                 const int rt = t >> 2, ct = t & 3;
@@ -294,7 +302,7 @@ __global__ __launch_bounds__(512, 1) void gcn_attn2_bwd_kernel(const float* xin,
         }
         // dMt += dP^T X  (tile (nt, kt): rows n of dP^T, columns k of X) ; dd += column sums of dP
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < TU; ++u) {
             const int t = wv + u * nw;
             if (t < 16) {
                 const int nt = t >> 2, kt = t & 3;
@@ -309,7 +317,7 @@ __global__ __launch_bounds__(512, 1) void gcn_attn2_bwd_kernel(const float* xin,
     }
     float* out = partials + (int64_t)blockIdx.x * (65 * 64);
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < TU; ++u) {
         const int t = wv + u * nw;
         if (t < 16) {
             const int nt = t >> 2, kt = t & 3;
@@ -355,10 +363,19 @@ extern "C" int twog_gcn_attn2_bwd(const float* x, const float* md, const float* 
     const bool with_m = lds_bwd_bytes(n_nodes, true) <= 160 * 1024;
     const size_t lds = lds_bwd_bytes(n_nodes, with_m);
     if (lds > 160 * 1024) return -3;
-    static std::atomic<uint32_t> lds_attr_done{0};
-    twog_allow_dynamic_lds(gcn_attn2_bwd_kernel, 160 * 1024, lds_attr_done);
-    hipLaunchKernelGGL(gcn_attn2_bwd_kernel, dim3(n_blocks), dim3(512), lds, (hipStream_t)stream, x, md, adj, dz,
-                       n_frames, n_nodes, dx_att, partials, with_m ? 1 : 0);
+    // 16 waves: the phases are lists of 9 ... 16 independent 16x16 tiles, each a chain of 12-16 dependent MFMAs -- with 8 waves
+    // every list takes two rounds with half the waves idle in the second (TWOG_GCN_ATTN2_WAVES=8: the 8-wave form)
+    static const int waves = getenv("TWOG_GCN_ATTN2_WAVES") ? atoi(getenv("TWOG_GCN_ATTN2_WAVES")) : 16;
+    static std::atomic<uint32_t> lds_attr_done{0}, lds_attr_done16{0};
+    if (waves == 16) {
+        twog_allow_dynamic_lds(gcn_attn2_bwd_kernel<1024>, 160 * 1024, lds_attr_done16);
+        hipLaunchKernelGGL(gcn_attn2_bwd_kernel<1024>, dim3(n_blocks), dim3(1024), lds, (hipStream_t)stream, x, md, adj, dz,
+                           n_frames, n_nodes, dx_att, partials, with_m ? 1 : 0);
+    } else {
+        twog_allow_dynamic_lds(gcn_attn2_bwd_kernel<512>, 160 * 1024, lds_attr_done);
+        hipLaunchKernelGGL(gcn_attn2_bwd_kernel<512>, dim3(n_blocks), dim3(512), lds, (hipStream_t)stream, x, md, adj, dz,
+                           n_frames, n_nodes, dx_att, partials, with_m ? 1 : 0);
+    }
     TWOG_CHECK_LAUNCH();
     return 0;
 }
