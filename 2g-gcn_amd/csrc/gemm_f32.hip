@@ -1893,18 +1893,22 @@ static int pick_xl_split(int tiles, int kmax, size_t ws_bytes) {
     // (us, S = 1 / 2 / 3 / 4 / 6 / 8): 176 tiles K = 1 536: 26.0 / 28.1 / 27.4 / 25.3 / 27.7 / 28.4; 160 tiles: 25.7 / 27.7 /
     // 23.6 / 24.2 / 24.7 / 25.7; 320 tiles K = 1 536: 40.8 / 36.6 / 37.0 / 36.4 / 39.2 / 41.7; 320 tiles K = 512: 18.6 /
     // 17.6 / 18.7 / 20.2 -- the gains are a third of what the byte count alone predicts (every workgroup pays ~4 us of
-    // prologue and hand-off that only its sibling on the CU can hide), so a split must promise 10 %.
+    // prologue and hand-off that only its sibling on the CU can hide), so a split must promise 15 %: that leaves the 176-tile
+    // BiGRU backward carry (model -12.5 %, measured -3 %) unsplit -- its 80 idle CUs are what the side stream's weight-gradient
+    // GEMMs run on (ops.tggcn_backward); split, the step gains 0.13 ms and every one of those GEMMs takes 8-16 % longer
+    // (bs64, same box: 63.84 / 63.93 ms at 10 %, 63.97 / 64.02 at 15 %, 64.34 without XL; 128x128-class time per step 28.56 / 27.51 / 27.61).
     auto cost = [&](int S) {
         const int r = (tiles * S + 255) / 256;
         return r * ((kt + S - 1) / S) + (S > 1 ? 3 + r : 0);
     };
     int best = 1;
     int best_c = cost(1);
+    static const int min_gain = getenv("TWOG_X3_XL_GAIN") ? atoi(getenv("TWOG_X3_XL_GAIN")) : 15;   // per cent the model must promise
     static const int cand[] = {2, 3, 4};
     for (int S : cand) {
         if (S > by_ws || kt / S < 8) break;
         const int c = force > 1 ? (S == force ? -1 : (1 << 20)) : cost(S);
-        if (c * 10 <= best_c * 9) { best_c = c; best = S; }
+        if (c * 100 <= best_c * (100 - min_gain)) { best_c = c; best = S; }
     }
     return best;
 }
