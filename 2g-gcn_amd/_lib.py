@@ -160,6 +160,8 @@ LOSS_MAX_TERMS, LOSS_BLOCKS = 16, 64  # TWOG_LOSS_MAX_TERMS, TWOG_LOSS_BLOCKS
 _I, _L, _F, _P = C.c_int, C.c_int64, C.c_float, C.c_void_p
 SIGNATURES = {
     'twog_gemm_f32': [C.POINTER(Gemm), _I, _I, _I, _P, C.c_size_t, _P],
+    'twog_stream_create_masked': [_I, C.POINTER(C.c_void_p)],
+    'twog_stream_destroy': [_P],
     'twog_gemm_colsum_fused': [C.POINTER(Gemm), _I, _I, _I, _P, C.c_size_t],
     'twog_gemm_last_class': [],
     'twog_chain_workspace_bytes': [],

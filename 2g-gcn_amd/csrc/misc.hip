@@ -375,6 +375,29 @@ extern "C" int twog_debug_occupy(int n_blocks, int lds_bytes, int usec, void* st
     return 0;
 }
 
+// A stream whose kernels may only use n_cus compute units: bit i of the mask is CU i / n_xcd of XCD i % n_xcd (the driver deals
+// the bits round-robin over the XCDs), so the low n_cus bits are n_cus / 8 CUs on each of the eight XCDs -- the share a
+// launch-per-step recurrence leaves idle (ops.tggcn_backward runs weight-gradient GEMMs there beside the BiGRU backward chain).
+// Returns 0 and the stream, or a negative code when the runtime refuses (the caller then uses an ordinary stream).
+extern "C" int twog_stream_create_masked(int n_cus, void** stream_out) {
+    if (!stream_out || n_cus <= 0) return -2;
+    int dev = 0, total = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return -2;
+    if (hipDeviceGetAttribute(&total, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || total <= 0) return -2;
+    if (n_cus > total) n_cus = total;
+    uint32_t mask[16] = {0};
+    const int words = (total + 31) / 32;
+    if (words > 16) return -2;
+    for (int i = 0; i < n_cus; ++i) mask[i >> 5] |= 1u << (i & 31);
+    hipStream_t st = nullptr;
+    if (hipExtStreamCreateWithCUMask(&st, (uint32_t)words, mask) != hipSuccess) { (void)hipGetLastError(); return -3; }
+    *stream_out = st;
+    return 0;
+}
+extern "C" int twog_stream_destroy(void* stream) {
+    return stream && hipStreamDestroy((hipStream_t)stream) != hipSuccess ? -1 : 0;
+}
+
 extern "C" int twog_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
                               float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale,
                               void* stream) {

@@ -138,12 +138,22 @@ class HipKernels:
 
     _side_streams = {}
 
-    def side_stream(self, dev):
-        i = self._dev_index(dev)
-        st = HipKernels._side_streams.get(i)
+    def side_stream(self, dev, cus=0):
+        """cus > 0: a stream restricted to that many compute units (twog_stream_create_masked: cus / 8 on each XCD), so that
+        what runs on it leaves the other CUs to the caller's stream; None when the runtime refuses the mask. cus = 0: an
+        ordinary second stream."""
+        key = (self._dev_index(dev), int(cus))
+        st = HipKernels._side_streams.get(key)
         if st is None:
-            st = HipKernels._side_streams[i] = torch.cuda.Stream(device=dev)
-        return HipKernels._Side(st)
+            if cus > 0:
+                with torch.cuda.device(dev):
+                    h = C.c_void_p()
+                    rc = self.lib.twog_stream_create_masked(int(cus), C.byref(h))
+                st = torch.cuda.ExternalStream(h.value, device=dev) if rc == 0 and h.value else False
+            else:
+                st = torch.cuda.Stream(device=dev)
+            HipKernels._side_streams[key] = st
+        return HipKernels._Side(st) if st else None
 
     def debug_occupy(self, n_blocks, lds_bytes, usec):
         """Diagnostics (tests): n_blocks workgroups holding lds_bytes of LDS each for usec microseconds on the current stream."""

@@ -1681,6 +1681,7 @@ def tggcn_backward(K, plan: Plan, P, S, x_human, x_objects, objects_mask, d_outp
                     dW_hh.zero_()
                 G.add(c + '.weight_hh', dW_hh)
 
+            weight_grads.rows = bs * T * E   # (its tall reductions' length: what the side-stream split below goes by)
             pgrads.append(weight_grads)
             # d xx (frame-level part of the GRUCell input) -> entity-row gradient columns [h, h+fw)
             if ssp is None:
@@ -1710,6 +1711,7 @@ def tggcn_backward(K, plan: Plan, P, S, x_human, x_objects, objects_mask, d_outp
                     G.add(_SEG_MLP[r] + '.0.weight', dWp[i * h:(i + 1) * h])
                     G.add(_SEG_MLP[r] + '.0.bias', dbp[i * h:(i + 1) * h])
 
+            sender_grads.rows = bs * T * E
             pgrads.append(sender_grads)
     side = None
     # Default on where the frame-level BiGRU backward runs launch by launch (real batches); not beside its persistent launch
@@ -1904,15 +1906,34 @@ def tggcn_backward(K, plan: Plan, P, S, x_human, x_objects, objects_mask, d_outp
         dhfrs.append(dhfr)
         types.append(dict(d_out=dhfr, save=save, out=hfr, w_hh_f=P[name + '_bd_rnn.weight_hh_l0'],
                           w_hh_r=P[name + '_bd_rnn.weight_hh_l0_reverse']))
+    after_chain = []
     if side_on and pgrads:
         # beside the frame-level BiGRU chain (launch per step: 176 of 256 compute units busy at ~10 % of the matrix pipe)
         G.flush()
-        side = K.side_stream(dev)      # starts behind everything issued so far on the caller's stream
+        # TWOG_SIDE_CUS=n (measured and NOT the default): the side stream may only use n compute units
+        # (hipExtStreamCreateWithCUMask, n / 8 per XCD), the chain keeps the others and its per-step latency; the masked
+        # stream gets the humans' gradients (a quarter of the objects' at H = 2, O = 8), the rest follows the chain on the
+        # caller's stream. The mask does what it should -- the chain runs in 5.2 ms instead of 11.7 beside the unmasked
+        # stream -- and the step LOSES 7-13 ms (64.7 -> 72.4 at 80 CUs, 71.1 at 128, 78.0 at 48): GEMM launches shaped for
+        # 256 CUs crawl on a fraction of them and the join waits for them; even a perfect split could gain 0.2 ms (the
+        # chain alone 5.2 ms + 7.9 ms of gradient GEMMs - what 31 % of the chip finishes in 5.2 ms = 11.5, against 11.7 now).
+        # profiles/r05_side_stream_cu_mask.txt. Default 0: the unmasked stream with everything on it.
+        cus = int(os.environ.get('TWOG_SIDE_CUS', '0'))
+        side = K.side_stream(dev, cus) if cus > 0 else None
+        if side is not None:
+            rmin = min(fn.rows for fn in pgrads)
+            on_side = [fn for fn in pgrads if fn.rows == rmin] if any(fn.rows != rmin for fn in pgrads) else pgrads[:len(pgrads) // 2]
+            after_chain = [fn for fn in pgrads if fn not in on_side]
+        else:
+            side = K.side_stream(dev)      # starts behind everything issued so far on the caller's stream
+            on_side = pgrads
         with side:
-            for fn in pgrads:
+            for fn in on_side:
                 fn()
             G.flush()
     res = K.bigru_bwd(types, bs, T, h, allow_persistent=defer_stage0 or getattr(p, 'stage_hook', None) is None)
+    for fn in after_chain:
+        fn()
     if defer_stage0:
         _stage_done(p, 0, G)
     for (name, Ev, dEv, E, _), hfr, (dgi, dgh) in zip(ents, HFR, res):

@@ -589,6 +589,12 @@ int twog_fill_zero(void* p, size_t nbytes, void* stream);
 /* Diagnostics (tests): n_blocks workgroups of 256 threads holding lds_bytes of LDS each spin for `usec` microseconds --
  * the co-tenant a persistent launch must survive (see TWOG_PERSIST_NOT_RESIDENT). No reference counterpart. */
 int twog_debug_occupy(int n_blocks, int lds_bytes, int usec, void* stream);
+
+/* A stream restricted to n_cus compute units (hipExtStreamCreateWithCUMask; the low n_cus mask bits = n_cus / 8 CUs on each
+ * XCD). Host plumbing of this library's own backward pass (weight-gradient GEMMs beside a launch-per-step recurrence that
+ * leaves those CUs idle); no counterpart in the reference. Returns 0, or < 0 when the runtime refuses. */
+int twog_stream_create_masked(int n_cus, void** stream_out);
+int twog_stream_destroy(void* stream);
 /* n_blocks <= TWOG_COPY_MAX copies dst[i] = src[i], i < n floats, of contiguous fp32 blocks in ONE launch. The host uses it
  * to rebuild, at EVERY forward call, the packed operands the time loops read (w_smsg_* / b_smsg_* of twog_segrnn_t: the
  * reference applies the four segment-level sender MLPs one by one, vhoi/models.py:1051-1098, :1145-1190, :1239-1285,
