@@ -140,6 +140,48 @@ def test_in_place_gradient_route_equals_autograd_accumulation(fake_backend):
         assert float((got2[n] - 2 * g).abs().max()) <= 1e-5 * scale, n
 
 
+@pytest.mark.parametrize('sinks', [False, True])
+def test_bias_gradient_taken_by_the_held_weight_gradient_gemm(sinks, fake_backend, monkeypatch):
+    """ops._Grads holds a tall dW = dY^T X problem for one call; the colsum(dY) that follows attaches to it (twog_gemm_t::
+    a_colsum: the GEMM that streams dY also returns its column sums) -- with and without gradient sinks the parameter
+    gradients must equal the route with separate column-sum launches (TWOG_DW_COLSUM=0), and the pairing must actually
+    happen (the double counts the GEMM problems that carry a request)."""
+    z, meta = load_g4('c2_stage1')
+    noise = torch.from_numpy(z['gumbel_noise'])
+
+    def run(fused):
+        monkeypatch.setenv('TWOG_DW_COLSUM', '1' if fused else '0')
+        fk = FakeKernels()
+        twog_kernels._set_backend_for_tests(fk)
+        n_req = [0]
+        inner = fk.gemm
+
+        def gemm(problems, **kw):
+            n_req[0] += sum(1 for p in problems if p.get('colsum') is not None)
+            return inner(problems, **kw)
+        fk.gemm = gemm
+        m = build_model(meta)
+        m.train()
+        m._gumbel_noise_override = noise if len(noise) else None
+        if sinks:
+            for p in m.parameters():
+                p.grad = torch.zeros_like(p)
+            ops.enable_grad_sinks(m.parameters())
+        out = m(**g4_inputs(z))
+        sum((o * o).sum() for o in out if o.requires_grad).backward()
+        return {n: (None if p.grad is None else p.grad.clone()) for n, p in m.named_parameters()}, n_req[0]
+
+    ref, n0 = run(False)
+    got, n1 = run(True)
+    assert n0 == 0 and n1 >= 10, (n0, n1)
+    for n, g in ref.items():
+        if g is None:
+            assert got[n] is None, n
+            continue
+        scale = float(g.abs().max()) + 1e-12
+        assert float((got[n] - g).abs().max()) <= 2e-6 * scale, n
+
+
 @pytest.mark.parametrize('case', ['c2_stage1', 'c1_stage2', 'c5_stage1'])
 def test_gradient_stages_are_final_when_the_hook_fires(case, fake_backend):
     """distributed.DataParallel starts a stage's all-reduce from ops' stage hook: at that moment every gradient of the
