@@ -28,6 +28,14 @@ class Gemm(C.Structure):  # twog_gemm_t
                 ('a_colsum', C.c_void_p), ('a_colsum_accumulate', C.c_int32), ('pad2_', C.c_int32)]
 
 
+GUARD_MAX = 16
+
+
+class Guard(C.Structure):  # twog_guard_t
+    _fields_ = [('words', C.c_void_p * GUARD_MAX), ('out', C.c_void_p * GUARD_MAX), ('n', C.c_int64 * GUARD_MAX),
+                ('n_words', C.c_int32), ('n_out', C.c_int32)]
+
+
 class GruStep(C.Structure):  # twog_gru_step_t
     _fields_ = [('gi', Rows), ('gi2', Rows), ('gh', Rows), ('h_prev', Rows), ('h_out', Rows), ('save', Rows),
                 ('u', C.c_void_p), ('u_ld_outer', C.c_int64), ('u_ld_inner', C.c_int64), ('u_inner', C.c_int32),
@@ -160,6 +168,7 @@ LOSS_MAX_TERMS, LOSS_BLOCKS = 16, 64  # TWOG_LOSS_MAX_TERMS, TWOG_LOSS_BLOCKS
 _I, _L, _F, _P = C.c_int, C.c_int64, C.c_float, C.c_void_p
 SIGNATURES = {
     'twog_gemm_f32': [C.POINTER(Gemm), _I, _I, _I, _P, C.c_size_t, _P],
+    'twog_guard_outputs': [C.POINTER(Guard), _P],
     'twog_stream_create_masked': [_I, C.POINTER(C.c_void_p)],
     'twog_stream_destroy': [_P],
     'twog_gemm_colsum_fused': [C.POINTER(Gemm), _I, _I, _I, _P, C.c_size_t],

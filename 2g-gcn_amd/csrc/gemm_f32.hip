@@ -1977,6 +1977,11 @@ static int gemm_impl(const twog_gemm_t* problems, int n_problems, int a_kmajor, 
                      size_t workspace_bytes, void* chain_ws, size_t chain_ws_bytes, void* stream) {
     if (n_problems <= 0) return 0;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    {   // a_colsum requests are checked for EVERY chunk before the first launch: refused as a whole (-5), never half done
+        bool any_cs = false;
+        for (int i = 0; i < n_problems; ++i) any_cs = any_cs || problems[i].a_colsum != nullptr;
+        if (any_cs && (chain_ws || !twog_gemm_colsum_fused(problems, n_problems, a_kmajor, b_kmajor, workspace, workspace_bytes))) return -5;
+    }
     int done = 0;
     while (done < n_problems) {
         const int n = (n_problems - done) < MAXP ? (n_problems - done) : MAXP;
@@ -1986,7 +1991,6 @@ static int gemm_impl(const twog_gemm_t* problems, int n_problems, int a_kmajor, 
         bool big;
         int bm;
         prepare_group(pr, n, a_kmajor, b_kmajor, workspace, workspace_bytes, g, order, big, bm);
-        if (!colsums_served(pr, n, a_kmajor, b_kmajor, g, big)) return -5;   // an a_colsum request this launch would not serve
         static const int depth = getenv("TWOG_GEMM_DEPTH") ? atoi(getenv("TWOG_GEMM_DEPTH")) : 0;  // tuning knob
         const int d128 = depth ? (depth & 3) : 2, d64 = depth ? ((depth >> 2) & 3) : 2;
         int rc;

@@ -375,6 +375,25 @@ extern "C" int twog_debug_occupy(int n_blocks, int lds_bytes, int usec, void* st
     return 0;
 }
 
+// Loud failure without a host round trip: if any of the (host-pinned, device-readable) error words of the pass's persistent
+// launches is non-zero, every output tensor of the pass is overwritten with NaN. Enqueued behind the asynchronous copies that
+// fill those words, so the caller need not wait for them before it goes on to enqueue the backward pass (kernels.py).
+__global__ __launch_bounds__(256) void guard_outputs_kernel(const twog_guard_t g) {
+    bool bad = false;
+    for (int i = 0; i < g.n_words; ++i) bad = bad || (__builtin_nontemporal_load(g.words[i]) != 0);
+    if (!bad) return;
+    float* o = g.out[blockIdx.x];
+    const float nan = __builtin_nanf("");
+    for (int64_t i = threadIdx.x; i < g.n[blockIdx.x]; i += blockDim.x) o[i] = nan;
+}
+extern "C" int twog_guard_outputs(const twog_guard_t* g, void* stream) {
+    if (!g || g->n_words < 0 || g->n_words > TWOG_GUARD_MAX || g->n_out < 0 || g->n_out > TWOG_GUARD_MAX) return -2;
+    if (g->n_words == 0 || g->n_out == 0) return 0;
+    hipLaunchKernelGGL(guard_outputs_kernel, dim3(g->n_out), dim3(256), 0, (hipStream_t)stream, *g);
+    TWOG_CHECK_LAUNCH();
+    return 0;
+}
+
 // A stream whose kernels may only use n_cus compute units: bit i of the mask is CU i / n_xcd of XCD i % n_xcd (the driver deals
 // the bits round-robin over the XCDs), so the low n_cus bits are n_cus / 8 CUs on each of the eight XCDs -- the share a
 // launch-per-step recurrence leaves idle (ops.tggcn_backward runs weight-gradient GEMMs there beside the BiGRU backward chain).

@@ -563,6 +563,29 @@ class HipKernels:
                                're-admitted one checked launch at a time (TWOG_BIGRU_PERSIST=0 TWOG_SEG_PERSIST=0 switch '
                                'them off for good).')
 
+    def guard_persistent(self, dev, outs):
+        """End of a forward pass that a backward pass will follow: instead of waiting for the pass's deferred error words
+        (verify_persistent drains the stream, and the backward pass is then enqueued into an idle device: ~1 ms per 8-clip
+        step), ONE small launch behind them overwrites `outs` with NaN if any is set. The words stay pending: the check at
+        the end of the backward pass (or at the start of the next forward) raises. True when nothing is pending or the guard
+        was enqueued; False -> the caller verifies at once."""
+        i = self._dev_index(dev if dev is not None else torch.device('cuda', torch.cuda.current_device()))
+        pending = HipKernels._lazy.get(i)
+        if not pending:
+            return True
+        outs = [o for o in outs if o is not None and o.numel()]
+        if (len(pending) > L.GUARD_MAX or len(outs) > L.GUARD_MAX or os.environ.get('TWOG_PERSIST_GUARD', '1') == '0'
+                or any(o.dtype != torch.float32 or not o.is_contiguous() for o in outs)):
+            return False
+        g = L.Guard()
+        for k, (_, host, _) in enumerate(pending):
+            g.words[k] = host.data_ptr()
+        for k, o in enumerate(outs):
+            g.out[k], g.n[k] = o.data_ptr(), o.numel()
+        g.n_words, g.n_out = len(pending), len(outs)
+        self._check(self.lib.twog_guard_outputs(C.byref(g), self._stream()), 'twog_guard_outputs')
+        return True
+
     def bigru_persistent(self, arr, n, bs, h, dev=None):
         """True when the frame-level recurrence runs as the persistent launch: where the library serves the shape and
         rates it the faster path (small batches: at most one 16-row tile per wave). TWOG_BIGRU_PERSIST=1: wherever it is

@@ -1204,8 +1204,10 @@ def segment_recurrence_general_bwd(K, p, P, G, bufs, gi_unused, u, objects_mask,
     return out
 
 
-def tggcn_forward(K, plan: Plan, P, x_human, x_objects, objects_mask, human_seg, object_seg, noise, training, bn_bufs):
-    """Returns (outputs list, saved dict). P: dict name -> parameter tensor."""
+def tggcn_forward(K, plan: Plan, P, x_human, x_objects, objects_mask, human_seg, object_seg, noise, training, bn_bufs,
+                  backward_follows=False):
+    """Returns (outputs list, saved dict). P: dict name -> parameter tensor. backward_follows: the caller records an autograd
+    node (the deferred checks of persistent launches may then wait for the end of the backward pass)."""
     p = plan
     P = _Params(P)
     bs, T, H, O, N, h = p.bs, p.T, p.H, p.O, p.N, p.h
@@ -1213,6 +1215,8 @@ def tggcn_forward(K, plan: Plan, P, x_human, x_objects, objects_mask, human_seg,
     steps = getattr(p, 'steps', None)   # steps_per_example (bs,): only the optional position features read it
     S = {'steps': steps}  # saved for backward
     nF = bs * T
+    if hasattr(K, 'verify_persistent'):
+        K.verify_persistent(dev)   # (words a guarded forward pass left behind when no backward pass came for them)
 
     def empty(*shape):
         return torch.empty(*shape, dtype=torch.float32, device=dev)
@@ -1493,7 +1497,11 @@ def tggcn_forward(K, plan: Plan, P, x_human, x_objects, objects_mask, human_seg,
     # buffers per step late)
     S['outputs'] = [o.detach() for o in outputs]
     if hasattr(K, 'verify_persistent'):
-        K.verify_persistent(dev)   # persistent launches of this pass whose error word was left for the end of the pass
+        # persistent launches of this pass whose error word was left for the end of the pass: when a backward pass follows,
+        # a guard launch (outputs -> NaN if a word is set) stands in for the host's wait and the words are read at the end
+        # of the backward pass; a forward-only call waits here
+        if not (backward_follows and hasattr(K, 'guard_persistent') and K.guard_persistent(dev, S['outputs'])):
+            K.verify_persistent(dev)
     return outputs, S
 
 
@@ -2103,7 +2111,7 @@ class TGGCNFunction(torch.autograd.Function):
         K = get_kernels()
         P = dict(zip(names, params))
         outputs, S = tggcn_forward(K, plan, P, x_human, x_objects, objects_mask, human_seg, object_seg, noise,
-                                   training, bn_bufs)
+                                   training, bn_bufs, backward_follows=any(ctx.needs_input_grad))
         ctx.plan, ctx.names, ctx.P = plan, names, P
         ctx.inputs = (x_human, x_objects, objects_mask)
         # The saved state goes through save_for_backward: the autograd engine owns its lifetime, as for any torch op -- the

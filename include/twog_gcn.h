@@ -590,6 +590,19 @@ int twog_fill_zero(void* p, size_t nbytes, void* stream);
  * the co-tenant a persistent launch must survive (see TWOG_PERSIST_NOT_RESIDENT). No reference counterpart. */
 int twog_debug_occupy(int n_blocks, int lds_bytes, int usec, void* stream);
 
+/* Persistent launches checked at the end of a pass (see twog_bigru_fwd_persistent): `words` are the host-pinned copies of
+ * their error words (device-readable), filled by asynchronous copies enqueued before this call. If any is non-zero, every
+ * `out[i]` (n[i] floats) is overwritten with NaN -- the pass's results can then not be consumed silently while the host
+ * check (which raises) is left for the end of the backward pass. Host plumbing; no counterpart in the reference. */
+#define TWOG_GUARD_MAX 16
+typedef struct {
+    const uint32_t* words[TWOG_GUARD_MAX];
+    float* out[TWOG_GUARD_MAX];
+    int64_t n[TWOG_GUARD_MAX];
+    int32_t n_words, n_out;
+} twog_guard_t;
+int twog_guard_outputs(const twog_guard_t* g, void* stream);
+
 /* A stream restricted to n_cus compute units (hipExtStreamCreateWithCUMask; the low n_cus mask bits = n_cus / 8 CUs on each
  * XCD). Host plumbing of this library's own backward pass (weight-gradient GEMMs beside a launch-per-step recurrence that
  * leaves those CUs idle); no counterpart in the reference. Returns 0, or < 0 when the runtime refuses. */

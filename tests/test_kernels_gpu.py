@@ -694,6 +694,36 @@ def test_persistent_launch_failure_found_at_the_end_of_the_pass_raises_and_the_n
     HipKernels._lazy.clear()
 
 
+def test_guard_launch_poisons_the_outputs_of_a_pass_whose_persistent_launch_gave_up(K, monkeypatch):
+    """When a backward pass follows, the forward pass does not wait for its deferred error words (that wait drains the stream
+    and the backward pass starts on an idle device: ~1 ms per 8-clip step): one guard launch behind them turns the pass's
+    outputs into NaN if any word is set, and the words are read -- and raise -- at the end of the backward pass. Here: a
+    clean pass leaves the outputs alone; with a forced give-up (TWOG_PERSIST_SPIN_LIMIT=0) every guarded tensor is NaN and
+    verify_persistent raises afterwards."""
+    from twog_gcn_amd.kernels import HipKernels
+    run = _persist_rig(K)
+    HipKernels._backoff.clear()
+    HipKernels._lazy.clear()
+    monkeypatch.setenv('TWOG_PERSIST_CHECK', 'lazy')
+    outs = [torch.ones(1000, device=DEV), torch.full((3, 7), 2.0, device=DEV)]
+    _, ran = run()
+    assert ran == (True, True, True, True) and len(HipKernels._lazy[0]) == 4
+    assert K.guard_persistent(torch.device(DEV), outs)
+    torch.cuda.synchronize()
+    assert float(outs[0].sum()) == 1000.0 and float(outs[1].sum()) == 42.0
+    K.verify_persistent()
+    monkeypatch.setenv('TWOG_PERSIST_SPIN_LIMIT', '0')
+    _, ran = run()
+    assert ran == (True, True, True, True)
+    assert K.guard_persistent(torch.device(DEV), outs)
+    torch.cuda.synchronize()
+    assert bool(torch.isnan(outs[0]).all()) and bool(torch.isnan(outs[1]).all())
+    with pytest.raises(RuntimeError, match='could not keep its grid resident'):
+        K.verify_persistent()
+    HipKernels._backoff.clear()
+    HipKernels._lazy.clear()
+
+
 def test_persistent_launch_beside_a_tenant_that_holds_compute_units(K, monkeypatch):
     """The real thing: another stream holds half of the compute units (twog_debug_occupy: 128 workgroups with 100 KB of LDS
     each, for 60 ms), so half of a persistent grid is resident and waits for the half that is not. With a spin limit of

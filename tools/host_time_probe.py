@@ -8,6 +8,8 @@ import time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench as B
+if len(sys.argv) > 1:
+    B.select_workload(sys.argv[1])   # c2 / c5 / ...: BASELINE configurations other than the bs64 headline
 import twog_gcn_amd  # noqa
 from twog_gcn_amd.models import TGGCN
 from twog_gcn_amd.kernels import get_kernels
