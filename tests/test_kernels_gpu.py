@@ -754,6 +754,30 @@ def test_persistent_launch_beside_a_tenant_that_holds_compute_units(K, monkeypat
     HipKernels._backoff.clear()
 
 
+def test_masked_side_stream_runs_the_same_kernels_on_a_subset_of_the_compute_units(K):
+    """twog_stream_create_masked (the TWOG_SIDE_CUS experiment of ops.tggcn_backward: weight-gradient GEMMs on 80 of the 256
+    CUs beside a launch-per-step recurrence; measured slower and off by default): a GEMM issued on the masked
+    stream gives the bits of the same launch on the caller's stream, the join orders it before the caller's next launch,
+    and a second request for the same mask returns the cached stream."""
+    dev = torch.device(DEV)
+    side = K.side_stream(dev, 80)
+    if side is None:
+        pytest.skip('the runtime refused hipExtStreamCreateWithCUMask')
+    g = torch.Generator().manual_seed(21)
+    A, B = torch.randn(4096, 512, generator=g).to(DEV), (torch.randn(2048, 512, generator=g) * 0.1).to(DEV)
+    ref = torch.empty(4096, 2048, device=DEV)
+    K.gemm([dict(A=A, B=B, C=ref)])
+    out = torch.zeros(4096, 2048, device=DEV)
+    torch.cuda.synchronize()
+    with side:
+        K.gemm([dict(A=A, B=B, C=out)])
+    side.join()
+    doubled = out * 2          # on the caller's stream, behind the join
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref) and torch.equal(doubled, ref * 2)
+    assert K.side_stream(dev, 80).stream is side.stream
+
+
 def test_tape_run_replays_recorded_calls_with_affine_descriptors(K):
     """twog_tape_run: two consecutive steps of a loop are recorded (descriptor arrays kept, nothing issued); step a + k is
     run with every 64-bit descriptor word a + k (b - a). A GEMM, a gate step and row operations over per-step slots of
