@@ -910,7 +910,8 @@ __device__ __forceinline__ void gemm_tile(const Group& g, const GateArgs* ga) {
     constexpr int A_ELEMS = AKM ? BK * LDA : BM * LDA;
     constexpr int B_ELEMS = BKM ? BK * LDB : BN * LDB;
     // (X3 on the 64-row class: two stages of three bf16 planes per operand, 2 x 6 x 64 rows x 2 XK bytes, XK = 16 KS)
-    constexpr int SMEM_FLOATS = (X3 && BM == 128) ? 2 * X3_STAGE / 4
+    constexpr int SMEM_FLOATS = (X3 && BM == 128 && BN == 64) ? 2 * KU * 3 * (128 + 64) * 32 / 4   // 128x64 chain tile: 2 stages x KU images
+                                : (X3 && BM == 128) ? 2 * X3_STAGE / 4
                                 : (X3 && BM == 64 && 12 * 64 * 8 * KS * KU > 2 * (A_ELEMS + B_ELEMS)) ? 12 * 64 * 8 * KS * KU : 2 * (A_ELEMS + B_ELEMS);
     __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS];
 
@@ -1058,7 +1059,12 @@ __device__ __forceinline__ void gemm_tile(const Group& g, const GateArgs* ga) {
     const bool fast = a_vec && b_vec && ((k_end - k_begin) % BK == 0);
     if constexpr (X3) {
         // (the host launches X3 kernels for aligned operands and whole k-tiles only)
-        if constexpr (BM == 128) {
+        if constexpr (BM == 128 && BN == 64) {
+            // 128 x 64 chain tile (round 5): eight waves of 32 x 32, row-major A -- a tile takes in (128 + 64) K operand values
+            // for twice the products of a 64 x 64 tile's (64 + 64) K
+            static_assert(!X3 || BM != 128 || BN != 64 || (NT == 512 && KS == 1 && !AKM && !KG && !XS && !GATE), "X3: 128x64 chain tiles");
+            gemm_mainloop_x3s<BM, BN, NT, BKM, 1, 1, false, 2, true, KU>(A, B, M, N, m0, n0, k_begin, k_end, smem, acc);
+        } else if constexpr (BM == 128) {
             static_assert(!X3 || BM != 128 || (BN == 128 && NT == 512 && !GATE && KS == 1 && !XS), "X3: the 8-wave 128x128 class");
             f32x4 cs = {0.f, 0.f, 0.f, 0.f};
             const bool cs_on = AKM && BKM && !KG && G.cs != nullptr && tn_idx == 0;   // uniform over the workgroup
@@ -1332,6 +1338,12 @@ __global__ __launch_bounds__(256 * KS, 2) void gemm_x3s_kernel(const Group g) {
 template <int KS>
 __global__ __launch_bounds__(256 * KS, 2) void gemm_gate_bwd_x3s_kernel(const Group g, const GateArgs ga) {
     gemm_tile<64, 64, 256 * KS, false, true, 2, false, true, KS, false, true>(g, &ga);
+}
+
+// 128 x 64 tiles for chain launches with enough rows (pick_rows128): one 8-wave workgroup per CU, two k-tiles per barrier
+template <bool BKM>
+__global__ __launch_bounds__(512, 1) void gemm_x3su128_kernel(const Group g) {
+    gemm_tile<128, 64, 512, false, BKM, 2, false, false, 1, false, true, 2>(g, nullptr);
 }
 
 // KU k-tiles per barrier interval (launches that run one workgroup per CU: at most 256 tiles)
@@ -1939,6 +1951,48 @@ static bool colsums_served(const twog_gemm_t* pr, int n, int a_kmajor, int b_kma
     return a_kmajor && b_kmajor && big && w8 && plain && x3_128_ok(g);
 }
 
+// 128 x 64 tiles for a chain launch of the X3 64x64 class (gemm_x3su128_kernel): a launch is bound by the operand bytes its
+// busiest CU takes in -- rounds x (tile rows + tile columns) x K -- and 480 tiles of 64 x 64 (two per CU: 2 x 128) become 240
+// of 128 x 64 (one per CU: 192), 320 become 160. Taken when that count falls by 15 % and at least half the chip stays busy.
+// TWOG_X3_ROWS128=0: never.
+static bool rows128_pays(const Group& g) {
+    static const int on = getenv("TWOG_X3_ROWS128") ? atoi(getenv("TWOG_X3_ROWS128")) : 1;
+    if (!on) return false;
+    int t64 = 0, t128 = 0;
+    for (int i = 0; i < g.n; ++i) {
+        const Prob& P = g.p[i];
+        if (P.M < 128 || P.batch > 1) return false;
+        t64 += ((P.M + 63) / 64) * P.tiles_n;
+        t128 += ((P.M + 127) / 128) * P.tiles_n;
+    }
+    if (t128 < 128 || t128 > 256) return false;
+    const int c64 = ((t64 + 255) / 256) * 128, c128 = ((t128 + 255) / 256) * 192;
+    return c128 * 100 <= c64 * 85;
+}
+// the tile bookkeeping of prepare_group again for another tile height
+static void retile_rows(Group& g, int bm) {
+    int t = 0;
+    g.n_cls = 0;
+    for (int i = 0; i < g.n; ++i) {
+        Prob& P = g.p[i];
+        P.tiles_m = (P.M + bm - 1) / bm;
+        P.tile_start = t;
+        const int ntiles = P.batch * P.tiles_m * P.tiles_n;
+        if (i == 0 || P.K != g.p[i - 1].K) {
+            g.cls_start[g.n_cls] = t;
+            g.cls_ntiles[g.n_cls] = 0;
+            ++g.n_cls;
+        }
+        g.cls_ntiles[g.n_cls - 1] += ntiles;
+        t += ntiles;
+    }
+    for (int c = 0, rot = 0; c < g.n_cls; ++c) {
+        g.cls_rot[c] = rot & 7;
+        rot += g.cls_ntiles[c] & 7;
+    }
+    g.total_tiles = t;
+}
+
 static int gemm_impl(const twog_gemm_t* problems, int n_problems, int a_kmajor, int b_kmajor, void* workspace,
                      size_t workspace_bytes, void* chain_ws, size_t chain_ws_bytes, void* stream);
 
@@ -2007,6 +2061,16 @@ static int gemm_impl(const twog_gemm_t* problems, int n_problems, int a_kmajor, 
         int kmax_ = 0;
         for (int i = 0; i < n; ++i) kmax_ = pr[i].K > kmax_ ? pr[i].K : kmax_;
         const bool ks = ks_on && !big && !a_kmajor && !grouped && g.splitk == 1 && g.total_tiles <= 384 && kmax_ >= 256;
+        if (!big && bm == 64 && !grouped && chain_ws && x3s_ok(g, a_kmajor, 32) && rows128_pays(g)) {
+            retile_rows(g, 128);
+            g_last_class |= TWOG_GEMM_CLASS_X3 | TWOG_GEMM_CLASS_WAVES8;
+            dim3 grid(g.total_tiles, 1), block(512);
+            if (b_kmajor) hipLaunchKernelGGL((gemm_x3su128_kernel<true>), grid, block, 0, st, g);
+            else hipLaunchKernelGGL((gemm_x3su128_kernel<false>), grid, block, 0, st, g);
+            TWOG_CHECK_LAUNCH();
+            done += n;
+            continue;
+        }
         if (!big && bm == 64 && !grouped && chain_ws && x3s_ok(g, a_kmajor, 32) && xl_setup(g, kmax_, chain_ws, chain_ws_bytes)) {
             g_last_class |= TWOG_GEMM_CLASS_X3 | TWOG_GEMM_CLASS_XSPLIT;
             dim3 grid(g.total_tiles, g.splitk), block(256);

@@ -1687,7 +1687,7 @@ probs = [prob(128, 1536, 512, True, 0, False, 1), prob(128, 1536, 1024, False, 0
 run(probs, True if forced else auto(probs))
 print('OK')
 """ % (ROOT, bkm, force)
-    env = dict(os.environ, TWOG_GEMM_XSPLIT=force)
+    env = dict(os.environ, TWOG_GEMM_XSPLIT=force, TWOG_X3_ROWS128='0')
     r = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and 'OK' in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
 
@@ -1749,8 +1749,9 @@ print('RES ' + json.dumps(res))
 """ % (ROOT,)
     out = {}
     for mode in ('1', '0'):
-        r = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, TWOG_GEMM_X3=mode, TWOG_GEMM_XSPLIT='1'),
-                           capture_output=True, text=True, timeout=900)   # XSPLIT=1: no split over workgroups (fp32 kernels)
+        r = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, TWOG_GEMM_X3=mode, TWOG_GEMM_XSPLIT='1', TWOG_X3_ROWS128='0'),
+                           capture_output=True, text=True, timeout=900)   # XSPLIT=1: no split over workgroups (fp32 kernels);
+                                                                          # ROWS128=0: like with like (the 128-row chain tiles sum k in ONE wave group where the native kernels use two: their own test)
         assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
         out[mode] = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('RES ')][0][4:])
     X3 = twog_kernels.get_kernels().GEMM_X3
@@ -1898,7 +1899,7 @@ torch.save(outs, sys.argv[1])
     got = {}
     for ku in ('1', '2'):
         with tempfile.NamedTemporaryFile(suffix='.pt') as f:
-            r = subprocess.run([sys.executable, '-c', code, f.name], env=dict(os.environ, TWOG_X3S_KU=ku, TWOG_GEMM_XSPLIT='1', TWOG_X3_XL='1'),
+            r = subprocess.run([sys.executable, '-c', code, f.name], env=dict(os.environ, TWOG_X3S_KU=ku, TWOG_GEMM_XSPLIT='1', TWOG_X3_XL='1', TWOG_X3_ROWS128='0'),
                                capture_output=True, text=True, timeout=600)
             assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
             got[ku] = torch.load(f.name)
@@ -1978,7 +1979,7 @@ torch.save(dict(outs=outs, split_seen=split_seen), sys.argv[1])
     got = {}
     for force in ('1', '0', '2', '3', '4'):
         with tempfile.NamedTemporaryFile(suffix='.pt') as f:
-            r = subprocess.run([sys.executable, '-c', code, f.name, force], env=dict(os.environ, TWOG_X3_XL=force, TWOG_GEMM_XSPLIT='1'),
+            r = subprocess.run([sys.executable, '-c', code, f.name, force], env=dict(os.environ, TWOG_X3_XL=force, TWOG_GEMM_XSPLIT='1', TWOG_X3_ROWS128='0'),
                                capture_output=True, text=True, timeout=600)
             assert r.returncode == 0, force + ': ' + r.stdout[-1500:] + r.stderr[-3000:]
             got[force] = torch.load(f.name)
@@ -1989,6 +1990,68 @@ torch.save(dict(outs=outs, split_seen=split_seen), sys.argv[1])
         for a, b in zip(base, got[force]['outs']):
             assert torch.isfinite(b).all()
             assert float((a - b).abs().max()) <= 2e-6 * float(a.abs().max()) + 1e-7, (force, float((a - b).abs().max()), float(a.abs().max()))
+
+
+def test_gemm_x3_chain_tiles_of_128_rows():
+    """Chain launches of the X3 64x64 class whose rows allow it run 128 x 64 tiles (gemm_x3su128_kernel, rows128_pays): a tile
+    takes in (128 + 64) K operand values for twice the products of (64 + 64) K. In a child process per setting
+    (TWOG_X3_ROWS128 = 0 / 1): the segment level's backward projection launch at bs64 (four problems with two output widths:
+    480 -> 240 tiles), d_mg alone (320 -> 160), the sender MLPs with bias + ReLU (row-major B), a ragged last row tile, and a
+    shape the rule leaves alone (176 tiles -> 88: fewer than half the CUs). Against fp64; the two tilings agree to 2e-6 (the
+    64-row kernels of the smaller launches split k between two wave groups: another summation order); every launch is
+    bit-identical from launch to launch."""
+    code = r"""
+import sys, torch
+sys.path.insert(0, %r)
+import twog_gcn_amd
+from twog_gcn_amd.kernels import get_kernels
+K = get_kernels(); DEV = 'cuda:0'; on = sys.argv[2] == '1'
+g = torch.Generator().manual_seed(14)
+outs, taken = [], []
+def prob(M, N, Kk, bkm, bias, act, acc):
+    A = torch.randn(M, Kk, generator=g).to(DEV)
+    B = (torch.randn((Kk, N) if bkm else (N, Kk), generator=g) * 0.1).to(DEV)
+    return dict(A=A, B=B, C0=torch.randn(M, N, generator=g).to(DEV), bias=torch.randn(N, generator=g).to(DEV) if bias else None,
+                act=act, accumulate=acc)
+def run(probs, bkm, expect):
+    res = []
+    for rep in range(2):
+        ps = [dict({k: v for k, v in p.items() if k != 'C0'}, C=p['C0'].clone()) for p in probs]
+        K.gemm(ps, b_kmajor=bkm, chain=True)
+        res.append([p['C'] for p in ps])
+    cls = K.gemm_last_class()
+    assert cls & K.GEMM_X3, hex(cls)
+    t128 = bool(cls & K.GEMM_WAVES8) and not cls & K.GEMM_KSPLIT and not cls & K.GEMM_TILE128
+    assert t128 == (on and expect), (hex(cls), on, expect)
+    taken.append(t128)
+    for p, C, C2 in zip(probs, res[0], res[1]):
+        assert torch.equal(C, C2), 'launch-to-launch difference'
+        ref = p['A'].double() @ (p['B'].double() if bkm else p['B'].double().t())
+        if p['bias'] is not None: ref = ref + p['bias'].double()
+        if p['accumulate']: ref = ref + p['C0'].double()
+        if p['act']: ref = torch.relu(ref)
+        err = (C.double() - ref).abs().max().item()
+        assert err <= 2e-6 * ref.abs().max().item(), (err / ref.abs().max().item(), tuple(C.shape))
+        outs.append(C.cpu())
+run([prob(256, 512, 1536, True, False, 0, True), prob(256, 1024, 1536, True, False, 0, False),
+     prob(1024, 512, 1536, True, False, 0, True), prob(1024, 1024, 1536, True, False, 0, False)], True, True)   # 480 -> 240 tiles
+run([prob(1280, 1024, 1536, True, False, 0, False)], True, True)     # 320 -> 160
+run([prob(1280, 1024, 512, False, True, 1, False)], False, True)     # sender MLPs: bias + ReLU, row-major B
+run([prob(1290, 1024, 1024, True, False, 0, True)], True, True)      # ragged last row tile (11 x 16 = 176 tiles)
+run([prob(1408, 512, 1536, True, False, 0, True)], True, False)      # 88 tiles of 128 rows: left to the 64-row kernels
+torch.save(dict(outs=outs, taken=taken), sys.argv[1])
+""" % (ROOT,)
+    import tempfile
+    got = {}
+    for on in ('0', '1'):
+        with tempfile.NamedTemporaryFile(suffix='.pt') as f:
+            r = subprocess.run([sys.executable, '-c', code, f.name, on], env=dict(os.environ, TWOG_X3_ROWS128=on, TWOG_X3_XL='1', TWOG_GEMM_XSPLIT='1'),
+                               capture_output=True, text=True, timeout=600)
+            assert r.returncode == 0, on + ': ' + r.stdout[-1500:] + r.stderr[-3000:]
+            got[on] = torch.load(f.name)
+    assert got['0']['taken'] == [False] * 5 and got['1']['taken'] == [True, True, True, True, False]
+    for a, b in zip(got['0']['outs'], got['1']['outs']):
+        assert float((a - b).abs().max()) <= 2e-6 * float(a.abs().max()) + 1e-7
 
 
 def test_ssp_gather_with_segment_level_placement(K):
