@@ -248,6 +248,7 @@ __global__ __launch_bounds__(256, 1) void bigru_persist_fwd_kernel(const PArgs P
         }
         // publish step s of this wave's tiles: the wave drains its stores, then one lane signals
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        twog_jitter();
         if (lane == 0) __hip_atomic_fetch_add(pub, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
         for (int i = 0; i < TW; ++i) {
@@ -383,6 +384,7 @@ __global__ __launch_bounds__(256, 1) void bigru_persist_bwd_kernel(const BArgs P
             lanes_sync();
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        twog_jitter();
         if (lane == 0) __hip_atomic_fetch_add(pub, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
         for (int gte = 0; gte < 3; ++gte) {

@@ -42,16 +42,35 @@ inline bool twog_persist_grid_fits(K kernel, int grid, size_t lds, int n_cus) {
         (void)hipGetLastError();
         return false;
     }
-#ifndef TWOG_SP_STAMPS   // (the diagnostic build with phase stamps may spill a few registers; its numbers are read as shares)
+#if !defined(TWOG_SP_STAMPS) && !defined(TWOG_PERSIST_ALLOW_SCRATCH)
+    // (the diagnostic build with phase stamps may spill a few registers, its numbers are read as shares; ALLOW_SCRATCH is the
+    // root-cause build of tools/persist_stress.py, which runs the spilling variant on purpose)
     if (attr.localSizeBytes != 0) return false;
 #endif
     return per_cu >= 1 && (int64_t)per_cu * n_cus >= grid;
 }
 
+// Diagnostic build only (-DTWOG_PERSIST_JITTER, `make jitter` -> lib2ggcn_hip_jitter.so; tests/test_kernels_gpu.py::
+// test_persistent_hand_offs_hold_under_jitter): a pseudo-random pause of 0 ... ~4 us per wave in front of EVERY publish and
+// EVERY poll of the persistent launches, so that the order in which workgroups reach their hand-offs differs from launch to
+// launch and from step to step -- a hand-off that only holds by timing shows as a wrong word. The shipped library has none.
+#ifdef TWOG_PERSIST_JITTER
+__device__ __forceinline__ void twog_jitter() {
+    // wave-uniform: the cycle counter read through a scalar register, mixed with the workgroup and wave ids
+    unsigned x = (unsigned)__builtin_readcyclecounter() ^ (blockIdx.x * 0x9E3779B9u) ^ ((threadIdx.x >> 6) * 0x85EBCA6Bu);
+    x ^= x >> 15; x *= 0x2C1B3C6Du; x ^= x >> 12; x *= 0x297A2D39u; x ^= x >> 15;
+    const int n = __builtin_amdgcn_readfirstlane((int)(x & 15u));
+    for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(10);   // 10 x 64 cycles each
+}
+#else
+__device__ __forceinline__ void twog_jitter() {}
+#endif
+
 // Waits until *counter >= want (agent scope). Returns false when the wave has to leave the kernel (see above).
 __device__ __forceinline__ bool twog_wait_counter(const unsigned* counter, unsigned want, unsigned* error, int spin_limit,
                                                   int lane) {
     int ok = 1;
+    twog_jitter();
     if (lane == 0) {
         int spins = 0;
         if (spin_limit <= 0) {   // test hook: give up at once

@@ -246,6 +246,7 @@ __device__ __forceinline__ bool group_wait(const unsigned* c0, unsigned want0, c
 __device__ __forceinline__ void group_signal(unsigned* counter) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    if (threadIdx.x < 64) twog_jitter();
     if (threadIdx.x == 0) __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
@@ -594,12 +595,29 @@ __device__ __forceinline__ bool p2_step(const SegArgs& P, const Geo& G, int s, f
     // on the fp32 matrix pipe (see mac_f32). (Measured and not kept: 3 x bf16 with one accumulator per tile for the two-tile
     // object rows -- 7.7 against 9.2 us of this loop at h = 512, but 26 registers per lane in scratch, and wrong results
     // at h = 64 with eight chunks; profiles/r05_seg_persist_stamps.txt.)
+#ifdef TWOG_SP_P2_X3
+    // ROOT-CAUSE BUILD ONLY (`make diag`, tools/persist_stress.py; DESIGN "persistent launches: the spilling build"): the
+    // round-5 variant of this loop that needed scratch memory and gave wrong results on the full grid -- 3 x bf16 products
+    // with one accumulator per tile. Never part of the shipped library.
+    k_stream<KW2, MK>(rs_mg, off, nkb, wave, [&](int j, const f32x4 (&A)[MK][2]) {
+        Planes Ap[MK];
+#pragma unroll
+        for (int i = 0; i < MK; ++i) Ap[i] = split8(A[i][0], A[i][1]);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const Planes B = split8(Wr[j][c].a, Wr[j][c].b);
+#pragma unroll
+            for (int i = 0; i < MK; ++i) mac6_one(acc[i][c], Ap[i], B);
+        }
+    });
+#else
     k_stream<KW2, MK>(rs_mg, off, nkb, wave, [&](int j, const f32x4 (&A)[MK][2]) {
 #pragma unroll
         for (int c = 0; c < 3; ++c)
 #pragma unroll
             for (int i = 0; i < MK; ++i) mac_f32(acc[i][c], A[i][0], A[i][1], Wr[j][c]);
     });
+#endif
     f32x4 gh[NPASS][3];
 #pragma unroll
     for (int ps = 0; ps < NPASS; ++ps) {
@@ -1264,6 +1282,10 @@ bool make_plan(const twog_segrnn_t& S, int n_cus, SegPlan& pl) {
     int max_chunks = n_cus / (2 * 4 * ns);
     if (max_chunks < 1) return false;
     if (max_chunks > 16) max_chunks = 16;
+#ifdef TWOG_PERSIST_ALLOW_SCRATCH
+    // root-cause build only: a smaller grid for the same kernel instance (tools/persist_stress.py)
+    if (const char* e = getenv("TWOG_SP_MAX_CHUNKS")) { const int v = atoi(e); if (v >= 1 && v < max_chunks) max_chunks = v; }
+#endif
     int n_chunks = max_chunks < bs ? max_chunks : bs;
     int cpc = (bs + n_chunks - 1) / n_chunks;
     n_chunks = (bs + cpc - 1) / cpc;

@@ -263,15 +263,43 @@ class GumbelSource:
         return g
 
 
-def discrete_estimator(p, strategy, threshold, gumbel):
+class DecisionTape:
+    """Test aid for comparing two runs of this file at different precisions (tools/parity_fuzz.py: fp32 and fp64). Every
+    HARD decision of the path -- `soft > threshold` of the estimators, the three comparisons of the local-maximum filter
+    -- passes through the tape: a recording tape keeps the boolean tensors of a run in call order, a replaying tape hands
+    the recorded ones back in place of the second run's own comparisons, so that both runs follow the same discrete
+    path (and `differing` counts the elements the second run would have decided otherwise). Without a tape (the default)
+    every comparison is used as computed -- the behaviour the golden vectors pin."""
+
+    def __init__(self, recorded=None):
+        self.replay = recorded is not None
+        self.recorded = [] if recorded is None else list(recorded)
+        self.i, self.differing = 0, 0
+
+    def __call__(self, cond):
+        if not self.replay:
+            self.recorded.append(cond.detach().clone())
+            return cond
+        got = self.recorded[self.i]
+        self.i += 1
+        assert got.shape == cond.shape, (got.shape, cond.shape)
+        self.differing += int((got != cond).sum())
+        return got
+
+
+def _as_computed(cond):
+    return cond
+
+
+def discrete_estimator(p, strategy, threshold, gumbel, decide=_as_computed):
     if strategy in {'straight-through', 'st'}:
-        z = (p > threshold).float()
+        z = decide(p > threshold).to(p.dtype)
         return (z - p).detach() + p, p  # forward value z, d/dp = 1 (distributions.py:39-53)
     elif strategy in {'gumbel-sigmoid', 'gs'}:
         pp = torch.cat([p, 1.0 - p], dim=-1)
         y = torch.log(pp + 1e-20) + gumbel(pp.size())
         y = torch.softmax(y / 1.0, dim=-1)[:, :1]
-        z = (y > threshold).float()
+        z = decide(y > threshold).to(y.dtype)
         return (z - y).detach() + y, y
     raise ValueError(f'strategy must be either straight-through or gumbel-sigmoid, not {strategy}.')
 
@@ -282,7 +310,7 @@ def _gate_mlp(sd, name, x, n_layers):
     return torch.sigmoid(_lin(sd, f'{name}.{2 * (n_layers - 1)}', x))
 
 
-def filter_soft_decisions(ux_s, thr):
+def filter_soft_decisions(ux_s, thr, decide=_as_computed):
     """vhoi/models.py:1637-1664."""
     out = []
     T = len(ux_s)
@@ -290,8 +318,8 @@ def filter_soft_decisions(ux_s, thr):
         u = ux_s[t]
         um1 = ux_s[t - 1] if t else torch.zeros_like(u)
         up1 = ux_s[t + 1] if t + 1 < T else torch.zeros_like(u)
-        cond = (u > um1) & (u > up1) & (u >= thr)
-        uh = (u >= thr).float()
+        cond = decide(u > um1) & decide(u > up1) & decide(u >= thr)
+        uh = decide(u >= thr).to(u.dtype)
         uh = (uh - u).detach() + u
         out.append(torch.where(cond, uh, torch.clamp(uh, max=0.0)))
     return out
@@ -346,9 +374,12 @@ def periodic_embedding(x, hidden):
 # ----------------------------------------------------------------------------------------------------------------
 def tggcn_forward(sd, cfg, x_human, x_objects, objects_mask, human_segmentation=None, objects_segmentation=None,
                   human_human_distances=None, human_object_distances=None, object_object_distances=None,
-                  steps_per_example=None, inspect_model=False, training=True, gumbel_noise=None, aux=None):
+                  steps_per_example=None, inspect_model=False, training=True, gumbel_noise=None, aux=None,
+                  decisions=None):
     """Returns the reference's output list (6 tensors without affordance heads, 12 with). ``aux`` (a dict) receives
-    intermediates used by the unit tests: bn_state, gumbel noise drawn, geometry feature, xx_hs/xx_os ..."""
+    intermediates used by the unit tests: bn_state, gumbel noise drawn, geometry feature, xx_hs/xx_os ...
+    ``decisions``: an optional DecisionTape (see there); None = every comparison as computed."""
+    decide = _as_computed if decisions is None else decisions
     cfg = full_cfg(cfg)
     aux = {} if aux is None else aux
     hid = cfg['hidden_size']
@@ -425,7 +456,7 @@ def tggcn_forward(sd, cfg, x_human, x_objects, objects_mask, human_segmentation=
             else:
                 gi = gate_in + ([x_tt] if x_tt is not None else [])
                 p = _gate_mlp(sd, 'update_human_segment_mlp', torch.cat(gi, dim=-1), n_gate)
-                u, us = discrete_estimator(p, strat, thr, gumbel)
+                u, us = discrete_estimator(p, strat, thr, gumbel, decide)
                 if t == T - 1:
                     u = torch.ones_like(u)  # in-place override, cuts the gradient (models.py:701-702)
             ux_hs[h].append(u)
@@ -460,7 +491,7 @@ def tggcn_forward(sd, cfg, x_human, x_objects, objects_mask, human_segmentation=
                 else:  # gate input order differs from xx_os order: [x, h, m_ho, m_oo, m_so]  (models.py:1527)
                     gi = [t_ for t_ in [x_o[:, t, k], h_of[:, t, k], m_ho, m_oo, m_so, x_tt] if t_ is not None]
                     p = _gate_mlp(sd, 'update_object_segment_mlp', torch.cat(gi, dim=-1), n_gate)
-                    u, us = discrete_estimator(p, strat, thr, gumbel)
+                    u, us = discrete_estimator(p, strat, thr, gumbel, decide)
                     if ostrat in {'conditional_on_human', 'coh'} and u_h is not None:
                         u = u * u_h
                 if t == T - 1:
@@ -470,8 +501,8 @@ def tggcn_forward(sd, cfg, x_human, x_objects, objects_mask, human_segmentation=
             xx_os[k].append(torch.cat(parts, dim=-1))
     # E. optional filters / position features (models.py:751-779)
     if cfg['filter_discrete_updates']:
-        ux_hs = [filter_soft_decisions(u, thr) for u in ux_hss]
-        ux_os = [filter_soft_decisions(u, thr) for u in ux_oss]
+        ux_hs = [filter_soft_decisions(u, thr, decide) for u in ux_hss]
+        ux_os = [filter_soft_decisions(u, thr, decide) for u in ux_oss]
     if cfg['add_time_position'] and cfg['time_position_strategy'] == 's':
         x_time = pos_embed(time_tensor(steps_per_example, T, periodic), 'time_position_mlp')
         xx_hs = [[torch.cat([a, b], dim=-1) for a, b in zip(xs, x_time)] for xs in xx_hs]

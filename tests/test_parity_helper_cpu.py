@@ -56,6 +56,56 @@ def test_conditioning_moves_a_case_off_the_relu_boundary():
     assert not relu_boundary.boundary_layers(m, fwd(), width=8.0)
 
 
+PLANTED = [   # (configuration switches, layer, T): one (row / pair, unit) of the layer is put exactly on zero through its bias
+    (dict(attention_style='v1'), 'objects_to_human_message_att_mlp.0', 3),                # concat score, frame level
+    (dict(attention_style='v1'), 'objects_to_object_segment_message_att_mlp.0', 2),      # concat score, segment level
+    (dict(attention_style='v4'), 'humans_to_object_message_att_mlp', 3),                  # bilinear score, frame level
+    (dict(attention_style='v4'), 'objects_to_human_segment_message_att_mlp', 2),         # bilinear score, segment level
+    (dict(message_granularity='v2'), 'objects_to_object_message_mlp.0', 3),               # receiver-specific message
+    (dict(message_type='v1'), 'human_object_pairwise_relation_mlp.0', 3),                 # relational: pairwise g
+    (dict(message_type='v1'), 'object_human_full_relation_mlp.0', 3),                     # relational: full f
+    (dict(discrete_networks_num_layers=3), 'update_object_segment_mlp.0', 3),             # gate network, first hidden layer
+    (dict(discrete_networks_num_layers=3), 'update_object_segment_mlp.2', 3),             # gate network, second hidden layer
+    (dict(add_time_position=1, time_position_strategy='u'), 'time_position_mlp.0', 3),    # position feature
+]
+
+
+@pytest.mark.parametrize('extra,layer,T', PLANTED, ids=[f'{p[1]}-{i}' for i, p in enumerate(PLANTED)])
+def test_every_relu_layer_of_the_general_forms_is_covered(extra, layer, T):
+    """tests/relu_boundary.py recomputes the pre-activations of EVERY ReLU layer the path has -- also the per-pair layers of
+    the general message forms, the attention-score functions, the hidden layers of the gate networks and the position
+    features. For each: a unit planted on the boundary is found in the layer that owns it, and
+    condition_case moves the case off it. (Segment-level scores are planted in a chain of two steps, whose first states
+    do not depend on the score function: a softmax over equal scores.)"""
+    from twog_gcn_amd.models import TGGCN
+    torch.manual_seed(3)
+    N, h, bs, H, O = 26, 16, 2, 2, 4
+    cfg = dict(tp.STAGE1)
+    cfg.update(extra)
+    m = TGGCN(input_size=(2048 + 4 * N, 2048), num_classes=(13, None), hidden_size=h, gcn_node=N, **cfg).train()
+    x_human, x_objects, mask = tp._synthetic(bs, T, H, O, N, 2)
+    mask[0, -1] = 0
+    m._gumbel_noise_override = torch.distributions.gumbel.Gumbel(0.0, 1.0).sample((T * (H + O), bs, 2))
+    steps = torch.full((bs,), float(T))
+
+    def fwd():
+        return m(x_human, x_objects, mask, steps_per_example=steps)
+
+    P = dict(m.named_parameters())
+    for rnd in range(3):   # (the planted bias is a rounded fp32 number: a second pass removes what the rounding left)
+        its = [i for i in relu_boundary._layers(m, fwd()) if i.layer == layer]
+        assert its, ('layer not covered', layer, sorted({i.layer for i in relu_boundary._layers(m, fwd())}))
+        pre, mag = its[0].pre_mag()
+        row = int(mag[:, 0].argmax())                    # a row / pair that exists (and whose features are not all zero)
+        with torch.no_grad():
+            P[layer + '.bias'][0] -= pre[row, 0].to(torch.float32)
+    found = relu_boundary.boundary_layers(m, fwd(), width=8.0)
+    assert 0 in found.get(layer, torch.tensor([])).tolist(), (layer, found)
+    rounds, nudged = relu_boundary.condition_case(m, fwd)
+    assert rounds >= 1 and nudged.get(layer, 0) >= 1
+    assert not relu_boundary.boundary_layers(m, fwd(), width=8.0)
+
+
 def test_a_planted_one_percent_gradient_error_fails_the_gate(monkeypatch):
     """The gate must catch what the old escape clause let through: a 1 % error in ONE kernel's backward (here the ReLU
     backward of the test double scaled by 1.01) moves the gradients upstream of it by about a percent -- far beyond
