@@ -780,7 +780,13 @@ __device__ __forceinline__ void gemm_mainloop_x3s(const twog_rows_t A, const two
 #pragma unroll
             for (int i = 0; i < NPB; ++i) {
                 if (NPB * NT == FB || b_on[i]) {
+#ifdef TWOG_PROBE_NO_BSPLIT   // timing probe only (wrong results): what the split of the B operand costs a chain launch
+                    ph = i32x2{__builtin_bit_cast(int, r.b[u][i][0]), __builtin_bit_cast(int, r.b[u][i][1])};
+                    pm = i32x2{__builtin_bit_cast(int, r.b[u][i][2]), __builtin_bit_cast(int, r.b[u][i][3])};
+                    pl = ph;
+#else
                     split3(r.b[u][i], ph, pm, pl);
+#endif
                     *reinterpret_cast<i32x2*>(base + sb_off[i]) = ph;
                     *reinterpret_cast<i32x2*>(base + sb_off[i] + PB) = pm;
                     *reinterpret_cast<i32x2*>(base + sb_off[i] + 2 * PB) = pl;

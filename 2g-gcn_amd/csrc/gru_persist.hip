@@ -103,7 +103,7 @@ __global__ __launch_bounds__(256, 1) void bigru_persist_fwd_kernel(const PArgs P
     constexpr int D = TWC == 1 ? NKB : (TWC == 2 ? (NKB < 8 ? NKB : 8) : (NKB < 3 ? NKB : 3));
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int h = 32 * NKB, n_wg = h / 16;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i16 = lane & 15, g4 = lane >> 4;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), i16 = lane & 15, g4 = lane >> 4;
     const int combo = (int)blockIdx.x % P.n_combos, slice = (int)blockIdx.x / P.n_combos;
     const PCombo& C = P.c[combo];
     const PGroup& G = P.g[C.group];
@@ -298,7 +298,7 @@ __global__ __launch_bounds__(256, 1) void bigru_persist_bwd_kernel(const BArgs P
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int h = 32 * NKH, n_wg = h / 16, NKB = 3 * NKH;
     constexpr int D = NKB < 24 ? NKB : 24;   // k-blocks of d_gh in flight
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i16 = lane & 15, g4 = lane >> 4;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), i16 = lane & 15, g4 = lane >> 4;
     const int combo = (int)blockIdx.x % P.n_combos, slice = (int)blockIdx.x / P.n_combos;
     const PCombo& C = P.c[combo];
     const BGroup& G = P.g[C.group];
@@ -522,6 +522,7 @@ extern "C" int twog_bigru_fwd_persistent(const twog_bigru_t* types, int n_types,
     P.error = P.pub + MAXC * 4;
     P.n_combos = n_combos; P.bs = bs; P.T = T;
     P.spin_limit = twog_persist_spin_limit();
+    twog_jitter_configure();   // (no-op in the shipped library)
     const int grid = n_combos * (hidden / 16);
     const size_t lds = (size_t)(hidden / 32) * 9 * 1024 + 4 * 16 * 20 * 4;
     int twc = 1;
@@ -598,6 +599,7 @@ extern "C" int twog_bigru_bwd_persistent(const twog_bigru_bwd_t* types, int n_ty
     P.error = P.pub + MAXC * 4;
     P.n_combos = n_combos; P.bs = bs; P.T = T;
     P.spin_limit = twog_persist_spin_limit();
+    twog_jitter_configure();   // (no-op in the shipped library)
     const int grid = n_combos * (hidden / 16);
     const size_t lds = (size_t)(3 * hidden / 32) * 3 * 1024 + 4 * 16 * 20 * 4;
     hipStream_t st = (hipStream_t)stream;

@@ -13,8 +13,9 @@
 #include <stdlib.h>
 #include "twog_common.h"
 
-// polls (each an L2 round trip plus an s_sleep, ~1 us) before a wait gives up: seconds by default;
-// TWOG_PERSIST_SPIN_LIMIT overrides. 0 is the test hook of the recovery path: every wait gives up at once, whether or not
+// polls (each an L2 round trip plus an s_sleep, ~1 us) before a wait gives up: 2^16, i.e. several times the ~20 ms of a
+// whole training step at the batches these launches serve (a healthy hand-off takes microseconds; round 5 waited 2^24 polls,
+// ~16 s per timed-out wait: ADVICE r05); TWOG_PERSIST_SPIN_LIMIT overrides. 0 is the test hook of the recovery path: every wait gives up at once, whether or not
 // its counter has arrived (an idle device hands over within a poll or two, so a small positive limit proves nothing).
 inline int twog_persist_spin_limit() {
     const char* e = getenv("TWOG_PERSIST_SPIN_LIMIT");
@@ -22,7 +23,7 @@ inline int twog_persist_spin_limit() {
         const long v = strtol(e, nullptr, 10);
         if (v >= 0) return (int)(v > (1L << 30) ? (1L << 30) : v);
     }
-    return 1 << 24;
+    return 1 << 16;
 }
 
 // true if `grid` workgroups of `kernel` (256 threads, `lds` bytes of dynamic LDS) can be resident at once on a device with
@@ -55,14 +56,23 @@ inline bool twog_persist_grid_fits(K kernel, int grid, size_t lds, int n_cus) {
 // EVERY poll of the persistent launches, so that the order in which workgroups reach their hand-offs differs from launch to
 // launch and from step to step -- a hand-off that only holds by timing shows as a wrong word. The shipped library has none.
 #ifdef TWOG_PERSIST_JITTER
+// pause length mask (0 ... mask units of ~0.27 us); TWOG_JITTER_MASK=0 runs the SAME binary without pauses (the control of
+// tools/persist_stress.py: is a wrong result a matter of timing or of the generated code?)
+static __device__ unsigned twog_jitter_mask_dev = 15u;
+inline void twog_jitter_configure() {
+    unsigned m = 15u;
+    if (const char* e = getenv("TWOG_JITTER_MASK")) m = (unsigned)strtoul(e, nullptr, 10);
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(twog_jitter_mask_dev), &m, sizeof(m));
+}
 __device__ __forceinline__ void twog_jitter() {
     // wave-uniform: the cycle counter read through a scalar register, mixed with the workgroup and wave ids
     unsigned x = (unsigned)__builtin_readcyclecounter() ^ (blockIdx.x * 0x9E3779B9u) ^ ((threadIdx.x >> 6) * 0x85EBCA6Bu);
     x ^= x >> 15; x *= 0x2C1B3C6Du; x ^= x >> 12; x *= 0x297A2D39u; x ^= x >> 15;
-    const int n = __builtin_amdgcn_readfirstlane((int)(x & 15u));
+    const int n = __builtin_amdgcn_readfirstlane((int)(x & twog_jitter_mask_dev));
     for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(10);   // 10 x 64 cycles each
 }
 #else
+inline void twog_jitter_configure() {}
 __device__ __forceinline__ void twog_jitter() {}
 #endif
 

@@ -168,7 +168,11 @@ template <int NJ, int MK, class F>
 __device__ __forceinline__ void k_stream(const __amdgpu_buffer_rsrc_t rs, const uint32_t (&off)[MK], int nkb, int wave, F&& body) {
     constexpr int CH = NJ < 4 ? NJ : 4, NG = (NJ + CH - 1) / CH;
     typedef f32x4 Buf[CH][MK][2];
+#ifdef TWOG_SP_P2_X3_ALLJ   // root-cause build: every k-block slot multiplied (zero weights beyond the reduction), see below
+    Buf b0 = {}, b1 = {};
+#else
     Buf b0, b1;   // two named buffers (no run-time buffer index: that would put the fragments into scratch memory)
+#endif
     auto load = [&](int g, Buf& buf) {
 #pragma unroll
         for (int jj = 0; jj < CH; ++jj) {
@@ -186,7 +190,12 @@ __device__ __forceinline__ void k_stream(const __amdgpu_buffer_rsrc_t rs, const 
 #pragma unroll
         for (int jj = 0; jj < CH; ++jj) {
             const int j = g * CH + jj, kb = wave + 4 * j;
+#ifdef TWOG_SP_P2_X3_ALLJ
+            (void)kb;
+            if (j < NJ) body(j, buf[jj]);
+#else
             if (j < NJ && kb < nkb) body(j, buf[jj]);
+#endif
         }
     };
     load(0, b0);
@@ -217,7 +226,7 @@ __device__ __forceinline__ void put_part1(float* part, int n_tiles, int wave, in
 // sums the waves' partial tiles in wave order into res[tile][16][RS]; all 256 threads; ends with a barrier
 __device__ __forceinline__ void combine_parts(const float* part, float* res, int n_tiles, int n_waves_used) {
     __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     for (int tile = wave; tile < n_tiles; tile += 4) {
         f32x4 v = *reinterpret_cast<const f32x4*>(part + ((size_t)tile * 64 + lane) * 4);
         for (int w = 1; w < n_waves_used; ++w)
@@ -231,7 +240,7 @@ __device__ __forceinline__ void combine_parts(const float* part, float* res, int
 // wave 0 waits for (up to) two counters; the whole workgroup learns the outcome. Returns false -> everybody leaves.
 __device__ __forceinline__ bool group_wait(const unsigned* c0, unsigned want0, const unsigned* c1, unsigned want1,
                                            unsigned* error, int spin_limit, int* flag) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (wave == 0) {
         bool ok = twog_wait_counter(c0, want0, error, spin_limit, lane);
         if (ok && c1) ok = twog_wait_counter(c1, want1, error, spin_limit, lane);
@@ -312,7 +321,7 @@ __device__ __forceinline__ bool p1_step(const SegArgs& P, const Geo& G, int s, f
     constexpr int MK = RK == 0 ? MH : MO, MT = MH + MO;
     constexpr int NPAIR = MT * (MT + 1) / 2;
     constexpr int T_SH = 0, T_SO = MH, T_G = MH + MO, T_GRAM = T_G + 3 * MK, NTILES = T_GRAM + NPAIR;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i16 = lane & 15, g4 = lane >> 4;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), i16 = lane & 15, g4 = lane >> 4;
     const int H = P.H, O = P.O, h = P.h, T = P.T, E_K = RK == 0 ? H : O;
     const int dir = G.dir, t = dir == 0 ? s : T - 1 - s, tp = dir == 0 ? t - 1 : t + 1;
     const int nkb = h / 32;
@@ -556,7 +565,7 @@ template <int MK, int K>
 __device__ __forceinline__ bool p2_step(const SegArgs& P, const Geo& G, int s, float* part, float* res, int* flag,
                                         f32x4 (&h_own)[(MK * 16 + 63) / 64], const WFrag (&Wr)[KW2][3]) {
     constexpr int NTILES = 3 * MK, NPASS = (MK * 16 + 63) / 64;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i16 = lane & 15, g4 = lane >> 4;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), i16 = lane & 15, g4 = lane >> 4;
     const int h = P.h, T = P.T, E_K = K == 0 ? P.H : P.O, R_K = K == 0 ? G.RH : G.RO;
     const int dir = G.dir, t = dir == 0 ? s : T - 1 - s;
     const int ns = h / 16, nkb = 2 * h / 32;
@@ -682,7 +691,7 @@ struct FwdLds { float *part, *res, *sG, *sW, *sMask, *sBias; int* flag; };
 // into the bf16 planes at every use. Nothing but states and messages moves per step.
 template <int MH, int MO, int RK>
 __device__ __forceinline__ void role_p1(const SegArgs& P, const Geo& G, const FwdLds& M) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nkb = P.h / 32;
     WFrag Wr[KW1][5];
 #pragma unroll
@@ -711,7 +720,7 @@ __device__ __forceinline__ void role_p1(const SegArgs& P, const Geo& G, const Fw
 
 template <int MK, int K>
 __device__ __forceinline__ void role_p2(const SegArgs& P, const Geo& G, const FwdLds& M) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nkb = 2 * P.h / 32;
     WFrag Wr[KW2][3];
 #pragma unroll
@@ -820,7 +829,7 @@ template <int MH, int MO, int RK>
 __device__ __forceinline__ bool q1_step(const SegBwdArgs& P, const Geo& G, int s, float* part, float* res, float* msT,
                                         float* sW, float* sDW, int* flag, const WFrag (&Wr)[KW3][2]) {
     constexpr int MK = RK == 0 ? MH : MO, NTILES = 2 * MK;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i16 = lane & 15, g4 = lane >> 4;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), i16 = lane & 15, g4 = lane >> 4;
     const int H = P.H, O = P.O, h = P.h, T = P.T, E_K = RK == 0 ? H : O, R_K = RK == 0 ? G.RH : G.RO;
     const int dir = G.dir, t = dir == 0 ? s : T - 1 - s;
     const int ns = h / 16, nkb = 3 * h / 32;
@@ -935,7 +944,7 @@ __device__ __forceinline__ bool q2_step(const SegBwdArgs& P, const Geo& G, int s
                                         float* sDW, float* sC, int* flag, f32x4 (&direct)[(MK * 16 + 63) / 64],
                                         f32x4 (&c_hh)[(MK * 16 + 63) / 64], const WFrag (&We)[KW2], const WFrag (&Wh)[KW3]) {
     constexpr int NPASS = (MK * 16 + 63) / 64;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i16 = lane & 15, g4 = lane >> 4;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), i16 = lane & 15, g4 = lane >> 4;
     const int H = P.H, O = P.O, E = H + O, h = P.h, T = P.T, E_K = K == 0 ? H : O, R_K = K == 0 ? G.RH : G.RO;
     const int dir = G.dir, t = dir == 0 ? s : T - 1 - s, tp = dir == 0 ? t - 1 : t + 1;
     const int tn = dir == 0 ? t + 1 : t - 1;   // the time of chain step s + 1 (processed before this one)
@@ -1185,7 +1194,7 @@ struct BwdLds { float *part, *res, *msT, *sW, *sDW, *sC; int* flag; };
 // weights once, into registers (see the forward roles): k-major operands here
 template <int MH, int MO, int RK>
 __device__ __forceinline__ void role_q1(const SegBwdArgs& P, const Geo& G, const BwdLds& M) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nkb = 3 * P.h / 32;
     WFrag Wr[KW3][2];
 #pragma unroll
@@ -1201,7 +1210,7 @@ __device__ __forceinline__ void role_q1(const SegBwdArgs& P, const Geo& G, const
 
 template <int MK, int K>
 __device__ __forceinline__ void role_q2(const SegBwdArgs& P, const Geo& G, const BwdLds& M) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     WFrag We[KW2], Wh[KW3];
 #pragma unroll
     for (int j = 0; j < KW2; ++j) {
@@ -1352,6 +1361,7 @@ extern "C" int twog_segrnn_fwd_persistent(const twog_segrnn_t* desc, void* sync,
     P.cpc = pl.cpc; P.n_chunks = pl.n_chunks; P.pair_mask = pl.pair_mask;
     P.scale = S.att_scale;
     P.spin_limit = twog_persist_spin_limit();
+    twog_jitter_configure();   // (no-op in the shipped library)
     P.gi[0] = S.gi_h; P.gi[1] = S.gi_o; P.u[0] = S.u_h; P.u[1] = S.u_o; P.mask = S.obj_mask;
     for (int d = 0; d < 2; ++d) {
         P.w_hh[0][d] = S.w_hh_h[d]; P.w_hh[1][d] = S.w_hh_o[d];
@@ -1438,6 +1448,7 @@ extern "C" int twog_segrnn_bwd_persistent(const twog_segrnn_t* desc, const twog_
     P.cpc = pl.cpc; P.n_chunks = pl.n_chunks; P.dw_pad = bwd_dw_pad(S, pl.cpc);
     P.scale = S.att_scale;
     P.spin_limit = twog_persist_spin_limit();
+    twog_jitter_configure();   // (no-op in the shipped library)
     P.u[0] = S.u_h; P.u[1] = S.u_o;
     for (int d = 0; d < 2; ++d) {
         P.w_hh[0][d] = S.w_hh_h[d]; P.w_hh[1][d] = S.w_hh_o[d];

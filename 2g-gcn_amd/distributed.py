@@ -154,6 +154,7 @@ class DataParallel:
             _kernels.HipKernels.shared_devices.add(torch.cuda.current_device())   # per device, not per process
         rank = dist.get_rank(process_group) if self.collective else 0
         self._works, self._launched = [], set()
+        self._markers, self._late_failure = [], None
         self.collective_calls = 0   # collectives issued so far (tests assert the path really ran)
         from . import ops
         # Everything this wrapper hangs beside the model (ops.set_model_extra: a weak-KEYED table) refers back to the wrapper
@@ -228,6 +229,7 @@ class DataParallel:
     def zero_grad(self):
         self.flat.zero_grad()
         self._works, self._launched = [], set()
+        self._markers, self._late_failure = [], None
 
     def _reduce_range(self, begin, end):
         g = self.flat.grad
@@ -242,7 +244,29 @@ class DataParallel:
         if stage in self._launched or stage not in self.flat.stage_ranges:
             return
         self._launched.add(stage)
+        self._poison_if_a_persistent_launch_gave_up(self.flat.stage_ranges[stage][0])
         self._reduce_range(*self.flat.stage_ranges[stage])
+
+    def _poison_if_a_persistent_launch_gave_up(self, begin):
+        """A persistent launch of this rank's backward pass that could not keep its grid resident leaves incomplete
+        gradients behind, and its error word is only read at the end of the pass (kernels.py: reading it at once costs
+        ~1.2 ms per 8-clip step). The all-reduce about to be issued would spread those gradients to every rank:
+        so ONE small launch in front of it (twog_guard_outputs, on the stream the all-reduce is ordered behind) turns the
+        first element of this stage's range into NaN if a pending word is set. The sum carries the NaN to every rank, and
+        all_reduce_gradients() raises on ALL of them before any optimizer sees the buffer."""
+        K = get_kernels()
+        if not hasattr(K, 'guard_persistent') or not self.flat.grad.is_cuda:
+            return
+        marker = self.flat.grad[begin:begin + 1]
+        if not K.guard_persistent(self.flat.grad.device, [marker]):
+            # (too many pending words for one guard launch, or the guard is switched off: read the words now -- a wait --
+            # and poison from the host; never raise in front of a collective the other ranks are entering)
+            try:
+                K.verify_persistent(self.flat.grad.device)
+            except RuntimeError as e:
+                self._late_failure = e
+                marker.fill_(float('nan'))
+        self._markers.append(begin)
 
     def all_reduce_gradients(self):
         """Sum-all-reduce of the flat gradient buffer: whatever the backward pass has not started yet is launched here
@@ -257,6 +281,34 @@ class DataParallel:
         for w in self._works:
             w.wait()
         self._works = []
+        self._raise_if_any_rank_failed()
+
+    def _raise_if_any_rank_failed(self):
+        """After the collectives: this rank's deferred error words (kernels.verify_persistent) and the NaN markers of every
+        rank (see _poison_if_a_persistent_launch_gave_up). Raises on every rank alike; the step is to be repeated."""
+        K = get_kernels()
+        mine = self._late_failure
+        self._late_failure = None
+        if hasattr(K, 'verify_persistent') and self.flat.grad.is_cuda:
+            try:
+                K.verify_persistent(self.flat.grad.device)
+            except RuntimeError as e:
+                mine = e
+        markers, self._markers = self._markers, []
+        poisoned = False
+        if markers:
+            vals = torch.stack([self.flat.grad[b] for b in markers]).cpu()
+            poisoned = not bool(torch.isfinite(vals).all())
+        if mine is not None and not poisoned and self.world > 1:
+            # (a failure the guard launch did not see -- the word landed after it ran: cannot happen with the words ordered
+            # on the stream in front of the guard, but the other ranks must not step on what this rank knows is incomplete)
+            self.flat.grad.fill_(float('nan'))
+        if mine is not None:
+            raise mine
+        if poisoned:
+            raise RuntimeError('a rank of this group could not complete a persistent launch of its backward pass (or produced '
+                               'a non-finite gradient): the all-reduced gradient buffer is marked NaN on every rank and must '
+                               'not reach the optimizer. Repeat the step (zero_grad, forward, backward).')
 
     def shard(self, tensor, rank=None):
         """This rank's contiguous slice [r*bs/W, (r+1)*bs/W) of a global batch."""

@@ -2034,7 +2034,10 @@ def tggcn_backward(K, plan: Plan, P, S, x_human, x_objects, objects_mask, d_outp
     G.flush()
     if side is not None:
         side.join()
-    if hasattr(K, 'verify_persistent'):
+    if hasattr(K, 'verify_persistent') and getattr(p, 'stage_hook', None) is None:
+        # (under a data-parallel wrapper the deferred words are read by DataParallel.all_reduce_gradients, AFTER the
+        # collectives every rank has to join: a rank that raised here would leave the others waiting in an all-reduce, and a
+        # failed launch's incomplete gradients are poisoned on the device in front of each stage's all-reduce -- see there)
         K.verify_persistent(dev)
     return G.g
 

@@ -56,6 +56,9 @@ WORKLOADS = {
     'c3': dict(H=2, O=8, N=34, h=512, bs=64, classes=13, name='Synthetic T=120 N=34 C=512 (BASELINE configs[2])'),
     'c2': dict(H=2, O=4, N=26, h=512, bs=8, classes=13, name='MPHOI-72 layout hs512 bs8 (BASELINE configs[1])'),
     'c5': dict(H=2, O=9, N=30, h=64, bs=16, classes=14, name='Bimanual layout h=64, 16 clips per GPU (BASELINE configs[4])'),
+    # "also run h=512" (BASELINE.md section 4 prices it at 49.8 GFLOP per clip forward)
+    'c5_hs512': dict(H=2, O=9, N=30, h=512, bs=16, classes=14,
+                     name='Bimanual layout at h=512, 16 clips per GPU (SURVEY section 8 C5 "also run h=512")'),
     # the constructor's OWN defaults (vhoi/models.py:179-190: relational + receiver-specific messages, concat attention, no
     # segment-level messages, h = 128) and the same with segment-level messages: the general single-relation kernels
     # (relation.hip) and the host-composed segment loop -- no shipped configuration uses them; informational
@@ -260,7 +263,7 @@ def _cpu_model():
     return 'unknown'
 
 
-def cpu_baseline(sample_frames=None, sample_clips=4, repeats=3):
+def cpu_baseline(sample_frames=None, sample_clips=4, repeats=3, threads=None):
     """The oracle (port of the reference's PyTorch-CPU path) on a bounded sample of the same workload: `sample_clips`
     full-length clips, 1 warm-up + `repeats` timed forward+backward passes (median reported; forward alone as well) --
     about 30 s of CPU work on the GPU box's 16 granted cores. (`sample_frames` < T shortens the clips; the cost is
@@ -270,8 +273,10 @@ def cpu_baseline(sample_frames=None, sample_clips=4, repeats=3):
     import twog_gcn_amd  # noqa: F401
     from twog_gcn_amd.models import TGGCN
     from twog_gcn_amd.hostcpu import effective_cpu_count
-    # the reference's default resources.num_threads is 32 (conf/config.yaml:9); never more than the cgroup grants
-    cores = min(32, effective_cpu_count())
+    # the reference's default resources.num_threads is 32 (conf/config.yaml:9); `value` never uses more than the cgroup
+    # grants (threads=None); by_config also times the reference's literal setting of 32 threads on those cores
+    granted = effective_cpu_count()
+    cores = min(32, granted) if threads is None else threads
     torch.set_num_threads(cores)
     torch.manual_seed(0)
     m = TGGCN(input_size=(2048 + 4 * N_NODES, 2048), num_classes=(N_CLASSES, None), **CFG)
@@ -299,14 +304,36 @@ def cpu_baseline(sample_frames=None, sample_clips=4, repeats=3):
             t_all.append(t2 - t0)
     med = lambda v: sorted(v)[len(v) // 2]
     clips = nb * Ts / T
-    return dict(value=clips / med(t_all), unit='clips/s', cores=cores, kind='port', cpu_model=_cpu_model(),
+    return dict(value=clips / med(t_all), unit='clips/s', cores=min(cores, granted), kind='port', cpu_model=_cpu_model(),
                 threads=cores, repeats=repeats, warmup=1, sample_clips=nb, sample_frames=Ts,
                 protocol='r02: 1 warm-up + 3 timed forward+backward passes of 4 full-length clips, median (round 1 timed ONE '
                          'pass of 8 clips: values are not comparable across that change)',
                 sample=f'{nb} clips x {Ts} of {T} frames (H={H},O={O},N={N_NODES},h={CFG["hidden_size"]}); 1 warm-up + '
-                       f'{repeats} timed forward+backward passes, median {med(t_all):.1f} s (all: '
+                       f'{repeats} timed forward+backward passes, {cores} threads on {granted} granted cores, median {med(t_all):.1f} s (all: '
                        f'{", ".join(f"{t:.1f}" for t in t_all)})' + ('' if Ts == T else ', scaled linearly in frames'),
                 forward_clips_per_s=clips / med(t_fwd), forward_seconds=[round(t, 2) for t in t_fwd])
+
+
+def cpu_baseline_all(workload):
+    """The `cpu_baseline` object of the bench line: `value` as before (the workload's own shape, as many threads as cores
+    are granted, 4 clips, 1 + 3 passes) plus `by_config`: the configs[1] bs8 layout and the reference's literal
+    `resources.num_threads: 32` (conf/config.yaml:9) beside it, each on a smaller sample (2 clips, 1 + 2 passes) so that the
+    whole leg stays within about two minutes."""
+    from twog_gcn_amd.hostcpu import effective_cpu_count
+    granted = min(32, effective_cpu_count())
+    main_ = cpu_baseline()
+    keep = ('value', 'unit', 'threads', 'cores', 'forward_clips_per_s', 'sample')
+    by = {f'{workload}_threads{granted}': {k: main_[k] for k in keep}}
+    plan = [(workload, 32)] if granted != 32 else []
+    if workload == 'c3':
+        plan += [('c2', granted)] + ([('c2', 32)] if granted != 32 else [])
+    for wl, thr in plan:
+        select_workload(wl)
+        r = cpu_baseline(sample_clips=2, repeats=2, threads=thr)
+        by[f'{wl}_threads{thr}'] = {k: r[k] for k in keep}
+    select_workload(workload)
+    main_['by_config'] = by
+    return main_
 
 
 def cpu_baseline_in_child(workload='c3', timeout_s=420):
@@ -365,7 +392,7 @@ def main():
     if args.batch is None:
         args.batch = BS
     if args.cpu_baseline_only:
-        print(json.dumps(cpu_baseline()), flush=True)
+        print(json.dumps(cpu_baseline_all(args.workload)), flush=True)
         return
     if args.gpus < 1:
         ap.error('--gpus must be >= 1')
@@ -803,6 +830,12 @@ def main():
         host_all = sum(v[0] for v in agg.values())
         lib = sum(c['flops'] for c in cm.values()) * prof_steps
         result['x3_share_of_gemm_flops'] = ((host_x3 + (lib if x3_on else 0.0)) / (host_all + lib)) if host_all + lib > 0 else None
+        # which form of each recurrence served this shape (persistent = one launch for all time steps, csrc/gru_persist.hip /
+        # seg_persist.hip; otherwise one launch per dependency level, csrc/gru.hip / segrnn.hip)
+        result['recurrence_paths'] = {
+            n: ('persistent launch' if getattr(_K, f, False) else 'launch per step')
+            for n, f in (('bigru_fwd', 'last_bigru_persistent'), ('bigru_bwd', 'last_bigru_bwd_persistent'),
+                         ('segrnn_fwd', 'last_segrnn_persistent'), ('segrnn_bwd', 'last_segrnn_bwd_persistent'))}
         if dist_diag is not None:
             result['distributed_diagnostics'] = dist_diag
         if fwd_only is not None:

@@ -176,3 +176,70 @@ def test_first_gradient_all_reduce_is_issued_behind_the_persistent_backward_laun
     assert log_f.index('stage0') < log_f.index('stage1') < log_f.index('stage2'), log_f
     assert calls_f >= 3 and calls_p == 0
     assert torch.equal(g_f, g_p) and torch.isfinite(g_f).all()
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# a persistent backward launch that gives up leaves incomplete gradients; its error word is read late.
+# Under a data-parallel wrapper those gradients must not reach the other ranks' optimizers: a guard launch in front of
+# each stage's all-reduce marks the stage NaN on the device when a pending word is set, the sum carries the mark to
+# every rank, and all_reduce_gradients() raises on all of them (the failing rank does NOT raise inside backward, where its
+# peers would be left waiting in a collective).
+def _late_failure_worker(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+    torch.cuda.set_device(0)
+    dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', 0))
+    import twog_gcn_amd  # noqa: F401
+    from twog_gcn_amd import kernels
+    from twog_gcn_amd.distributed import DataParallel
+    from twog_gcn_amd.models import TGGCN
+    K = kernels.get_kernels()
+    torch.manual_seed(0)
+    xh, xo, mask, tgt, noise = (t.to(DEV) for t in _batch(4, T=6))
+    model = TGGCN(input_size=(2048 + 4 * 26, 2048), num_classes=(13, None), hidden_size=64, gcn_node=26,
+                  attention_style='v3', discrete_optimization_strategy='gs', message_segment=True, message_type='v2',
+                  message_granularity='v1', message_aggregation='att', object_segment_update_strategy='ind').to(DEV).train()
+    dp = DataParallel(model, bucket_mb=1, force_collectives=True)
+    model._gumbel_noise_override = noise
+    seg = torch.ones(xh.shape[:3], device=DEV)
+
+    def step(fail_backward):
+        dp.zero_grad()
+        out = model(xh, xo, mask, human_segmentation=seg)
+        loss = torch.nn.functional.nll_loss(out[4], tgt) + torch.nn.functional.nll_loss(out[5], tgt)
+        if fail_backward:
+            os.environ['TWOG_PERSIST_SPIN_LIMIT'] = '0'   # the library's test hook: every wait gives up at once
+        try:
+            loss.backward()                                # must NOT raise: the peers are entering their collectives
+        finally:
+            os.environ.pop('TWOG_PERSIST_SPIN_LIMIT', None)
+        dp.all_reduce_gradients()
+
+    os.environ['TWOG_PERSIST_CHECK'] = 'lazy'              # the steady state: error words read at the end of the pass
+    step(False)
+    torch.cuda.synchronize()
+    ret['clean_finite'] = bool(torch.isfinite(dp.flat.grad).all())
+    ret['persistent_ran'] = bool(K.last_segrnn_bwd_persistent and K.last_bigru_bwd_persistent)
+    try:
+        step(True)
+        ret['raised'] = None
+    except RuntimeError as e:
+        ret['raised'] = str(e)[:300]
+    torch.cuda.synchronize()
+    begins = [b for b, _ in dp.flat.stage_ranges.values()]
+    ret['markers_nan'] = [bool(torch.isnan(dp.flat.grad[b])) for b in begins]
+    step(False)                                            # and the step after it is clean again (launch-per-step path)
+    torch.cuda.synchronize()
+    ret['after_finite'] = bool(torch.isfinite(dp.flat.grad).all())
+    dp.close()
+    dist.destroy_process_group()
+
+
+def test_a_persistent_backward_launch_that_gives_up_poisons_the_all_reduce_and_raises_after_it():
+    port = 40500 + os.getpid() % 2000
+    ret = mp.Manager().dict()
+    mp.spawn(_late_failure_worker, args=(1, port, ret), nprocs=1, join=True)
+    assert ret['clean_finite'] and ret['persistent_ran'], dict(ret)
+    assert ret['raised'] and 'persistent launch' in ret['raised'], dict(ret)
+    assert any(ret['markers_nan']), dict(ret)              # the stage(s) issued behind the failed launches carry the mark
+    assert ret['after_finite'], dict(ret)

@@ -1032,6 +1032,30 @@ def test_segment_recurrence_persistent_hand_offs_hold_under_uneven_load(K, monke
             assert torch.equal(a, b), f'repetition {rep}: {k} of the persistent launch under load differs from the solo run'
 
 
+def test_persistent_hand_offs_hold_under_jitter(tmp_path):
+    """the four persistent launches (BiGRU forward / backward, segment forward / backward) at the
+    BASELINE configs[0] / [1] / [4] shapes, 200 times each, in the JITTER build of the library (`make jitter`:
+    persist_common.h::twog_jitter, a pseudo-random pause of 0 ... ~4 us per wave in front of every publish and every poll, so
+    the order in which workgroups reach their hand-offs changes from step to step) -- every word of every output equal to
+    the shipped library's. A hand-off that only holds by timing shows as a wrong word; the shipped and the jitter build run
+    the same arithmetic in the same order. Both builds run in child processes (one library per process)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    jit = os.path.join(root, '2g-gcn_amd', 'lib2ggcn_hip_jitter.so')
+    if not os.path.exists(jit):   # the diagnostic build is not part of `make all`: build it here (hipcc is on the GPU box too)
+        subprocess.run(['make', '-C', os.path.join(root, '2g-gcn_amd', 'csrc'), 'jitter', '-j4'], check=True, capture_output=True)
+    ref = str(tmp_path / 'persist_ref.pt')
+    tool = os.path.join(root, 'tools', 'persist_jitter_check.py')
+    env = {k: v for k, v in os.environ.items() if k != 'TWOG_LIB_PATH'}
+    r = subprocess.run([sys.executable, tool, 'write', ref, '1'], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    r = subprocess.run([sys.executable, tool, 'check', ref, '200'], env=dict(env, TWOG_LIB_PATH=jit), capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert '0 tensors differ' in r.stdout, r.stdout[-500:]
+
+
 def test_grouped_column_sums_equal_the_single_calls_bit_for_bit(K):
     """twog_colsum_n (the bias gradients of a backward stage in one pair of launches) against one twog_colsum call per
     problem: strided views, a row scale, ragged column counts (vector and scalar paths), accumulation into existing values,

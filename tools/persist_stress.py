@@ -61,6 +61,14 @@ for rep in range(reps):
                     at = sel[(tt == (s_first if d == 0 else T - 1 - s_first))]
                     first[d] = dict(step=s_first, clips=sorted(set(at[:, 2].tolist()))[:8], ents=sorted(set(at[:, 3].tolist()))[:12],
                                     cols=(int(at[:, 4].min()), int(at[:, 4].max())), words=len(at))
+            if k == 'hs_o' and os.environ.get('TWOG_STRESS_DETAIL') and 0 in first:
+                # the first wrong step of direction 0 in detail: per (clip, entity) row the number of wrong columns
+                s0 = first[0]['step']
+                at = idx[(idx[:, 0] == 0) & (idx[:, 1] == s0)]
+                rows = {}
+                for _, _, b_, e_, c_ in at.tolist():
+                    rows.setdefault((b_, e_), []).append(c_)
+                print('   detail hs_o dir 0 step', s0, {r: (len(c), min(c), max(c)) for r, c in sorted(rows.items())[:40]}, flush=True)
             chunks = sorted(set((idx[:, 2] // cpc).tolist()))
             line.append(f'  {k}: {n} wrong words, chunks {chunks}, first wrong step per direction {first}, '
                         f'max |diff| {float((a - b).abs().max()):.3e}')
