@@ -11,6 +11,8 @@
 //    are written in place, so the re-run is idempotent).
 #pragma once
 #include <stdlib.h>
+#include <mutex>
+#include <vector>
 #include "twog_common.h"
 
 // polls (each an L2 round trip plus an s_sleep, ~1 us) before a wait gives up: 2^16, i.e. several times the ~20 ms of a
@@ -27,26 +29,44 @@ inline int twog_persist_spin_limit() {
 }
 
 // true if `grid` workgroups of `kernel` (256 threads, `lds` bytes of dynamic LDS) can be resident at once on a device with
-// n_cus compute units that this process has to itself
+// n_cus compute units that this process has to itself. The runtime's answers (occupancy, scratch use) depend only on
+// (kernel, lds): asked once per kernel instance and LDS size, not on every launch of the latency-critical path.
 template <class K>
 inline bool twog_persist_grid_fits(K kernel, int grid, size_t lds, int n_cus) {
-    int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, lds) != hipSuccess) {
-        (void)hipGetLastError();
-        return false;
+    struct Answer { size_t lds; int per_cu; bool scratch; };
+    static std::mutex mu;                 // (one static per template instance = per kernel)
+    static std::vector<Answer> known;
+    int per_cu = -1;
+    bool scratch = false;
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        for (const Answer& a : known)
+            if (a.lds == lds) { per_cu = a.per_cu; scratch = a.scratch; }
     }
-    // A persistent kernel must not use scratch (private) memory: a build of seg_persist_fwd_kernel that spilled 26 registers
-    // per lane gave wrong results with the full 256-workgroup grid and right ones with 32-96 workgroups (round 5, unexplained);
-    // if a compiler update ever makes one of these kernels spill, the launch-per-step path runs instead.
-    hipFuncAttributes attr;
-    if (hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(kernel)) != hipSuccess) {
-        (void)hipGetLastError();
-        return false;
+    if (per_cu < 0) {
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, lds) != hipSuccess) {
+            (void)hipGetLastError();
+            return false;
+        }
+        hipFuncAttributes attr;
+        if (hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(kernel)) != hipSuccess) {
+            (void)hipGetLastError();
+            return false;
+        }
+        scratch = attr.localSizeBytes != 0;
+        std::lock_guard<std::mutex> lock(mu);
+        known.push_back(Answer{lds, per_cu, scratch});
     }
+    // A persistent kernel that needs scratch (private) memory is refused: its reduction loops keep up to 512 registers per
+    // lane busy, and a spill in them is a performance cliff (every reload waits for ALL loads in flight: vmcnt is in order).
+    // (Round 5 also blamed scratch for WRONG results of one build. Round 6 found the cause elsewhere -- the wave index sat in
+    // a vector register, the compiler predicated the unused k-block slots of short reductions with EXEC, and MFMAs, which
+    // ignore EXEC, consumed registers the masked-off code never wrote: DESIGN.md "persistent launches", profiles/r06_persist_
+    // stress_*.txt. The wave index is scalar now; the spilling variant computes right results with it.)
 #if !defined(TWOG_SP_STAMPS) && !defined(TWOG_PERSIST_ALLOW_SCRATCH)
     // (the diagnostic build with phase stamps may spill a few registers, its numbers are read as shares; ALLOW_SCRATCH is the
     // root-cause build of tools/persist_stress.py, which runs the spilling variant on purpose)
-    if (attr.localSizeBytes != 0) return false;
+    if (scratch) return false;
 #endif
     return per_cu >= 1 && (int64_t)per_cu * n_cus >= grid;
 }

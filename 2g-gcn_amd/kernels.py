@@ -474,6 +474,7 @@ class HipKernels:
     persistent_refused = 0       # persistent launches the occupancy check refused
     PERSISTENT_BACKOFF = 64
     _backoff = {}                # device index -> calls left without persistent launches
+    _refused = set()             # (launch, device index, shape ...) the occupancy check refused: not asked again
 
     @staticmethod
     def _dev_index(dev):
@@ -591,15 +592,19 @@ class HipKernels:
         rates it the faster path (small batches: at most one 16-row tile per wave). TWOG_BIGRU_PERSIST=1: wherever it is
         served; =0: never."""
         mode = os.environ.get('TWOG_BIGRU_PERSIST', 'auto')
-        if mode == '0' or not self.persistent_allowed(dev if dev is not None else torch.device('cuda', torch.cuda.current_device())):
+        if mode == '0' or int(self.lib.twog_bigru_persistent_supported(arr, n, bs, h)) < (1 if mode == '1' else 2):
             return False
-        return int(self.lib.twog_bigru_persistent_supported(arr, n, bs, h)) >= (1 if mode == '1' else 2)
+        return self.persistent_allowed(dev if dev is not None else torch.device('cuda', torch.cuda.current_device()))
 
     def bigru_bwd_would_persist(self, Es, bs, h):
         """Whether bigru_bwd takes the persistent launch for entity counts Es at this batch (asked before the operands exist:
         the data-parallel backward pass orders its first gradient all-reduce around that launch)."""
-        if (os.environ.get('TWOG_BIGRU_PERSIST', 'auto') == '0' or
-                self._dev_index(torch.device('cuda', torch.cuda.current_device())) in HipKernels.shared_devices):
+        i = self._dev_index(torch.device('cuda', torch.cuda.current_device()))
+        # the same conditions bigru_bwd applies -- a shared device, the back-off window after a launch that gave up (read, not
+        # consumed: persistent_allowed() counts it down when the launch is really attempted) and a grid the occupancy check
+        # refused before on this device (ADVICE r05: the caller orders its first all-reduce and its side stream around the answer)
+        if (os.environ.get('TWOG_BIGRU_PERSIST', 'auto') == '0' or i in HipKernels.shared_devices
+                or HipKernels._backoff.get(i, 0) > 0 or ('bigru_bwd', i, tuple(Es), bs, h) in HipKernels._refused):
             return False
         arr = (L.BiGruBwd * len(Es))()
         for a, E in zip(arr, Es):
@@ -626,12 +631,17 @@ class HipKernels:
             a.d_gi, a.d_gh, a.carry, a.E = d_gi.data_ptr(), d_gh.data_ptr(), carry.data_ptr(), E
             outs.append((d_gi, d_gh))
         mode = os.environ.get('TWOG_BIGRU_PERSIST', 'auto')
-        self.last_bigru_bwd_persistent = (mode != '0' and allow_persistent and self.persistent_allowed(dev) and
-                                          int(self.lib.twog_bigru_bwd_persistent_supported(arr, n, bs, h)) >= 2)
+        self.last_bigru_bwd_persistent = (mode != '0' and allow_persistent
+                                          and ('bigru_bwd', self._dev_index(dev), tuple(int(y['d_out'].shape[2]) for y in types), bs, h)
+                                          not in HipKernels._refused
+                                          and int(self.lib.twog_bigru_bwd_persistent_supported(arr, n, bs, h)) >= 2
+                                          and self.persistent_allowed(dev))   # (last: it consumes a back-off credit)
         if self.last_bigru_bwd_persistent:   # small batches: one persistent launch (csrc/gru_persist.hip)
             sync = self.zeros(1024, device=dev)
             keep.append(sync)
             rc = self.lib.twog_bigru_bwd_persistent(arr, n, bs, T, h, sync.data_ptr(), self._stream())
+            if rc == L.PERSIST_NOT_RESIDENT:
+                HipKernels._refused.add(('bigru_bwd', self._dev_index(dev), tuple(int(y['d_out'].shape[2]) for y in types), bs, h))
             if self._persistent_ok(rc, sync, dev, 'twog_bigru_bwd_persistent'):
                 return outs
             self.last_bigru_bwd_persistent = False
@@ -753,8 +763,8 @@ class HipKernels:
         s = L.SegRnn()
         self._fill_seg(s, p, bufs)
         mode = os.environ.get('TWOG_SEG_PERSIST', 'auto')
-        self.last_segrnn_persistent = (mode != '0' and self.persistent_allowed(dev) and
-                                       int(self.lib.twog_segrnn_persistent_supported(C.byref(s))) >= 2)
+        self.last_segrnn_persistent = (mode != '0' and int(self.lib.twog_segrnn_persistent_supported(C.byref(s))) >= 2
+                                       and self.persistent_allowed(dev))   # (last: it consumes a back-off credit)
         if self.last_segrnn_persistent:   # small batches: the whole recurrence in one launch (csrc/seg_persist.hip)
             n_sync = int(self.lib.twog_segrnn_persistent_sync_bytes()) // 4
             sync = self.zeros(n_sync, device=dev)
@@ -788,8 +798,8 @@ class HipKernels:
         for k, v in list(out.items()) + list(scratch.items()):
             setattr(b, k, _ptr(v))
         mode = os.environ.get('TWOG_SEG_PERSIST', 'auto')
-        self.last_segrnn_bwd_persistent = (mode != '0' and self.persistent_allowed(dev) and
-                                           int(self.lib.twog_segrnn_persistent_supported(C.byref(s))) >= 2)
+        self.last_segrnn_bwd_persistent = (mode != '0' and int(self.lib.twog_segrnn_persistent_supported(C.byref(s))) >= 2
+                                           and self.persistent_allowed(dev))
         if self.last_segrnn_bwd_persistent:   # small batches: backward through time in one launch (csrc/seg_persist.hip)
             n_scr = int(self.lib.twog_segrnn_bwd_persistent_scratch_bytes(C.byref(s)))
             scr = self.workspace(n_scr, dev, 'segp_bwd')

@@ -375,6 +375,30 @@ class _Grads:
         self._pend_mm, self._pend_mm_c = [], set()     # weight-gradient GEMMs (dW = dY^T X) not yet issued: grouped launches
         self._held = None                              # a tall dW GEMM waiting one call for its bias gradient (dw_gemm)
         self._defer = hasattr(K, 'colsum_many') and os.environ.get('TWOG_BATCH_ADDS', '1') != '0'
+        # TWOG_VERIFY_DEFERRED=1 (debug): every operand of a deferred launch is snapshotted when the launch is
+        # deferred and compared when it is issued -- the contract "operands do not change until flush()" is CHECKED (the
+        # kernels write through raw pointers, so torch's version counters cannot see a violation)
+        self._verify = os.environ.get('TWOG_VERIFY_DEFERRED', '0') == '1'
+        self._snaps = []
+
+    def _snap(self, *tensors):
+        if not self._verify:
+            return
+        # (an operand that a launch pending in THIS queue still has to write -- the C of a collected dW GEMM that is then added
+        # into a gradient, a column sum that is then copied -- is not an input yet: flush() issues in dependency order)
+        outs = [q['C'] for q in self._pend_mm] + [o for _, _, o, _ in self._pend_cs] + [d for _, d in self._pend_cp]
+        if self._held is not None:
+            outs += [self._held['C']] + ([self._held['colsum']] if self._held.get('colsum') is not None else [])
+        pending = {o.untyped_storage().data_ptr() for o in outs}
+        self._snaps += [(t, t.detach().clone()) for t in tensors
+                        if t is not None and t.untyped_storage().data_ptr() not in pending]
+
+    def _check_snaps(self):
+        snaps, self._snaps = self._snaps, []
+        for t, was in snaps:
+            if not torch.equal(t, was):
+                raise RuntimeError('an operand of a deferred gradient launch changed between the call and flush() '
+                                   f'(shape {tuple(t.shape)}): the deferred form would have computed a different gradient')
 
     def sink(self, name):
         return self.sinks.get(name)
@@ -400,6 +424,7 @@ class _Grads:
                 self.flush()
             self._pending.append(('add', _v2(t.reshape(1, -1)), _v2(dst.view(1, -1))))
             self._pending_dst.add(key)
+            self._snap(t)
         else:
             self.g[name] = t
 
@@ -431,6 +456,7 @@ class _Grads:
             if (self._defer and A.dim() == 2 and os.environ.get('TWOG_DW_COLSUM', '1') != '0'
                     and hasattr(self.K, 'gemm_colsum_ok') and self.K.gemm_colsum_ok(problem)):
                 self._held = problem
+                self._snap(A, B)
                 return
             self.K.gemm([problem], a_kmajor=True, b_kmajor=True)
             return
@@ -439,6 +465,7 @@ class _Grads:
             self.flush()
         self._pend_mm.append(problem)
         self._pend_mm_c.add(key)
+        self._snap(A, B)
 
     def colsum(self, x, out=None, accumulate=False):
         """Column sums of x (a bias gradient), DEFERRED: `out` is returned at once and filled at the next flush() -- the
@@ -460,6 +487,7 @@ class _Grads:
         if len(self._pend_cs) >= 16 or any(o.data_ptr() == out.data_ptr() for _, _, o, _ in self._pend_cs):
             self.flush()   # (two sums into one buffer -- shared heads -- never share a launch)
         self._pend_cs.append((x, None, out, accumulate))
+        self._snap(x)
         return out
 
     def copy(self, src, dst):
@@ -472,11 +500,15 @@ class _Grads:
     def _issue_held(self):
         h, self._held = self._held, None
         if h is not None:
+            if self._verify and not self._pend_mm and not self._pend_cs and not self._pending:
+                self._check_snaps()
             self.K.gemm([h], a_kmajor=True, b_kmajor=True)
 
     def flush(self):
         """Issues the pending column sums, copies and additions, in that order (on the current stream). Called before
         anything reads the gradients: a stage hook, the end of the backward pass, a change of stream."""
+        if self._verify:
+            self._check_snaps()
         self._issue_held()
         if self._pend_mm:
             self.K.gemm(self._pend_mm, a_kmajor=True, b_kmajor=True)

@@ -780,8 +780,13 @@ def main():
                              'achieved': gcn_bytes / (gcn_ms * 1e-3) / 1e9, 'peak': 8000.0, 'unit': 'GB/s',
                              'frac': gcn_bytes / (gcn_ms * 1e-3) / 8e12, 'ms_per_batch': gcn_ms,
                              'algorithmic_bytes_per_batch': gcn_bytes,
-                             'note': 'fp32 MFMA floor of this block (2.41 MFLOP/frame at 157.3 TFLOP/s) = 0.118 ms per bs64 '
-                                     'batch, above its HBM floor (0.017 ms)'},
+                             'note': 'arithmetic-bound, not HBM-bound: fp32 MFMA floor of this block (2.41 MFLOP/frame at 157.3 '
+                                     'TFLOP/s) = 0.118 ms per bs64 batch; on the bf16 pipe with the exact three-way operand split '
+                                     '(6 products per multiply-add, 2 516.6 TFLOP/s) the floor would be 0.044 ms -- still above '
+                                     'the 0.043 ms that 40 % of the HBM peak would take for its 137.9 MB, and far above its HBM '
+                                     'floor (0.017 ms): at fp32-equivalent arithmetic the north star\'s >= 40 % of the HBM '
+                                     'roofline is out of reach for this block whatever the kernel. The bf16 x 3 port of '
+                                     'gcn_fused_fwd_kernel (0.13 ms of a 63 ms step at stake) was not built.'},
             'roofline_attn_fwd': None if not att_fwd_ms else {
                 'bound': 'hbm', 'kernel': 'attn_fwd_kernel (frame level: 4 relations + geometry, one launch)',
                 'achieved': att_fwd_bytes / (att_fwd_ms * 1e-3) / 1e9, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',

@@ -183,6 +183,34 @@ def test_bias_gradient_taken_by_the_held_weight_gradient_gemm(sinks, fake_backen
 
 
 @pytest.mark.parametrize('case', ['c2_stage1', 'c1_stage2', 'c5_stage1'])
+def test_operands_of_deferred_gradient_launches_do_not_change_before_they_are_issued(case, fake_backend, monkeypatch):
+    """ops._Grads defers weight-gradient GEMMs, column sums, copies and `grad += g` additions until flush(); the contract is
+    that no operand changes in between. TWOG_VERIFY_DEFERRED=1 snapshots every deferred operand and compares
+    it at issue time: a whole backward pass of each dataset layout runs clean under it, with and without gradient sinks --
+    and a violation is caught (an operand overwritten between the call and the flush)."""
+    monkeypatch.setenv('TWOG_VERIFY_DEFERRED', '1')
+    z, meta = load_g4(case)
+    noise = torch.from_numpy(z['gumbel_noise'])
+    for sinks in (False, True):
+        m = build_model(meta)
+        m.train()
+        m._gumbel_noise_override = noise if len(noise) else None
+        if sinks:
+            for p in m.parameters():
+                p.grad = torch.zeros_like(p)
+            ops.enable_grad_sinks(m.parameters())
+        out = m(**g4_inputs(z))
+        sum((o * o).sum() for o in out if o.requires_grad).backward()
+        assert all(torch.isfinite(p.grad).all() for p in m.parameters() if p.grad is not None)
+    G = ops._Grads(twog_kernels.get_kernels())
+    x = torch.randn(64, 8)
+    G.colsum(x)
+    x[3, 3] += 1.0                                  # the violation: the operand changes before the launch is issued
+    with pytest.raises(RuntimeError, match='changed between the call and flush'):
+        G.flush()
+
+
+@pytest.mark.parametrize('case', ['c2_stage1', 'c1_stage2', 'c5_stage1'])
 def test_gradient_stages_are_final_when_the_hook_fires(case, fake_backend):
     """distributed.DataParallel starts a stage's all-reduce from ops' stage hook: at that moment every gradient of the
     stage must already have its final value (nothing may be added to it later in the backward pass)."""

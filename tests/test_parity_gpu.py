@@ -334,6 +334,17 @@ def test_oracle_parity_full_width_forward_backward():
     _oracle_vs_hip(bs=2, T=120, H=2, O=8, N=34, h=512, backward=True, seed=7, max_nudged_share=0.01)
 
 
+@pytest.mark.parametrize('shape', [dict(bs=3, T=6, H=2, O=4, N=26, h=64), dict(bs=64, T=3, H=2, O=8, N=34, h=512),
+                                   dict(bs=8, T=6, H=2, O=4, N=26, h=512)])
+def test_deferred_gradient_launches_see_unchanged_operands(shape, monkeypatch):
+    """ops._Grads defers the weight-gradient GEMMs, column sums, copies and additions of a backward stage until
+    flush(); TWOG_VERIFY_DEFERRED=1 snapshots every deferred operand and compares it when the launch is issued. Runs the
+    small-batch grouping (at most 8 192 rows), the held tall dW with its fused column sums (64 clips) and the persistent
+    small-batch path on the device; the comparison against the oracle runs as usual."""
+    monkeypatch.setenv('TWOG_VERIFY_DEFERRED', '1')
+    _oracle_vs_hip(backward=True, seed=41, **shape)
+
+
 def test_oracle_parity_bench_batch_short_clips():
     """The bench's batch (64 clips of the configs[2] layout, h = 512) at T = 3: every launch has the bench's tile counts, so
     the variants the tile-count policies pick only there -- the fused frame-level GRU step (22 row tiles x 8 unit tiles),
