@@ -153,7 +153,7 @@ __device__ __forceinline__ void store_tile(const TileRegs<ROWS, COLS, NT>& t, fl
 // LDS by the caller (gemm_tile). For launches with fewer tiles than CUs (the recurrent chains) this puts two waves on
 // every SIMD and halves the dependent MFMA chain of a tile: +1 % on the bs64 step, +7 % at 8 clips per GPU. (The
 // k-loop of such a launch is NOT bound by its MFMAs or by load latency -- a prefetch distance of 4 changed nothing --
-// but by the ~27 GB/s a lone 64x64 tile pulls through its CU's L2 port at 16 FLOP/B; measured)
+// but by the ~27 GB/s a lone 64x64 tile pulls through its CU's L2 port at 16 FLOP/B; measured, see profiles/HISTORY.md section 8.)
 // G3 (fused GRU forward step, gemm_gru_fwd_kernel): B holds the three gate blocks of a GRU weight, [3N][K] rows r | z | n,
 // and the tile's 192 columns are 64 hidden units x 3 gates laid out so that accumulator b of every wave is gate b of
 // the SAME 32 units: tile column c -> gate (c % 96) / 32, unit n0 + 32 * (c / 96) + c % 32. N counts hidden units.
@@ -583,7 +583,7 @@ __device__ __forceinline__ void gemm_mainloop_x3(const twog_rows_t A, const twog
         // zero (tools/x3_bias_probe.py: on same-sign operands six accumulations per 16 k into the running sum gave a
         // relative bias of -4.3e-7 at K = 1 536 and -2.1e-6 at K = 61 440, where the fp32 MFMA has 4e-10). TMPACC (build-time
         // option TWOG_X3_TMPACC=1; NOT the default: with four register stages the kernel sits at its 128-VGPR budget and the
-        // 16-register temporary spills 360-570 bytes per lane into scratch -- DESIGN.md section 8):
+        // 16-register temporary spills 360-570 bytes per lane into scratch -- profiles/HISTORY.md section 8):
         // the products of one k-step are chained through a FRESH accumulator (C = 0: its roundings are relative to one
         // k-step's partial sum) and that partial sum is added to the running sum by 16 fp32 VALU adds per block (round to
         // nearest even, unbiased); the B fragments of a block are read right before its chain, so the temporary takes the
@@ -666,7 +666,7 @@ __device__ __forceinline__ void gemm_mainloop_x3(const twog_rows_t A, const twog
 }
 
 // X3 for the 64-row tile class (the recurrent chains at a real batch: 160 ... 960 tiles of K = 512 ... 1 536, MFMA-bound
-// in fp32: DESIGN.md section 8): the same exact three-way bf16 split and six chunk products as gemm_mainloop_x3, for
+// in fp32: profiles/HISTORY.md section 8): the same exact three-way bf16 split and six chunk products as gemm_mainloop_x3, for
 //   64 x 64 tiles with 4 waves (KS = 1, k-tiles of 16) or 8 waves = two k-groups (KS = 2, k-tiles of 32: group g multiplies
 //   k-step g), and the fused GRU forward step's 64 x 192 gate-aware tiles (G3, three accumulators per wave).
 // A is always row-major here (previous states / gradients of a chain step); B is row-major ([N][K] weights: forward) or
@@ -1385,7 +1385,7 @@ __global__ __launch_bounds__(512, 2) void gemm_gate_bwd_ks_kernel(const Group g,
 // the segment gate u -- from the accumulators: no gh round trip through memory, no gate launch. Same arithmetic as
 // gru_step_fwd_kernel (gru.hip); r, z, n and W_hn h + b_hn are saved for the backward chain as before.
 // A workgroup stages 64 + 192 operand rows per k-tile (24 FLOP/B instead of the 64x64 tile's 16 -- these launches are
-// bound by the L2 port of their CU) and the unit tile index is the block's XCD, so each L2 keeps
+// bound by the L2 port of their CU, profiles/HISTORY.md section 8) and the unit tile index is the block's XCD, so each L2 keeps
 // one 192-row slice of every weight.
 struct GruFwdProb {
     twog_rows_t A, B, A2, B2;      // previous states x W_hh; aggregated messages x W_ih[:, msg] (K2 == 0: absent)
@@ -2312,7 +2312,7 @@ int twog_internal_gemm_gru_fwd(const twog_gemm_t* gh, const twog_gemm_t* gim, co
     }
     if (!(mode & 4)) {
         // Cost model (us of fp32 MFMA work per CU at 614 GFLOP/s, tiles dealt in rounds over 256 CUs; measured at BASELINE
-        // size): the fused launch runs rounds of 64 x 192 x K tiles, the pair it replaces rounds of
+        // size, profiles/HISTORY.md section 8): the fused launch runs rounds of 64 x 192 x K tiles, the pair it replaces rounds of
         // 64 x 64 x K tiles plus a gate launch (~7 us). bs64, h = 512: frame level 20.5 vs 3 x 6.8 + 7 -> fused (measured
         // 39 vs 43 us); segment level (K = 1 536, 160 tiles) 61 vs 2 x 20.5 + 7 -> unfused (measured +2.5 ms per step
         // fused); 8 clips: 20.5 vs 6.8 + 7 -> unfused (measured 31.5 vs 39.7 ms per step forced). Short reductions stay

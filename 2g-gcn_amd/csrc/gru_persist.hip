@@ -62,6 +62,10 @@ __device__ __forceinline__ uint32_t pack_hi16(uint32_t lo, uint32_t hi) { return
 
 // eight consecutive fp32 values -> the three bf16 planes of an MFMA fragment (element j = value j), by truncation: exact
 __device__ __forceinline__ void split8(const f32x4 a, const f32x4 b, bf16x8& ph, bf16x8& pm, bf16x8& pl) {
+#ifdef TWOG_GP_PROBE_NOSPLIT   // timing probe only (wrong results): what the per-wave split of the streamed states costs
+    ph = __builtin_bit_cast(bf16x8, a); pm = __builtin_bit_cast(bf16x8, b); pl = ph;
+    return;
+#endif
     uint32_t x[8], r1[8], r2[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -476,7 +480,7 @@ static int plan(const int* E_of_type, int n_types, int bs, int hidden, int n_cus
 
 // 2 if twog_bigru_fwd_persistent serves this shape on the current device AND is the faster path (every wave owns at
 // most one row tile: the small-batch regime, where a step is a latency chain -- 9.2 us per step against 17.4 at 8
-// clips; with more tiles per wave the launch-per-step path wins: 48 against 31 us at 64 clips);
+// clips; with more tiles per wave the launch-per-step path wins: 48 against 31 us at 64 clips, see profiles/HISTORY.md);
 // 1 if it is served but slower; 0 if it is not served.
 extern "C" int twog_bigru_persistent_supported(const twog_bigru_t* types, int n_types, int bs, int hidden) {
     int dev = 0, n_cus = 0;

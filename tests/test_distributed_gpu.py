@@ -115,7 +115,7 @@ def test_rccl_single_rank_collective_path_on_the_device():
 
 
 # --------------------------------------------------------------------------------------------------------------------
-# Ordering of the first gradient all-reduce around the persistent backward launches (VERDICT r04
+# Ordering of the first gradient all-reduce around the persistent backward launches (profiles/HISTORY.md section 6 / 8, VERDICT r04
 # item 8): RCCL's kernels hold compute units until the peers arrive, a persistent launch needs all of them -- so the
 # stage-0 all-reduce (heads + segment level) is issued BEHIND the persistent frame-level backward launch, and nothing
 # is in flight when the persistent segment-level backward launch runs. One rank over RCCL with force_collectives=True

@@ -1803,7 +1803,7 @@ def test_gemm_x3_same_sign_and_wide_exponent_operands():
     to nearest (bias 4e-10 on the same data). The 64x64 class keeps the five small products in a second accumulator (one
     accumulation into the main one per 16 k: -4e-8 at K = 1 536); the 128x128 class has no registers for that at two
     workgroups per CU and adds all six into the running sum (-4.3e-7 at K = 1 536, -2.1e-6 at K = 61 440); the fix that
-    chains each k-step through a fresh accumulator (TWOG_X3_TMPACC=1) exists at build time and spills.
+    chains each k-step through a fresh accumulator (TWOG_X3_TMPACC=1) exists at build time and spills (profiles/HISTORY.md section 8).
     On SIGNED operands -- every GEMM of this model multiplies by signed weights or signed gradients -- the bias is 3e-9.
     Required: the class bit (X3 ran); the same-sign bias within the caps above (the documented state, so that a change for
     the worse fails); signed cases: |mean| <= 1e-7 of sum |a b|; max error <= 3e-6 of sum |a b| everywhere."""

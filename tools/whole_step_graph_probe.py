@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Can a whole training step (forward + criterion + backward + fused Adam) of a HOST-COMPOSED configuration be captured
 into one torch.cuda.CUDAGraph (= hipGraph) and replayed? For the shipped configuration the step is GPU-bound and direct
-launches win; the constructor-default configurations are composed launch by launch from Python and are
+launches win (profiles/HISTORY.md section 5); the constructor-default configurations are composed launch by launch from Python and are
 host-bound. Prints eager vs replay time per step and checks that N replayed steps leave the same parameters as N eager ones.
 
 usage: python tools/whole_step_graph_probe.py [defaults_seg|defaults|c2] [steps]"""
