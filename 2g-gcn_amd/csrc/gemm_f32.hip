@@ -464,11 +464,16 @@ __device__ __forceinline__ int x3_swz(int k) { return ((k & 3) << 2) | ((k >> 2)
 
 // cs (k-major A only): when cs_on, every thread also adds the A values it stages (4 consecutive tile columns of one k row per
 // k-tile) into cs -- the column sums of A over this workgroup's k-range, finished by gemm_tile (twog_gemm_t::a_colsum).
-template <bool AKM, bool BKM, bool KG, bool TTMP = false>
+// KU (round 6): k-tiles per barrier interval, KU sub-images per LDS stage -- for launches of at most one tile per CU (the
+// segment level's per-step projection: 240 tiles), where ONE workgroup per CU moves through a barrier every 12 MFMAs per wave
+// and nothing else hides the fragment reads and the barrier's skew. KU = 2 needs 2 x 2 x 24 KB of LDS and ~64 more registers:
+// one workgroup per CU, which is what such a launch has anyway. Same MFMA sequence into the same accumulators: bit-identical.
+template <bool AKM, bool BKM, bool KG, bool TTMP = false, int KU = 1>
 __device__ __forceinline__ void gemm_mainloop_x3(const twog_rows_t A, const twog_rows_t B, int M, int N, int m0, int n0,
                                                  int k_begin, int k_end, float* smem, f32x16 (&acc)[1][2], f32x4& cs, bool cs_on) {
     constexpr int BM = 128, BN = 128, NT = 512, XK = X3_BK;
     constexpr bool TMP = TWOG_X3_TMPACC || TTMP;
+    static_assert(KU == 1 || (!AKM && !BKM && !KG && !TMP), "KU > 1: the row-major (forward) form only");
     constexpr int PA = AKM ? X3_TPLANE : X3_RPLANE, PB = BKM ? X3_TPLANE : X3_RPLANE;
     char* lds = reinterpret_cast<char*>(smem);   // stage b: A planes at b * X3_STAGE, B planes behind them
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -501,7 +506,7 @@ __device__ __forceinline__ void gemm_mainloop_x3(const twog_rows_t A, const twog
             sb_off = 3 * PA + rr * X3_RROW + 16 * ((cq >> 1) ^ ((rr >> 4) & 1)) + 8 * (cq & 1);
         }
     }
-    struct Stage { f32x4 a, b; };
+    struct Stage { f32x4 a, b; f32x4 a2[KU > 1 ? KU - 1 : 1], b2[KU > 1 ? KU - 1 : 1]; };   // (a2 / b2: k-tiles 1 .. KU-1 of the interval)
     // KG: a k-major operand whose rows (= k) are (outer, inner) grouped, e.g. "all but the first time step of every clip":
     // the (outer, inner) position of this thread's row is carried from k-tile to k-tile (k only moves forward; the clamped
     // tail repeats the last tile), no division in the loop. Offsets stay below 2^32 bytes (vec_ok).
@@ -534,10 +539,18 @@ __device__ __forceinline__ void gemm_mainloop_x3(const twog_rows_t A, const twog
             const int sb = (int)(BKM ? (uint32_t)k0 * (uint32_t)B.ld_outer * 4u : (uint32_t)k0 * 4u);
             r.b = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_b, (int)ob, sb, 0));
         }
+        if constexpr (KU > 1) {
+#pragma unroll
+            for (int u = 1; u < KU; ++u) {
+                const int su = (int)((uint32_t)(k0 + u * XK) * 4u);
+                r.a2[u - 1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, (int)oa, su, 0));
+                r.b2[u - 1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_b, (int)ob, su, 0));
+            }
+        }
     };
-    const int nkt = (k_end - k_begin) / XK;
+    const int nkt = (k_end - k_begin) / (XK * KU);
     auto split_store = [&](const Stage& r, int buf, int t) {   // t: index of the k-tile held by r (clamped repeats: t >= nkt)
-        char* base = lds + buf * X3_STAGE;
+        char* base = lds + buf * KU * X3_STAGE;
         i32x2 ph, pm, pl;
         if constexpr (AKM && BKM && !KG) {
             if (cs_on && t < nkt) cs += r.a;
@@ -550,6 +563,20 @@ __device__ __forceinline__ void gemm_mainloop_x3(const twog_rows_t A, const twog
         *reinterpret_cast<i32x2*>(base + sb_off) = ph;
         *reinterpret_cast<i32x2*>(base + sb_off + PB) = pm;
         *reinterpret_cast<i32x2*>(base + sb_off + 2 * PB) = pl;
+        if constexpr (KU > 1) {
+#pragma unroll
+            for (int u = 1; u < KU; ++u) {
+                char* bu = base + u * X3_STAGE;
+                split3(r.a2[u - 1], ph, pm, pl);
+                *reinterpret_cast<i32x2*>(bu + sa_off) = ph;
+                *reinterpret_cast<i32x2*>(bu + sa_off + PA) = pm;
+                *reinterpret_cast<i32x2*>(bu + sa_off + 2 * PA) = pl;
+                split3(r.b2[u - 1], ph, pm, pl);
+                *reinterpret_cast<i32x2*>(bu + sb_off) = ph;
+                *reinterpret_cast<i32x2*>(bu + sb_off + PB) = pm;
+                *reinterpret_cast<i32x2*>(bu + sb_off + 2 * PB) = pl;
+            }
+        }
     };
     // fragment addressing: lane l = (r = l & 31 row / column of the 32x32 block, h = l >> 5 half of the 16-deep k-step)
     const int r32 = lane & 31, h = lane >> 5;
@@ -575,7 +602,9 @@ __device__ __forceinline__ void gemm_mainloop_x3(const twog_rows_t A, const twog
         return __builtin_bit_cast(bf16x8, v);
     };
     auto compute = [&](int buf) {
-        const char* base = lds + buf * X3_STAGE;
+#pragma unroll
+      for (int u_ = 0; u_ < KU; ++u_) {
+        const char* base = lds + (buf * KU + u_) * X3_STAGE;
         // X3_PRODUCTS chunk products per block, smallest terms first. 6 (shipped): everything >= 2^-16 |a b|; 8 (TWOG_X3_PRODUCTS=8
         // at build time): also m l and l m -- measured identical to three digits (profiles/r04_x3_products_6_vs_8*.txt).
         // WHERE the products are added matters more than how many there are: the bf16 MFMA's accumulate is not a
@@ -621,6 +650,7 @@ __device__ __forceinline__ void gemm_mainloop_x3(const twog_rows_t A, const twog
             for (int b = 0; b < 2; ++b)
                 acc[0][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[PI[t]], bf[b][PJ[t]], acc[0][b], 0, 0, 0);
         }
+      }
     };
     // Four register stages and two LDS stages, one barrier per k-tile: the loads of k-tile t + 4 are issued before the MFMAs
     // of tile t (a k-tile of 16 lasts under two microseconds at this matrix rate: two stages do not cover a miss to HBM);
@@ -628,8 +658,8 @@ __device__ __forceinline__ void gemm_mainloop_x3(const twog_rows_t A, const twog
     // of the split issues between the MFMAs). Loads past the last k-tile are clamped to it instead of branched around (see
     // gemm_mainloop); the redundant tiles are stored but never read.
     if (nkt <= 0) return;
-    const int k_last = k_begin + (nkt - 1) * XK;
-    auto kof = [&](int t) { return min(k_begin + t * XK, k_last); };
+    const int k_last = k_begin + (nkt - 1) * XK * KU;
+    auto kof = [&](int t) { return min(k_begin + t * XK * KU, k_last); };
 #if TWOG_X3_TMPACC
     // (TMPACC: two register stages -- the temporary accumulator takes the registers of the other two)
     Stage r0, r1;
@@ -917,7 +947,7 @@ __device__ __forceinline__ void gemm_tile(const Group& g, const GateArgs* ga) {
     constexpr int B_ELEMS = BKM ? BK * LDB : BN * LDB;
     // (X3 on the 64-row class: two stages of three bf16 planes per operand, 2 x 6 x 64 rows x 2 XK bytes, XK = 16 KS)
     constexpr int SMEM_FLOATS = (X3 && BM == 128 && BN == 64) ? 2 * KU * 3 * (128 + 64) * 32 / 4   // 128x64 chain tile: 2 stages x KU images
-                                : (X3 && BM == 128) ? 2 * X3_STAGE / 4
+                                : (X3 && BM == 128) ? 2 * KU * X3_STAGE / 4
                                 : (X3 && BM == 64 && 12 * 64 * 8 * KS * KU > 2 * (A_ELEMS + B_ELEMS)) ? 12 * 64 * 8 * KS * KU : 2 * (A_ELEMS + B_ELEMS);
     __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS];
 
@@ -1074,7 +1104,7 @@ __device__ __forceinline__ void gemm_tile(const Group& g, const GateArgs* ga) {
             static_assert(!X3 || BM != 128 || (BN == 128 && NT == 512 && !GATE && KS == 1 && !XS), "X3: the 8-wave 128x128 class");
             f32x4 cs = {0.f, 0.f, 0.f, 0.f};
             const bool cs_on = AKM && BKM && !KG && G.cs != nullptr && tn_idx == 0;   // uniform over the workgroup
-            gemm_mainloop_x3<AKM, BKM, KG, TTMP>(A, B, M, N, m0, n0, k_begin, k_end, smem, acc, cs, cs_on);
+            gemm_mainloop_x3<AKM, BKM, KG, TTMP, KU>(A, B, M, N, m0, n0, k_begin, k_end, smem, acc, cs, cs_on);
             if constexpr (AKM && BKM && !KG) {
                 if (cs_on) {
                     // thread (k row tid / 32, column quad tid % 32) holds its k rows' sums: the 16 k rows are added in row order
@@ -1329,6 +1359,10 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(const Group g) {
 template <bool AKM, bool BKM, bool KG>
 __global__ __launch_bounds__(512, 4) void gemm_x3_kernel(const Group g) {   // 4 waves per SIMD = two workgroups per CU: <= 128 VGPRs
     gemm_tile<128, 128, 512, AKM, BKM, 2, KG, false, 1, false, true>(g, nullptr);
+}
+// forward (row-major) form with two k-tiles per barrier interval: one workgroup per CU (launches of at most one tile per CU)
+__global__ __launch_bounds__(512, 2) void gemm_x3_nn_ku2_kernel(const Group g) {
+    gemm_tile<128, 128, 512, false, false, 2, false, false, 1, false, true, 2>(g, nullptr);
 }
 // dW = dY^T X with every k-step's products through a fresh accumulator (TTMP): one workgroup per CU
 template <bool KG>
@@ -1622,7 +1656,15 @@ int launch(Group& g, int akm, int bkm, hipStream_t st) {
         // X3 (fp32-exact operands on the bf16 matrix cores, gemm_mainloop_x3): aligned operands, whole k-tiles, plain rows
         if (x3_128_ok(g)) {
             static const int split_acc = getenv("TWOG_X3_DW_SPLIT_ACC") ? atoi(getenv("TWOG_X3_DW_SPLIT_ACC")) : 0;
-            if (!akm && !bkm) hipLaunchKernelGGL((gemm_x3_kernel<false, false, false>), grid, block, 0, st, g);
+            // at most one tile per CU, whole pairs of k-tiles, no split-K: two k-tiles per barrier interval. Built and measured
+            // in round 6 (VERDICT r05 item 7's "raise the 128x128 class"), SLOWER: the segment level's 240-tile projection launch
+            // 47.4 -> 49.8 us, the 64-clip step 65.59 -> 65.84 ms (same box, alternating twice): profiles/r06_gemm128_ku2_ab.txt.
+            // Off by default (TWOG_X3_KU128=1 selects it).
+            static const int ku128 = getenv("TWOG_X3_KU128") ? atoi(getenv("TWOG_X3_KU128")) : 0;
+            bool ku2 = ku128 != 0 && !akm && !bkm && g.splitk == 1 && g.total_tiles <= 256;
+            for (int i = 0; i < g.n; ++i) ku2 = ku2 && (g.p[i].K % (2 * X3_BK)) == 0;
+            if (ku2) hipLaunchKernelGGL(gemm_x3_nn_ku2_kernel, grid, block, 0, st, g);
+            else if (!akm && !bkm) hipLaunchKernelGGL((gemm_x3_kernel<false, false, false>), grid, block, 0, st, g);
             else if (!akm && bkm && !kg) hipLaunchKernelGGL((gemm_x3_kernel<false, true, false>), grid, block, 0, st, g);
             else if (!akm && bkm) hipLaunchKernelGGL((gemm_x3_kernel<false, true, true>), grid, block, 0, st, g);
             else if (akm && bkm && split_acc && !kg) hipLaunchKernelGGL((gemm_x3_tt_split_acc_kernel<false>), grid, block, 0, st, g);

@@ -104,7 +104,10 @@ __device__ __forceinline__ f32x4 mfma(const bf16x8 a, const bf16x8 b, const f32x
 template <int NKB, int TWC>
 __global__ __launch_bounds__(256, 1) void bigru_persist_fwd_kernel(const PArgs P) {
     constexpr int TW = TWC;
-    constexpr int D = TWC == 1 ? NKB : (TWC == 2 ? (NKB < 8 ? NKB : 8) : (NKB < 3 ? NKB : 3));
+#ifndef TWOG_GP_D4
+#define TWOG_GP_D4 3
+#endif
+    constexpr int D = TWC == 1 ? NKB : (TWC == 2 ? (NKB < 8 ? NKB : 8) : (NKB < TWOG_GP_D4 ? NKB : TWOG_GP_D4));
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int h = 32 * NKB, n_wg = h / 16;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), i16 = lane & 15, g4 = lane >> 4;
