@@ -32,6 +32,17 @@
 #include "twog_common.h"
 #include "persist_common.h"
 
+// The wave index is read through a SCALAR register: every per-wave condition (`kb = wave + 4 j < nkb`: is this k-block slot
+// of the wave in use?) is then a scalar branch. Left in a vector register (round 5) the compiler has to treat those
+// conditions as divergent and predicates the slot's code with EXEC -- which MFMAs ignore, and under which register copies /
+// zero-initialisations do not execute: a variant of P2 then multiplied registers nobody had written.
+// -DTWOG_SP_VECTOR_WAVE rebuilds that form (`make diag`, tools/persist_stress.py): never part of the shipped library.
+#ifdef TWOG_SP_VECTOR_WAVE
+#define TWOG_SP_WAVE_INDEX ((int)(threadIdx.x >> 6))
+#else
+#define TWOG_SP_WAVE_INDEX __builtin_amdgcn_readfirstlane(threadIdx.x >> 6)
+#endif
+
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -164,9 +175,9 @@ __device__ __forceinline__ void mac_f32(f32x4& c, const f32x4 a0, const f32x4 a1
 // The reduction loop of one product, this wave's k-blocks (kb = wave, wave + 4, ...; at most NJ of them): the A fragments of
 // MK row tiles come from a handed-off buffer (sc1 loads, byte offsets off[i] + 128 kb), four k-blocks in flight beside the
 // four being multiplied (a round trip to the other XCDs' L2 is ~2 us: with two in flight the loop waited for every pair); body(j, A) multiplies k-block number j of this wave with the weights the caller keeps in registers.
-template <int NJ, int MK, class F>
+template <int NJ, int MK, int CHMAX = 4, class F>
 __device__ __forceinline__ void k_stream(const __amdgpu_buffer_rsrc_t rs, const uint32_t (&off)[MK], int nkb, int wave, F&& body) {
-    constexpr int CH = NJ < 4 ? NJ : 4, NG = (NJ + CH - 1) / CH;
+    constexpr int CH = NJ < CHMAX ? NJ : CHMAX, NG = (NJ + CH - 1) / CH;
     typedef f32x4 Buf[CH][MK][2];
 #ifdef TWOG_SP_P2_X3_ALLJ   // root-cause build: every k-block slot multiplied (zero weights beyond the reduction), see below
     Buf b0 = {}, b1 = {};
@@ -226,7 +237,7 @@ __device__ __forceinline__ void put_part1(float* part, int n_tiles, int wave, in
 // sums the waves' partial tiles in wave order into res[tile][16][RS]; all 256 threads; ends with a barrier
 __device__ __forceinline__ void combine_parts(const float* part, float* res, int n_tiles, int n_waves_used) {
     __syncthreads();
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63, wave = TWOG_SP_WAVE_INDEX;
     for (int tile = wave; tile < n_tiles; tile += 4) {
         f32x4 v = *reinterpret_cast<const f32x4*>(part + ((size_t)tile * 64 + lane) * 4);
         for (int w = 1; w < n_waves_used; ++w)
@@ -240,7 +251,7 @@ __device__ __forceinline__ void combine_parts(const float* part, float* res, int
 // wave 0 waits for (up to) two counters; the whole workgroup learns the outcome. Returns false -> everybody leaves.
 __device__ __forceinline__ bool group_wait(const unsigned* c0, unsigned want0, const unsigned* c1, unsigned want1,
                                            unsigned* error, int spin_limit, int* flag) {
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63, wave = TWOG_SP_WAVE_INDEX;
     if (wave == 0) {
         bool ok = twog_wait_counter(c0, want0, error, spin_limit, lane);
         if (ok && c1) ok = twog_wait_counter(c1, want1, error, spin_limit, lane);
@@ -321,7 +332,7 @@ __device__ __forceinline__ bool p1_step(const SegArgs& P, const Geo& G, int s, f
     constexpr int MK = RK == 0 ? MH : MO, MT = MH + MO;
     constexpr int NPAIR = MT * (MT + 1) / 2;
     constexpr int T_SH = 0, T_SO = MH, T_G = MH + MO, T_GRAM = T_G + 3 * MK, NTILES = T_GRAM + NPAIR;
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), i16 = lane & 15, g4 = lane >> 4;
+    const int lane = threadIdx.x & 63, wave = TWOG_SP_WAVE_INDEX, i16 = lane & 15, g4 = lane >> 4;
     const int H = P.H, O = P.O, h = P.h, T = P.T, E_K = RK == 0 ? H : O;
     const int dir = G.dir, t = dir == 0 ? s : T - 1 - s, tp = dir == 0 ? t - 1 : t + 1;
     const int nkb = h / 32;
@@ -565,7 +576,7 @@ template <int MK, int K>
 __device__ __forceinline__ bool p2_step(const SegArgs& P, const Geo& G, int s, float* part, float* res, int* flag,
                                         f32x4 (&h_own)[(MK * 16 + 63) / 64], const WFrag (&Wr)[KW2][3]) {
     constexpr int NTILES = 3 * MK, NPASS = (MK * 16 + 63) / 64;
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), i16 = lane & 15, g4 = lane >> 4;
+    const int lane = threadIdx.x & 63, wave = TWOG_SP_WAVE_INDEX, i16 = lane & 15, g4 = lane >> 4;
     const int h = P.h, T = P.T, E_K = K == 0 ? P.H : P.O, R_K = K == 0 ? G.RH : G.RO;
     const int dir = G.dir, t = dir == 0 ? s : T - 1 - s;
     const int ns = h / 16, nkb = 2 * h / 32;
@@ -601,14 +612,17 @@ __device__ __forceinline__ bool p2_step(const SegArgs& P, const Geo& G, int s, f
         const int r = min(i * 16 + i16, R_K - 1), bl = r / E_K, e = r - bl * E_K, b = G.b0 + bl;
         off[i] = 4u * (uint32_t)(((((int64_t)dir * P.bs + b) * T + t) * E_K + e) * (2 * h) + 8 * g4);
     }
-    // on the fp32 matrix pipe (see mac_f32). (Measured and not kept: 3 x bf16 with one accumulator per tile for the two-tile
-    // object rows -- 7.7 against 9.2 us of this loop at h = 512, but 26 registers per lane in scratch, and wrong results
-    // at h = 64 with eight chunks; profiles/r05_seg_persist_stamps.txt.)
-#ifdef TWOG_SP_P2_X3
-    // ROOT-CAUSE BUILD ONLY (`make diag`, tools/persist_stress.py; DESIGN "persistent launches: the spilling build"): the
-    // round-5 variant of this loop that needed scratch memory and gave wrong results on the full grid -- 3 x bf16 products
-    // with one accumulator per tile. Never part of the shipped library.
-    k_stream<KW2, MK>(rs_mg, off, nkb, wave, [&](int j, const f32x4 (&A)[MK][2]) {
+    // 3 x bf16 products, one accumulator per tile (round 6): the compiler keeps the weight slice as bf16 PLANES across the
+    // time loop (288 registers instead of 192 of raw fp32: the split is hoisted, nothing is split per step), and with three
+    // k-blocks of messages in flight instead of four the kernel fits its 512 registers without scratch: 27.2 -> 26.1 us per
+    // step at 8 clips x h 512, 18.2 -> 17.2 at one clip (profiles/r06_seg_persist_p2_x3.txt). Round 5 had measured this loop
+    // faster too but got wrong results from it and blamed its scratch use -- the cause was the vector-register wave index
+    // (see the top of this file). -DTWOG_SP_P2_F32 rebuilds the fp32-pipe loop (v_mfma_f32_16x16x4_f32, exact fp32 products).
+#ifndef TWOG_SP_P2_F32
+#ifndef TWOG_SP_P2_CH
+#define TWOG_SP_P2_CH 3
+#endif
+    k_stream<KW2, MK, TWOG_SP_P2_CH>(rs_mg, off, nkb, wave, [&](int j, const f32x4 (&A)[MK][2]) {
         Planes Ap[MK];
 #pragma unroll
         for (int i = 0; i < MK; ++i) Ap[i] = split8(A[i][0], A[i][1]);
@@ -691,7 +705,7 @@ struct FwdLds { float *part, *res, *sG, *sW, *sMask, *sBias; int* flag; };
 // into the bf16 planes at every use. Nothing but states and messages moves per step.
 template <int MH, int MO, int RK>
 __device__ __forceinline__ void role_p1(const SegArgs& P, const Geo& G, const FwdLds& M) {
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63, wave = TWOG_SP_WAVE_INDEX;
     const int nkb = P.h / 32;
     WFrag Wr[KW1][5];
 #pragma unroll
@@ -720,7 +734,7 @@ __device__ __forceinline__ void role_p1(const SegArgs& P, const Geo& G, const Fw
 
 template <int MK, int K>
 __device__ __forceinline__ void role_p2(const SegArgs& P, const Geo& G, const FwdLds& M) {
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63, wave = TWOG_SP_WAVE_INDEX;
     const int nkb = 2 * P.h / 32;
     WFrag Wr[KW2][3];
 #pragma unroll
@@ -825,11 +839,11 @@ __device__ __forceinline__ Planes load_wk(const float* w, int64_t ld, int k0, in
 }
 
 // ---- Q1 of receiver kind RK: one step
-template <int MH, int MO, int RK>
+template <int MH, int MO, int RK, bool X3Q1>
 __device__ __forceinline__ bool q1_step(const SegBwdArgs& P, const Geo& G, int s, float* part, float* res, float* msT,
                                         float* sW, float* sDW, int* flag, const WFrag (&Wr)[KW3][2]) {
     constexpr int MK = RK == 0 ? MH : MO, NTILES = 2 * MK;
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), i16 = lane & 15, g4 = lane >> 4;
+    const int lane = threadIdx.x & 63, wave = TWOG_SP_WAVE_INDEX, i16 = lane & 15, g4 = lane >> 4;
     const int H = P.H, O = P.O, h = P.h, T = P.T, E_K = RK == 0 ? H : O, R_K = RK == 0 ? G.RH : G.RO;
     const int dir = G.dir, t = dir == 0 ? s : T - 1 - s;
     const int ns = h / 16, nkb = 3 * h / 32;
@@ -865,12 +879,29 @@ __device__ __forceinline__ bool q1_step(const SegBwdArgs& P, const Geo& G, int s
         const int r = min(i * 16 + i16, R_K - 1), bl = r / E_K, e = r - bl * E_K, b = G.b0 + bl;
         off[i] = 4u * (uint32_t)((((int64_t)b * T + t) * E_K + e) * (6 * h) + dir * 3 * h + 8 * g4);
     }
-    k_stream<KW3, MK>(rs_gi, off, nkb, wave, [&](int j, const f32x4 (&A)[MK][2]) {
+    // d_mg = d_gi W_ih[:, messages]: 3 x bf16 products with one accumulator per tile where the reduction is long (X3Q1, the host
+    // picks it for h >= 256: 28.1 -> 26.2 us per step at 8 clips x h 512; at h = 64 -- one or two k-blocks per wave -- the
+    // fp32 pipe without the split is faster: 10.3 against 10.7 us; profiles/r06_seg_persist_p2_x3.txt), else exact fp32 products
+    if constexpr (X3Q1) {
+        k_stream<KW3, MK, 3>(rs_gi, off, nkb, wave, [&](int j, const f32x4 (&A)[MK][2]) {
+            Planes Ap[MK];
 #pragma unroll
-        for (int blk = 0; blk < 2; ++blk)
+            for (int i = 0; i < MK; ++i) Ap[i] = split8(A[i][0], A[i][1]);
 #pragma unroll
-            for (int i = 0; i < MK; ++i) mac_f32(acc[i][blk], A[i][0], A[i][1], Wr[j][blk]);
-    });
+            for (int blk = 0; blk < 2; ++blk) {
+                const Planes B = split8(Wr[j][blk].a, Wr[j][blk].b);
+#pragma unroll
+                for (int i = 0; i < MK; ++i) mac6_one(acc[i][blk], Ap[i], B);
+            }
+        });
+    } else {
+        k_stream<KW3, MK>(rs_gi, off, nkb, wave, [&](int j, const f32x4 (&A)[MK][2]) {
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+                for (int i = 0; i < MK; ++i) mac_f32(acc[i][blk], A[i][0], A[i][1], Wr[j][blk]);
+        });
+    }
 #pragma unroll
     for (int i = 0; i < MK; ++i) { put_part1(part, NTILES, wave, i * 2, lane, acc[i][0]); put_part1(part, NTILES, wave, i * 2 + 1, lane, acc[i][1]); }
     SP_STAMP(1);   // loads + products
@@ -944,7 +975,7 @@ __device__ __forceinline__ bool q2_step(const SegBwdArgs& P, const Geo& G, int s
                                         float* sDW, float* sC, int* flag, f32x4 (&direct)[(MK * 16 + 63) / 64],
                                         f32x4 (&c_hh)[(MK * 16 + 63) / 64], const WFrag (&We)[KW2], const WFrag (&Wh)[KW3]) {
     constexpr int NPASS = (MK * 16 + 63) / 64;
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), i16 = lane & 15, g4 = lane >> 4;
+    const int lane = threadIdx.x & 63, wave = TWOG_SP_WAVE_INDEX, i16 = lane & 15, g4 = lane >> 4;
     const int H = P.H, O = P.O, E = H + O, h = P.h, T = P.T, E_K = K == 0 ? H : O, R_K = K == 0 ? G.RH : G.RO;
     const int dir = G.dir, t = dir == 0 ? s : T - 1 - s, tp = dir == 0 ? t - 1 : t + 1;
     const int tn = dir == 0 ? t + 1 : t - 1;   // the time of chain step s + 1 (processed before this one)
@@ -1029,10 +1060,18 @@ __device__ __forceinline__ bool q2_step(const SegBwdArgs& P, const Geo& G, int s
                 const int r = min(i * 16 + i16, R_K - 1), bl = r / E_K, e = r - bl * E_K, b = G.b0 + bl;
                 off[i] = 4u * (uint32_t)(((((int64_t)dir * P.bs + b) * T + tn) * E_K + e) * (2 * h) + 8 * g4);
             }
+#ifdef TWOG_SP_Q2_X3   // (experiment, as in P2: 3 x bf16 products with one accumulator)
+            k_stream<KW2, MK, 3>(rs_p, off, nkb, wave, [&](int j, const f32x4 (&A)[MK][2]) {
+                const Planes B = split8(We[j].a, We[j].b);
+#pragma unroll
+                for (int i = 0; i < MK; ++i) mac6_one(acc[i], split8(A[i][0], A[i][1]), B);
+            });
+#else
             k_stream<KW2, MK>(rs_p, off, nkb, wave, [&](int j, const f32x4 (&A)[MK][2]) {
 #pragma unroll
                 for (int i = 0; i < MK; ++i) mac_f32(acc[i], A[i][0], A[i][1], We[j]);
             });
+#endif
 #pragma unroll
             for (int i = 0; i < MK; ++i) put_part1(part, MK, wave, i, lane, acc[i]);
         }
@@ -1171,10 +1210,18 @@ __device__ __forceinline__ bool q2_step(const SegBwdArgs& P, const Geo& G, int s
             const int r = min(i * 16 + i16, R_K - 1), bl = r / E_K, e = r - bl * E_K, b = G.b0 + bl;
             off[i] = 4u * (uint32_t)((((int64_t)b * T + t) * E_K + e) * (6 * h) + dir * 3 * h + 8 * g4);
         }
+#ifdef TWOG_SP_Q2_X3
+        k_stream<KW3, MK, 3>(rs_gh, off, nkb, wave, [&](int j, const f32x4 (&A)[MK][2]) {
+            const Planes B = split8(Wh[j].a, Wh[j].b);
+#pragma unroll
+            for (int i = 0; i < MK; ++i) mac6_one(acc[i], split8(A[i][0], A[i][1]), B);
+        });
+#else
         k_stream<KW3, MK>(rs_gh, off, nkb, wave, [&](int j, const f32x4 (&A)[MK][2]) {
 #pragma unroll
             for (int i = 0; i < MK; ++i) mac_f32(acc[i], A[i][0], A[i][1], Wh[j]);
         });
+#endif
 #pragma unroll
         for (int i = 0; i < MK; ++i) put_part1(part, MK, wave, i, lane, acc[i]);
         combine_parts(part, res, MK, min(4, nkb));
@@ -1192,9 +1239,9 @@ __device__ __forceinline__ bool q2_step(const SegBwdArgs& P, const Geo& G, int s
 struct BwdLds { float *part, *res, *msT, *sW, *sDW, *sC; int* flag; };
 
 // weights once, into registers (see the forward roles): k-major operands here
-template <int MH, int MO, int RK>
+template <int MH, int MO, int RK, bool X3Q1>
 __device__ __forceinline__ void role_q1(const SegBwdArgs& P, const Geo& G, const BwdLds& M) {
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63, wave = TWOG_SP_WAVE_INDEX;
     const int nkb = 3 * P.h / 32;
     WFrag Wr[KW3][2];
 #pragma unroll
@@ -1205,12 +1252,12 @@ __device__ __forceinline__ void role_q1(const SegBwdArgs& P, const Geo& G, const
             Wr[j][blk] = kb < nkb ? load_wk_raw(P.w_ihm[RK][G.dir], P.ld_ih[RK], kb * 32, blk * P.h + G.slice * 16, lane) : wfrag_zero();
     }
     for (int s = P.T - 1; s >= 0; --s)
-        if (!q1_step<MH, MO, RK>(P, G, s, M.part, M.res, M.msT, M.sW, M.sDW, M.flag, Wr)) return;
+        if (!q1_step<MH, MO, RK, X3Q1>(P, G, s, M.part, M.res, M.msT, M.sW, M.sDW, M.flag, Wr)) return;
 }
 
 template <int MK, int K>
 __device__ __forceinline__ void role_q2(const SegBwdArgs& P, const Geo& G, const BwdLds& M) {
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63, wave = TWOG_SP_WAVE_INDEX;
     WFrag We[KW2], Wh[KW3];
 #pragma unroll
     for (int j = 0; j < KW2; ++j) {
@@ -1230,7 +1277,7 @@ __device__ __forceinline__ void role_q2(const SegBwdArgs& P, const Geo& G, const
         if (!q2_step<MK, K>(P, G, s, M.part, M.res, M.msT, M.sW, M.sDW, M.sC, M.flag, direct, c_hh, We, Wh)) return;
 }
 
-template <int MH, int MO>
+template <int MH, int MO, bool X3Q1>
 __global__ __launch_bounds__(256, 1) void seg_persist_bwd_kernel(const SegBwdArgs P) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NT_MAX = 2 * (MH > MO ? MH : MO);
@@ -1253,8 +1300,8 @@ __global__ __launch_bounds__(256, 1) void seg_persist_bwd_kernel(const SegBwdArg
     const int n_sc = P.cpc * (P.H > P.O ? P.H : P.O) * E;
     int* flag = reinterpret_cast<int*>(sC + (n_sc > 4 * P.dw_pad ? n_sc : 4 * P.dw_pad));   // (sC also holds the dL/dw half sums)
     BwdLds M{part, res, msT, sW, sDW, sC, flag};
-    if (G.role == 0) role_q1<MH, MO, 0>(P, G, M);
-    else if (G.role == 1) role_q1<MH, MO, 1>(P, G, M);
+    if (G.role == 0) role_q1<MH, MO, 0, X3Q1>(P, G, M);
+    else if (G.role == 1) role_q1<MH, MO, 1, X3Q1>(P, G, M);
     else if (G.role == 2) role_q2<MH, 0>(P, G, M);
     else role_q2<MO, 1>(P, G, M);
 }
@@ -1472,16 +1519,17 @@ extern "C" int twog_segrnn_bwd_persistent(const twog_segrnn_t* desc, const twog_
     const size_t lds = bwd_lds(S, pl);
     if (lds > 160 * 1024) return -2;
     hipStream_t st = (hipStream_t)stream;
-#define TWOG_SPB_LAUNCH(MH_, MO_)                                                                             \
+#define TWOG_SPB_LAUNCH(MH_, MO_, X3_)                                                                        \
     do {                                                                                                      \
         static std::atomic<uint32_t> done{0};                                                                 \
-        twog_allow_dynamic_lds(seg_persist_bwd_kernel<MH_, MO_>, 160 * 1024, done);                           \
-        if (!twog_persist_grid_fits(seg_persist_bwd_kernel<MH_, MO_>, pl.grid, lds, n_cus))                  \
+        twog_allow_dynamic_lds(seg_persist_bwd_kernel<MH_, MO_, X3_>, 160 * 1024, done);                      \
+        if (!twog_persist_grid_fits(seg_persist_bwd_kernel<MH_, MO_, X3_>, pl.grid, lds, n_cus))             \
             return TWOG_PERSIST_NOT_RESIDENT;                                                                 \
-        hipLaunchKernelGGL((seg_persist_bwd_kernel<MH_, MO_>), dim3(pl.grid), dim3(256), lds, st, P);         \
+        hipLaunchKernelGGL((seg_persist_bwd_kernel<MH_, MO_, X3_>), dim3(pl.grid), dim3(256), lds, st, P);    \
     } while (0)
-    if (pl.mo == 1) TWOG_SPB_LAUNCH(1, 1);
-    else TWOG_SPB_LAUNCH(1, 2);
+    const bool x3q1 = S.hidden >= 256;   // (see q1_step)
+    if (pl.mo == 1) { if (x3q1) TWOG_SPB_LAUNCH(1, 1, true); else TWOG_SPB_LAUNCH(1, 1, false); }
+    else { if (x3q1) TWOG_SPB_LAUNCH(1, 2, true); else TWOG_SPB_LAUNCH(1, 2, false); }
 #undef TWOG_SPB_LAUNCH
     TWOG_CHECK_LAUNCH();
     // the parked d_u sums (skipped after a launch that gave up: the caller re-runs the pass, which adds into d_u itself)

@@ -12,9 +12,10 @@ cp gpurun_out/pmc_summary.csv gpurun_out/${TAG}_bench_bs64_pmc_summary.csv
 cp gpurun_out/gemm128_hbm_traffic.json gpurun_out/${TAG}_gemm128_hbm_traffic.json
 rm -rf gpurun_out/pmc
 bash tools/prof_c2.sh $TAG > /dev/null 2>&1
-for w in c2 c5 defaults defaults_seg; do
+for w in c2 c5 c5_hs512 defaults defaults_seg; do
   python3 bench.py --workload $w > gpurun_out/${TAG}_bench_$w.json 2> gpurun_out/${TAG}_bench_$w.err
 done
+python3 bench.py --workload c2 --batch 64 --no-cpu-baseline > gpurun_out/${TAG}_bench_c2_bs64.json 2> gpurun_out/${TAG}_bench_c2_bs64.err
 python3 bench.py > gpurun_out/${TAG}_bench_line.json 2> gpurun_out/${TAG}_bench_line.err
 tail -3 gpurun_out/${TAG}_bench_line.err
 head -12 gpurun_out/${TAG}_bench_bs64_step_breakdown.txt
