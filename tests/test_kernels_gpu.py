@@ -233,6 +233,43 @@ def test_gemm_split_k_in_launch_combine_equals_the_reduce_launch_bit_for_bit(K, 
     assert split_seen, 'no case took the split-K path'
 
 
+_KU_CHILD = """
+import sys, torch
+sys.path.insert(0, sys.argv[1])
+import twog_gcn_amd
+from twog_gcn_amd.kernels import get_kernels
+K = get_kernels()
+out = {}
+for (M, N, Kd, seed) in ((1280, 1536, 1024, 1), (512, 1536, 512, 2), (2000, 1000, 96, 3), (128, 128, 32, 4)):
+    g = torch.Generator().manual_seed(500 + seed)
+    A, B, bias = torch.randn(M, Kd, generator=g).cuda(), torch.randn(N, Kd, generator=g).cuda(), torch.randn(N, generator=g).cuda()
+    C = torch.empty(M, N, device='cuda')
+    K.gemm([dict(A=A, B=B, C=C, bias=bias, act=1)], split_k_workspace=False)
+    ref = torch.relu(A.double() @ B.double().t() + bias.double())
+    out[(M, N, Kd)] = (C.cpu(), K.gemm_last_class(), float((C.double() - ref).abs().max() / ref.abs().max()))
+torch.save(out, sys.argv[2])
+"""
+
+
+def test_gemm_x3_128_class_two_k_tiles_per_barrier_option_is_bit_identical(K, tmp_path):
+    """TWOG_X3_KU128=1 (round 6, off by default: measured slower, profiles/r06_gemm128_ku2_ab.txt): forward-form launches of the
+    bf16x3 128x128 class with at most one tile per CU run gemm_x3_nn_ku2_kernel -- two k-tiles per barrier interval, the same MFMA
+    sequence into the same accumulators. Every output word must equal the default kernel's, with bias + ReLU epilogue, a ragged
+    problem, a K that is not a multiple of 32 (falls back to the default kernel) and a single k-pair."""
+    res = {}
+    for ku in ('0', '1'):
+        f = tmp_path / f'ku{ku}.pt'
+        r = subprocess.run([sys.executable, '-c', _KU_CHILD, ROOT, str(f)], env=dict(os.environ, TWOG_X3_KU128=ku, TWOG_GEMM_TILE='128'),
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[ku] = torch.load(f)
+    for k in res['0']:
+        (a, ca, ea), (b, cb, eb) = res['0'][k], res['1'][k]
+        assert ca & K.GEMM_TILE128 and ca & K.GEMM_X3, (k, hex(ca))
+        assert ea < 2e-6 and eb < 2e-6, (k, ea, eb)
+        assert torch.equal(a, b), f'{k}: two k-tiles per barrier interval changed the result'
+
+
 def test_gemm_column_sums_of_a_from_the_same_pass(K):
     """twog_gemm_t::a_colsum: the dW = dY^T X launch of the bf16x3 128x128 class (k-major A and B) also returns the column sums
     of dY -- the layer's bias gradient -- from the values it stages anyway (workgroups of the first column panel add them per
