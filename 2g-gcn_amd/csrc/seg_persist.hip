@@ -87,6 +87,9 @@ __device__ __forceinline__ uint32_t pack_hi16(uint32_t lo, uint32_t hi) { return
 // eight consecutive fp32 values -> the three bf16 planes of an MFMA fragment (element j = value j), by truncation: exact
 struct Planes { bf16x8 h, m, l; };
 __device__ __forceinline__ Planes split8(const f32x4 a, const f32x4 b) {
+#ifdef TWOG_SP_PROBE_NOSPLIT   // timing probe only (wrong results): what the split of the streamed fragments costs a step
+    { Planes q; q.h = __builtin_bit_cast(bf16x8, a); q.m = __builtin_bit_cast(bf16x8, b); q.l = q.h; return q; }
+#endif
     uint32_t x[8], r1[8], r2[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
