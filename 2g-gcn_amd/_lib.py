@@ -170,6 +170,7 @@ SIGNATURES = {
     'twog_gemm_f32': [C.POINTER(Gemm), _I, _I, _I, _P, C.c_size_t, _P],
     'twog_guard_outputs': [C.POINTER(Guard), _P],
     'twog_stream_create_masked': [_I, C.POINTER(C.c_void_p)],
+    'twog_stream_create_low_priority': [C.POINTER(C.c_void_p)],
     'twog_stream_destroy': [_P],
     'twog_gemm_colsum_fused': [C.POINTER(Gemm), _I, _I, _I, _P, C.c_size_t],
     'twog_gemm_last_class': [],

@@ -413,6 +413,15 @@ extern "C" int twog_stream_create_masked(int n_cus, void** stream_out) {
     *stream_out = st;
     return 0;
 }
+extern "C" int twog_stream_create_low_priority(void** stream_out) {
+    if (!stream_out) return -2;
+    int least = 0, greatest = 0;
+    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) { (void)hipGetLastError(); return -3; }
+    hipStream_t st = nullptr;
+    if (hipStreamCreateWithPriority(&st, hipStreamNonBlocking, least) != hipSuccess) { (void)hipGetLastError(); return -3; }
+    *stream_out = st;
+    return 0;
+}
 extern "C" int twog_stream_destroy(void* stream) {
     return stream && hipStreamDestroy((hipStream_t)stream) != hipSuccess ? -1 : 0;
 }

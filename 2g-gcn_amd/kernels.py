@@ -150,6 +150,13 @@ class HipKernels:
                     h = C.c_void_p()
                     rc = self.lib.twog_stream_create_masked(int(cus), C.byref(h))
                 st = torch.cuda.ExternalStream(h.value, device=dev) if rc == 0 and h.value else False
+            elif os.environ.get('TWOG_SIDE_PRIORITY', 'normal') == 'low':
+                # (experiment, round 6: the side stream's GEMM workgroups at the lowest queue priority, so that the chain's
+                # workgroups on the caller's stream win free compute units; profiles/r06_side_stream_priority_ab.txt)
+                with torch.cuda.device(dev):
+                    h = C.c_void_p()
+                    rc = self.lib.twog_stream_create_low_priority(C.byref(h))
+                st = torch.cuda.ExternalStream(h.value, device=dev) if rc == 0 and h.value else torch.cuda.Stream(device=dev)
             else:
                 st = torch.cuda.Stream(device=dev)
             HipKernels._side_streams[key] = st

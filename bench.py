@@ -317,7 +317,7 @@ def cpu_baseline(sample_frames=None, sample_clips=4, repeats=3, threads=None):
 def cpu_baseline_all(workload):
     """The `cpu_baseline` object of the bench line: `value` as before (the workload's own shape, as many threads as cores
     are granted, 4 clips, 1 + 3 passes) plus `by_config`: the configs[1] bs8 layout and the reference's literal
-    `resources.num_threads: 32` (conf/config.yaml:9) beside it, each on a smaller sample (2 clips, 1 + 2 passes; 1 clip, 1 + 1
+    `resources.num_threads: 32` (conf/config.yaml:9) beside it, each on a smaller sample (2 clips, 1 + 2 passes; 2 clips x 30 frames, 1 + 1
     passes for the oversubscribed 32-thread setting) so that the whole leg stays within about two and a half minutes."""
     from twog_gcn_amd.hostcpu import effective_cpu_count
     granted = min(32, effective_cpu_count())
@@ -329,8 +329,10 @@ def cpu_baseline_all(workload):
         plan += [('c2', granted)] + ([('c2', 32)] if granted != 32 else [])
     for wl, thr in plan:
         select_workload(wl)
-        # (32 threads on fewer granted cores is oversubscribed -- 4.5 x slower on a 16-core grant: one clip, 1 + 1 passes)
-        r = cpu_baseline(sample_clips=1, repeats=1, threads=thr) if thr > granted else cpu_baseline(sample_clips=2, repeats=2, threads=thr)
+        # (32 threads on fewer granted cores is oversubscribed -- 4.5 x slower on a 16-core grant with 2 clips per pass, 15 x with
+        # one: 2 clips x 30 of the 120 frames, 1 + 1 passes, scaled linearly in frames)
+        r = (cpu_baseline(sample_frames=30, sample_clips=2, repeats=1, threads=thr) if thr > granted
+             else cpu_baseline(sample_clips=2, repeats=2, threads=thr))
         by[f'{wl}_threads{thr}'] = {k: r[k] for k in keep}
     select_workload(workload)
     main_['by_config'] = by

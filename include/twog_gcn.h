@@ -607,6 +607,10 @@ int twog_guard_outputs(const twog_guard_t* g, void* stream);
  * XCD). Host plumbing of this library's own backward pass (weight-gradient GEMMs beside a launch-per-step recurrence that
  * leaves those CUs idle); no counterpart in the reference. Returns 0, or < 0 when the runtime refuses. */
 int twog_stream_create_masked(int n_cus, void** stream_out);
+/* A stream of the LOWEST priority the device offers (hipDeviceGetStreamPriorityRange / hipStreamCreateWithPriority): the side
+ * stream of the same backward pass (TWOG_SIDE_PRIORITY=low) -- its GEMM workgroups then yield free compute units to the
+ * launch-per-step recurrence on the caller's stream. Returns 0, or < 0 when the runtime refuses. */
+int twog_stream_create_low_priority(void** stream_out);
 int twog_stream_destroy(void* stream);
 /* n_blocks <= TWOG_COPY_MAX copies dst[i] = src[i], i < n floats, of contiguous fp32 blocks in ONE launch. The host uses it
  * to rebuild, at EVERY forward call, the packed operands the time loops read (w_smsg_* / b_smsg_* of twog_segrnn_t: the
