@@ -255,7 +255,7 @@ class DataParallel:
         first element of this stage's range into NaN if a pending word is set. The sum carries the NaN to every rank, and
         all_reduce_gradients() raises on ALL of them before any optimizer sees the buffer."""
         K = get_kernels()
-        if not hasattr(K, 'guard_persistent') or not self.flat.grad.is_cuda:
+        if not hasattr(K, 'guard_persistent'):
             return
         marker = self.flat.grad[begin:begin + 1]
         if not K.guard_persistent(self.flat.grad.device, [marker]):
@@ -289,7 +289,7 @@ class DataParallel:
         K = get_kernels()
         mine = self._late_failure
         self._late_failure = None
-        if hasattr(K, 'verify_persistent') and self.flat.grad.is_cuda:
+        if hasattr(K, 'verify_persistent'):
             try:
                 K.verify_persistent(self.flat.grad.device)
             except RuntimeError as e:

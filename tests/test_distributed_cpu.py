@@ -345,3 +345,64 @@ def test_discarded_wrapper_and_model_are_collected_without_close():
     assert all(ret['c']), ret['c']
     assert all(ret['a']), ret['a']
     assert all(ret['b']), ret['b']
+
+
+# A persistent launch of ONE rank's backward pass gives up late: no rank may step on the all-reduced
+# gradients, and no rank may be left waiting in a collective. Two gloo ranks; the torch test double of the kernel interface
+# with the two hooks of the HIP backend the protocol uses -- guard_persistent (on the device: marks the tensors NaN if an error
+# word is pending) and verify_persistent (reads the words, raises) -- where rank 0 plays the rank whose launch gave up.
+def _late_failure_worker(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import twog_gcn_amd  # noqa: F401
+    from twog_gcn_amd import kernels
+    from twog_gcn_amd.distributed import DataParallel
+    from tests.fake_kernels import FakeKernels
+
+    class Failing(FakeKernels):
+        failed = False            # "an error word of this pass is set"
+
+        def guard_persistent(self, dev, outs):
+            if self.failed:
+                for o in outs:
+                    o.fill_(float('nan'))
+            return True
+
+        def verify_persistent(self, dev=None):
+            if self.failed:
+                self.failed = False
+                raise RuntimeError('twog_segrnn_bwd_persistent: a persistent launch could not keep its grid resident')
+
+    fk = Failing()
+    kernels._set_backend_for_tests(fk)
+    torch.set_num_threads(2)
+    model = _tiny_model(seed=0)
+    dp = DataParallel(model, bucket_mb=1)
+    xh, xo, mask, tgt, noise = _batch(4)
+    sl = slice(rank * 2, rank * 2 + 2)
+    out = {}
+    for step, fail in enumerate((False, True, False)):
+        dp.zero_grad()
+        loss = _loss(model, xh[sl], xo[sl], mask[sl], tgt[sl], noise[:, sl])
+        fk.failed = fail and rank == 0     # a launch of THIS backward pass gives up
+        loss.backward()                    # never raises: the peers are in their collectives
+        try:
+            dp.all_reduce_gradients()
+            out[step] = ('ok', bool(torch.isfinite(dp.flat.grad).all()))
+        except RuntimeError as e:
+            out[step] = ('raised', str(e)[:80])
+    ret[rank] = out
+    dist.destroy_process_group()
+
+
+def test_a_late_persistent_failure_on_one_rank_raises_on_every_rank_after_the_collectives():
+    port = 29500 + (os.getpid() * 7 + 3) % 2000
+    ret = mp.Manager().dict()
+    mp.spawn(_late_failure_worker, args=(2, port, ret), nprocs=2, join=True)
+    for rank in (0, 1):
+        o = ret[rank]
+        assert o[0] == ('ok', True), (rank, o)
+        assert o[1][0] == 'raised', (rank, o)          # BOTH ranks: the one whose launch gave up and its peer
+        assert o[2] == ('ok', True), (rank, o)          # and the next step is clean on both
+    assert 'persistent launch' in ret[0][1][1] and 'rank of this group' in ret[1][1][1], dict(ret)
