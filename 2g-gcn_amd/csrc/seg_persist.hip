@@ -1063,8 +1063,11 @@ __device__ __forceinline__ bool q2_step(const SegBwdArgs& P, const Geo& G, int s
                 const int r = min(i * 16 + i16, R_K - 1), bl = r / E_K, e = r - bl * E_K, b = G.b0 + bl;
                 off[i] = 4u * (uint32_t)(((((int64_t)dir * P.bs + b) * T + tn) * E_K + e) * (2 * h) + 8 * g4);
             }
+#ifndef TWOG_SP_Q2_CH
+#define TWOG_SP_Q2_CH 3
+#endif
 #ifdef TWOG_SP_Q2_X3   // (experiment, as in P2: 3 x bf16 products with one accumulator)
-            k_stream<KW2, MK, 3>(rs_p, off, nkb, wave, [&](int j, const f32x4 (&A)[MK][2]) {
+            k_stream<KW2, MK, TWOG_SP_Q2_CH>(rs_p, off, nkb, wave, [&](int j, const f32x4 (&A)[MK][2]) {
                 const Planes B = split8(We[j].a, We[j].b);
 #pragma unroll
                 for (int i = 0; i < MK; ++i) mac6_one(acc[i], split8(A[i][0], A[i][1]), B);
@@ -1214,7 +1217,7 @@ __device__ __forceinline__ bool q2_step(const SegBwdArgs& P, const Geo& G, int s
             off[i] = 4u * (uint32_t)((((int64_t)b * T + t) * E_K + e) * (6 * h) + dir * 3 * h + 8 * g4);
         }
 #ifdef TWOG_SP_Q2_X3
-        k_stream<KW3, MK, 3>(rs_gh, off, nkb, wave, [&](int j, const f32x4 (&A)[MK][2]) {
+        k_stream<KW3, MK, TWOG_SP_Q2_CH>(rs_gh, off, nkb, wave, [&](int j, const f32x4 (&A)[MK][2]) {
             const Planes B = split8(Wh[j].a, Wh[j].b);
 #pragma unroll
             for (int i = 0; i < MK; ++i) mac6_one(acc[i], split8(A[i][0], A[i][1]), B);
