@@ -94,6 +94,10 @@ class Plan:
         self.mean_pool = (not self.relational) and c['message_aggregation'] in {'mp', 'mean_pooling'}
         self.att_style = ('concat' if style in {'v1', 'concat'} else 'general' if style in {'v4', 'general'} else 'dot')
         self.dists = None   # distance tensors of this call (distance-based attention), set by the model's forward
+        # more entities than the tuned four-relations kernel holds in registers (MAX_H = 4, MAX_O = 12 of csrc/attn.hip:22; the
+        # reference's datasets have at most 2 humans and 9 objects): the general single-relation kernels serve up to 16
+        # receivers / senders per relation (csrc/relation.hip MAXE) -- complete, not tuned; beyond that the library refuses
+        self.many_entities = H > 4 or O > 12
         self.has_bias = bool(c.get('bias', True))
         self.n_gate_hidden = int(c.get('discrete_networks_num_layers', 1)) - 1
         ostrat = c['object_segment_update_strategy']
@@ -139,7 +143,7 @@ class Plan:
     def general_frame(self):
         """True when the frame-level messages need the general single-relation kernels (relation.hip) instead of the
         tuned four-relations kernel (attn.hip: sender-only messages + dot-product attention / mean pooling)."""
-        return (self.relational or self.specific or
+        return (self.relational or self.specific or self.many_entities or
                 (not self.mean_pool and (self.att_style != 'dot' or self.dists is not None)))
 
     def general_segment(self):

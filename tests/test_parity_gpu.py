@@ -587,9 +587,18 @@ def test_edge_cases_vs_oracle(bs, T, H, O, N, h, mask_mode):
     assert all(torch.isfinite(p.grad).all() for p in m.parameters() if p.grad is not None)
 
 
+@pytest.mark.parametrize('H,O,N', [(2, 14, 40), (5, 3, 34), (3, 16, 50)])
+def test_more_entities_than_the_tuned_attention_kernel_holds(H, O, N):
+    """Round 6: the tuned four-relations kernel keeps at most 4 humans and 12 objects in registers
+    (csrc/attn.hip:22; the reference has no such limit, its datasets at most 2 and 9). Larger clips are routed to the general
+    single-relation kernels (up to 16 receivers / senders per relation, both levels) instead of raising: forward + backward
+    against the oracle."""
+    _oracle_vs_hip(bs=2, T=5, H=H, O=O, N=N, h=32, backward=True, seed=19, max_nudged_share=0.10)
+
+
 def test_limits_fail_loudly():
-    """More objects than the attention kernel supports must raise, not silently fall back."""
-    N, h, O = 26, 16, 13
+    """More entities than ANY kernel of the path supports must raise, not silently fall back."""
+    N, h, O = 26, 16, 17
     m = TGGCN(input_size=(2048 + 4 * N, 2048), num_classes=(13, None), hidden_size=h, gcn_node=N, **STAGE1).to(DEV)
     with pytest.raises(RuntimeError):
         m(torch.rand(1, 2, 2, 2048 + 4 * N, device=DEV), torch.rand(1, 2, O, 2048, device=DEV), torch.ones(1, O, device=DEV),

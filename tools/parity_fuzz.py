@@ -132,6 +132,17 @@ def one_case(rng, idx, dev=DEV, dry=False, run_seed=0):
         if rng2.random() < 0.125:
             bs, T = rng2.randint(6, 14), rng2.randint(10, 18)
     O, N = rng.randint(1, 12), rng.choice([19, 26, 30, 34, 21, 40])
+    if run_seed >= 1000:
+        # sweeps with seed >= 1000 also draw clips with MORE entities than the tuned attention kernel holds (H > 4 or O > 12:
+        # served by the general single-relation kernels since round 6) for one case in eight, again from a generator of
+        # their own (the main sequence, and with it every recorded case, is unchanged)
+        rng3 = random.Random((run_seed << 21) + idx)
+        if rng3.random() < 0.125:
+            if rng3.random() < 0.5:
+                O = rng3.randint(13, 16)
+            else:
+                H = rng3.randint(3, 5)
+            N = rng3.choice([40, 46, 50])
     h = rng.choice([16, 32, 48, 64, 80, 16, 32, 48, 64, 80, 256, 128, 64])   # 256: four column tiles per GEMM problem; 64 / 128 / 256: the persistent segment launches (round 5)
     if H == 1:
         cfg['message_humans_to_human'] = False
