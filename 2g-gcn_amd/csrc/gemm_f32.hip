@@ -1830,6 +1830,15 @@ static void prepare_group(const twog_gemm_t* pr, int n, int a_kmajor, int b_kmaj
             if (want8 && best8 + 0.08 < best) want8 = 0;   // (48 tiles x 8 splits of 1 920 at K = 15 360: 0.150 against 0.138 ms)
         }
         if (want8) want = want8;
+        // (experiment, round 6: SHORT workgroups for the tall dW reductions -- TWOG_GEMM_SLAB_K=k asks for splits of about k
+        // reduction rows, a multiple of 8, as many as the workspace holds -- so that a launch chain on another stream finds
+        // free compute units sooner; profiles/r06_dw_short_slabs_beside_the_chain.txt. Off by default.)
+        static const int slab_k = getenv("TWOG_GEMM_SLAB_K") ? atoi(getenv("TWOG_GEMM_SLAB_K")) : 0;
+        if (slab_k > 0 && big && a_kmajor && b_kmajor && force_split <= 0 && t <= 512 && kmax >= 4 * slab_k) {
+            int s8 = ((kmax / slab_k + 7) / 8) * 8;
+            while (s8 > want && (size_t)s8 * t * BMN * BMN * sizeof(float) + SPLITK_TICKET_BYTES + (size_t)(s8 + 1) * t * 128 * sizeof(float) > workspace_bytes) s8 -= 8;
+            if (s8 > want) want = s8;
+        }
         // the first 16 KB of the workspace are the arrival tickets of the in-launch combine (LA, gemm_tile): zero when the
         // workspace is first handed over, returned to zero by every launch. OFF by default -- measured on one box, same
         // session: bs64 step 69.32 ms with it against 68.57 ms with slabs + splitk_reduce_kernel, 8-clip step 16.32 against
