@@ -1370,29 +1370,44 @@ __global__ __launch_bounds__(512, 2) void gemm_x3_tt_split_acc_kernel(const Grou
     gemm_tile<128, 128, 512, true, true, 2, KG, false, 1, false, true, 1, true>(g, nullptr);
 }
 
+// Issue priority of the waves of a recurrent chain's launches (s_setprio, 0-3): beside the side stream's dW GEMMs a chain
+// workgroup shares its CU with two GEMM workgroups, and the SIMD's arbiter serves equal-priority waves in turn.
+#ifndef TWOG_CHAIN_PRIO
+#define TWOG_CHAIN_PRIO 0
+#endif
+#if TWOG_CHAIN_PRIO > 0
+#define TWOG_CHAIN_SETPRIO() __builtin_amdgcn_s_setprio(TWOG_CHAIN_PRIO)
+#else
+#define TWOG_CHAIN_SETPRIO() ((void)0)
+#endif
 // X3 on the 64x64 class (gemm_mainloop_x3s): 4 waves, or 8 waves = two k-groups; plain and gate-fused epilogues
 template <bool BKM, int KS>
 __global__ __launch_bounds__(256 * KS, 2) void gemm_x3s_kernel(const Group g) {
+    TWOG_CHAIN_SETPRIO();
     gemm_tile<64, 64, 256 * KS, false, BKM, 2, false, false, KS, false, true>(g, nullptr);
 }
 template <int KS>
 __global__ __launch_bounds__(256 * KS, 2) void gemm_gate_bwd_x3s_kernel(const Group g, const GateArgs ga) {
+    TWOG_CHAIN_SETPRIO();
     gemm_tile<64, 64, 256 * KS, false, true, 2, false, true, KS, false, true>(g, &ga);
 }
 
 // 128 x 64 tiles for chain launches with enough rows (pick_rows128): one 8-wave workgroup per CU, two k-tiles per barrier
 template <bool BKM>
 __global__ __launch_bounds__(512, 1) void gemm_x3su128_kernel(const Group g) {
+    TWOG_CHAIN_SETPRIO();
     gemm_tile<128, 64, 512, false, BKM, 2, false, false, 1, false, true, 2>(g, nullptr);
 }
 
 // KU k-tiles per barrier interval (launches that run one workgroup per CU: at most 256 tiles)
 template <bool BKM, int KS, int KU>
 __global__ __launch_bounds__(256 * KS, KS == 2 ? 1 : 2) void gemm_x3su_kernel(const Group g) {
+    TWOG_CHAIN_SETPRIO();
     gemm_tile<64, 64, 256 * KS, false, BKM, 2, false, false, KS, false, true, KU>(g, nullptr);
 }
 template <int KS, int KU>
 __global__ __launch_bounds__(256 * KS, KS == 2 ? 1 : 2) void gemm_gate_bwd_x3su_kernel(const Group g, const GateArgs ga) {
+    TWOG_CHAIN_SETPRIO();
     gemm_tile<64, 64, 256 * KS, false, true, 2, false, true, KS, false, true, KU>(g, &ga);
 }
 
@@ -1436,6 +1451,7 @@ struct GruFwdGroup {
 
 template <int D, int KS, bool X3 = false>
 __global__ __launch_bounds__(256 * KS, 1) void gemm_gru_fwd_kernel(const GruFwdGroup g) {
+    TWOG_CHAIN_SETPRIO();
     constexpr int BM = 64, BN = 192, NT = 256 * KS, TM = 1, TN = 3;
     // X3 (bf16 x 3 on the bf16 matrix cores, see gemm_mainloop_x3s): two stages of three bf16 planes of both operand tiles
     __shared__ __attribute__((aligned(16))) float smem[X3 ? 2 * 3 * (BM + BN) * (16 * KS) * 2 / 4 : 2 * (BM + BN) * (BK + 4)];
