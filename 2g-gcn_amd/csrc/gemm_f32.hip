@@ -468,15 +468,21 @@ __device__ __forceinline__ int x3_swz(int k) { return ((k & 3) << 2) | ((k >> 2)
 // segment level's per-step projection: 240 tiles), where ONE workgroup per CU moves through a barrier every 12 MFMAs per wave
 // and nothing else hides the fragment reads and the barrier's skew. KU = 2 needs 2 x 2 x 24 KB of LDS and ~64 more registers:
 // one workgroup per CU, which is what such a launch has anyway. Same MFMA sequence into the same accumulators: bit-identical.
-template <bool AKM, bool BKM, bool KG, bool TTMP = false, int KU = 1>
+// KS = 2 (round 6): SIXTEEN waves = two k-groups of eight, each with its own pair of LDS stages and its own half of the
+// reduction (the caller passes the group's k-range; both halves hold the same number of k-tiles, so the workgroup-wide
+// barriers match) -- four waves per SIMD for launches of at most ONE tile per CU, which is what the two co-resident
+// workgroups of a big launch have and an 8-wave tile alone on its CU has not. gemm_tile adds the two partial tiles.
+template <bool AKM, bool BKM, bool KG, bool TTMP = false, int KU = 1, int KS = 1>
 __device__ __forceinline__ void gemm_mainloop_x3(const twog_rows_t A, const twog_rows_t B, int M, int N, int m0, int n0,
                                                  int k_begin, int k_end, float* smem, f32x16 (&acc)[1][2], f32x4& cs, bool cs_on) {
     constexpr int BM = 128, BN = 128, NT = 512, XK = X3_BK;
     constexpr bool TMP = TWOG_X3_TMPACC || TTMP;
     static_assert(KU == 1 || (!AKM && !BKM && !KG && !TMP), "KU > 1: the row-major (forward) form only");
+    static_assert(KS == 1 || (KS == 2 && KU == 1 && !AKM && !BKM && !KG && !TMP), "KS = 2: the row-major (forward) form only");
     constexpr int PA = AKM ? X3_TPLANE : X3_RPLANE, PB = BKM ? X3_TPLANE : X3_RPLANE;
-    char* lds = reinterpret_cast<char*>(smem);   // stage b: A planes at b * X3_STAGE, B planes behind them
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // stage b: A planes at b * X3_STAGE, B planes behind them (k-group 1: behind k-group 0's two stages)
+    char* lds = reinterpret_cast<char*>(smem) + (KS == 2 ? (int)(threadIdx.x >> 9) * 2 * KU * X3_STAGE : 0);
+    const int tid = KS == 2 ? (int)(threadIdx.x & 511) : (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = (wave >> 1) * 32, wn = (wave & 1) * 64;
     using ARegs = TileRegs<(AKM ? XK : BM), (AKM ? BM : XK), NT>;
     using BRegs = TileRegs<(BKM ? XK : BN), (BKM ? BN : XK), NT>;
@@ -947,7 +953,7 @@ __device__ __forceinline__ void gemm_tile(const Group& g, const GateArgs* ga) {
     constexpr int B_ELEMS = BKM ? BK * LDB : BN * LDB;
     // (X3 on the 64-row class: two stages of three bf16 planes per operand, 2 x 6 x 64 rows x 2 XK bytes, XK = 16 KS)
     constexpr int SMEM_FLOATS = (X3 && BM == 128 && BN == 64) ? 2 * KU * 3 * (128 + 64) * 32 / 4   // 128x64 chain tile: 2 stages x KU images
-                                : (X3 && BM == 128) ? 2 * KU * X3_STAGE / 4
+                                : (X3 && BM == 128) ? KS * 2 * KU * X3_STAGE / 4
                                 : (X3 && BM == 64 && 12 * 64 * 8 * KS * KU > 2 * (A_ELEMS + B_ELEMS)) ? 12 * 64 * 8 * KS * KU : 2 * (A_ELEMS + B_ELEMS);
     __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS];
 
@@ -1011,7 +1017,7 @@ __device__ __forceinline__ void gemm_tile(const Group& g, const GateArgs* ga) {
     const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) % (NTG / 64), kgrp = (threadIdx.x >> 6) / (NTG / 64);
     const int li = lane & 31, kh = lane >> 5;
     const int wm = (wave >> 1) * WM, wn = (wave & 1) * WN;
-    static_assert(KS == 1 || (KS == 2 && TM * TN == 1), "the in-workgroup k-split is written for the 64x64 class");
+    static_assert(KS == 1 || (KS == 2 && (TM * TN == 1 || (X3 && BM == 128 && BN == 128))), "the in-workgroup k-split: the 64x64 class and the X3 128x128 tile");
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -1101,9 +1107,13 @@ __device__ __forceinline__ void gemm_tile(const Group& g, const GateArgs* ga) {
             static_assert(!X3 || BM != 128 || BN != 64 || (NT == 512 && KS == 1 && !AKM && !KG && !XS && !GATE), "X3: 128x64 chain tiles");
             gemm_mainloop_x3s<BM, BN, NT, BKM, 1, 1, false, 2, true, KU>(A, B, M, N, m0, n0, k_begin, k_end, smem, acc);
         } else if constexpr (BM == 128) {
-            static_assert(!X3 || BM != 128 || (BN == 128 && NT == 512 && !GATE && KS == 1 && !XS), "X3: the 8-wave 128x128 class");
+            static_assert(!X3 || BM != 128 || (BN == 128 && NT == 512 * KS && !GATE && !XS), "X3: the 8-wave (16-wave: KS = 2) 128x128 class");
             f32x4 cs = {0.f, 0.f, 0.f, 0.f};
             const bool cs_on = AKM && BKM && !KG && G.cs != nullptr && tn_idx == 0;   // uniform over the workgroup
+            if constexpr (KS == 2) {   // (host: whole PAIRS of k-tiles, so both k-groups run the same number of barriers)
+                const int half = (k_end - k_begin) / 2;
+                gemm_mainloop_x3<AKM, BKM, KG, TTMP, KU, 2>(A, B, M, N, m0, n0, k_begin + kgrp * half, k_begin + (kgrp + 1) * half, smem, acc, cs, cs_on);
+            } else
             gemm_mainloop_x3<AKM, BKM, KG, TTMP, KU>(A, B, M, N, m0, n0, k_begin, k_end, smem, acc, cs, cs_on);
             if constexpr (AKM && BKM && !KG) {
                 if (cs_on) {
@@ -1134,15 +1144,23 @@ __device__ __forceinline__ void gemm_tile(const Group& g, const GateArgs* ga) {
     if constexpr (KS == 2) {
         // add the two k-groups' partial tiles (fixed order: group 0 + group 1) through LDS; group 0 runs the epilogue
         __syncthreads();   // every wave is done with the operand tiles
-        float* red = smem + ((wave * 16) << 6) + lane;
+        float* red = smem + ((wave * TM * TN * 16) << 6) + lane;
         if (kgrp == 1) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) red[r << 6] = acc[0][0][r];
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int b = 0; b < TN; ++b)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) red[((a * TN + b) * 16 + r) << 6] = acc[a][b][r];
         }
         __syncthreads();
         if (kgrp == 1) return;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[0][0][r] += red[r << 6];
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int b = 0; b < TN; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[a][b][r] += red[((a * TN + b) * 16 + r) << 6];
     }
 
     if constexpr (XS) {
@@ -1365,6 +1383,10 @@ __global__ __launch_bounds__(512, 2) void gemm_x3_nn_ku2_kernel(const Group g) {
     gemm_tile<128, 128, 512, false, false, 2, false, false, 1, false, true, 2>(g, nullptr);
 }
 // dW = dY^T X with every k-step's products through a fresh accumulator (TTMP): one workgroup per CU
+// 16 waves = two k-groups on one tile (KS = 2): launches of at most one tile per CU (the segment level's per-step projection)
+__global__ __launch_bounds__(1024, 1) void gemm_x3_nn_k2_kernel(const Group g) {
+    gemm_tile<128, 128, 1024, false, false, 2, false, false, 2, false, true>(g, nullptr);
+}
 template <bool KG>
 __global__ __launch_bounds__(512, 2) void gemm_x3_tt_split_acc_kernel(const Group g) {
     gemm_tile<128, 128, 512, true, true, 2, KG, false, 1, false, true, 1, true>(g, nullptr);
@@ -1679,7 +1701,17 @@ int launch(Group& g, int akm, int bkm, hipStream_t st) {
             static const int ku128 = getenv("TWOG_X3_KU128") ? atoi(getenv("TWOG_X3_KU128")) : 0;
             bool ku2 = ku128 != 0 && !akm && !bkm && g.splitk == 1 && g.total_tiles <= 256;
             for (int i = 0; i < g.n; ++i) ku2 = ku2 && (g.p[i].K % (2 * X3_BK)) == 0;
-            if (ku2) hipLaunchKernelGGL(gemm_x3_nn_ku2_kernel, grid, block, 0, st, g);
+            // at most one tile per CU, whole pairs of k-tiles: 16 waves, the reduction halved between two k-groups. Built and measured
+            // in round 6 (four waves per SIMD on a lone tile, as two co-resident workgroups of a big launch have): NO gain -- the
+            // 240-tile projection launch 47.0 -> 46.3 us, the step unchanged. The sixteen waves meet at ONE barrier per k-tile, so their
+            // LDS phases (768 cycles of plane stores + fragment reads per k-tile on the CU) and their MFMA phases (768 cycles per
+            // SIMD) still alternate instead of overlapping, which is what two independent workgroups get for free.
+            // Off by default (TWOG_X3_K2=1 selects it). profiles/r06_gemm128_two_k_groups.txt
+            static const int k2_on = getenv("TWOG_X3_K2") ? atoi(getenv("TWOG_X3_K2")) : 0;
+            bool k2 = k2_on != 0 && !ku2 && !akm && !bkm && g.splitk == 1 && g.total_tiles <= 256;
+            for (int i = 0; i < g.n; ++i) k2 = k2 && (g.p[i].K % (2 * X3_BK)) == 0 && g.p[i].K >= 8 * X3_BK;
+            if (k2) hipLaunchKernelGGL(gemm_x3_nn_k2_kernel, grid, dim3(1024), 0, st, g);
+            else if (ku2) hipLaunchKernelGGL(gemm_x3_nn_ku2_kernel, grid, block, 0, st, g);
             else if (!akm && !bkm) hipLaunchKernelGGL((gemm_x3_kernel<false, false, false>), grid, block, 0, st, g);
             else if (!akm && bkm && !kg) hipLaunchKernelGGL((gemm_x3_kernel<false, true, false>), grid, block, 0, st, g);
             else if (!akm && bkm) hipLaunchKernelGGL((gemm_x3_kernel<false, true, true>), grid, block, 0, st, g);

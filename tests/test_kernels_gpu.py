@@ -259,7 +259,7 @@ def test_gemm_x3_128_class_two_k_tiles_per_barrier_option_is_bit_identical(K, tm
     res = {}
     for ku in ('0', '1'):
         f = tmp_path / f'ku{ku}.pt'
-        r = subprocess.run([sys.executable, '-c', _KU_CHILD, ROOT, str(f)], env=dict(os.environ, TWOG_X3_KU128=ku, TWOG_GEMM_TILE='128'),
+        r = subprocess.run([sys.executable, '-c', _KU_CHILD, ROOT, str(f)], env=dict(os.environ, TWOG_X3_KU128=ku, TWOG_X3_K2='0', TWOG_GEMM_TILE='128'),
                            capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         res[ku] = torch.load(f)
@@ -268,6 +268,32 @@ def test_gemm_x3_128_class_two_k_tiles_per_barrier_option_is_bit_identical(K, tm
         assert ca & K.GEMM_TILE128 and ca & K.GEMM_X3, (k, hex(ca))
         assert ea < 2e-6 and eb < 2e-6, (k, ea, eb)
         assert torch.equal(a, b), f'{k}: two k-tiles per barrier interval changed the result'
+
+
+def test_gemm_x3_128_class_sixteen_wave_tile_for_launches_of_one_tile_per_cu(K, tmp_path):
+    """Round 6, TWOG_X3_K2=1 (off by default: measured no faster, profiles/r06_gemm128_two_k_groups.txt): forward-form launches
+    of the bf16x3 128x128 class with at most one tile per CU (the segment level's per-step projection: 240 tiles) run
+    gemm_x3_nn_k2_kernel -- 16 waves, the reduction halved between two k-groups of eight, the two partial tiles added in fixed
+    order. Same products, one more fp32 addition per element: against
+    fp64 both stay inside the class's 2e-6, they differ from each other by rounding only, and two runs agree bit for bit. A K
+    that is not a whole pair of k-tiles, or shorter than eight k-tiles, keeps the 8-wave kernel (identical words)."""
+    res = {}
+    for tag, k2 in (('off', '0'), ('on', '1'), ('again', '1')):
+        f = tmp_path / f'k2{tag}.pt'
+        r = subprocess.run([sys.executable, '-c', _KU_CHILD, ROOT, str(f)], env=dict(os.environ, TWOG_X3_K2=k2, TWOG_GEMM_TILE='128'),
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[tag] = torch.load(f)
+    for k in res['off']:
+        (a, ca, ea), (b, cb, eb), (c, _, _) = res['off'][k], res['on'][k], res['again'][k]
+        assert ca & K.GEMM_TILE128 and ca & K.GEMM_X3 and cb == ca, (k, hex(ca), hex(cb))
+        assert ea < 2e-6 and eb < 2e-6, (k, ea, eb)
+        assert torch.equal(b, c), f'{k}: two runs of the 16-wave tile differ'
+        if k[2] % 32 or k[2] < 128:
+            assert torch.equal(a, b), k
+        else:
+            assert not torch.equal(a, b), f'{k}: the 16-wave kernel did not run'
+            assert ((a - b).abs().max() / a.abs().max()).item() < 3e-6, k
 
 
 def test_gemm_column_sums_of_a_from_the_same_pass(K):
