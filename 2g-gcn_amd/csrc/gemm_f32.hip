@@ -472,7 +472,12 @@ __device__ __forceinline__ int x3_swz(int k) { return ((k & 3) << 2) | ((k >> 2)
 // reduction (the caller passes the group's k-range; both halves hold the same number of k-tiles, so the workgroup-wide
 // barriers match) -- four waves per SIMD for launches of at most ONE tile per CU, which is what the two co-resident
 // workgroups of a big launch have and an 8-wave tile alone on its CU has not. gemm_tile adds the two partial tiles.
-template <bool AKM, bool BKM, bool KG, bool TTMP = false, int KU = 1, int KS = 1>
+// PIPE (round 6): the fragment reads of k-tile t + 1 are issued BEFORE the MFMAs of k-tile t (two fragment sets in registers,
+// three LDS stages: tile t + 1 is read and tile t + 2 stored while tile t is multiplied). Without it every wave of the
+// workgroup reads its nine fragments right behind the barrier and multiplies afterwards: the CU's LDS phase (768 cycles per
+// k-tile) and its MFMA phase (768 per SIMD) alternate. ~36 more registers: ONE workgroup per CU (the launches of at most one
+// tile per CU). Same MFMA sequence into the same accumulators: bit-identical.
+template <bool AKM, bool BKM, bool KG, bool TTMP = false, int KU = 1, int KS = 1, bool PIPE = false>
 __device__ __forceinline__ void gemm_mainloop_x3(const twog_rows_t A, const twog_rows_t B, int M, int N, int m0, int n0,
                                                  int k_begin, int k_end, float* smem, f32x16 (&acc)[1][2], f32x4& cs, bool cs_on) {
     constexpr int BM = 128, BN = 128, NT = 512, XK = X3_BK;
@@ -666,6 +671,63 @@ __device__ __forceinline__ void gemm_mainloop_x3(const twog_rows_t A, const twog
     if (nkt <= 0) return;
     const int k_last = k_begin + (nkt - 1) * XK * KU;
     auto kof = [&](int t) { return min(k_begin + t * XK * KU, k_last); };
+    if constexpr (PIPE) {
+        static_assert(!PIPE || (KU == 1 && KS == 1 && !TMP), "PIPE: one k-tile per interval, one k-group, products into the running sum");
+        constexpr int PI[8] = {2, 1, 2, 0, 1, 1, 0, 0}, PJ[8] = {1, 2, 0, 2, 1, 0, 1, 0};
+        constexpr int FIRST = 8 - X3_PRODUCTS;
+        auto frags = [&](int buf, bf16x8 (&af)[3], bf16x8 (&bf)[2][3]) {
+            const char* base = lds + buf * X3_STAGE;
+#pragma unroll
+            for (int p = 0; p < 3; ++p) af[p] = AKM ? frag_t(base + p * PA, tchA) : frag_r(base + p * PA, fa_r);
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+                    bf[b][p] = BKM ? frag_t(base + 3 * PA + p * PB, tchB + 4 * b) : frag_r(base + p * PB, fb_r + b * 32 * X3_RROW);
+        };
+        auto mfmas = [&](const bf16x8 (&af)[3], const bf16x8 (&bf)[2][3]) {
+#pragma unroll
+            for (int t = FIRST; t < 8; ++t)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+                    acc[0][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[PI[t]], bf[b][PJ[t]], acc[0][b], 0, 0, 0);
+        };
+        Stage r0, r1, r2, r3;
+        gload(r0, kof(0));
+        gload(r1, kof(1));
+        gload(r2, kof(2));
+        gload(r3, kof(3));
+        split_store(r0, 0, 0);
+        __syncthreads();
+        bf16x8 fa0[3], fb0[2][3], fa1[3], fb1[2][3];
+        frags(0, fa0, fb0);
+        split_store(r1, 1, 1);
+        gload(r0, kof(4));
+        gload(r1, kof(5));
+        __syncthreads();
+        // iteration t: fragment set "cur" holds tile t, LDS stage s1 tile t + 1; tile t + 2 goes from its registers into stage s2
+        int s1 = 1, s2 = 2;
+        auto rot = [&]() { s1 = s2; s2 = s2 == 2 ? 0 : s2 + 1; };
+        int kt = 0;
+        for (; kt + 3 < nkt; kt += 4) {
+            frags(s1, fa1, fb1); mfmas(fa0, fb0); split_store(r2, s2, kt + 2); gload(r2, kof(kt + 6)); __syncthreads(); rot();
+            frags(s1, fa0, fb0); mfmas(fa1, fb1); split_store(r3, s2, kt + 3); gload(r3, kof(kt + 7)); __syncthreads(); rot();
+            frags(s1, fa1, fb1); mfmas(fa0, fb0); split_store(r0, s2, kt + 4); gload(r0, kof(kt + 8)); __syncthreads(); rot();
+            frags(s1, fa0, fb0); mfmas(fa1, fb1); split_store(r1, s2, kt + 5); gload(r1, kof(kt + 9)); __syncthreads(); rot();
+        }
+        // up to three k-tiles left: set 0 holds tile kt, stage s1 tile kt + 1, r2 tile kt + 2
+        if (kt < nkt) {
+            if (kt + 1 < nkt) frags(s1, fa1, fb1);
+            mfmas(fa0, fb0);
+            if (kt + 2 < nkt) { split_store(r2, s2, kt + 2); __syncthreads(); }
+        }
+        if (kt + 1 < nkt) {
+            if (kt + 2 < nkt) frags(s2, fa0, fb0);
+            mfmas(fa1, fb1);
+        }
+        if (kt + 2 < nkt) mfmas(fa0, fb0);
+        return;
+    }
 #if TWOG_X3_TMPACC
     // (TMPACC: two register stages -- the temporary accumulator takes the registers of the other two)
     Stage r0, r1;
@@ -942,7 +1004,7 @@ __device__ __forceinline__ void gemm_mainloop_x3s(const twog_rows_t A, const two
 // counters are zero again at the launch boundary (graph replays need no memset node). The hand-off form is the
 // guide's split-K recipe (cdna_hip_programming.md section 5 item 2 / MI355X_MICROARCH.md "Valid forms": sc1 payload,
 // every storing wave drained, workgroup barrier, one relaxed agent atomic; the last arriver's loads all sc1).
-template <int BM, int BN, int NT, bool AKM, bool BKM, int D, bool KG, bool GATE, int KS = 1, bool XS = false, bool X3 = false, int KU = 1, bool TTMP = false>
+template <int BM, int BN, int NT, bool AKM, bool BKM, int D, bool KG, bool GATE, int KS = 1, bool XS = false, bool X3 = false, int KU = 1, bool TTMP = false, bool PIPE = false>
 __device__ __forceinline__ void gemm_tile(const Group& g, const GateArgs* ga) {
     constexpr int NTG = NT / KS;
     constexpr int WM = BM / (NTG / 128), WN = BN / 2;  // per-wave tile; the waves of a k-group in a (NTG/128) x 2 grid
@@ -953,7 +1015,7 @@ __device__ __forceinline__ void gemm_tile(const Group& g, const GateArgs* ga) {
     constexpr int B_ELEMS = BKM ? BK * LDB : BN * LDB;
     // (X3 on the 64-row class: two stages of three bf16 planes per operand, 2 x 6 x 64 rows x 2 XK bytes, XK = 16 KS)
     constexpr int SMEM_FLOATS = (X3 && BM == 128 && BN == 64) ? 2 * KU * 3 * (128 + 64) * 32 / 4   // 128x64 chain tile: 2 stages x KU images
-                                : (X3 && BM == 128) ? KS * 2 * KU * X3_STAGE / 4
+                                : (X3 && BM == 128) ? (PIPE ? 3 : KS * 2 * KU) * X3_STAGE / 4
                                 : (X3 && BM == 64 && 12 * 64 * 8 * KS * KU > 2 * (A_ELEMS + B_ELEMS)) ? 12 * 64 * 8 * KS * KU : 2 * (A_ELEMS + B_ELEMS);
     __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS];
 
@@ -1114,7 +1176,7 @@ __device__ __forceinline__ void gemm_tile(const Group& g, const GateArgs* ga) {
                 const int half = (k_end - k_begin) / 2;
                 gemm_mainloop_x3<AKM, BKM, KG, TTMP, KU, 2>(A, B, M, N, m0, n0, k_begin + kgrp * half, k_begin + (kgrp + 1) * half, smem, acc, cs, cs_on);
             } else
-            gemm_mainloop_x3<AKM, BKM, KG, TTMP, KU>(A, B, M, N, m0, n0, k_begin, k_end, smem, acc, cs, cs_on);
+            gemm_mainloop_x3<AKM, BKM, KG, TTMP, KU, 1, PIPE>(A, B, M, N, m0, n0, k_begin, k_end, smem, acc, cs, cs_on);
             if constexpr (AKM && BKM && !KG) {
                 if (cs_on) {
                     // thread (k row tid / 32, column quad tid % 32) holds its k rows' sums: the 16 k rows are added in row order
@@ -1383,6 +1445,11 @@ __global__ __launch_bounds__(512, 2) void gemm_x3_nn_ku2_kernel(const Group g) {
     gemm_tile<128, 128, 512, false, false, 2, false, false, 1, false, true, 2>(g, nullptr);
 }
 // dW = dY^T X with every k-step's products through a fresh accumulator (TTMP): one workgroup per CU
+// fragment reads one k-tile ahead of the MFMAs (PIPE): one workgroup per CU
+template <bool AKM, bool BKM, bool KG>
+__global__ __launch_bounds__(512, 1) void gemm_x3_pipe_kernel(const Group g) {
+    gemm_tile<128, 128, 512, AKM, BKM, 2, KG, false, 1, false, true, 1, false, true>(g, nullptr);
+}
 // 16 waves = two k-groups on one tile (KS = 2): launches of at most one tile per CU (the segment level's per-step projection)
 __global__ __launch_bounds__(1024, 1) void gemm_x3_nn_k2_kernel(const Group g) {
     gemm_tile<128, 128, 1024, false, false, 2, false, false, 2, false, true>(g, nullptr);
@@ -1710,7 +1777,18 @@ int launch(Group& g, int akm, int bkm, hipStream_t st) {
             static const int k2_on = getenv("TWOG_X3_K2") ? atoi(getenv("TWOG_X3_K2")) : 0;
             bool k2 = k2_on != 0 && !ku2 && !akm && !bkm && g.splitk == 1 && g.total_tiles <= 256;
             for (int i = 0; i < g.n; ++i) k2 = k2 && (g.p[i].K % (2 * X3_BK)) == 0 && g.p[i].K >= 8 * X3_BK;
-            if (k2) hipLaunchKernelGGL(gemm_x3_nn_k2_kernel, grid, dim3(1024), 0, st, g);
+            // fragment reads one k-tile ahead (PIPE, one workgroup per CU): TWOG_X3_PIPE bit 0 = the forward-form launches of at
+            // most one tile per CU, bit 1 = every forward-form launch, bit 2 = the dX / dW forms too. Built and measured in round 6,
+            // bit-identical and SLOWER: the 240-tile projection launch +3 us, the big launches with one pipelined workgroup per CU
+            // lose to two unpipelined ones (roofline.frac 0.430 -> 0.398 forward forms, 0.347 all forms). Off by default.
+            // profiles/r06_gemm128_fragment_reads_ahead.txt
+            static const int pipe_on = getenv("TWOG_X3_PIPE") ? atoi(getenv("TWOG_X3_PIPE")) : 0;
+            const bool one_per_cu = g.splitk == 1 && g.total_tiles <= 256;
+            const bool pipe_nn = !akm && !bkm && (((pipe_on & 1) && one_per_cu) || (pipe_on & 2));
+            if (pipe_nn) hipLaunchKernelGGL((gemm_x3_pipe_kernel<false, false, false>), grid, block, 0, st, g);
+            else if ((pipe_on & 4) && !akm && bkm && !kg) hipLaunchKernelGGL((gemm_x3_pipe_kernel<false, true, false>), grid, block, 0, st, g);
+            else if ((pipe_on & 4) && akm && bkm && !kg && !split_acc) hipLaunchKernelGGL((gemm_x3_pipe_kernel<true, true, false>), grid, block, 0, st, g);
+            else if (k2) hipLaunchKernelGGL(gemm_x3_nn_k2_kernel, grid, dim3(1024), 0, st, g);
             else if (ku2) hipLaunchKernelGGL(gemm_x3_nn_ku2_kernel, grid, block, 0, st, g);
             else if (!akm && !bkm) hipLaunchKernelGGL((gemm_x3_kernel<false, false, false>), grid, block, 0, st, g);
             else if (!akm && bkm && !kg) hipLaunchKernelGGL((gemm_x3_kernel<false, true, false>), grid, block, 0, st, g);

@@ -240,7 +240,7 @@ import twog_gcn_amd
 from twog_gcn_amd.kernels import get_kernels
 K = get_kernels()
 out = {}
-for (M, N, Kd, seed) in ((1280, 1536, 1024, 1), (512, 1536, 512, 2), (2000, 1000, 96, 3), (128, 128, 32, 4)):
+for (M, N, Kd, seed) in ((1280, 1536, 1024, 1), (512, 1536, 512, 2), (2000, 1000, 96, 3), (128, 128, 32, 4), (640, 384, 112, 5), (256, 256, 16, 6), (384, 512, 208, 7)):
     g = torch.Generator().manual_seed(500 + seed)
     A, B, bias = torch.randn(M, Kd, generator=g).cuda(), torch.randn(N, Kd, generator=g).cuda(), torch.randn(N, generator=g).cuda()
     C = torch.empty(M, N, device='cuda')
@@ -259,7 +259,7 @@ def test_gemm_x3_128_class_two_k_tiles_per_barrier_option_is_bit_identical(K, tm
     res = {}
     for ku in ('0', '1'):
         f = tmp_path / f'ku{ku}.pt'
-        r = subprocess.run([sys.executable, '-c', _KU_CHILD, ROOT, str(f)], env=dict(os.environ, TWOG_X3_KU128=ku, TWOG_X3_K2='0', TWOG_GEMM_TILE='128'),
+        r = subprocess.run([sys.executable, '-c', _KU_CHILD, ROOT, str(f)], env=dict(os.environ, TWOG_X3_KU128=ku, TWOG_X3_K2='0', TWOG_X3_PIPE='0', TWOG_GEMM_TILE='128'),
                            capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         res[ku] = torch.load(f)
@@ -280,7 +280,7 @@ def test_gemm_x3_128_class_sixteen_wave_tile_for_launches_of_one_tile_per_cu(K, 
     res = {}
     for tag, k2 in (('off', '0'), ('on', '1'), ('again', '1')):
         f = tmp_path / f'k2{tag}.pt'
-        r = subprocess.run([sys.executable, '-c', _KU_CHILD, ROOT, str(f)], env=dict(os.environ, TWOG_X3_K2=k2, TWOG_GEMM_TILE='128'),
+        r = subprocess.run([sys.executable, '-c', _KU_CHILD, ROOT, str(f)], env=dict(os.environ, TWOG_X3_K2=k2, TWOG_X3_PIPE='0', TWOG_GEMM_TILE='128'),
                            capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         res[tag] = torch.load(f)
@@ -289,11 +289,30 @@ def test_gemm_x3_128_class_sixteen_wave_tile_for_launches_of_one_tile_per_cu(K, 
         assert ca & K.GEMM_TILE128 and ca & K.GEMM_X3 and cb == ca, (k, hex(ca), hex(cb))
         assert ea < 2e-6 and eb < 2e-6, (k, ea, eb)
         assert torch.equal(b, c), f'{k}: two runs of the 16-wave tile differ'
-        if k[2] % 32 or k[2] < 128:
+        if k[2] % 32 or k[2] < 128 or k[0] * k[1] > 256 * 128 * 128:
             assert torch.equal(a, b), k
         else:
             assert not torch.equal(a, b), f'{k}: the 16-wave kernel did not run'
             assert ((a - b).abs().max() / a.abs().max()).item() < 3e-6, k
+
+
+def test_gemm_x3_128_class_fragment_reads_one_k_tile_ahead_is_bit_identical(K, tmp_path):
+    """Round 6: gemm_x3_pipe_kernel reads the fragments of k-tile t + 1 before it multiplies k-tile t (two fragment sets, three
+    LDS stages, one workgroup per CU) -- the same MFMA sequence into the same accumulators as gemm_x3_kernel. Every output word
+    must equal the unpipelined kernel's (TWOG_X3_PIPE=0), with bias + ReLU epilogue, a ragged problem, reductions of 6, 2 and 64
+    k-tiles (main loop + every remainder length)."""
+    res = {}
+    for pipe in ('0', '3'):
+        f = tmp_path / f'pipe{pipe}.pt'
+        r = subprocess.run([sys.executable, '-c', _KU_CHILD, ROOT, str(f)], env=dict(os.environ, TWOG_X3_PIPE=pipe, TWOG_X3_K2='0', TWOG_GEMM_TILE='128'),
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[pipe] = torch.load(f)
+    for k in res['0']:
+        (a, ca, ea), (b, cb, eb) = res['0'][k], res['3'][k]
+        assert ca & K.GEMM_TILE128 and ca & K.GEMM_X3, (k, hex(ca))
+        assert ea < 2e-6 and eb < 2e-6, (k, ea, eb)
+        assert torch.equal(a, b), f'{k}: reading the fragments one k-tile ahead changed the result'
 
 
 def test_gemm_column_sums_of_a_from_the_same_pass(K):
