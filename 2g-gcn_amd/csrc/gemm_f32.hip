@@ -1750,6 +1750,8 @@ static bool x3_128_ok(const Group& g) {
     return ok;
 }
 
+thread_local int g_dw_one_per_cu = getenv("TWOG_DW_ONE_PER_CU") ? atoi(getenv("TWOG_DW_ONE_PER_CU")) : 0;
+
 template <int BM, int BN, int NT, int D>
 int launch(Group& g, int akm, int bkm, hipStream_t st) {
     g_last_class_x3 = 0;
@@ -1795,6 +1797,14 @@ int launch(Group& g, int akm, int bkm, hipStream_t st) {
             else if (!akm && bkm) hipLaunchKernelGGL((gemm_x3_kernel<false, true, true>), grid, block, 0, st, g);
             else if (akm && bkm && split_acc && !kg) hipLaunchKernelGGL((gemm_x3_tt_split_acc_kernel<false>), grid, block, 0, st, g);
             else if (akm && bkm && split_acc) hipLaunchKernelGGL((gemm_x3_tt_split_acc_kernel<true>), grid, block, 0, st, g);
+            else if (akm && bkm && g_dw_one_per_cu) {
+                // (experiment, round 6: the dW launches of a side stream with ONE workgroup per CU -- 40 KB of unused dynamic LDS
+                // on top of the 48 KB of stages -- so that half of every CU's registers stay free for a 4-wave chain workgroup;
+                // twog_gemm_dw_one_per_cu(1) / TWOG_DW_ONE_PER_CU=1; profiles/r06_dw_one_workgroup_per_cu.txt)
+                static std::atomic<uint32_t> a0{0}, a1{0};
+                if (!kg) { twog_allow_dynamic_lds(gemm_x3_kernel<true, true, false>, 40 * 1024, a0); hipLaunchKernelGGL((gemm_x3_kernel<true, true, false>), grid, block, 40 * 1024, st, g); }
+                else { twog_allow_dynamic_lds(gemm_x3_kernel<true, true, true>, 40 * 1024, a1); hipLaunchKernelGGL((gemm_x3_kernel<true, true, true>), grid, block, 40 * 1024, st, g); }
+            }
             else if (akm && bkm && !kg) hipLaunchKernelGGL((gemm_x3_kernel<true, true, false>), grid, block, 0, st, g);
             else if (akm && bkm) hipLaunchKernelGGL((gemm_x3_kernel<true, true, true>), grid, block, 0, st, g);
             else if (!kg) hipLaunchKernelGGL((gemm_x3_kernel<true, false, false>), grid, block, 0, st, g);
