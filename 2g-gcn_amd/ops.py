@@ -376,6 +376,7 @@ class _Grads:
         self.K, self.g, self.sinks, self.known = K, {}, sinks or {}, known
         self._pending, self._pending_dst = [], set()   # `dst += t` operations not yet issued (one launch per 16: flush())
         self._pend_cs, self._pend_cp = [], []          # column sums / copies not yet issued (issued before the additions)
+        self._pend_mm_wide = True
         self._pend_mm, self._pend_mm_c = [], set()     # weight-gradient GEMMs (dW = dY^T X) not yet issued: grouped launches
         self._held = None                              # a tall dW GEMM waiting one call for its bias gradient (dw_gemm)
         self._defer = hasattr(K, 'colsum_many') and os.environ.get('TWOG_BATCH_ADDS', '1') != '0'
@@ -449,27 +450,38 @@ class _Grads:
         # step one by one against 15.03 / 14.75 grouped; 64 clips 66.61 / 66.05 one by one against 69.41 / 69.36 grouped (a tall
         # reduction alone gets the XCD-dealt split-K that a mixed group does not)
         rows = A.shape[0] if A.dim() == 2 else A.shape[0] * A.shape[1]
-        if (not self._defer or os.environ.get('TWOG_BATCH_DW', '1') == '0' or A.shape[-1] < 128 or B.shape[-1] < 128
-                or rows > 8192 or not plain(A) or not plain(B)):
+        wide = A.shape[-1] >= 128 and B.shape[-1] >= 128 and rows <= 8192 and plain(A) and plain(B)
+        # NARROW problems (an operand under 128 columns: every weight of a model with hidden_size 64, the heads) take the 64x64
+        # class whatever they are grouped with, each a split-K launch of a few tiles + a reduce launch of ~36 + 12 us: at 16
+        # clips x h 64 (BASELINE configs[4]) 47 such pairs were a quarter of the step. They share launches among themselves
+        # (round 6; TWOG_BATCH_DW_NARROW_ROWS=0: one by one). Only short reductions, as above.
+        narrow = ((A.shape[-1] < 128 or B.shape[-1] < 128) and 0 < rows <= int(os.environ.get('TWOG_BATCH_DW_NARROW_ROWS', '20000')))
+        if narrow and self._holdable(problem):
+            narrow = False   # (a launch that can take its layer's bias gradient along keeps doing that: the held route below)
+        if not self._defer or os.environ.get('TWOG_BATCH_DW', '1') == '0' or not (wide or narrow):
             self._issue_held()
             if problem['C'].data_ptr() in self._pend_mm_c:
                 self.flush()   # (a collected problem writes the same buffer: keep the order)
             # a tall problem waits for ONE more call: the bias gradient of the same layer is asked for right after its weight
             # gradient (colsum(dY) after dW = dY^T X), and the GEMM that already streams dY takes the column sums on the
             # way (twog_gemm_t::a_colsum) -- 1.3 ms of column-sum launches re-reading 4 GB per bs64 step otherwise
-            if (self._defer and A.dim() == 2 and os.environ.get('TWOG_DW_COLSUM', '1') != '0'
-                    and hasattr(self.K, 'gemm_colsum_ok') and self.K.gemm_colsum_ok(problem)):
+            if self._holdable(problem):
                 self._held = problem
                 self._snap(A, B)
                 return
             self.K.gemm([problem], a_kmajor=True, b_kmajor=True)
             return
         key = problem['C'].data_ptr()
-        if key in self._pend_mm_c or len(self._pend_mm) >= 8:
-            self.flush()
+        if key in self._pend_mm_c or len(self._pend_mm) >= 8 or (self._pend_mm and self._pend_mm_wide != wide):
+            self.flush()   # (wide and narrow problems never share a launch: the narrow ones would pull the group to their class)
         self._pend_mm.append(problem)
         self._pend_mm_c.add(key)
+        self._pend_mm_wide = wide
         self._snap(A, B)
+
+    def _holdable(self, problem):
+        return (self._defer and problem['A'].dim() == 2 and os.environ.get('TWOG_DW_COLSUM', '1') != '0'
+                and hasattr(self.K, 'gemm_colsum_ok') and self.K.gemm_colsum_ok(problem))
 
     def colsum(self, x, out=None, accumulate=False):
         """Column sums of x (a bias gradient), DEFERRED: `out` is returned at once and filled at the next flush() -- the

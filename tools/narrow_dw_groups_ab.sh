@@ -1,0 +1,14 @@
+#!/bin/bash
+# Round 6: narrow weight-gradient problems (an operand under 128 columns) in grouped launches (ops._Grads.dw_gemm) against one by
+# one (TWOG_BATCH_DW_NARROW_ROWS=0). One box, alternating.
+run() {  # workload, label, env...
+  local w=$1; local label=$2; shift; shift
+  env "$@" python3 bench.py --workload $w --no-cpu-baseline --steps 20 --warmup 5 2>/dev/null | python3 -c "
+import json,sys
+l=[x for x in sys.stdin if x.startswith('{')][-1]; d=json.loads(l)
+print('%-10s %-22s %7.2f ms  %7.1f clips/s' % ('$w', '$label', d['ms_per_step'], d['value']))"
+}
+for w in c5 defaults c2 c3 c5; do
+  run $w "one by one" TWOG_BATCH_DW_NARROW_ROWS=0
+  run $w "grouped (default)" A=1
+done
